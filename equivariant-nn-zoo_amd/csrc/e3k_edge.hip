@@ -1,0 +1,357 @@
+// Edge geometry kernels for gfx950: displacement vectors, real spherical harmonics (l <= 3),
+// Bessel radial basis x cutoff envelope — forward and backward.
+//
+// Replaces (paths relative to /root/reference):
+//   computeEdgeVector                         e3_layers/data/compute_edge.py:13-36
+//   SphericalEncoding -> o3.SphericalHarmonics e3_layers/nn/embedding.py:163-178   
+//   RadialBasisEncoding = BesselBasis * cutoff e3_layers/nn/embedding.py:114-127,31-40,26-29,210-219
+//
+// All of these are O(E) elementwise streams (<= 100 B per edge); one lane per edge.
+#include "e3k_common.h"
+
+namespace e3k {
+
+// ---------------------------------------------------------------------------------------
+// edge vectors
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void edge_vector_fwd_kernel(const float* __restrict__ pos,
+                                                               const int32_t* __restrict__ src,
+                                                               const int32_t* __restrict__ dst, int64_t E,
+                                                               float* __restrict__ vec, float* __restrict__ len) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int s = src[e], d = dst[e];
+  const float vx = pos[3 * (int64_t)d + 0] - pos[3 * (int64_t)s + 0];
+  const float vy = pos[3 * (int64_t)d + 1] - pos[3 * (int64_t)s + 1];
+  const float vz = pos[3 * (int64_t)d + 2] - pos[3 * (int64_t)s + 2];
+  vec[3 * e + 0] = vx;
+  vec[3 * e + 1] = vy;
+  vec[3 * e + 2] = vz;
+  if (len) len[e] = sqrtf(vx * vx + vy * vy + vz * vz);
+}
+
+__global__ __launch_bounds__(256) void edge_vector_bwd_kernel(const float* __restrict__ g_vec,
+                                                               const float* __restrict__ g_len,
+                                                               const float* __restrict__ vec,
+                                                               const float* __restrict__ len,
+                                                               const int32_t* __restrict__ dst_ptr,
+                                                               const int32_t* __restrict__ dst_perm,
+                                                               const int32_t* __restrict__ src_ptr,
+                                                               const int32_t* __restrict__ src_perm, int64_t N,
+                                                               float* __restrict__ g_pos) {
+  const int64_t n = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  float ax = 0.f, ay = 0.f, az = 0.f;
+  auto edge_grad = [&](int e, float sign) {
+    float gx = g_vec ? g_vec[3 * (int64_t)e + 0] : 0.f;
+    float gy = g_vec ? g_vec[3 * (int64_t)e + 1] : 0.f;
+    float gz = g_vec ? g_vec[3 * (int64_t)e + 2] : 0.f;
+    if (g_len) {
+      const float l = len[e];
+      const float f = l > 0.f ? g_len[e] / l : 0.f;
+      gx = fmaf(f, vec[3 * (int64_t)e + 0], gx);
+      gy = fmaf(f, vec[3 * (int64_t)e + 1], gy);
+      gz = fmaf(f, vec[3 * (int64_t)e + 2], gz);
+    }
+    ax = fmaf(sign, gx, ax);
+    ay = fmaf(sign, gy, ay);
+    az = fmaf(sign, gz, az);
+  };
+  for (int t = dst_ptr[n]; t < dst_ptr[n + 1]; ++t) edge_grad(dst_perm[t], 1.f);
+  for (int t = src_ptr[n]; t < src_ptr[n + 1]; ++t) edge_grad(src_perm[t], -1.f);
+  g_pos[3 * n + 0] = ax;
+  g_pos[3 * n + 1] = ay;
+  g_pos[3 * n + 2] = az;
+}
+
+// ---------------------------------------------------------------------------------------
+// spherical harmonics, component normalisation, polar axis y
+// forward-mode duals give value and d/dx, d/dy, d/dz in one evaluation
+// ---------------------------------------------------------------------------------------
+struct D3 {
+  float v, dx, dy, dz;
+};
+__device__ __forceinline__ D3 operator*(const D3& a, const D3& b) {
+  return {a.v * b.v, fmaf(a.v, b.dx, a.dx * b.v), fmaf(a.v, b.dy, a.dy * b.v), fmaf(a.v, b.dz, a.dz * b.v)};
+}
+__device__ __forceinline__ D3 operator+(const D3& a, const D3& b) { return {a.v + b.v, a.dx + b.dx, a.dy + b.dy, a.dz + b.dz}; }
+__device__ __forceinline__ D3 operator-(const D3& a, const D3& b) { return {a.v - b.v, a.dx - b.dx, a.dy - b.dy, a.dz - b.dz}; }
+__device__ __forceinline__ D3 operator*(float s, const D3& a) { return {s * a.v, s * a.dx, s * a.dy, s * a.dz}; }
+
+struct ShArgs {
+  int n_ls;
+  int ls[8];
+  int normalize, normalization;
+};
+
+__device__ __forceinline__ float sh_norm_factor(int l, int normalization) {
+  if (normalization == 1) return 0.28209479177387814f;          // 1/sqrt(4 pi)
+  if (normalization == 2) return rsqrtf((float)(2 * l + 1));    // 'norm'
+  return 1.0f;
+}
+
+// evaluates degree l into out[0..2l]; returns count
+__device__ __forceinline__ int sh_eval(int l, const D3& x, const D3& y, const D3& z, D3* out) {
+  const float s3 = 1.7320508075688772f, s5 = 2.23606797749979f, s15 = 3.872983346207417f, s7 = 2.6457513110645907f;
+  if (l == 0) {
+    out[0] = {1.f, 0.f, 0.f, 0.f};
+    return 1;
+  }
+  if (l == 1) {
+    out[0] = s3 * x;
+    out[1] = s3 * y;
+    out[2] = s3 * z;
+    return 3;
+  }
+  const D3 x2 = x * x, y2 = y * y, z2 = z * z;
+  const D3 x2z2 = x2 + z2;
+  D3 q[5];
+  q[0] = s15 * (x * z);
+  q[1] = s15 * (x * y);
+  q[2] = s5 * (y2 - 0.5f * x2z2);
+  q[3] = s15 * (y * z);
+  q[4] = (0.5f * s15) * (z2 - x2);
+  if (l == 2) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) out[i] = q[i];
+    return 5;
+  }
+  // l == 3
+  const float a = 1.0801234497346435f;  // sqrt(42)/6
+  const float b = 1.6201851746019651f;  // sqrt(168)/8
+  const D3 f = 4.0f * y2 - x2z2;
+  out[0] = a * (q[0] * z + q[4] * x);
+  out[1] = s7 * (q[0] * y);
+  out[2] = b * (f * x);
+  out[3] = (0.5f * s7) * (y * (2.0f * y2 - 3.0f * x2z2));
+  out[4] = b * (z * f);
+  out[5] = s7 * (q[4] * y);
+  out[6] = a * (q[4] * z - q[0] * x);
+  return 7;
+}
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void sph_harm_kernel(const float* __restrict__ vec, const float* __restrict__ g_sh,
+                                                        int64_t E, ShArgs sa, int dim, float* __restrict__ sh,
+                                                        float* __restrict__ g_vec) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const float vx = vec[3 * e], vy = vec[3 * e + 1], vz = vec[3 * e + 2];
+  float ux = vx, uy = vy, uz = vz, inv = 1.f;
+  if (sa.normalize) {
+    const float r = sqrtf(vx * vx + vy * vy + vz * vz);
+    inv = 1.0f / fmaxf(r, 1e-12f);
+    ux *= inv;
+    uy *= inv;
+    uz *= inv;
+  }
+  const D3 x{ux, 1.f, 0.f, 0.f}, y{uy, 0.f, 1.f, 0.f}, z{uz, 0.f, 0.f, 1.f};
+  int off = 0;
+  float gx = 0.f, gy = 0.f, gz = 0.f;
+  for (int i = 0; i < sa.n_ls; ++i) {
+    const int l = sa.ls[i];
+    D3 out[7];
+    const int cnt = sh_eval(l, x, y, z, out);
+    const float nf = sh_norm_factor(l, sa.normalization);
+    for (int m = 0; m < cnt; ++m) {
+      if constexpr (!BWD) {
+        sh[e * dim + off + m] = nf * out[m].v;
+      } else {
+        const float g = nf * g_sh[e * dim + off + m];
+        gx = fmaf(g, out[m].dx, gx);
+        gy = fmaf(g, out[m].dy, gy);
+        gz = fmaf(g, out[m].dz, gz);
+      }
+    }
+    off += cnt;
+  }
+  if constexpr (BWD) {
+    if (sa.normalize) {
+      // u = v / |v|:  dL/dv = (g - u (u . g)) / |v|
+      const float dot = gx * ux + gy * uy + gz * uz;
+      gx = (gx - ux * dot) * inv;
+      gy = (gy - uy * dot) * inv;
+      gz = (gz - uz * dot) * inv;
+    }
+    g_vec[3 * e] = gx;
+    g_vec[3 * e + 1] = gy;
+    g_vec[3 * e + 2] = gz;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// radial basis
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void cutoff_eval(float r, float r_max, float p, int kind, float& c, float& dc) {
+  const float x = r / r_max;
+  if (kind == 1) {
+    // (x-1)^2 (x+1)^2 = (x^2-1)^2 on |x| < 1
+    if (fabsf(x) < 1.0f) {
+      const float q = x * x - 1.0f;
+      c = q * q;
+      dc = 4.0f * q * x / r_max;
+    } else {
+      c = 0.f;
+      dc = 0.f;
+    }
+    return;
+  }
+  if (x < 1.0f) {
+    const float xp = powf(x, p);
+    const float c0 = (p + 1.0f) * (p + 2.0f) * 0.5f, c1 = p * (p + 2.0f), c2 = p * (p + 1.0f) * 0.5f;
+    c = 1.0f - c0 * xp + c1 * xp * x - c2 * xp * x * x;
+    const float xpm1 = (x != 0.0f) ? xp / x : 0.0f;  // x^(p-1)
+    dc = (-c0 * p * xpm1 + c1 * (p + 1.0f) * xp - c2 * (p + 2.0f) * xp * x) / r_max;
+  } else {
+    c = 0.f;
+    dc = 0.f;
+  }
+}
+
+constexpr int RB_MAXB = 64;
+
+__global__ __launch_bounds__(256) void radial_fwd_kernel(const float* __restrict__ r, int64_t E,
+                                                          const float* __restrict__ bw, int nb, float r_max,
+                                                          float r_min, float p, int one_over_r, int kind,
+                                                          float* __restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const float rv = r[e];
+  const float delta = r_max - r_min, pref = 2.0f / delta;
+  float c, dc;
+  cutoff_eval(rv, r_max, p, kind, c, dc);
+  const float scale = one_over_r ? pref * c / rv : pref * c;
+  for (int n = 0; n < nb; ++n) out[e * nb + n] = sinf(bw[n] * rv / delta) * scale;
+}
+
+__global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict__ r, const float* __restrict__ g_out,
+                                                          int64_t E, const float* __restrict__ bw, int nb, float r_max,
+                                                          float r_min, float p, int one_over_r, int kind,
+                                                          float* __restrict__ g_r, float* __restrict__ g_w) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool valid = e < E;
+  const float rv = valid ? r[e] : 1.0f;
+  const float delta = r_max - r_min, pref = 2.0f / delta;
+  float c, dc;
+  cutoff_eval(rv, r_max, p, kind, c, dc);
+  const float inv_r = one_over_r ? 1.0f / rv : 1.0f;
+  float gr = 0.f;
+  for (int n = 0; n < nb; ++n) {
+    const float w = bw[n];
+    const float arg = w * rv / delta;
+    float sn, cs;
+    sincosf(arg, &sn, &cs);
+    const float g = valid ? g_out[e * nb + n] : 0.f;
+    // out = pref * sin(arg) * inv_r * c
+    float dbasis = pref * cs * (w / delta) * inv_r;
+    if (one_over_r) dbasis -= pref * sn * inv_r * inv_r;
+    gr = fmaf(g, dbasis * c + pref * sn * inv_r * dc, gr);
+    if (g_w) {
+      const float gw = wave_sum(g * pref * cs * (rv / delta) * inv_r * c);
+      if ((threadIdx.x & 63) == 0) atomicAdd(g_w + n, gw);
+    }
+  }
+  if (g_r && valid) g_r[e] = gr;
+}
+
+}  // namespace e3k
+
+extern "C" int e3k_edge_vector_fwd(const float* pos, const int32_t* src, const int32_t* dst, int64_t E,
+                                   float* edge_vec, float* edge_len, void* stream) {
+  if (E < 0) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!pos || !src || !dst || !edge_vec) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::edge_vector_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     pos, src, dst, E, edge_vec, edge_len);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_edge_vector_bwd(const float* g_vec, const float* g_len, const float* edge_vec,
+                                   const float* edge_len, const int32_t* dst_ptr, const int32_t* dst_perm,
+                                   const int32_t* src_ptr, const int32_t* src_perm, int64_t N, float* g_pos,
+                                   void* stream) {
+  if (N < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!dst_ptr || !src_ptr || !g_pos || (!g_vec && !g_len)) return E3K_ERR_INVALID;
+  if (g_len && (!edge_vec || !edge_len)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::edge_vector_bwd_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     g_vec, g_len, edge_vec, edge_len, dst_ptr, dst_perm, src_ptr, src_perm, N, g_pos);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+namespace {
+int make_sh_args(const int32_t* ls, int32_t n_ls, int32_t normalize, int32_t normalization, e3k::ShArgs& sa, int& dim) {
+  if (!ls || n_ls <= 0 || n_ls > 8) return E3K_ERR_INVALID;
+  if (normalization < 0 || normalization > 2) return E3K_ERR_INVALID;
+  dim = 0;
+  sa.n_ls = n_ls;
+  for (int i = 0; i < n_ls; ++i) {
+    if (ls[i] < 0) return E3K_ERR_INVALID;
+    if (ls[i] > 3) return E3K_ERR_UNSUPPORTED;
+    sa.ls[i] = ls[i];
+    dim += 2 * ls[i] + 1;
+  }
+  sa.normalize = normalize;
+  sa.normalization = normalization;
+  return E3K_OK;
+}
+}  // namespace
+
+/* `ls` is a HOST array (copied into the kernel arguments). */
+extern "C" int e3k_sph_harm_fwd(const float* vec, int64_t E, const int32_t* ls, int32_t n_ls, int32_t normalize,
+                                int32_t normalization, float* sh, void* stream) {
+  e3k::ShArgs sa{};
+  int dim = 0;
+  const int rc = make_sh_args(ls, n_ls, normalize, normalization, sa, dim);
+  if (rc != E3K_OK) return rc;
+  if (E < 0) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!vec || !sh) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::sph_harm_kernel<false>, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     vec, (const float*)nullptr, E, sa, dim, sh, (float*)nullptr);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_sph_harm_bwd(const float* vec, const float* g_sh, int64_t E, const int32_t* ls, int32_t n_ls,
+                                int32_t normalize, int32_t normalization, float* g_vec, void* stream) {
+  e3k::ShArgs sa{};
+  int dim = 0;
+  const int rc = make_sh_args(ls, n_ls, normalize, normalization, sa, dim);
+  if (rc != E3K_OK) return rc;
+  if (E < 0) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!vec || !g_sh || !g_vec) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::sph_harm_kernel<true>, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     vec, g_sh, E, sa, dim, (float*)nullptr, g_vec);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_radial_basis_fwd(const float* r, int64_t E, const float* bessel_w, int32_t n_basis, float r_max,
+                                    float r_min, float p, int32_t one_over_r, int32_t cutoff_kind, float* out,
+                                    void* stream) {
+  if (E < 0 || n_basis <= 0 || n_basis > e3k::RB_MAXB || !(r_max > r_min)) return E3K_ERR_INVALID;
+  if (cutoff_kind < 0 || cutoff_kind > 1) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!r || !bessel_w || !out) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::radial_fwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r, E,
+                     bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, out);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t E, const float* bessel_w,
+                                    int32_t n_basis, float r_max, float r_min, float p, int32_t one_over_r,
+                                    int32_t cutoff_kind, float* g_r, float* g_w, void* stream) {
+  if (E < 0 || n_basis <= 0 || n_basis > e3k::RB_MAXB || !(r_max > r_min)) return E3K_ERR_INVALID;
+  if (cutoff_kind < 0 || cutoff_kind > 1) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!r || !g_out || !bessel_w || (!g_r && !g_w)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::radial_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r,
+                     g_out, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}

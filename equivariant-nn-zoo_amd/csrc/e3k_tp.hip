@@ -1,0 +1,461 @@
+// Fused 'uvu' Clebsch-Gordan tensor product + destination reduce for gfx950 (MI355X).
+//
+// Replaces, per convolution layer of the reference:
+//   x[edge_src] gather            e3_layers/nn/message_passing.py:96,105   (never materialised here)
+//   o3.TensorProduct 'uvu'        e3_layers/nn/pointwise.py:78-85,94-98   (per-edge external weights)
+//   scatter over edge_dst         e3_layers/nn/message_passing.py:109     (no atomics here)
+//
+// Execution shape (one wave = one work item, no LDS, no atomics):
+//   work item = (node n, group g, 64-channel chunk c); lane = channel u.
+//   A group is one input irrep block (degree L1, template parameter) with up to NQ(L1) paths,
+//   at most one per (l2, l3) slot.  The wave walks the in-edges of n (CSR by destination,
+//   edge ids ascending => same summation order as the reference's CPU index_add_), keeps the
+//   whole group output  sum_q (2 l3_q + 1)  in registers at compile-time slot offsets and
+//   writes each output row exactly once, as 256-byte rows in the channel-fastest layout.
+//   Per edge it reads: 2 L1 + 1 coalesced 256-B rows of x[src] (L2-resident: a graph's rows
+//   stay on one XCD thanks to xcd_remap), one 256-B row of w per path (the HBM stream: every
+//   weight element is read exactly once per pass) and <= 9 wave-uniform floats of sh[e]
+//   (scalar loads).  Wigner-3j coefficients are instruction literals (e3k_cg_gen.h).
+//
+// Backward: bwd_w has the forward's shape (per destination node; writes grad_w[e] rows,
+// optionally reduces grad_sh[e] over lanes), bwd_x walks the out-edges of a source node
+// (CSR by source) and accumulates grad_x in registers.
+#include <type_traits>
+
+#include "e3k_common.h"
+#include "e3k_cg_gen.h"
+
+static_assert(E3K_MAXQ == E3K_TP_MAXQ, "e3k.h and e3k_cg_gen.h disagree on the slot count");
+static_assert(E3K_L2MAX == 2, "YRegs below is written for sh degrees 0..2");
+
+namespace e3k {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+struct YRegs {
+  float y0[1];
+  float y1[3];
+  float y2[5];
+};
+template <int L2>
+__device__ __forceinline__ auto& yref(YRegs& y) {
+  if constexpr (L2 == 0) return y.y0;
+  else if constexpr (L2 == 1) return y.y1;
+  else return y.y2;
+}
+
+struct TpArgs {
+  const float* x;      // [N, d_in]  cf
+  const float* sh;     // [E, d_sh]
+  const float* w;      // [E, W]
+  const float* g_out;  // [N, d_mid] cf (backward)
+  float* out;          // [N, d_mid] cf (forward)
+  float* g_w;          // [E, W]
+  float* g_sh;         // [E, d_sh]
+  float* g_x;          // [N, d_in]
+  const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
+  const int32_t* ptr;  // CSR row pointers [N+1]
+  const int32_t* perm; // CSR edge ids [E]
+  int32_t d_in, d_sh, W, d_mid;
+  int64_t n_items;
+};
+
+struct GroupRegs {
+  int x_off, mul;
+  unsigned mask;
+  int y_off[3];
+};
+
+__device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, const e3k_tp_group& g) {
+  // wave-uniform addresses: these become scalar loads
+  if (g.y_off[0] >= 0) y.y0[0] = yr[g.y_off[0]];
+  if (g.y_off[1] >= 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) y.y1[j] = yr[g.y_off[1] + j];
+  }
+  if (g.y_off[2] >= 0) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) y.y2[j] = yr[g.y_off[2] + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+template <int L1>
+__global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                     const int2* __restrict__ gc, int n_gc) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
+  if (item >= a.n_items) return;
+  const int node = uniform((int)(item / n_gc));
+  const int gci = uniform((int)(item % n_gc));
+  const int2 gcv = gc[gci];
+  const e3k_tp_group& g = groups[uniform(gcv.x)];
+  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
+  const bool active = u < g.mul;
+  const int mul = g.mul;
+  const unsigned mask = g.mask;
+
+  float acc[S::TOTAL];
+#pragma unroll
+  for (int i = 0; i < S::TOTAL; ++i) acc[i] = 0.0f;
+
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  if (beg < end) {
+    // software pipeline: the loads of edge t+1 are issued before edge t is consumed
+    float xn[D1], wn[S::NQ];
+    YRegs yn;
+    auto issue = [&](int t) {
+      const int e = uniform(a.perm[t]);
+      const int s = uniform(a.nbr[e]);
+      const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off + u;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) xn[i] = active ? xr[i * mul] : 0.0f;
+      const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
+      static_for<0, S::NQ>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        if (mask & (1u << Q)) wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
+      });
+      load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
+    };
+    issue(beg);
+    for (int t = beg; t < end; ++t) {
+      float xc[D1], wc[S::NQ];
+      YRegs yc = yn;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) xc[i] = xn[i];
+#pragma unroll
+      for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
+      if (t + 1 < end) issue(t + 1);
+      static_for<0, S::NQ>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+        if (mask & (1u << Q)) {
+          const float wv = wc[Q] * g.coeff[Q];
+          float tt[2 * L3 + 1];
+          CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+#pragma unroll
+          for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
+        }
+      });
+    }
+  }
+  if (active) {
+    float* __restrict__ orow = a.out + (int64_t)node * a.d_mid + u;
+    static_for<0, S::NQ>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) orow[g.out_off[Q] + k * g.out_stride[Q]] = acc[OFF + k];
+      }
+    });
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward wrt the per-edge weights (and optionally the spherical harmonics)
+// ------------------------------------------------------------------------------------------
+template <int L1, bool WITH_SH>
+__global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                       const int2* __restrict__ gc, int n_gc) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
+  if (item >= a.n_items) return;
+  const int node = uniform((int)(item / n_gc));
+  const int gci = uniform((int)(item % n_gc));
+  const int2 gcv = gc[gci];
+  const e3k_tp_group& g = groups[uniform(gcv.x)];
+  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
+  const bool active = u < g.mul;
+  const int mul = g.mul;
+  const unsigned mask = g.mask;
+
+  // incoming gradient of this node's group outputs, resident for the whole edge walk
+  float go[S::TOTAL];
+  {
+    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid + u;
+    static_for<0, S::NQ>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k)
+        go[OFF + k] = ((mask & (1u << Q)) && active) ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
+    });
+  }
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]);
+    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off + u;
+    float xc[D1];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = active ? xr[i * mul] : 0.0f;
+    YRegs yc;
+    load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
+    float* __restrict__ gwr = a.g_w + (int64_t)e * a.W + u;
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
+    YRegs gy;
+    if constexpr (WITH_SH) {
+      gy.y0[0] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gy.y1[j] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) gy.y2[j] = 0.0f;
+    }
+    static_for<0, S::NQ>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
+        float tt[2 * L3 + 1], gk[2 * L3 + 1];
+        CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+        float dot = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) {
+          gk[k] = go[OFF + k];
+          dot = fmaf(gk[k], tt[k], dot);
+        }
+        if (active) gwr[g.w_off[Q]] = dot * g.coeff[Q];
+        if constexpr (WITH_SH) {
+          const float wv = active ? wr[g.w_off[Q]] * g.coeff[Q] : 0.0f;
+          CG<L1, L2, L3>::xg(xc, gk, wv, yref<L2>(gy));
+        }
+      }
+    });
+    if constexpr (WITH_SH) {
+      float* __restrict__ gsr = a.g_sh + (int64_t)e * a.d_sh;
+      const bool lane0 = (threadIdx.x & 63) == 0;
+      if (g.y_off[0] >= 0) {
+        const float v = wave_sum(gy.y0[0]);
+        if (lane0) atomicAdd(gsr + g.y_off[0], v);
+      }
+      if (g.y_off[1] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const float v = wave_sum(gy.y1[j]);
+          if (lane0) atomicAdd(gsr + g.y_off[1] + j, v);
+        }
+      }
+      if (g.y_off[2] >= 0) {
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+          const float v = wave_sum(gy.y2[j]);
+          if (lane0) atomicAdd(gsr + g.y_off[2] + j, v);
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// backward wrt the node features: walk the out-edges of a source node
+// ------------------------------------------------------------------------------------------
+template <int L1>
+__global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                       const int2* __restrict__ gc, int n_gc) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int b = xcd_remap(blockIdx.x, gridDim.x);
+  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
+  if (item >= a.n_items) return;
+  const int node = uniform((int)(item / n_gc));
+  const int gci = uniform((int)(item % n_gc));
+  const int2 gcv = gc[gci];
+  const e3k_tp_group& g = groups[uniform(gcv.x)];
+  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
+  const bool active = u < g.mul;
+  const int mul = g.mul;
+  const unsigned mask = g.mask;
+
+  float gx[D1];
+#pragma unroll
+  for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int d = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
+    const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
+    static_for<0, S::NQ>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q];
+      if (mask & (1u << Q)) {
+        float gk[2 * L3 + 1];
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = active ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
+        const float wv = active ? wr[g.w_off[Q]] * g.coeff[Q] : 0.0f;
+        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wv, gx);
+      }
+    });
+  }
+  if (active) {
+    float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off + u;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) gxr[i * mul] = gx[i];
+  }
+}
+
+}  // namespace e3k
+
+// ------------------------------------------------------------------------------------------
+// plan + C ABI
+// ------------------------------------------------------------------------------------------
+struct e3k_tp_plan {
+  int32_t n_groups, d_in, d_sh, w_numel, d_mid;
+  e3k_tp_group* d_groups;
+  int2* d_gc[E3K_L1MAX + 1];
+  int32_t n_gc[E3K_L1MAX + 1];
+};
+
+extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
+  if (l1max) *l1max = E3K_L1MAX;
+  if (l2max) *l2max = E3K_L2MAX;
+  if (l3max) *l3max = E3K_L3MAX;
+}
+
+extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, int32_t d_in, int32_t d_sh,
+                                  int32_t w_numel, int32_t d_mid, e3k_tp_plan** out) {
+  if (!groups || n_groups <= 0 || !out) return E3K_ERR_INVALID;
+  for (int i = 0; i < n_groups; ++i) {
+    const e3k_tp_group& g = groups[i];
+    if (g.l1 < 0 || g.mul <= 0) return E3K_ERR_INVALID;
+    if (g.l1 > E3K_L1MAX) return E3K_ERR_UNSUPPORTED;
+  }
+  e3k_tp_plan* p = new e3k_tp_plan();
+  p->n_groups = n_groups;
+  p->d_in = d_in;
+  p->d_sh = d_sh;
+  p->w_numel = w_numel;
+  p->d_mid = d_mid;
+  p->d_groups = nullptr;
+  for (int l = 0; l <= E3K_L1MAX; ++l) {
+    p->d_gc[l] = nullptr;
+    p->n_gc[l] = 0;
+  }
+  if (hipMalloc(&p->d_groups, sizeof(e3k_tp_group) * n_groups) != hipSuccess) {
+    delete p;
+    return E3K_ERR_LAUNCH;
+  }
+  if (hipMemcpy(p->d_groups, groups, sizeof(e3k_tp_group) * n_groups, hipMemcpyHostToDevice) != hipSuccess) {
+    e3k_tp_plan_destroy(p);
+    return E3K_ERR_LAUNCH;
+  }
+  for (int l = 0; l <= E3K_L1MAX; ++l) {
+    int cnt = 0;
+    for (int i = 0; i < n_groups; ++i)
+      if (groups[i].l1 == l) cnt += (groups[i].mul + 63) / 64;
+    if (!cnt) continue;
+    int2* host = new int2[cnt];
+    int k = 0;
+    for (int i = 0; i < n_groups; ++i)
+      if (groups[i].l1 == l)
+        for (int c = 0; c < (groups[i].mul + 63) / 64; ++c) host[k++] = make_int2(i, c);
+    hipError_t e1 = hipMalloc(&p->d_gc[l], sizeof(int2) * cnt);
+    hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_gc[l], host, sizeof(int2) * cnt, hipMemcpyHostToDevice) : e1;
+    delete[] host;
+    if (e2 != hipSuccess) {
+      e3k_tp_plan_destroy(p);
+      return E3K_ERR_LAUNCH;
+    }
+    p->n_gc[l] = cnt;
+  }
+  *out = p;
+  return E3K_OK;
+}
+
+extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
+  if (!p) return;
+  if (p->d_groups) (void)hipFree(p->d_groups);
+  for (int l = 0; l <= E3K_L1MAX; ++l)
+    if (p->d_gc[l]) (void)hipFree(p->d_gc[l]);
+  delete p;
+}
+
+namespace {
+enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X };
+
+template <int L1>
+void launch_one(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
+  const int n_gc = p->n_gc[L1];
+  if (!n_gc || N <= 0) return;
+  e3k::TpArgs args = a;
+  args.n_items = N * n_gc;
+  const int64_t blocks = (args.n_items + 3) / 4;
+  dim3 grid((unsigned)blocks), block(256);
+  switch (kind) {
+    case TP_FWD:
+      hipLaunchKernelGGL(e3k::tp_fwd_kernel<L1>, grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      break;
+    case TP_BWD_W:
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<L1, false>), grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      break;
+    case TP_BWD_W_SH:
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<L1, true>), grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      break;
+    case TP_BWD_X:
+      hipLaunchKernelGGL(e3k::tp_bwd_x_kernel<L1>, grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      break;
+  }
+}
+
+int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
+  static_assert(E3K_L1MAX == 3, "extend the dispatch below when the CG tables grow");
+  launch_one<0>(kind, a, p, N, st);
+  launch_one<1>(kind, a, p, N, st);
+  launch_one<2>(kind, a, p, N, st);
+  launch_one<3>(kind, a, p, N, st);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+}  // namespace
+
+extern "C" int e3k_tp_fwd(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w,
+                          const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                          float* out, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !w || !src || !dst_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = w; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_FWD, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w,
+                            const float* g_out, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm,
+                            int64_t N, int64_t E, float* g_w, float* g_sh, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0 || E == 0) return E3K_OK;
+  if (!x || !sh || !g_out || !src || !dst_ptr || !dst_perm || !g_w) return E3K_ERR_INVALID;
+  if (g_sh && !w) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = w; a.g_out = g_out; a.g_w = g_w; a.g_sh = g_sh;
+  a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(g_sh ? TP_BWD_W_SH : TP_BWD_W, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out,
+                            const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E,
+                            float* g_x, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !w || !dst || !src_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.sh = sh; a.w = w; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_X, a, plan, N, (hipStream_t)stream);
+}

@@ -1,0 +1,91 @@
+"""Per-batch graph topology for the HIP kernels: int32 endpoints plus CSR by destination and
+by source.
+
+The reference scatters messages with ``scatter(edge_features, edge_dst, dim=0, dim_size=N)``
+(``e3_layers/nn/message_passing.py:109``), i.e. an ``index_add_`` whose CPU summation order is
+ascending edge id.  The fused kernel instead walks, for every destination node, the list of its
+in-edges; building that list with a *stable* sort keeps the ascending-edge-id order inside every
+segment, so the sum order (and hence fp32 rounding) follows the reference's CPU path, with no
+atomics.  The by-source CSR serves the backward pass (grad wrt node features, grad wrt pos).
+
+torch is used here as plumbing only (sort / bincount / cumsum on the device, once per batch).
+"""
+from __future__ import annotations
+
+import weakref
+from dataclasses import dataclass
+from typing import Dict, Optional
+
+import torch
+
+TOPO_KEYS = ("_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm")
+
+
+@dataclass
+class GraphTopo:
+    src: torch.Tensor       # int32 [E]
+    dst: torch.Tensor       # int32 [E]
+    dst_ptr: torch.Tensor   # int32 [N+1]
+    dst_perm: torch.Tensor  # int32 [E]
+    src_ptr: torch.Tensor   # int32 [N+1]
+    src_perm: torch.Tensor  # int32 [E]
+
+    @property
+    def num_nodes(self) -> int:
+        return self.dst_ptr.numel() - 1
+
+    @property
+    def num_edges(self) -> int:
+        return self.src.numel()
+
+    def as_dict(self) -> Dict[str, torch.Tensor]:
+        return {k: getattr(self, k[len("_e3k_"):]) for k in TOPO_KEYS}
+
+    @staticmethod
+    def from_dict(data) -> Optional["GraphTopo"]:
+        if all(k in data for k in TOPO_KEYS):
+            return GraphTopo(*(data[k] for k in TOPO_KEYS))
+        return None
+
+
+def _csr(index: torch.Tensor, num_nodes: int):
+    perm = torch.argsort(index, stable=True)
+    counts = torch.bincount(index, minlength=num_nodes)
+    ptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=index.device)
+    ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
+    return ptr, perm.to(torch.int32)
+
+
+def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
+    """edge_index: int64 [2, E] (row 0 = source, row 1 = destination)."""
+    if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+    if edge_index.numel() and int(num_nodes) >= 2 ** 31:
+        raise ValueError("node ids must fit in int32")
+    src64, dst64 = edge_index[0].contiguous(), edge_index[1].contiguous()
+    dst_ptr, dst_perm = _csr(dst64, num_nodes)
+    src_ptr, src_perm = _csr(src64, num_nodes)
+    return GraphTopo(src64.to(torch.int32), dst64.to(torch.int32), dst_ptr, dst_perm, src_ptr, src_perm)
+
+
+_cache: "Dict[int, tuple]" = {}
+
+
+def get_topology(data, num_nodes: int) -> GraphTopo:
+    """Topology carried by the batch if present, else built from ``data['edge_index']`` and
+    memoised on the identity of that tensor."""
+    topo = GraphTopo.from_dict(data)
+    if topo is not None and topo.num_nodes == num_nodes and topo.num_edges == data["edge_index"].shape[1]:
+        return topo
+    ei = data["edge_index"]
+    key = id(ei)
+    hit = _cache.get(key)
+    if hit is not None:
+        ref, version, n, topo = hit
+        if ref() is ei and version == ei._version and n == num_nodes:
+            return topo
+    topo = build_topology(ei, num_nodes)
+    if len(_cache) > 64:
+        _cache.clear()
+    _cache[key] = (weakref.ref(ei), ei._version, num_nodes, topo)
+    return topo

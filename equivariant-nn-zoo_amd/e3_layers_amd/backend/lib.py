@@ -1,0 +1,136 @@
+"""ctypes binding of ``csrc/libe3k.so`` (the C ABI declared in ``include/e3k.h``).
+
+The library is built in-tree by ``make -C equivariant-nn-zoo_amd/csrc`` (driven by
+``__graft_entry__.build()``).  There is **no fallback**: if the shared object is missing or a
+call returns a non-zero status a ``RuntimeError`` is raised — the product path never routes
+through a CPU or eager-PyTorch implementation.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
+LIB_PATH = os.path.join(CSRC_DIR, "libe3k.so")
+
+TP_MAXQ = 8
+
+
+class GemmProblem(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("A2", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("M1", C.c_int32), ("M2", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("V", C.c_int32), ("accumulate", C.c_int32),
+        ("a_r1", C.c_int64), ("a_r2", C.c_int64), ("a_k", C.c_int64),
+        ("a2_r1", C.c_int64),
+        ("b_k", C.c_int64), ("b_n", C.c_int64),
+        ("c_r1", C.c_int64), ("c_r2", C.c_int64), ("c_n", C.c_int64),
+        ("alpha", C.c_float), ("_pad", C.c_int32),
+    ]
+
+
+class TpGroup(C.Structure):
+    _fields_ = [
+        ("l1", C.c_int32), ("x_off", C.c_int32), ("mul", C.c_int32), ("mask", C.c_uint32),
+        ("y_off", C.c_int32 * 4),
+        ("w_off", C.c_int32 * TP_MAXQ), ("out_off", C.c_int32 * TP_MAXQ), ("out_stride", C.c_int32 * TP_MAXQ),
+        ("coeff", C.c_float * TP_MAXQ),
+    ]
+
+
+class Block(C.Structure):
+    _fields_ = [("off", C.c_int32), ("mul", C.c_int32), ("dim", C.c_int32), ("_pad", C.c_int32)]
+
+
+class GateSeg(C.Structure):
+    _fields_ = [
+        ("kind", C.c_int32), ("in_off", C.c_int32), ("gate_off", C.c_int32), ("out_off", C.c_int32),
+        ("mul", C.c_int32), ("dim", C.c_int32), ("act", C.c_int32), ("cst", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/e3k.h declares must appear here (tests check it)
+_P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+SIGNATURES = {
+    "e3k_strerror": (C.c_char_p, [C.c_int]),
+    "e3k_version": (C.c_int, []),
+    "e3k_tp_limits": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "e3k_gemm": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
+    "e3k_gemm_wgrad": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
+    "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
+    "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
+    "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
+    "e3k_edge_vector_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
+    "e3k_sph_harm_fwd": (C.c_int, [_P, _I64, C.POINTER(_I32), _I32, _I32, _I32, _P, _P]),
+    "e3k_sph_harm_bwd": (C.c_int, [_P, _P, _I64, C.POINTER(_I32), _I32, _I32, _I32, _P, _P]),
+    "e3k_radial_basis_fwd": (C.c_int, [_P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P]),
+    "e3k_radial_basis_bwd": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P]),
+    "e3k_tp_plan_create": (C.c_int, [C.POINTER(TpGroup), _I32, _I32, _I32, _I32, _I32, C.POINTER(_P)]),
+    "e3k_tp_plan_destroy": (None, [_P]),
+    "e3k_tp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
+    "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
+    "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
+    "e3k_relayout": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _P, _P]),
+    "e3k_gate_fwd": (C.c_int, [_P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
+    "e3k_gate_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
+    "e3k_layernorm_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
+    "e3k_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
+    "e3k_segment_sum": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libe3k.so once; raise loudly if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libe3k.so not found at {LIB_PATH}: build it with `make -C {CSRC_DIR}` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the HIP path."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().e3k_strerror(code).decode()
+        raise RuntimeError(f"{what} failed: {msg} (e3k status {code})")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def require_cuda(*tensors: torch.Tensor) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "e3_layers_amd kernels run on the GPU only (got a CPU tensor); there is no CPU "
+                "fallback in the product path — the float64 CPU restatement lives in oracle/ for tests."
+            )
+
+
+def f32c(t: torch.Tensor) -> torch.Tensor:
+    """Contiguous fp32 view/copy."""
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()

@@ -1,0 +1,4 @@
+from .config_dict import ConfigDict
+from . import config_energy, config_energy_force, config_diffusion
+
+__all__ = ["ConfigDict", "config_energy", "config_energy_force", "config_diffusion"]

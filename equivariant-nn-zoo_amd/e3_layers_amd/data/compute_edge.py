@@ -1,0 +1,96 @@
+"""Edge geometry entry points of the layer graph.
+
+``computeEdgeVector`` mirrors ``e3_layers/data/compute_edge.py:13-36`` (edge_vec = pos[dst] -
+pos[src], edge_length) and runs the HIP kernel of ``csrc/e3k_edge.hip``; as the first layer of
+every model (``e3_layers/configs/layer_configs.py:43``) it also attaches the per-batch CSR
+topology the fused convolution needs (``backend/graph.py``).
+
+``computeEdgeIndex`` mirrors ``e3_layers/data/compute_edge.py:38-113`` with the intent recorded
+in SURVEY.md appendix C: per graph all ordered pairs in (src slow, dst fast) order, keep
+``|pos_src - pos_dst| < r_max`` (strict, fp32) or ``criteria``, drop self loops, keep
+pre-existing edges and carry their edge attributes (zero rows for new edges).  It is host-side
+integer plumbing written with vectorised torch ops (no per-graph Python scan); the edge order is
+bit-identical to the reference's when run on the same device type.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+from torch import Tensor
+
+from ..backend import ops
+from ..backend.graph import get_topology
+
+
+def computeEdgeVector(data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]], key: str = "pos",
+                      with_lengths: bool = True):
+    attrs["edge_vector"] = ("edge", "1x1o")
+    attrs["edge_length"] = ("edge", "1x0e")
+    pos = data[key]
+    if "edge_vector" in data:
+        if with_lengths and "edge_length" not in data:
+            data["edge_length"] = torch.linalg.norm(data["edge_vector"], dim=-1)
+        return data, attrs
+    topo = get_topology(data, pos.shape[0])
+    data.update(topo.as_dict())
+    vec, length = ops.edge_vector(pos, topo)
+    data["edge_vector"] = vec
+    if with_lengths:
+        data["edge_length"] = length
+    return data, attrs
+
+
+def _all_pairs(n_nodes: Tensor, device) -> Tensor:
+    """[2, sum n_g^2] candidate edges, graphs concatenated, (i, j) lexicographic inside a graph."""
+    n = n_nodes.reshape(-1).to("cpu", torch.long)
+    if n.numel() == 0 or int(n.sum()) == 0:
+        return torch.zeros(2, 0, dtype=torch.long, device=device)
+    start = torch.cumsum(n, 0) - n
+    sq = n * n
+    graph = torch.repeat_interleave(torch.arange(n.numel()), sq)
+    local = torch.arange(int(sq.sum())) - torch.repeat_interleave(torch.cumsum(sq, 0) - sq, sq)
+    ng = n[graph]
+    src = torch.div(local, ng, rounding_mode="floor") + start[graph]
+    dst = local % ng + start[graph]
+    return torch.stack([src, dst]).to(device)
+
+
+def computeEdgeIndex(data, attrs, r_max: float = None, key: str = "pos", criteria=None):
+    pos = torch.as_tensor(data[key], dtype=torch.get_default_dtype())
+    n_nodes = data["_n_nodes"]
+    total = int(n_nodes.sum())
+    cand = _all_pairs(n_nodes, pos.device)
+    dist = torch.linalg.norm(pos[cand[0]] - pos[cand[1]], dim=-1)
+    keep = dist < r_max
+    if criteria is not None:
+        keep = torch.logical_or(keep, criteria(data, cand))
+    keep = torch.logical_and(keep, cand[0] != cand[1])
+    had_edges = "edge_index" in data
+    if had_edges:
+        old = data["edge_index"]
+        old_id = old[0] * total + old[1]
+        cand_id = cand[0] * total + cand[1]          # strictly increasing
+        at = torch.searchsorted(cand_id, old_id)
+        if not bool((cand_id[at.clamp(max=cand_id.numel() - 1)] == old_id).all()):
+            raise ValueError("an existing edge connects two different graphs")
+        keep[at] = True
+    edge_index = cand[:, keep]
+    if had_edges:
+        where = torch.searchsorted(edge_index[0] * total + edge_index[1], old_id)
+        for k in list(attrs.keys()):
+            if attrs[k][0] == "edge" and k in data:
+                prev = data[k]
+                fresh = torch.zeros((edge_index.shape[1],) + tuple(prev.shape[1:]), dtype=prev.dtype, device=pos.device)
+                fresh[where] = prev
+                data[k] = fresh
+    seg = torch.repeat_interleave(torch.arange(n_nodes.numel(), device=pos.device), n_nodes.reshape(-1).to(pos.device))
+    n_edges = torch.bincount(seg[edge_index[0]], minlength=n_nodes.numel()).view(-1, 1)
+    attrs["_n_edges"] = ("graph", "1x0e")
+    data["_n_edges"] = n_edges
+    # stale per-edge caches belong to the old edge set
+    for k in ("_edge_segment", "_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
+              "edge_vector", "edge_length"):
+        if k in data:
+            data.pop(k)
+    return {"edge_index": edge_index}, attrs

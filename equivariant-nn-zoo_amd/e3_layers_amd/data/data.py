@@ -1,0 +1,327 @@
+"""``Data`` / ``Batch``: dict-of-tensors graph containers (host-side plumbing).
+
+Interface contract taken from the reference (``e3_layers/data/data.py:13-96,170-202`` and
+``e3_layers/data/batch.py:10-201``; SURVEY.md §8b "Batch contract"):
+
+* ``attrs[key] = (is_per, irreps)`` with ``is_per`` in {'node','edge','graph'}; a described
+  tensor is stored as ``[count, irreps.dim]``;
+* keys containing ``index`` or ``face`` concatenate on the last dimension, everything else on
+  dim 0; ``edge_index`` is offset by the running node count when graphs are batched;
+* ``_n_nodes`` / ``_n_edges`` are ``[G, 1]`` int64, ``_node_segment`` / ``_edge_segment`` are the
+  per-node / per-edge graph ids;
+* floats are stored as fp32 and integers as int64 by ``Batch.from_data_list``;
+* a ``Batch`` is dict-like by str key and list-like by int / slice / index array.
+
+Written vectorised: segments come from ``repeat_interleave`` on the tensor's own device (the
+reference builds Python lists per graph and syncs per element).
+"""
+from __future__ import annotations
+
+import copy
+from collections.abc import Sequence
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+
+from ..o3 import Irreps
+
+_INT_DTYPES = (torch.int64, torch.int32, torch.int16, torch.int8, torch.uint8, torch.bool)
+
+
+def feature_dim(spec) -> Optional[int]:
+    """Width implied by an attrs entry: an int, a digit string or an irreps string."""
+    if spec is None:
+        return None
+    if isinstance(spec, int):
+        return spec
+    if isinstance(spec, str) and spec.isdigit():
+        return int(spec)
+    try:
+        return Irreps(spec).dim
+    except (ValueError, TypeError):
+        return None
+
+
+def cat_dim(key: str) -> int:
+    return -1 if ("index" in key or "face" in key) else 0
+
+
+class Data:
+    def __init__(self, attrs=None, **tensors):
+        self.attrs = {} if attrs is None else attrs
+        self.data: Dict[str, torch.Tensor] = {}
+        self.device = None
+        for key, value in tensors.items():
+            self[key] = value
+
+    # ---- dict protocol ------------------------------------------------------
+    def keys(self):
+        return self.data.keys()
+
+    def items(self):
+        return list(self.data.items())
+
+    def values(self):
+        return self.data.values()
+
+    def __contains__(self, key) -> bool:
+        return key in self.data
+
+    def __iter__(self):
+        return iter(self.data)
+
+    def __len__(self) -> int:
+        return len(self.data)
+
+    def __getitem__(self, key):
+        return self.data[key]
+
+    def __setitem__(self, key, value):
+        if not isinstance(value, torch.Tensor):
+            value = torch.as_tensor(value)
+        width = feature_dim(self.attrs[key][1]) if key in self.attrs else None
+        if width is not None and not (value.dim() == 2 and value.shape[-1] == width):
+            value = value.reshape(-1, width)
+        self.data[key] = value
+
+    def update(self, other):
+        for key, value in (other.items() if hasattr(other, "items") else other):
+            self[key] = value
+        return self
+
+    def pop(self, key):
+        self.attrs.pop(key, None)
+        return self.data.pop(key, None)
+
+    def get(self, key, default=None):
+        return self.data.get(key, default)
+
+    # ---- counts -------------------------------------------------------------
+    def _count(self, kind: str) -> Optional[int]:
+        for key, value in self.data.items():
+            if key in self.attrs and self.attrs[key][0] == kind:
+                return value.shape[cat_dim(key)]
+        return None
+
+    @property
+    def n_nodes(self):
+        if "_n_nodes" in self.data:
+            return int(self.data["_n_nodes"].sum())
+        return self._count("node")
+
+    @property
+    def n_edges(self):
+        if "edge_index" in self.data:
+            return self.data["edge_index"].shape[-1]
+        return self._count("edge")
+
+    @property
+    def num_edges(self):
+        return self.data["edge_index"].shape[-1]
+
+    # ---- tensor plumbing ------------------------------------------------------
+    def apply(self, func, *keys):
+        for key in (keys or list(self.data.keys())):
+            self.data[key] = func(self.data[key])
+        return self
+
+    def to(self, device, **kwargs):
+        self.device = device
+        return self.apply(lambda t: t.to(device, **kwargs))
+
+    def cpu(self):
+        return self.to("cpu")
+
+    def cuda(self, device=None, non_blocking=False):
+        return self.to("cuda" if device is None else device, non_blocking=non_blocking)
+
+    def contiguous(self):
+        return self.apply(lambda t: t.contiguous())
+
+    def pin_memory(self):
+        return self.apply(lambda t: t.pin_memory())
+
+    def clone(self):
+        out = self.__class__.__new__(self.__class__)
+        out.attrs = copy.deepcopy(self.attrs)
+        out.data = {k: v.clone() for k, v in self.data.items()}
+        out.device = self.device
+        return out
+
+    def __repr__(self):
+        shapes = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in self.data.items()}
+        return f"{self.__class__.__name__}(attrs={self.attrs}, tensors={shapes})"
+
+
+def segment_ids(counts: torch.Tensor) -> torch.Tensor:
+    counts = counts.reshape(-1)
+    return torch.repeat_interleave(torch.arange(counts.numel(), device=counts.device), counts)
+
+
+class Batch(Data):
+    """Padding-free concatenation of graphs."""
+
+    def __init__(self, attrs=None, **tensors):
+        super().__init__(attrs, **tensors)
+        self._refresh_segments()
+
+    def _refresh_segments(self):
+        if "_n_nodes" in self.data:
+            self.nodeSegment()
+        if "_n_edges" in self.data:
+            self.edgeSegment()
+
+    def nodeSegment(self):
+        seg = self.data.get("_node_segment")
+        n = self.data["_n_nodes"]
+        if seg is None or seg.device != n.device:  # trusted when present: no device sync
+            seg = segment_ids(n)
+            self.data["_node_segment"] = seg
+        return seg
+
+    def edgeSegment(self):
+        seg = self.data.get("_edge_segment")
+        n = self.data["_n_edges"]
+        if seg is None or seg.device != n.device:
+            seg = segment_ids(n)
+            self.data["_edge_segment"] = seg
+        return seg
+
+    @staticmethod
+    def _total(counts: torch.Tensor) -> int:
+        return int(counts.sum()) if counts.numel() else 0
+
+    @property
+    def n_graphs(self) -> int:
+        return self.data["_n_nodes"].shape[0]
+
+    num_graphs = n_graphs
+
+    def __len__(self) -> int:
+        return self.n_graphs
+
+    # ---- construction ----------------------------------------------------------
+    @classmethod
+    def from_data_list(cls, lst: Sequence, attrs=None):
+        attrs = {} if attrs is None else attrs
+        attrs["_n_nodes"] = ("graph", "1x0e")
+        attrs["_n_edges"] = ("graph", "1x0e")
+        items = [dict(x.items()) if not isinstance(x, dict) else dict(x) for x in lst]
+        node_key = next((k for k in items[0] if k in attrs and attrs[k][0] == "node"), None)
+        for it in items:
+            if "_n_nodes" not in it:
+                if node_key is None:
+                    raise ValueError("cannot infer the number of nodes: no tensor is described as per-node")
+                width = feature_dim(attrs[node_key][1])
+                t = torch.as_tensor(it[node_key])
+                n = t.reshape(-1, width).shape[0] if width else t.shape[0]
+                it["_n_nodes"] = torch.full((1, 1), n, dtype=torch.long)
+            else:
+                it["_n_nodes"] = torch.as_tensor(it["_n_nodes"], dtype=torch.long).reshape(-1, 1)
+            if "edge_index" in it:
+                ei = torch.as_tensor(it["edge_index"]).long()
+                it["edge_index"] = ei
+                if "_n_edges" not in it:
+                    it["_n_edges"] = torch.full((1, 1), ei.shape[-1], dtype=torch.long)
+            if "_n_edges" in it:
+                it["_n_edges"] = torch.as_tensor(it["_n_edges"], dtype=torch.long).reshape(-1, 1)
+
+        merged: Dict[str, torch.Tensor] = {}
+        merged["_n_nodes"] = torch.cat([it["_n_nodes"] for it in items])
+        if "_n_edges" in items[0]:
+            merged["_n_edges"] = torch.cat([it["_n_edges"] for it in items])
+        for key in items[0]:
+            if key in merged or key in ("_node_segment", "_edge_segment"):
+                continue
+            if key == "edge_index":
+                parts, offset = [], 0
+                for it in items:
+                    parts.append(it[key] + offset)
+                    offset += int(it["_n_nodes"].sum())
+                merged[key] = torch.cat(parts, dim=-1)
+                continue
+            width = feature_dim(attrs[key][1]) if key in attrs else None
+            parts = []
+            for it in items:
+                t = torch.as_tensor(it[key])
+                parts.append(t.reshape(-1, width) if width is not None else t)
+            t = torch.cat(parts, dim=cat_dim(key))
+            merged[key] = t.long() if t.dtype in _INT_DTYPES else t.float()
+        return cls(attrs, **merged)
+
+    # ---- list-like access --------------------------------------------------------
+    def _offsets(self):
+        nn = self.data["_n_nodes"].reshape(-1).cpu()
+        node_off = torch.zeros(nn.numel() + 1, dtype=torch.long)
+        node_off[1:] = torch.cumsum(nn, 0)
+        edge_off = None
+        if "_n_edges" in self.data:
+            ne = self.data["_n_edges"].reshape(-1).cpu()
+            edge_off = torch.zeros(ne.numel() + 1, dtype=torch.long)
+            edge_off[1:] = torch.cumsum(ne, 0)
+        return node_off, edge_off
+
+    def get(self, idx, default=None):
+        if isinstance(idx, str):
+            return self.data.get(idx, default)
+        node_off, edge_off = self._offsets()
+        idx = int(idx)
+        if idx < 0:
+            idx += self.n_graphs
+        out = {}
+        for key, value in self.data.items():
+            if key in ("_node_segment", "_edge_segment") or key.startswith("_e3k_"):
+                continue
+            if key == "edge_index":
+                a, b = int(edge_off[idx]), int(edge_off[idx + 1])
+                out[key] = value[:, a:b] - int(node_off[idx])
+                continue
+            if key not in self.attrs:
+                continue
+            kind = self.attrs[key][0]
+            if kind == "graph":
+                a, b = idx, idx + 1
+            elif kind == "node":
+                a, b = int(node_off[idx]), int(node_off[idx + 1])
+            elif kind == "edge":
+                a, b = int(edge_off[idx]), int(edge_off[idx + 1])
+            else:
+                continue
+            out[key] = value[a:b]
+        return Data(self.attrs, **out)
+
+    def index_select(self, idx):
+        if isinstance(idx, slice):
+            idx = list(range(self.n_graphs))[idx]
+        elif isinstance(idx, torch.Tensor):
+            idx = idx.flatten().nonzero().flatten().tolist() if idx.dtype == torch.bool else idx.flatten().tolist()
+        elif isinstance(idx, np.ndarray):
+            idx = idx.flatten().nonzero()[0].tolist() if idx.dtype == np.bool_ else idx.flatten().tolist()
+        elif isinstance(idx, Sequence) and not isinstance(idx, str):
+            idx = list(idx)
+        else:
+            raise IndexError(f"unsupported batch index of type {type(idx).__name__}")
+        parts = [self.get(i) for i in idx]
+        attrs = {k: v for k, v in self.attrs.items() if k not in ("_node_segment", "_edge_segment")}
+        return Batch.from_data_list(parts, attrs)
+
+    def __getitem__(self, idx):
+        if isinstance(idx, str):
+            return self.data[idx]
+        if isinstance(idx, (int, np.integer)):
+            return self.get(idx)
+        return self.index_select(idx)
+
+    def __setitem__(self, key, value):
+        if not isinstance(key, str):
+            raise NotImplementedError("assigning a graph by integer index is not supported")
+        super().__setitem__(key, value)
+
+    def to(self, device, **kwargs):
+        super().to(device, **kwargs)
+        return self
+
+    def clone(self):
+        out = super().clone()
+        return out

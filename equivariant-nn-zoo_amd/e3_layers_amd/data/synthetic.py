@@ -1,0 +1,64 @@
+"""Seeded synthetic stand-ins for the datasets the BASELINE configs are quoted on (no dataset
+files exist offline).
+
+``synth_qm9(seed, B)``: QM9-like molecules — n = clamp(round(18 + 4.5 randn), 3, 29) atoms,
+species from {H .51, C .35, N .06, O .075, F .005}, positions by random tree growth (new atom
+1.0-1.55 A from a random existing atom, rejected within 0.95 A of any atom), target
+``total_energy = sum shift[Z] + 0.1 randn``.  Species are *type indices* into the first
+``num_types`` chemical symbols (X, H, He, Li, Be, B, C, N, O, F -> H=1, C=6, N=7, O=8, F=9),
+as the reference's ``type_names`` list implies (``e3_layers/configs/config_energy.py:47``).
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+
+from .compute_edge import computeEdgeIndex
+from .data import Batch, Data
+
+_SPECIES = torch.tensor([1, 6, 7, 8, 9])
+_PROBS = torch.tensor([0.51, 0.35, 0.06, 0.075, 0.005])
+
+
+def _grow_molecule(n: int, gen: torch.Generator) -> torch.Tensor:
+    pos = torch.zeros(n, 3)
+    placed = 1
+    while placed < n:
+        anchor = int(torch.randint(placed, (1,), generator=gen))
+        direction = torch.randn(3, generator=gen)
+        direction = direction / direction.norm().clamp(min=1e-9)
+        dist = 1.0 + 0.55 * float(torch.rand(1, generator=gen))
+        cand = pos[anchor] + dist * direction
+        if float((pos[:placed] - cand).norm(dim=1).min()) >= 0.95:
+            pos[placed] = cand
+            placed += 1
+    return pos
+
+
+def synth_qm9_list(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: Optional[float] = 4.0):
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    attrs = {"pos": ("node", "1x1o"), "species": ("node", "1x0e"), "total_energy": ("graph", "1x0e")}
+    out = []
+    for _ in range(n_mol):
+        n = int(min(29, max(3, round(18 + 4.5 * float(torch.randn(1, generator=gen))))))
+        z = _SPECIES[torch.multinomial(_PROBS, n, replacement=True, generator=gen)]
+        pos = _grow_molecule(n, gen).float()
+        e = 0.1 * float(torch.randn(1, generator=gen))
+        if shifts is not None:
+            e += float(sum(shifts[int(t)] for t in z))
+        sample = {"pos": pos, "species": z.view(-1, 1).long(), "total_energy": torch.tensor([[e]]),
+                  "_n_nodes": torch.tensor([[n]])}
+        if r_max is not None:
+            sample_attrs = dict(attrs)
+            new, _ = computeEdgeIndex(sample, sample_attrs, r_max=r_max)
+            sample["edge_index"] = new["edge_index"]
+        out.append(sample)
+    return out, attrs
+
+
+def synth_qm9(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: float = 4.0) -> Batch:
+    """A Batch with pos, species, total_energy, edge_index (cutoff r_max), _n_nodes, _n_edges."""
+    lst, attrs = synth_qm9_list(seed, n_mol, shifts, r_max)
+    return Batch.from_data_list(lst, dict(attrs))

@@ -1,0 +1,144 @@
+"""Edge / node embeddings — interfaces of ``e3_layers/nn/embedding.py``:
+``symmetricCutoff`` (:26-29), ``_poly_cutoff`` (:31-40), ``PolynomialCutoff`` (:43-71),
+``BesselBasis`` (:74-127), ``SphericalEncoding`` (:131-178), ``RadialBasisEncoding`` (:182-219),
+``Broadcast`` (:223-254), ``OneHotEncoding`` (:258-281), ``RelativePositionEncoding`` (:284-312).
+The arithmetic of the spherical and radial encodings runs in ``csrc/e3k_edge.hip``.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from ..backend import ops
+from ..o3 import Irreps
+from ..utils.utils import build
+from .sequential import Module
+
+
+class _Cutoff:
+    """Envelope selector; the function itself is evaluated inside the radial-basis kernel."""
+
+    def __init__(self, name: str, kind: int):
+        self.__name__, self.kind = name, kind
+
+    def __repr__(self):
+        return f"<cutoff {self.__name__}>"
+
+
+_poly_cutoff = _Cutoff("_poly_cutoff", 0)        # 1 - (p+1)(p+2)/2 x^p + p(p+2) x^(p+1) - p(p+1)/2 x^(p+2), x < 1
+symmetricCutoff = _Cutoff("symmetricCutoff", 1)  # (x-1)^2 (x+1)^2, |x| < 1
+
+
+class PolynomialCutoff(nn.Module):
+    def __init__(self, r_max: float, p: float = 6, cutoff=_poly_cutoff):
+        super().__init__()
+        assert p >= 2.0
+        self.p, self._factor, self.cutoff = float(p), 1.0 / float(r_max), cutoff
+
+
+class BesselBasis(nn.Module):
+    """Holds the (trainable) frequencies n*pi; evaluated fused with the cutoff."""
+
+    def __init__(self, r_max, r_min=0, num_basis=8, trainable=True, one_over_r=True):
+        super().__init__()
+        self.trainable, self.num_basis = trainable, num_basis
+        self.r_max, self.r_min = float(r_max), float(r_min)
+        self.prefactor = 2.0 / (self.r_max - self.r_min)
+        self.one_over_r = one_over_r
+        w = torch.linspace(start=1.0, end=num_basis, steps=num_basis) * math.pi
+        if trainable:
+            self.bessel_weights = nn.Parameter(w)
+        else:
+            self.register_buffer("bessel_weights", w)
+
+
+class SphericalEncoding(Module):
+    def __init__(self, irreps_out, edge_sh_normalization: str = "component", edge_sh_normalize: bool = True,
+                 irreps_in="1x1o"):
+        super().__init__()
+        self.init_irreps(vectors=irreps_in, spherical_harmonics=irreps_out, output_keys=["spherical_harmonics"])
+        self.mul = Irreps(self.irreps_in["vectors"])[0].mul
+        self.ls = []
+        for mi in Irreps(self.irreps_out["spherical_harmonics"]):
+            assert mi.mul == self.mul
+            self.ls.append(mi.ir.l)
+        self.normalize, self.normalization = bool(edge_sh_normalize), edge_sh_normalization
+
+    def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
+        vec = data["vectors"]
+        rows = vec.shape[0]
+        sh = ops.spherical_harmonics(vec.reshape(rows * self.mul, 3), self.ls, self.normalize, self.normalization)
+        return ({"spherical_harmonics": sh.view(rows, -1)},
+                {"spherical_harmonics": ("edge", self.irreps_out["spherical_harmonics"])})
+
+
+class RadialBasisEncoding(Module):
+    def __init__(self, r_max, trainable, irreps_out, r_min=0, polynomial_degree=6, basis=BesselBasis,
+                 cutoff=_poly_cutoff, irreps_in="1x0e", one_over_r=True):
+        super().__init__()
+        self.init_irreps(input=irreps_in, radial_embedding=irreps_out, output_keys=["radial_embedding"])
+        num_basis = Irreps(self.irreps_out["radial_embedding"])[0].mul
+        self.basis = basis(r_max, r_min, num_basis, trainable, one_over_r=one_over_r)
+        self.cutoff = PolynomialCutoff(r_max, p=polynomial_degree, cutoff=cutoff)
+        self.r_max = r_max
+
+    def forward(self, data, attrs):
+        x = data["input"]
+        b, c = self.basis, self.cutoff
+        out = ops.radial_basis(x.reshape(-1), b.bessel_weights, b.r_max, b.r_min, c.p, b.one_over_r, c.cutoff.kind)
+        return ({"radial_embedding": out.view(x.shape[0], -1)},
+                {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])})
+
+
+class Broadcast(Module):
+    """graph -> node / edge broadcast by segment ids (index plumbing)."""
+
+    def __init__(self, irreps_in, irreps_out, to):
+        super().__init__()
+        self.init_irreps(input=irreps_in, output=irreps_out, output_keys=["output"])
+        if to not in ("node", "edge"):
+            raise ValueError(to)
+        self.to_kind = to
+
+    def forward(self, data, attrs):
+        assert attrs["input"][0] == "graph"
+        seg = data["_node_segment"] if self.to_kind == "node" else data["_edge_segment"]
+        return {"output": data["input"][seg]}, {"output": (self.to_kind, self.irreps_out["output"])}
+
+
+class OneHotEncoding(Module):
+    num_types: int
+
+    def __init__(self, num_types: int, irreps_out, irreps_in="0x0e"):
+        super().__init__()
+        self.num_types = num_types
+        self.init_irreps(input=irreps_in, one_hot=irreps_out, output_keys="one_hot")
+
+    def forward(self, data, attrs):
+        idx = data["input"].squeeze(-1)
+        one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
+        return {"one_hot": one_hot}, {"one_hot": (attrs["input"][0], self.irreps_out["one_hot"])}
+
+
+class RelativePositionEncoding(Module):
+    def __init__(self, radial_encoding, segment, irreps_out, id=None):
+        super().__init__()
+        self.init_irreps(input=segment, output=irreps_out, id=id, output_keys=["output"])
+        cfg = {k: radial_encoding[k] for k in radial_encoding.keys()}
+        cfg["irreps_in"] = "1x0e"
+        cfg["irreps_out"] = self.irreps_out["output"]
+        self.radial = build(cfg)
+
+    def forward(self, data, attrs):
+        seg, ei = data["input"], data["edge_index"]
+        if "id" in self.irreps_in:
+            rel = data["id"][ei[0]] - data["id"][ei[1]]
+        else:
+            rel = ei[0] - ei[1]
+        mask = (seg[ei[0]] == seg[ei[1]]).float().view(-1, 1)
+        rel = mask * rel.view(-1, 1).float() + (1 - mask) * 1e5
+        out, _ = self.radial({"input": rel}, {"input": ("edge", "1x0e")})
+        return {"output": out["radial_embedding"]}, {"output": ("edge", self.irreps_out["output"])}

@@ -1,0 +1,137 @@
+"""``FactorizedConvolution`` and ``MessagePassing`` — the hot loop.
+
+Interfaces of ``e3_layers/nn/message_passing.py:21-124`` and ``:127-262``; the data flow is
+re-planned for MI355X:
+
+    reference (per layer, all [E, .] tensors materialised)      here
+    ------------------------------------------------------      -------------------------------------------
+    weight = fc(edge_radial)                     [E, W]          same, f32-MFMA GEMMs (e3k_gemm)
+    sc = FCTP(x, node_attrs)                     [N, out]        outer-mode GEMM, x (x) attrs never materialised
+    x  = linear_1(x)                             [N, in]         GEMM, output in channel-fastest (cf) layout
+    ef = tp(x[src], sh, weight) (+ Linear/edge)  [E, mid]->[E,out]   fused gather + CG product + per-destination
+    x  = scatter(ef, dst) / sqrt(avg) + sc       [N, out]        reduce in registers (e3k_tp_fwd) -> [N, mid];
+                                                                 the Linear commutes with the sum and runs on
+                                                                 nodes, accumulating into sc with the 1/sqrt(avg)
+                                                                 folded into alpha
+    Gate                                                         one elementwise kernel, cf -> e3nn layout
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional, Tuple
+
+import torch
+from torch import Tensor
+
+from ..backend import ops
+from ..backend.graph import get_topology
+from ..o3 import Irrep, Irreps
+from ..utils.utils import _is_mapping, activations, build, tp_path_exists
+from .core import FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, irreps_blocks
+from .pointwise import LayerNormalization, TensorProductExpansion
+from .sequential import Module
+
+
+class FactorizedConvolution(Module):
+    avg_num_neighbors: Optional[float]
+    use_sc: bool
+
+    def __init__(self, input_features, output_features, node_attrs, edge_radial, edge_spherical,
+                 invariant_layers=1, invariant_neurons=8, avg_num_neighbors=None, use_sc=True,
+                 nonlinearity_scalars: Dict[int, Callable] = {"e": "ssp"}, reduce=True) -> None:
+        super().__init__()
+        self.init_irreps(input_features=input_features, output_features=output_features, node_attrs=node_attrs,
+                         edge_radial=edge_radial, edge_spherical=edge_spherical, output_keys=["output_features"])
+        self.avg_num_neighbors = avg_num_neighbors
+        self.use_sc = use_sc
+        self.reduce = reduce
+        f_in = Irreps(self.irreps_in["input_features"])
+        f_out = Irreps(self.irreps_out["output_features"])
+        sh = Irreps(self.irreps_in["edge_spherical"])
+
+        self.linear_1 = Linear(f_in, f_in)
+        self.tp = TensorProductExpansion(f_in, (sh, "edge_spherical"), (f_out, "edge_features"), "uvu",
+                                         internal_weight=False)
+        n_radial = Irreps(self.irreps_in["edge_radial"]).num_irreps
+        self.fc = FullyConnectedNet([n_radial] + invariant_layers * [invariant_neurons] + [self.tp.tp.weight_numel],
+                                    activations["ssp"])
+        self.sc = None
+        if self.use_sc:
+            self.sc = FullyConnectedTensorProduct(f_in, Irreps(self.irreps_in["node_attrs"]), f_out)
+        self._in_blocks = tuple(irreps_blocks(f_in))
+        self._out_blocks = tuple(irreps_blocks(f_out))
+
+    def forward_cf(self, data: Dict[str, Tensor]) -> Tensor:
+        """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
+        x = data["input_features"]
+        weight = self.fc(data["edge_radial"])
+        topo = get_topology(data, x.shape[0])
+        x_cf = ops.relayout(x, self._in_blocks, True)
+        sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
+        x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
+        mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
+        scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
+        return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
+
+    def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
+        if self.reduce:
+            out = ops.relayout(self.forward_cf(data), self._out_blocks, False)
+        else:
+            # per-edge messages, no reduction: the reference's unfused module API
+            x = data["input_features"]
+            weight = self.fc(data["edge_radial"])
+            x1 = self.linear_1(x)
+            out = self.tp(left=x1[data["edge_index"][0]], right=data["edge_spherical"], weight=weight)
+        return ({"output_features": out},
+                {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
+
+
+class MessagePassing(Module):
+    """Convolution -> gate nonlinearity -> optional residual -> optional LayerNormalization."""
+
+    def __init__(self, input_features, output_features, node_attrs, edge_radial, edge_spherical, convolution,
+                 resnet: bool = False, nonlinearity_type: str = "gate",
+                 nonlinearity_scalars: Dict[int, Callable] = {"e": "ssp", "o": "tanh"},
+                 nonlinearity_gates: Dict[int, Callable] = {"e": "ssp", "o": "abs"}, normalize=False):
+        super().__init__()
+        self.init_irreps(input_features=input_features, output_features=output_features, node_attrs=node_attrs,
+                         edge_radial=edge_radial, edge_spherical=edge_spherical, output_keys=["output_features"])
+        assert nonlinearity_type in ("gate", "norm")
+        if nonlinearity_type != "gate":
+            raise NotImplementedError("nonlinearity_type='norm' (NormActivation) is not built; every shipped config uses 'gate'")
+        acts_s = {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]}
+        acts_g = {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}
+        sh = Irreps(self.irreps_in["edge_spherical"])
+        prev = Irreps(self.irreps_in["input_features"])
+        self.feature_irreps_hidden = Irreps(self.irreps_out["output_features"])
+
+        reachable = [mi for mi in self.feature_irreps_hidden if tp_path_exists(prev, sh, mi.ir)]
+        irreps_scalars = Irreps([mi for mi in reachable if mi.ir.l == 0])
+        irreps_gated = Irreps([mi for mi in reachable if mi.ir.l > 0])
+        irreps_layer_out = (irreps_scalars + irreps_gated).simplify()
+        irreps_gates = Irreps([(mi.mul, "0e") for mi in irreps_gated])
+        self.equivariant_nonlin = Gate(
+            irreps_scalars=irreps_scalars, act_scalars=[acts_s[mi.ir.p] for mi in irreps_scalars],
+            irreps_gates=irreps_gates, act_gates=[acts_g[mi.ir.p] for mi in irreps_gates],
+            irreps_gated=irreps_gated)
+        conv_irreps_out = self.equivariant_nonlin.irreps_in.simplify()
+        self.resnet = bool(resnet) and irreps_layer_out == prev
+        self.conv = build(convolution, input_features=input_features, output_features=conv_irreps_out,
+                          node_attrs=node_attrs, edge_radial=edge_radial, edge_spherical=edge_spherical)
+        self.normalize = normalize
+        if self.normalize:
+            self.norm = LayerNormalization(self.irreps_out["output_features"], self.irreps_out["output_features"])
+
+    def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
+        old_x = data["input_features"]
+        if isinstance(self.conv, FactorizedConvolution) and self.conv.reduce:
+            conv_cf = self.conv.forward_cf(data)
+        else:
+            out, _ = self.conv(data, attrs)
+            conv_cf = ops.relayout(out["output_features"], tuple(irreps_blocks(self.equivariant_nonlin.irreps_in)), True)
+        output = self.equivariant_nonlin(conv_cf)
+        if self.resnet:
+            output = old_x + output
+        if self.normalize:
+            output = self.norm({"input": output}, attrs)[0]["output"]
+        return ({"output_features": output},
+                {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})

@@ -1,0 +1,55 @@
+"""Output heads: ``GradientOutput`` (forces / scores by autograd through the HIP kernels) and
+``Pooling`` — interfaces of ``e3_layers/nn/output.py:19-53,56-74``.  ``Pairwise`` and
+``TensorProductContraction`` (legacy Hamiltonian head) are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from ..backend import ops
+from ..o3 import Irreps
+from ..utils.utils import _is_mapping, build
+from .sequential import Module
+
+
+class GradientOutput(Module):
+    def __init__(self, func, x, y, gradients, sign: float = 1.0, **kwargs):
+        super().__init__()
+        sign = float(sign)
+        assert sign in (1.0, -1.0)
+        self.sign = sign
+        self.init_irreps(x=x, y=y, gradients=gradients, output_keys=["gradients"])
+        assert Irreps(self.irreps_in["y"]).lmax == 0
+        if _is_mapping(func):
+            func = build(func, **kwargs)
+        self.func = func
+
+    def forward(self, data):
+        wrt = self.inputKeyMap(data)["x"]
+        old = wrt.requires_grad
+        wrt.requires_grad_(True)
+        output = self.func(data)
+        (grad,) = torch.autograd.grad(self.inputKeyMap(output)["y"].sum(), wrt, create_graph=self.training)
+        wrt.requires_grad_(old)
+        is_per = self.inputKeyMap(data.attrs)["x"][0]
+        output.attrs.update(self.outputKeyMap({"gradients": (is_per, self.irreps_out["gradients"])}))
+        output.update(self.outputKeyMap({"gradients": self.sign * grad}))
+        return output
+
+
+class Pooling(Module):
+    """node -> graph reduction over the (sorted) node segments."""
+
+    def __init__(self, irreps_in, irreps_out, reduce):
+        super().__init__()
+        self.init_irreps(input=irreps_in, output=irreps_out, output_keys=["output"])
+        assert reduce in ("sum", "mean")
+        self.reduce = reduce
+
+    def forward(self, data, attrs):
+        x = data["input"]
+        n = data["_n_nodes"].view(-1).to(x.device)
+        ptr = torch.zeros(n.numel() + 1, dtype=torch.int32, device=x.device)
+        ptr[1:] = torch.cumsum(n, 0).to(torch.int32)
+        out = ops.segment_sum(x, ptr, data["_node_segment"].to(x.device), self.reduce == "mean")
+        return {"output": out}, {"output": ("graph", self.irreps_out["output"])}

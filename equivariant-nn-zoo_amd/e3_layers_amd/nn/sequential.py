@@ -1,0 +1,79 @@
+"""Layer protocol and container.
+
+``Module.init_irreps`` and ``SequentialGraphNetwork`` follow the interface of
+``e3_layers/nn/sequential.py:12-39,42-88``: a layer is constructed with keyword irreps given
+either as ``irreps`` or as ``(irreps, custom_key)``; its ``forward(data, attrs)`` receives the
+batch dict with custom keys renamed to the layer's canonical names and returns only the new
+entries, which the container renames back and merges.  Plain callables ``(data, attrs) ->
+(data, attrs)`` are accepted as layers.  TorchScript (``config['jit']``) is accepted and ignored:
+the arithmetic is in HIP kernels.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+
+import torch
+from torch.profiler import record_function
+
+from ..data import Batch
+from ..o3 import Irreps
+from ..utils.utils import _is_mapping, build, keyMap
+
+
+class Module(torch.nn.Module):
+    def init_irreps(self, output_keys=(), **kwargs):
+        if isinstance(output_keys, str):
+            output_keys = [output_keys]
+        self.irreps_in, self.irreps_out = {}, {}
+        self.input_key_mapping, self.output_key_mapping = {}, {}
+        for key, value in kwargs.items():
+            if value is None:
+                continue
+            if isinstance(value, (str, Irreps)):
+                irreps, custom = value, key
+            elif isinstance(value, (list, tuple)) and len(value) == 2:
+                irreps, custom = value
+            else:
+                raise TypeError(f"{key}: expected irreps or (irreps, key), got {value!r}")
+            if key in output_keys:
+                self.irreps_out[key] = irreps
+                self.output_key_mapping[key] = custom
+            else:
+                self.irreps_in[key] = irreps
+                self.input_key_mapping[custom] = key
+
+    def inputKeyMap(self, x):
+        return keyMap(x, self.input_key_mapping)
+
+    def outputKeyMap(self, x):
+        return keyMap(x, self.output_key_mapping)
+
+
+class SequentialGraphNetwork(torch.nn.Sequential):
+    def __init__(self, **config):
+        self.layers = []
+        self.layer_configs = config["layers"]
+        modules = OrderedDict()
+        for key, value in self.layer_configs:
+            if _is_mapping(value):
+                module = build(value)
+                modules[key] = module
+                self.layers.append((key, module))
+            elif callable(value):
+                self.layers.append((key, value))
+            else:
+                raise TypeError(f"invalid config node for layer {key!r}")
+        super().__init__(modules)
+
+    def forward(self, batch):
+        data, attrs = batch.data, batch.attrs
+        for key, layer in self.layers:
+            with record_function(key):
+                mapped = isinstance(layer, Module)
+                d, a = (layer.inputKeyMap(data), layer.inputKeyMap(attrs)) if mapped else (data, attrs)
+                d, a = layer(d, a)
+                if mapped:
+                    d, a = layer.outputKeyMap(d), layer.outputKeyMap(a)
+                data.update(d)
+                attrs.update(a)
+        return Batch(attrs, **data)

@@ -1,0 +1,198 @@
+/*
+ * e3k.h — C ABI of libe3k.so, the MI355X (gfx950) kernels behind the e3_layers tensor-product
+ * message-passing path.
+ *
+ * The reference (20171130/Equivariant-NN-Zoo) has no native plugin interface: its hot path is
+ * Python that calls e3nn / torch_runstats operators.  Each entry point below
+ * therefore cites the *operator call site* it replaces (paths relative to /root/reference).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (PyTorch on the Python side); the
+ *    library allocates nothing except the opaque plans created by e3k_tp_plan_create;
+ *  - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises;
+ *  - return value: 0 = ok, <0 = error (see e3k_strerror); no exceptions cross the boundary;
+ *  - floating tensors are fp32, node/edge ids are int32 inside the library (the int64
+ *    `edge_index` of the reference's Batch is narrowed once per batch by the host shim);
+ *  - feature layouts: "e3nn" = each `mul x l` block stored [mul][2l+1] (reference layout,
+ *    README.md:108-110); "cf" = channel-fastest, block stored [2l+1][mul] (internal layout of
+ *    the fused convolution: 64 channels = 64 lanes read 256 contiguous bytes).
+ */
+#ifndef E3K_H
+#define E3K_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define E3K_OK 0
+#define E3K_ERR_INVALID (-1)     /* bad argument / unsupported shape */
+#define E3K_ERR_LAUNCH (-2)      /* hip launch or runtime error */
+#define E3K_ERR_UNSUPPORTED (-3) /* degree beyond the generated CG tables */
+
+#define E3K_TP_MAXQ 8 /* max (l2,l3) slots per input degree — must equal E3K_MAXQ of e3k_cg_gen.h */
+
+const char* e3k_strerror(int code);
+int e3k_version(void);
+/* compile-time limits of the generated Clebsch-Gordan tables: l1max, l2max, l3max */
+void e3k_tp_limits(int* l1max, int* l2max, int* l3max);
+
+/* ------------------------------------------------------------------------------------------
+ * Grouped strided GEMM on the f32 MFMA pipe (v_mfma_f32_32x32x2_f32).
+ * Replaces: o3.Linear (nn/message_passing.py:58,102; nn/pointwise.py:18,87,142),
+ *           e3nn.nn.FullyConnectedNet layers (nn/message_passing.py:74,93),
+ *           o3.FullyConnectedTensorProduct with scalar second operand (nn/message_passing.py:83,100).
+ *
+ * One problem computes, for rows (r1, r2), r1 < M1, r2 < M2:
+ *     C[r1, r2, n] = alpha * sum_k Aeff[r1, r2, k] * B[k, n]  (+ C if accumulate) (+ bias[n])
+ * with   A addr = A + r1*a_r1 + r2*a_r2 + k*a_k,  B addr = B + k*b_k + n*b_n,
+ *        C addr = C + r1*c_r1 + r2*c_r2 + n*c_n   (all strides in elements).
+ * Outer mode (V > 0): K = U*V and Aeff[r1,r2,u*V+v] = A[r1,r2,u] * A2[r1*a2_r1 + v]
+ * (the x (x) node_attrs operand of the self-connection, never materialised).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const float* A;
+  const float* A2;
+  const float* B;
+  float* C;
+  const float* bias;
+  int32_t M1, M2, N, K;
+  int32_t V;
+  int32_t accumulate;
+  int64_t a_r1, a_r2, a_k;
+  int64_t a2_r1;
+  int64_t b_k, b_n;
+  int64_t c_r1, c_r2, c_n;
+  float alpha;
+  int32_t _pad;
+} e3k_gemm_problem;
+
+int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream);
+
+/* Weight gradient ("TN"):  B[k, n] += alpha * sum_{r1,r2} Aeff[r1,r2,k] * C[r1,r2,n]
+ * (C is read as the incoming gradient, B is accumulated with fp32 atomics; the caller zeroes B). */
+int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream);
+
+/* Column sums: out[n] += sum_r G[r*ld + n]   (bias gradients) */
+int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream);
+
+/* Self-connection backward helper: H[(r1,r2),(u,v)] = dC . W^T was produced by e3k_gemm; this
+ * reduces it to  dX[r1,r2,u] (+)= sum_v A2[r1,v] H[..,(u,v)]  and  dA2[r1,v] += sum_{r2,u} X[r1,r2,u] H[..].
+ * X/dX addressed as x + r1*x_r1 + r2*x_r2 + u (cf layout). */
+int e3k_fctp_reduce_bwd(const float* H, const float* X, const float* A2, int32_t M1, int32_t M2, int32_t U,
+                        int32_t V, int64_t x_r1, int64_t x_r2, int64_t a2_r1, float* dX, int32_t dx_accumulate,
+                        float* dA2, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge geometry.  Replaces computeEdgeVector (data/compute_edge.py:13-36),
+ * o3.SphericalHarmonics via SphericalEncoding (nn/embedding.py:163-178) and
+ * BesselBasis x cutoff via RadialBasisEncoding (nn/embedding.py:114-127,31-40,210-219).
+ * ------------------------------------------------------------------------------------------ */
+int e3k_edge_vector_fwd(const float* pos, const int32_t* src, const int32_t* dst, int64_t E, float* edge_vec,
+                        float* edge_len, void* stream);
+/* g_pos[n] = sum_{e: dst=n} gv[e] - sum_{e: src=n} gv[e], gv = g_vec + g_len * vec/len; CSR by dst and by src */
+int e3k_edge_vector_bwd(const float* g_vec, const float* g_len, const float* edge_vec, const float* edge_len,
+                        const int32_t* dst_ptr, const int32_t* dst_perm, const int32_t* src_ptr,
+                        const int32_t* src_perm, int64_t N, float* g_pos, void* stream);
+
+/* lmask: bit l set => degree l present (l <= 3), output blocks in ascending-l order of the set
+ * bits, repeated per `ls` entry; normalization: 0 component, 1 integral, 2 norm. */
+int e3k_sph_harm_fwd(const float* vec, int64_t E, const int32_t* ls, int32_t n_ls, int32_t normalize,
+                     int32_t normalization, float* sh, void* stream);
+int e3k_sph_harm_bwd(const float* vec, const float* g_sh, int64_t E, const int32_t* ls, int32_t n_ls,
+                     int32_t normalize, int32_t normalization, float* g_vec, void* stream);
+
+/* cutoff_kind: 0 polynomial (p), 1 symmetric (x^2-1)^2 */
+int e3k_radial_basis_fwd(const float* r, int64_t E, const float* bessel_w, int32_t n_basis, float r_max, float r_min,
+                         float p, int32_t one_over_r, int32_t cutoff_kind, float* out, void* stream);
+int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t E, const float* bessel_w, int32_t n_basis,
+                         float r_max, float r_min, float p, int32_t one_over_r, int32_t cutoff_kind, float* g_r,
+                         float* g_w, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused 'uvu' tensor product + destination reduce.
+ * Replaces TensorProductExpansion.tp (nn/pointwise.py:78-85,94-99) applied to x[edge_src]
+ * (nn/message_passing.py:104-106) followed by scatter over edge_dst (:109).  The trailing
+ * per-edge o3.Linear of the reference (nn/pointwise.py:87-92,99) commutes with the sum and is
+ * applied on nodes by e3k_gemm.
+ *
+ * A group = one input irrep block (degree l1, `mul` channels at x_off in the cf row) and up
+ * to E3K_TP_MAXQ paths, at most one per (l2, l3) slot; slot q is the q-th valid (l2,l3) pair
+ * for l1 in the order of e3k_cg_gen.h (l2 ascending, then l3 ascending).
+ *   out[n, out_off[q] + k*out_stride[q] + u] =
+ *       sum_{e: dst(e)=n} coeff[q] * w[e, w_off[q]+u] * sum_ij C_ijk x[src(e), x_off + i*mul + u] sh[e, y_off[l2]+j]
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  int32_t l1, x_off, mul;
+  uint32_t mask; /* bit q set => slot q present */
+  int32_t y_off[4];
+  int32_t w_off[E3K_TP_MAXQ];
+  int32_t out_off[E3K_TP_MAXQ];
+  int32_t out_stride[E3K_TP_MAXQ];
+  float coeff[E3K_TP_MAXQ];
+} e3k_tp_group;
+
+typedef struct e3k_tp_plan e3k_tp_plan;
+
+int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, int32_t d_in, int32_t d_sh, int32_t w_numel,
+                       int32_t d_mid, e3k_tp_plan** plan);
+void e3k_tp_plan_destroy(e3k_tp_plan* plan);
+
+/* x [N,d_in] cf, sh [E,d_sh], w [E,w_numel]; src [E]; CSR by destination (dst_ptr [N+1],
+ * dst_perm [E] = edge ids grouped by destination, ascending inside a group); out [N,d_mid]. */
+int e3k_tp_fwd(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const int32_t* src,
+               const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out, void* stream);
+/* g_w [E,w_numel] written; g_sh [E,d_sh] accumulated with atomics when non-null (needs w). */
+int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out,
+                 const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                 float* g_w, float* g_sh, void* stream);
+/* g_x [N,d_in] written; CSR by source (src_ptr, src_perm), dst [E]. */
+int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
+                 const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Node-side elementwise kernels.
+ * ------------------------------------------------------------------------------------------ */
+/* activation ids: 0 identity, 1 ssp, 2 silu, 3 tanhlu, 4 tanh, 5 abs */
+int e3k_act_fwd(const float* x, int64_t n, int32_t act, float cst, float* y, void* stream);
+int e3k_act_bwd(const float* x, const float* g_y, int64_t n, int32_t act, float cst, float* g_x, void* stream);
+
+/* layout change of a feature row: blocks (off, mul, dim=2l+1); to_cf=1: [mul][dim] -> [dim][mul]. */
+typedef struct {
+  int32_t off, mul, dim, _pad;
+} e3k_block;
+int e3k_relayout(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,
+                 int32_t to_cf, float* y, void* stream);
+
+/* Gate (e3nn.nn.Gate, nn/message_passing.py:195-205,249): input row in cf layout
+ * [scalars | gates | gated blocks], output row in e3nn layout [act(scalars) | gated*act(gate)]. */
+typedef struct {
+  int32_t kind;    /* 0: scalar block with activation, 1: gated block */
+  int32_t in_off;  /* offset of the block in the input row */
+  int32_t gate_off;/* kind 1: offset of its gate scalars in the input row */
+  int32_t out_off; /* offset in the output row */
+  int32_t mul, dim;
+  int32_t act;     /* activation of the scalars (kind 0) or of the gates (kind 1) */
+  float cst;       /* its second-moment normalisation constant */
+} e3k_gate_seg;
+int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_t out_dim, const e3k_gate_seg* segs,
+                 int32_t n_segs, float* y, void* stream);
+int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int32_t in_dim, int32_t out_dim,
+                 const e3k_gate_seg* segs, int32_t n_segs, float* g_x, void* stream);
+
+/* per-irreps-block RMS normalisation (LayerNormalization, nn/pointwise.py:32-51), e3nn layout */
+int e3k_layernorm_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,
+                      const float* std, float* y, float* inv_norm, void* stream);
+int e3k_layernorm_bwd(const float* x, const float* g_y, const float* inv_norm, int64_t rows, int32_t row_dim,
+                      const e3k_block* blocks, int32_t n_blocks, const float* std, float* g_x, float* g_std,
+                      void* stream);
+
+/* sorted-segment sum (Pooling, nn/output.py:66-74): out[s, :] = sum_{r in [ptr[s], ptr[s+1])} x[r, :] (* 1/count if mean) */
+int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t dim, int32_t mean, float* out,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* E3K_H */
