@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py — molecules/s of the config_energy training step on MI355X (the BASELINE.json metric).
+
+A step = one pass of the hot path over one synthetic QM9-like batch, exactly what the reference's
+``Trainer.batch_step`` does (``e3_layers/run/trainer.py:358-399``): forward of the
+SequentialGraphNetwork, loss ``1e3 * MSE(total_energy)`` (``e3_layers/configs/config_energy.py:27``),
+backward, (gradient all-reduce when N > 1), Adam step.  Inputs are resident in HBM before the
+timed region.  Workload at every N: BASELINE.json configs[1] — config_energy, l_max=2, n_dim 64,
+5 layers, 256 molecules per GPU (weak scaling: graph-parallel data parallelism).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line carrying the metric plus
+  roofline     — fused TP+reduce forward kernel (e3k::tp_fwd_kernel): algorithmic bytes (SURVEY.md §8d
+                 variant A) / HIP-event time of its launches inside the timed region, vs 8 TB/s;
+  cpu_baseline — the oracle (unfused PyTorch restatement, kind "port") timed on the host cores
+                 on a bounded 32-molecule sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import torch
+import torch.distributed as dist
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--lmax", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU-baseline sample")
+    return ap.parse_args()
+
+
+def cpu_baseline(tree, shifts, n_mol):
+    """Oracle fwd+bwd on the host cores, fp32, one timed step on an n_mol-molecule sample."""
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from oracle import e3ref
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    net = e3ref.build(tree).float()
+
+    def step(batch):
+        data = {k: v for k, v in batch.data.items()}
+        t0 = time.perf_counter()
+        out, _ = net(data, dict(batch.attrs))
+        loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], batch["total_energy"])
+        t1 = time.perf_counter()
+        net.zero_grad(set_to_none=True)
+        loss.backward()
+        return t1 - t0, time.perf_counter() - t0
+
+    step(synth_qm9(1, 2, shifts))  # lazy-init warm-up, untimed
+    fwd, total = step(synth_qm9(0, n_mol, shifts))
+    return {
+        "value": round(n_mol / total, 4),
+        "unit": "molecules/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"oracle/e3ref.py fp32, 1 fwd+bwd step on synth_qm9(seed 0, {n_mol} molecules), same model; "
+                   f"{total:.1f} s total, forward-only {n_mol / fwd:.3f} molecules/s"),
+        "forward_only_value": round(n_mol / fwd, 4),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.configs import config_energy
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.parallel import FlatGradients, broadcast_parameters
+    from e3_layers_amd.utils import build, countParameters
+
+    cfg = config_energy.get_config(l_max=args.lmax)
+    tree = cfg.model_config
+    torch.manual_seed(0)
+    model = build(tree).to(dev)
+    broadcast_parameters(model)
+    flat = FlatGradients(model.parameters())
+    opt = torch.optim.Adam(flat.params, lr=cfg.learning_rate)
+
+    # every rank owns its own 256 molecules (weak scaling); seeded per rank, resident in HBM
+    batch = synth_qm9(1000 + rank, args.batch, config_energy.QM9_SHIFTS).to(dev)
+    batch.update(build_topology(batch["edge_index"], batch["pos"].shape[0]).as_dict())
+    target = batch["total_energy"]
+    n_nodes, n_edges = batch["pos"].shape[0], batch["edge_index"].shape[1]
+
+    def step():
+        out = model(batch.clone())
+        loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
+        flat.zero()
+        loss.backward()
+        flat.all_reduce_mean()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ops.PROFILE_TP = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    records, ops.PROFILE_TP = ops.PROFILE_TP, None
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # roofline of the fused TP+reduce forward kernel (rank 0's launches in the timed region)
+    tot_bytes, tot_ms = 0.0, 0.0
+    for start, end, n, e, plan in records:
+        tot_ms += start.elapsed_time(end)
+        tot_bytes += e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
+    n_launch = max(len(records), 1)
+    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    roofline = {
+        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "kernel": "e3k::tp_fwd_kernel", "launches": len(records),
+        "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "avg_launch_algorithmic_MB": round(tot_bytes / n_launch / 1e6, 2),
+    }
+
+    if rank == 0:
+        result = {
+            "metric": "molecules/s forward+backward, QM9 config_energy batch",
+            "value": round(world * args.batch * args.steps / elapsed, 2),
+            "unit": "molecules/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {
+                "workload": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU "
+                            f"(rank 0: N={n_nodes} nodes, E={n_edges} edges), fwd + 1e3*MSE + bwd + Adam",
+                "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
+                "parameters": countParameters(model), "final_loss": round(float(loss), 4),
+            },
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(tree, config_energy.QM9_SHIFTS, args.cpu_sample)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

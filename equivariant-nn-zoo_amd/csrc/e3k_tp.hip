@@ -89,18 +89,9 @@ __device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, c
 // forward
 // ------------------------------------------------------------------------------------------
 template <int L1>
-__global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
-                                                     const int2* __restrict__ gc, int n_gc) {
+__device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
-  if (item >= a.n_items) return;
-  const int node = uniform((int)(item / n_gc));
-  const int gci = uniform((int)(item % n_gc));
-  const int2 gcv = gc[gci];
-  const e3k_tp_group& g = groups[uniform(gcv.x)];
-  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
   const bool active = u < g.mul;
   const int mul = g.mul;
   const unsigned mask = g.mask;
@@ -166,18 +157,9 @@ __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_grou
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
 template <int L1, bool WITH_SH>
-__global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
-                                                       const int2* __restrict__ gc, int n_gc) {
+__device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
-  if (item >= a.n_items) return;
-  const int node = uniform((int)(item / n_gc));
-  const int gci = uniform((int)(item % n_gc));
-  const int2 gcv = gc[gci];
-  const e3k_tp_group& g = groups[uniform(gcv.x)];
-  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
   const bool active = u < g.mul;
   const int mul = g.mul;
   const unsigned mask = g.mask;
@@ -262,18 +244,9 @@ __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_gr
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
 template <int L1>
-__global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
-                                                       const int2* __restrict__ gc, int n_gc) {
+__device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const int b = xcd_remap(blockIdx.x, gridDim.x);
-  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);
-  if (item >= a.n_items) return;
-  const int node = uniform((int)(item / n_gc));
-  const int gci = uniform((int)(item % n_gc));
-  const int2 gcv = gc[gci];
-  const e3k_tp_group& g = groups[uniform(gcv.x)];
-  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
   const bool active = u < g.mul;
   const int mul = g.mul;
   const unsigned mask = g.mask;
@@ -308,6 +281,53 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// one launch per pass: a wave looks up its work item and branches (wave-uniformly) on the input degree
+// ------------------------------------------------------------------------------------------
+#define E3K_TP_PROLOGUE                                                        \
+  const int b = xcd_remap(blockIdx.x, gridDim.x);                              \
+  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);                    \
+  if (item >= a.n_items) return;                                               \
+  const int node = uniform((int)(item / n_gc));                                \
+  const int gci = uniform((int)(item % n_gc));                                 \
+  const int2 gcv = gc[gci];                                                    \
+  const e3k_tp_group& g = groups[uniform(gcv.x)];                              \
+  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
+
+__global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                     const int2* __restrict__ gc, int n_gc) {
+  E3K_TP_PROLOGUE
+  switch (g.l1) {
+    case 0: tp_fwd_body<0>(a, g, node, u); break;
+    case 1: tp_fwd_body<1>(a, g, node, u); break;
+    case 2: tp_fwd_body<2>(a, g, node, u); break;
+    default: tp_fwd_body<3>(a, g, node, u); break;
+  }
+}
+
+template <bool WITH_SH>
+__global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                       const int2* __restrict__ gc, int n_gc) {
+  E3K_TP_PROLOGUE
+  switch (g.l1) {
+    case 0: tp_bwd_w_body<0, WITH_SH>(a, g, node, u); break;
+    case 1: tp_bwd_w_body<1, WITH_SH>(a, g, node, u); break;
+    case 2: tp_bwd_w_body<2, WITH_SH>(a, g, node, u); break;
+    default: tp_bwd_w_body<3, WITH_SH>(a, g, node, u); break;
+  }
+}
+
+__global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                       const int2* __restrict__ gc, int n_gc) {
+  E3K_TP_PROLOGUE
+  switch (g.l1) {
+    case 0: tp_bwd_x_body<0>(a, g, node, u); break;
+    case 1: tp_bwd_x_body<1>(a, g, node, u); break;
+    case 2: tp_bwd_x_body<2>(a, g, node, u); break;
+    default: tp_bwd_x_body<3>(a, g, node, u); break;
+  }
+}
+
 }  // namespace e3k
 
 // ------------------------------------------------------------------------------------------
@@ -316,8 +336,8 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
 struct e3k_tp_plan {
   int32_t n_groups, d_in, d_sh, w_numel, d_mid;
   e3k_tp_group* d_groups;
-  int2* d_gc[E3K_L1MAX + 1];
-  int32_t n_gc[E3K_L1MAX + 1];
+  int2* d_gc;     // (group, 64-channel chunk) work list, all degrees
+  int32_t n_gc;
 };
 
 extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
@@ -341,10 +361,8 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
   p->w_numel = w_numel;
   p->d_mid = d_mid;
   p->d_groups = nullptr;
-  for (int l = 0; l <= E3K_L1MAX; ++l) {
-    p->d_gc[l] = nullptr;
-    p->n_gc[l] = 0;
-  }
+  p->d_gc = nullptr;
+  p->n_gc = 0;
   if (hipMalloc(&p->d_groups, sizeof(e3k_tp_group) * n_groups) != hipSuccess) {
     delete p;
     return E3K_ERR_LAUNCH;
@@ -353,24 +371,21 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     e3k_tp_plan_destroy(p);
     return E3K_ERR_LAUNCH;
   }
-  for (int l = 0; l <= E3K_L1MAX; ++l) {
+  {
     int cnt = 0;
-    for (int i = 0; i < n_groups; ++i)
-      if (groups[i].l1 == l) cnt += (groups[i].mul + 63) / 64;
-    if (!cnt) continue;
+    for (int i = 0; i < n_groups; ++i) cnt += (groups[i].mul + 63) / 64;
     int2* host = new int2[cnt];
     int k = 0;
     for (int i = 0; i < n_groups; ++i)
-      if (groups[i].l1 == l)
-        for (int c = 0; c < (groups[i].mul + 63) / 64; ++c) host[k++] = make_int2(i, c);
-    hipError_t e1 = hipMalloc(&p->d_gc[l], sizeof(int2) * cnt);
-    hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_gc[l], host, sizeof(int2) * cnt, hipMemcpyHostToDevice) : e1;
+      for (int c = 0; c < (groups[i].mul + 63) / 64; ++c) host[k++] = make_int2(i, c);
+    hipError_t e1 = hipMalloc(&p->d_gc, sizeof(int2) * cnt);
+    hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_gc, host, sizeof(int2) * cnt, hipMemcpyHostToDevice) : e1;
     delete[] host;
     if (e2 != hipSuccess) {
       e3k_tp_plan_destroy(p);
       return E3K_ERR_LAUNCH;
     }
-    p->n_gc[l] = cnt;
+    p->n_gc = cnt;
   }
   *out = p;
   return E3K_OK;
@@ -379,44 +394,36 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
 extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
   if (!p) return;
   if (p->d_groups) (void)hipFree(p->d_groups);
-  for (int l = 0; l <= E3K_L1MAX; ++l)
-    if (p->d_gc[l]) (void)hipFree(p->d_gc[l]);
+  if (p->d_gc) (void)hipFree(p->d_gc);
   delete p;
 }
 
 namespace {
 enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X };
 
-template <int L1>
-void launch_one(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
-  const int n_gc = p->n_gc[L1];
-  if (!n_gc || N <= 0) return;
+int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
+  static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
+  const int n_gc = p->n_gc;
+  if (!n_gc || N <= 0) return E3K_OK;
   e3k::TpArgs args = a;
   args.n_items = N * n_gc;
   const int64_t blocks = (args.n_items + 3) / 4;
+  if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
   switch (kind) {
     case TP_FWD:
-      hipLaunchKernelGGL(e3k::tp_fwd_kernel<L1>, grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      hipLaunchKernelGGL(e3k::tp_fwd_kernel, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
       break;
     case TP_BWD_W:
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<L1, false>), grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      hipLaunchKernelGGL(e3k::tp_bwd_w_kernel<false>, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
       break;
     case TP_BWD_W_SH:
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<L1, true>), grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      hipLaunchKernelGGL(e3k::tp_bwd_w_kernel<true>, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
       break;
     case TP_BWD_X:
-      hipLaunchKernelGGL(e3k::tp_bwd_x_kernel<L1>, grid, block, 0, st, args, p->d_groups, p->d_gc[L1], n_gc);
+      hipLaunchKernelGGL(e3k::tp_bwd_x_kernel, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
       break;
   }
-}
-
-int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
-  static_assert(E3K_L1MAX == 3, "extend the dispatch below when the CG tables grow");
-  launch_one<0>(kind, a, p, N, st);
-  launch_one<1>(kind, a, p, N, st);
-  launch_one<2>(kind, a, p, N, st);
-  launch_one<3>(kind, a, p, N, st);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

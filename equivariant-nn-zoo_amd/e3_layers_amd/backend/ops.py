@@ -19,6 +19,10 @@ from torch.autograd.function import once_differentiable
 from . import lib as L
 from .graph import GraphTopo
 
+# bench.py sets this to a list to collect (start_event, end_event, N, E, plan) per launch of the
+# fused TP+reduce forward kernel (HIP events on the launching stream); None = no profiling.
+PROFILE_TP = None
+
 ACT_IDS = {None: 0, "identity": 0, "ssp": 1, "silu": 2, "tanhlu": 3, "tanh": 4, "abs": 5}
 
 
@@ -356,8 +360,16 @@ class TpFn(torch.autograd.Function):
         assert x.shape[1] == plan.d_in and sh.shape[1] == plan.d_sh and w.shape == (e, plan.w_numel)
         assert topo.num_nodes == n and topo.num_edges == e
         out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
-        L.check(L.load().e3k_tp_fwd(plan.handle(x.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
+        handle = plan.handle(x.device)
+        prof = PROFILE_TP
+        if prof is not None:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        L.check(L.load().e3k_tp_fwd(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
                                     L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd")
+        if prof is not None:
+            ev1.record()
+            prof.append((ev0, ev1, n, e, plan))
         ctx.save_for_backward(x, sh, w)
         ctx.topo, ctx.plan = topo, plan
         return out

@@ -422,17 +422,21 @@ class TensorProduct(nn.Module):
             a = x1[:, s1[i1][0] : s1[i1][1]].reshape(z, m1, 2 * l1 + 1)
             b = x2[:, s2[i2][0] : s2[i2][1]].reshape(z, m2, 2 * l2 + 1)
             c = wigner_3j(l1, l2, lo).to(x1.dtype)
+            # materialised outer products x1 (x) x2 -> contraction with the 3j tensor as one GEMM
+            # (the contraction order opt_einsum_fx picks for e3nn's "zuv,ijk,zuvij->zuk")
             outer = torch.einsum("zui,zvj->zuvij", a, b)
+            d1, d2, d3 = 2 * l1 + 1, 2 * l2 + 1, 2 * lo + 1
+            t = (outer.reshape(z * m1 * m2, d1 * d2) @ c.reshape(d1 * d2, d3)).reshape(z, m1, m2, d3)
             if mode == "uvu":
                 if self.internal_weights:
-                    r = torch.einsum("uv,ijk,zuvij->zuk", w, c, outer)
+                    r = torch.einsum("uv,zuvk->zuk", w, t)
                 else:
-                    r = torch.einsum("zuv,ijk,zuvij->zuk", w, c, outer)
+                    r = torch.einsum("zuv,zuvk->zuk", w, t)
             else:
                 if self.internal_weights:
-                    r = torch.einsum("uvw,ijk,zuvij->zwk", w, c, outer)
+                    r = torch.einsum("uvw,zuvk->zwk", w, t)
                 else:
-                    r = torch.einsum("zuvw,ijk,zuvij->zwk", w, c, outer)
+                    r = torch.einsum("zuvw,zuvk->zwk", w, t)
             r = r * coeff
             outs[io] = r if outs[io] is None else outs[io] + r
         cols = []

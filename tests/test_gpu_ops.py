@@ -1,0 +1,365 @@
+"""GPU parity: every HIP operator (through the C ABI) against the float64 oracle on the same
+seeded inputs.  Tolerances are normwise relative errors; fp32 kernels vs a float64 reference,
+1e-5 is the north-star bound (BASELINE.json), most ops sit near 1e-7."""
+import math
+
+import pytest
+import torch
+
+from oracle import e3ref
+from tests.util import from_cf, rel_err, to_cf
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+GTOL = 2e-5
+
+
+def _grads(outs, ins, seeds):
+    return torch.autograd.grad(outs, ins, seeds, allow_unused=True)
+
+
+# ------------------------------------------------------------------------------------------
+def test_library_loads_and_limits(dev):
+    from e3_layers_amd.backend import lib as L
+    import ctypes as C
+
+    lib = L.load()
+    assert lib.e3k_version() >= 100
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    lib.e3k_tp_limits(C.byref(a), C.byref(b), C.byref(c))
+    from e3_layers_amd.nn.core import TP_L1MAX, TP_L2MAX, TP_L3MAX
+
+    assert (a.value, b.value, c.value) == (TP_L1MAX, TP_L2MAX, TP_L3MAX)
+
+
+def test_cpu_tensor_fails_loudly():
+    from e3_layers_amd.nn import Linear
+
+    lin = Linear("4x0e", "4x0e")
+    with pytest.raises(RuntimeError, match="GPU only"):
+        lin(torch.randn(3, 4))
+
+
+@pytest.mark.parametrize("rows", [1, 300])
+def test_relayout(dev, rows):
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.nn.core import irreps_blocks
+    from e3_layers_amd.o3 import Irreps
+
+    irreps = Irreps("8x0e+4x1o+3x1o+5x2e+64x3o")
+    x = torch.randn(rows, irreps.dim, device=dev)
+    y = ops.relayout(x, irreps_blocks(irreps), True)
+    assert torch.equal(y.cpu(), to_cf(x.cpu(), irreps))
+    assert torch.equal(ops.relayout(y, irreps_blocks(irreps), False), x)
+
+
+@pytest.mark.parametrize("in_layout,out_layout", [("e3nn", "e3nn"), ("cf", "cf"), ("e3nn", "cf"), ("cf", "e3nn")])
+def test_linear(dev, in_layout, out_layout):
+    from e3_layers_amd.nn import Linear
+
+    torch.manual_seed(0)
+    ir_in, ir_out = "8x0e+4x1o+3x1o+5x2e+2x0o", "6x0e+7x1o+2x2e+3x3o+5x0e"
+    lin = Linear(ir_in, ir_out, biases=True).to(dev)
+    with torch.no_grad():
+        lin.bias.normal_()
+    ref = e3ref.Linear(ir_in, ir_out, biases=True).double()
+    ref.load_state_dict({k: v.cpu() for k, v in lin.state_dict().items()})
+    rows = 333
+    x = torch.randn(rows, lin.irreps_in.dim, dtype=torch.float64)
+    xin = (to_cf(x, ir_in) if in_layout == "cf" else x).float().to(dev).requires_grad_(True)
+    y = lin(xin, in_layout=in_layout, out_layout=out_layout)
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    y_cmp = from_cf(y.cpu(), ir_out) if out_layout == "cf" else y.cpu()
+    assert rel_err(y_cmp, yr) < TOL
+    seed = torch.randn_like(yr)
+    seed_dev = (to_cf(seed, ir_out) if out_layout == "cf" else seed).float().to(dev)
+    gx, gw, gb = _grads(y, [xin, lin.weight, lin.bias], seed_dev)
+    rx, rw, rb = _grads(yr, [xr, ref.weight, ref.bias], seed)
+    gx_cmp = from_cf(gx.cpu(), ir_in) if in_layout == "cf" else gx.cpu()
+    assert rel_err(gx_cmp, rx) < GTOL
+    assert rel_err(gw, rw) < GTOL
+    assert rel_err(gb, rb) < GTOL
+
+
+def test_linear_large_shapes(dev):
+    """The shapes of config_energy layer 3's node linear: 64-channel blocks, vector loads."""
+    from e3_layers_amd.nn import Linear
+
+    torch.manual_seed(1)
+    ir = "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"
+    lin = Linear(ir, ir).to(dev)
+    ref = e3ref.Linear(ir, ir).double()
+    ref.load_state_dict({k: v.cpu() for k, v in lin.state_dict().items()})
+    x = torch.randn(1000, lin.irreps_in.dim, dtype=torch.float64)
+    xin = to_cf(x, ir).float().to(dev).requires_grad_(True)
+    y = lin(xin, in_layout="cf", out_layout="cf")
+    xr = x.clone().requires_grad_(True)
+    yr = ref(xr)
+    assert rel_err(from_cf(y.cpu(), ir), yr) < TOL
+    seed = torch.randn_like(yr)
+    gx, gw = _grads(y, [xin, lin.weight], to_cf(seed, ir).float().to(dev))
+    rx, rw = _grads(yr, [xr, ref.weight], seed)
+    assert rel_err(from_cf(gx.cpu(), ir), rx) < GTOL
+    assert rel_err(gw, rw) < GTOL
+
+
+def test_fully_connected_net(dev):
+    from e3_layers_amd.nn import FullyConnectedNet
+    from e3_layers_amd.utils import activations
+
+    torch.manual_seed(2)
+    hs = [8, 64, 64, 64, 300]
+    net = FullyConnectedNet(hs, activations["ssp"]).to(dev)
+    ref = e3ref.FullyConnectedNet(hs, "ssp").double()
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(1234, 8, dtype=torch.float64)
+    xin = x.float().to(dev).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y, yr = net(xin), ref(xr)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    params = list(net.parameters())
+    g = _grads(y, [xin] + params, seed.float().to(dev))
+    r = _grads(yr, [xr] + list(ref.parameters()), seed)
+    for a, b in zip(g, r):
+        assert rel_err(a, b) < GTOL
+
+
+def test_fctp_self_connection(dev):
+    from e3_layers_amd.nn import FullyConnectedTensorProduct
+
+    torch.manual_seed(3)
+    in1, in2, out = "16x0e+16x1o+8x2e+4x0o", "20x0e", "24x0e+16x0e+16x1o+8x2e+4x0o+3x3e"
+    tp = FullyConnectedTensorProduct(in1, in2, out).to(dev)
+    ref = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    assert ref.weight.numel() == tp.weight.numel()
+    ref.load_state_dict({k: v.cpu() for k, v in tp.state_dict().items()})
+    rows = 257
+    x = torch.randn(rows, tp.irreps_in1.dim, dtype=torch.float64)
+    a = torch.randn(rows, 20, dtype=torch.float64)
+    xin = to_cf(x, in1).float().to(dev).requires_grad_(True)
+    ain = a.float().to(dev).requires_grad_(True)
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    y, yr = tp(xin, ain), ref(xr, ar)
+    assert rel_err(from_cf(y.cpu(), out), yr) < TOL
+    seed = torch.randn_like(yr)
+    gx, ga, gw = _grads(y, [xin, ain, tp.weight], to_cf(seed, out).float().to(dev))
+    rx, ra, rw = _grads(yr, [xr, ar, ref.weight], seed)
+    assert rel_err(from_cf(gx.cpu(), in1), rx) < GTOL
+    assert rel_err(ga, ra) < GTOL
+    assert rel_err(gw, rw) < GTOL
+
+
+def test_gate(dev):
+    from e3_layers_amd.nn import Gate
+
+    torch.manual_seed(4)
+    sc, gt, gd = "8x0e+8x0o", "4x0e+6x0e+5x0e", "4x1o+6x2e+5x1e"
+    args = (sc, ["silu", "tanhlu"], gt, ["silu", "silu", "silu"], gd)
+    g = Gate(*args)
+    ref = e3ref.Gate(*args)
+    assert str(g.irreps_in) == e3ref.irreps_str(ref.irreps_in)
+    assert str(g.irreps_out) == e3ref.irreps_str(ref.irreps_out)
+    x = torch.randn(100, g.irreps_in.dim, dtype=torch.float64)
+    xin = to_cf(x, g.irreps_in).float().to(dev).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y, yr = g(xin), ref(xr)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    (gx,) = _grads(y, [xin], seed.float().to(dev))
+    (rx,) = _grads(yr, [xr], seed)
+    assert rel_err(from_cf(gx.cpu(), g.irreps_in), rx) < GTOL
+
+
+@pytest.mark.parametrize("ls", [[0, 1, 2], [0, 1, 2, 3], [2, 1]])
+@pytest.mark.parametrize("normalize", [True, False])
+@pytest.mark.parametrize("normalization", ["component", "integral", "norm"])
+def test_spherical_harmonics(dev, ls, normalize, normalization):
+    from e3_layers_amd.backend import ops
+
+    torch.manual_seed(5)
+    v = torch.randn(500, 3, dtype=torch.float64) * 2.0
+    vin = v.float().to(dev).requires_grad_(True)
+    vr = v.clone().requires_grad_(True)
+    y = ops.spherical_harmonics(vin, ls, normalize, normalization)
+    yr = e3ref.spherical_harmonics(ls, vr, normalize, normalization)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    (g,) = _grads(y, [vin], seed.float().to(dev))
+    (r,) = _grads(yr, [vr], seed)
+    assert rel_err(g, r) < GTOL
+
+
+@pytest.mark.parametrize("one_over_r,cutoff", [(True, "_poly_cutoff"), (False, "_poly_cutoff"), (False, "symmetricCutoff")])
+def test_radial_basis(dev, one_over_r, cutoff):
+    from e3_layers_amd import nn as pnn
+
+    torch.manual_seed(6)
+    mod = pnn.RadialBasisEncoding(4.0, True, "8x0e", cutoff=getattr(pnn, cutoff), one_over_r=one_over_r).to(dev)
+    ref = e3ref.RadialBasisEncoding(4.0, True, "8x0e", cutoff=cutoff, one_over_r=one_over_r).double()
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    r = torch.rand(777, dtype=torch.float64) * 4.6 + 0.4  # includes r > r_max
+    if cutoff == "symmetricCutoff":
+        r = r - 2.5  # negative arguments too
+    rin = r.float().to(dev).requires_grad_(True)
+    rr = r.clone().requires_grad_(True)
+    y = mod({"input": rin}, {"input": ("edge", "1x0e")})[0]["radial_embedding"]
+    yr = ref({"input": rr}, {"input": ("edge", "1x0e")})[0]["radial_embedding"]
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    g = _grads(y, [rin, mod.basis.bessel_weights], seed.float().to(dev))
+    rg = _grads(yr, [rr, ref.basis.bessel_weights], seed)
+    assert rel_err(g[0], rg[0]) < 5e-5  # derivative of the degree-8 envelope near r_max loses digits in fp32
+    assert rel_err(g[1], rg[1]) < GTOL
+
+
+def _random_graph(n_nodes, avg_deg, seed):
+    gen = torch.Generator().manual_seed(seed)
+    e = n_nodes * avg_deg
+    src = torch.randint(n_nodes, (e,), generator=gen)
+    dst = torch.randint(n_nodes, (e,), generator=gen)
+    dst[dst == src] = (dst[dst == src] + 1) % n_nodes
+    # leave some nodes without in-edges / out-edges
+    dst[dst == 0] = 1
+    src[src == n_nodes - 1] = 2
+    return torch.stack([src, dst])
+
+
+def test_edge_vector(dev):
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+
+    torch.manual_seed(7)
+    n = 50
+    ei = _random_graph(n, 9, 7)
+    pos = torch.randn(n, 3, dtype=torch.float64)
+    pin = pos.float().to(dev).requires_grad_(True)
+    pr = pos.clone().requires_grad_(True)
+    topo = build_topology(ei.to(dev), n)
+    vec, length = ops.edge_vector(pin, topo)
+    vr = pr[ei[1]] - pr[ei[0]]
+    lr = torch.linalg.norm(vr, dim=-1)
+    assert rel_err(vec, vr) < TOL and rel_err(length, lr) < TOL
+    s1, s2 = torch.randn_like(vr), torch.randn_like(lr)
+    (g,) = _grads([vec, length], [pin], [s1.float().to(dev), s2.float().to(dev)])
+    (r,) = _grads([vr, lr], [pr], [s1, s2])
+    assert rel_err(g, r) < GTOL
+
+
+def test_topology_matches_stable_sort(dev):
+    from e3_layers_amd.backend.graph import build_topology
+
+    ei = _random_graph(40, 6, 3)
+    t = build_topology(ei.to(dev), 40)
+    perm = t.dst_perm.cpu().long()
+    assert torch.equal(ei[1][perm], torch.sort(ei[1], stable=True).values)
+    # ascending edge ids inside every destination segment
+    ptr = t.dst_ptr.cpu().long()
+    for n in range(40):
+        seg = perm[ptr[n]:ptr[n + 1]]
+        assert torch.all(seg[1:] > seg[:-1])
+        assert torch.all(ei[1][seg] == n)
+    assert int(ptr[-1]) == ei.shape[1]
+
+
+@pytest.mark.parametrize("mul,left,out", [
+    (16, "16x0e+16x1o+16x2e", "16x0e+16x1o+16x2e+16x1e+16x3o"),
+    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
+    (96, "96x1o+96x3e", "96x0e+96x1o+96x2e+96x3e+96x2o"),
+    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o"),
+])
+def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
+    """fused gather + uvu product + per-destination reduce + node-side Linear  ==  the
+    reference's gather -> TensorProduct -> per-edge Linear -> scatter (oracle, float64)."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(8)
+    sh_ir = "1x0e+1x1o+1x2e"
+    n = 37
+    ei = _random_graph(n, 7, 11)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    ref = e3ref.TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).double()
+    assert ref.tp.weight_numel == mod.tp.weight_numel
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(n, mod.tp.irreps_in1.dim, dtype=torch.float64)
+    vec = torch.randn(e, 3, dtype=torch.float64)
+    sh = e3ref.spherical_harmonics([0, 1, 2], vec)
+    w = torch.randn(e, mod.tp.weight_numel, dtype=torch.float64)
+    xin = to_cf(x, left).float().to(dev).requires_grad_(True)
+    shin = sh.float().to(dev).requires_grad_(True)
+    win = w.float().to(dev).requires_grad_(True)
+    topo = build_topology(ei.to(dev), n)
+    mid = mod.tp.fused(xin, shin, win, topo)
+    y = mod.linear(mid, in_layout="cf", out_layout="e3nn")
+    xr, shr, wr = x.clone().requires_grad_(True), sh.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = e3ref.scatter(ref(left=xr[ei[0]], right=shr, weight=wr), ei[1], dim_size=n)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    gx, gsh, gw, gl = _grads(y, [xin, shin, win, mod.linear.weight], seed.float().to(dev))
+    rx, rsh, rw, rl = _grads(yr, [xr, shr, wr, ref.linear.weight], seed)
+    assert rel_err(from_cf(gx.cpu(), left), rx) < GTOL
+    assert rel_err(gw, rw) < GTOL
+    assert rel_err(gsh, rsh) < GTOL
+    assert rel_err(gl, rl) < GTOL
+    # the per-sample module API (no reduction) agrees with the oracle too
+    y_edges = mod(left=x[ei[0]].float().to(dev), right=sh.float().to(dev), weight=w.float().to(dev))
+    yr_edges = ref(left=x[ei[0]], right=sh, weight=w)
+    assert rel_err(y_edges, yr_edges) < TOL
+
+
+def test_tp_empty_and_isolated(dev):
+    """No edges at all, and nodes without in-edges: outputs are exact zeros."""
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    left, sh_ir = "8x0e+8x1o", "1x0e+1x1o+1x2e"
+    mod = TensorProductExpansion(left, (sh_ir, "s"), (left, "o"), "uvu", internal_weight=False).to(dev)
+    n = 5
+    x = torch.randn(n, 32, device=dev)
+    ei = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    topo = build_topology(ei, n)
+    mid = mod.tp.fused(x, torch.zeros(0, 9, device=dev), torch.zeros(0, mod.tp.weight_numel, device=dev), topo)
+    assert mid.shape == (n, mod.tp.d_mid) and float(mid.abs().max()) == 0.0
+
+
+def test_layer_norm(dev):
+    from e3_layers_amd import nn as pnn
+
+    torch.manual_seed(9)
+    ir = "8x0e+8x1o+4x2e"
+    mod = pnn.LayerNormalization(ir, ir).to(dev)
+    ref = e3ref.LayerNormalization(ir, ir).double()
+    with torch.no_grad():
+        mod.std.uniform_(0.5, 1.5)
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(64, 52, dtype=torch.float64)
+    xin, xr = x.float().to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    y = mod({"input": xin}, {})[0]["output"]
+    yr = ref({"input": xr}, {})[0]["output"]
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    g = _grads(y, [xin, mod.std], seed.float().to(dev))
+    r = _grads(yr, [xr, ref.std], seed)
+    assert rel_err(g[0], r[0]) < GTOL and rel_err(g[1], r[1]) < GTOL
+
+
+def test_pooling(dev):
+    from e3_layers_amd import nn as pnn
+
+    n_nodes = torch.tensor([[3], [1], [5], [2]])
+    seg = torch.repeat_interleave(torch.arange(4), n_nodes.view(-1))
+    x = torch.randn(11, 1, dtype=torch.float64)
+    for reduce in ("sum", "mean"):
+        mod = pnn.Pooling("1x0e", "1x0e", reduce)
+        xin = x.float().to(dev).requires_grad_(True)
+        y = mod({"input": xin, "_n_nodes": n_nodes.to(dev), "_node_segment": seg.to(dev)}, {"input": ("node", "1x0e")})[0]["output"]
+        yr = e3ref.scatter(x, seg, dim_size=4, reduce=reduce)
+        assert rel_err(y, yr) < TOL
+        (g,) = _grads(y, [xin], torch.ones_like(y))
+        expect = torch.ones(11, 1) if reduce == "sum" else (1.0 / n_nodes.view(-1)[seg].double()).view(-1, 1)
+        assert rel_err(g, expect) < TOL

@@ -1,0 +1,58 @@
+"""Shared helpers for the parity tests (product HIP path vs the float64 oracle)."""
+import torch
+
+from oracle import e3ref
+
+
+def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
+    """Normwise relative error ||a-b|| / ||b|| in float64."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    denom = float(b.norm())
+    return float((a - b).norm()) / (denom if denom > 0 else 1.0)
+
+
+def to_cf(x: torch.Tensor, irreps) -> torch.Tensor:
+    """[mul][2l+1] blocks -> [2l+1][mul] blocks (pure torch, for checking the relayout kernel)."""
+    cols, pos = [], 0
+    for mul, l, _ in e3ref.parse_irreps(str(irreps)):
+        d = 2 * l + 1
+        cols.append(x[:, pos:pos + mul * d].reshape(-1, mul, d).transpose(1, 2).reshape(-1, mul * d))
+        pos += mul * d
+    return torch.cat(cols, dim=1)
+
+
+def from_cf(x: torch.Tensor, irreps) -> torch.Tensor:
+    cols, pos = [], 0
+    for mul, l, _ in e3ref.parse_irreps(str(irreps)):
+        d = 2 * l + 1
+        cols.append(x[:, pos:pos + mul * d].reshape(-1, d, mul).transpose(1, 2).reshape(-1, mul * d))
+        pos += mul * d
+    return torch.cat(cols, dim=1)
+
+
+def oracle_like(product_model, config_tree, dtype=torch.float64):
+    """Oracle network built from the same config tree, carrying the product's parameters."""
+    orc = e3ref.build(config_tree)
+    sd = {("mods." + k if not k.startswith("func.") else k): v.detach().cpu() for k, v in product_model.state_dict().items()}
+    orc.load_state_dict(_rename(sd, orc))
+    return orc.to(dtype)
+
+
+def _rename(sd, orc):
+    want = set(orc.state_dict().keys())
+    out = {}
+    for k, v in sd.items():
+        if k in want:
+            out[k] = v
+        elif k.startswith("mods.func."):
+            out["func.mods." + k[len("mods.func."):]] = v
+        else:
+            out[k] = v
+    return out
+
+
+def batch_to_oracle(batch, dtype=torch.float64):
+    data = {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu())
+            for k, v in batch.data.items() if not k.startswith("_e3k_")}
+    return data, dict(batch.attrs)
