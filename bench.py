@@ -49,12 +49,14 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(tree, shifts, n_mol):
-    """Oracle fwd+bwd on the host cores, fp32, one timed step on an n_mol-molecule sample."""
+def cpu_baseline(tree, shifts, n_mol, budget_s=20.0):
+    """Oracle fwd+bwd on the host cores, fp32.  One timed step on a bounded sample: a 4-molecule
+    probe step is timed first and the sample is sized so that the timed step takes about
+    ``budget_s`` seconds (at most ``n_mol`` molecules)."""
     from e3_layers_amd.data.synthetic import synth_qm9
     from oracle import e3ref
 
-    cores = os.cpu_count() or 1
+    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds fork/join overhead on these op sizes
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = e3ref.build(tree).float()
@@ -70,14 +72,16 @@ def cpu_baseline(tree, shifts, n_mol):
         return t1 - t0, time.perf_counter() - t0
 
     step(synth_qm9(1, 2, shifts))  # lazy-init warm-up, untimed
+    _, probe = step(synth_qm9(2, 4, shifts))
+    n_mol = int(max(4, min(n_mol, 4 * budget_s / max(probe, 1e-3))))
     fwd, total = step(synth_qm9(0, n_mol, shifts))
     return {
         "value": round(n_mol / total, 4),
         "unit": "molecules/s",
         "cores": cores,
         "kind": "port",
-        "sample": (f"oracle/e3ref.py fp32, 1 fwd+bwd step on synth_qm9(seed 0, {n_mol} molecules), same model; "
-                   f"{total:.1f} s total, forward-only {n_mol / fwd:.3f} molecules/s"),
+        "sample": (f"oracle/e3ref.py fp32 on {cores} threads, 1 fwd+bwd step on synth_qm9(seed 0, {n_mol} molecules), "
+                   f"same model; {total:.1f} s total, forward-only {n_mol / fwd:.3f} molecules/s"),
         "forward_only_value": round(n_mol / fwd, 4),
     }
 
@@ -177,7 +181,7 @@ def main():
                 "workload": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU "
                             f"(rank 0: N={n_nodes} nodes, E={n_edges} edges), fwd + 1e3*MSE + bwd + Adam",
                 "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
-                "parameters": countParameters(model), "final_loss": round(float(loss), 4),
+                "parameters": countParameters(model), "final_loss": round(float(loss.detach()), 4),
             },
             "roofline": roofline,
         }
