@@ -1,0 +1,79 @@
+"""The C ABI: libe3k.so loads (no GPU needed), exports every symbol include/e3k.h declares, and the
+ctypes mirror of its structs has the layout the C compiler gives them.  No compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "e3k.h")
+
+
+def _declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(e3k_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from e3_layers_amd.backend import lib as L
+
+    if not os.path.exists(L.LIB_PATH):
+        import __graft_entry__
+
+        __graft_entry__.build()
+    handle = L.load()
+    names = _declared_functions()
+    assert len(names) >= 25
+    for name in names:
+        assert hasattr(handle, name), f"{name} declared in include/e3k.h but not exported by libe3k.so"
+        assert name in L.SIGNATURES, f"{name} has no ctypes signature in backend/lib.py"
+    assert handle.e3k_strerror(-3).decode().startswith("degree")
+    assert handle.e3k_version() >= 100
+
+
+def test_struct_layouts_match_the_c_compiler(tmp_path):
+    from e3_layers_amd.backend import lib as L
+
+    src = tmp_path / "sizes.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "e3k.h"\n'
+        "int main(void){\n"
+        'printf("%zu %zu %zu %zu\\n", sizeof(e3k_gemm_problem), sizeof(e3k_tp_group), sizeof(e3k_block), sizeof(e3k_gate_seg));\n'
+        'printf("%zu %zu %zu %zu\\n", offsetof(e3k_gemm_problem, M1), offsetof(e3k_gemm_problem, a_r1), offsetof(e3k_gemm_problem, alpha), offsetof(e3k_tp_group, coeff));\n'
+        "return 0;}\n")
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    sizes = [int(v) for v in out]
+    assert sizes[:4] == [C.sizeof(L.GemmProblem), C.sizeof(L.TpGroup), C.sizeof(L.Block), C.sizeof(L.GateSeg)]
+    assert sizes[4:] == [L.GemmProblem.M1.offset, L.GemmProblem.a_r1.offset, L.GemmProblem.alpha.offset, L.TpGroup.coeff.offset]
+
+
+def test_limits_agree_with_generated_header():
+    gen = open(os.path.join(ROOT, "equivariant-nn-zoo_amd", "csrc", "e3k_cg_gen.h")).read()
+    vals = {k: int(v) for k, v in re.findall(r"#define (E3K_L[123]MAX|E3K_MAXQ) (\d+)", gen)}
+    from e3_layers_amd.backend import lib as L
+    from e3_layers_amd.nn import core
+
+    assert (vals["E3K_L1MAX"], vals["E3K_L2MAX"], vals["E3K_L3MAX"]) == (core.TP_L1MAX, core.TP_L2MAX, core.TP_L3MAX)
+    assert vals["E3K_MAXQ"] == L.TP_MAXQ
+    for l1 in range(core.TP_L1MAX + 1):
+        m = re.search(r"struct Slots<%d> \{.*?L2\[\d+\] = \{([^}]*)\};.*?L3\[\d+\] = \{([^}]*)\};" % l1, gen, re.S)
+        l2s = [int(v) for v in m.group(1).split(",")]
+        l3s = [int(v) for v in m.group(2).split(",")]
+        assert list(zip(l2s, l3s)) == core.tp_slots(l1)
+
+
+def test_product_path_has_no_oracle_import():
+    """The shipped package must never import the oracle (or the reference)."""
+    pkg = os.path.join(ROOT, "equivariant-nn-zoo_amd")
+    for base, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(base, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(base, f)
+                assert "/root/reference" not in text, os.path.join(base, f)
