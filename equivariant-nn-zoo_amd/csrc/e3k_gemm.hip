@@ -6,16 +6,34 @@
 //   FullyConnectedNet layers           e3_layers/nn/message_passing.py:74,93      (radial MLP)
 //   FullyConnectedTensorProduct (sc)   e3_layers/nn/message_passing.py:83,100     (outer mode)
 //
-// forward / dgrad kernel  (e3k_gemm):   C[(r1,r2), n] = alpha * sum_k Aeff[(r1,r2), k] B[k, n]
-//   tile 128 rows x 64 cols x 32 k, 256 threads = 4 waves, wave w owns rows [32w, 32w+32) x 64 cols
-//   (two 32x32 accumulators).  A tile in LDS row-major with an odd row stride (33) so that the
-//   MFMA A fragment (lane -> row l&31, k l>>5) is bank-conflict free; B tile row-major [k][n].
-//   dgrad (dA = dC . B^T) is the same kernel with b_k / b_n swapped by the caller.
-//   Outer mode: Aeff[(r1,r2), u*V+v] = X[(r1,r2), u] * attrs[r1, v]; X and attrs tiles sit in
-//   LDS for the whole K loop and the product is formed when the fragment is read.
-// wgrad kernel (e3k_gemm_wgrad):         B[k, n] += alpha * sum_rows Aeff[row, k] G[row, n]
-//   tile 64 k x 64 n, rows split over blocks, 64-row chunks staged in natural row-major order
-//   (both MFMA operands are then conflict-free), fp32 atomics on the small output.
+// One problem:  C[(r1,r2), n] = alpha * sum_k Aeff[(r1,r2), k] B[k, n]  (+ C) (+ bias[n]),  rows are
+// (r1 < M1 nodes/edges, r2 < M2 = 2l+1 components) with independent strides, so the same kernels
+// serve the e3nn layout ([mul][2l+1]) and the channel-fastest layout ([2l+1][mul]).
+//
+// Kernels (256 threads = 4 waves, 32x32x2 f32 MFMA accumulators):
+//   gemm_kernel<WM>     forward / dgrad.  Tile (32*WM) x 64 x 32: WM=4 -> 128x64 (wave = 32 rows x 64 cols,
+//                       two accumulators), WM=2 -> 64x64 (wave = 32 x 32) for launches that would not fill
+//                       the chip with 128-row tiles.  A tile in LDS at an odd row stride (33): the MFMA A
+//                       fragment (lane -> row l&31, k l>>5) is bank-conflict free; B tile [k][n].  Global
+//                       loads are 16 B/lane into registers one K-step ahead of the MFMAs (issue early,
+//                       write LDS late).  dgrad (dA = dC . B^T) = same kernel, b_k / b_n swapped.
+//   gemm_smallk_kernel  K <= 64 (radial MLP, 64-channel node Linears): the A tile (128 x K) stays in LDS
+//                       while the block walks up to 8 column tiles, so A is read once per 512 columns and
+//                       the stores of one column tile drain under the MFMAs of the next: this GEMM is
+//                       bound by its output stream (E x W floats), not by the matrix pipe.
+//   gemm_outer_kernel   self-connection: Aeff[(r1,r2), u*V+v] = X[(r1,r2),u] * attrs[r1,v]; X and attrs
+//                       tiles sit in LDS for the whole K loop, the product is formed when the fragment is
+//                       read, so x (x) node_attrs (N x 1280 x (2l+1)) is never materialised.
+//   gemm_wgrad_kernel   B[k,n] += alpha * sum_rows Aeff[row,k] G[row,n]: tile 64 k x (64 or 128) n, rows
+//                       split over blocks, 64-row chunks staged in natural row-major order (both MFMA
+//                       operands conflict-free), fp32 atomics on the small output.
+//
+// Descriptors: up to 8 problems per launch.  The batch is uploaded once per launch into a device
+// ring by a one-block kernel and every workgroup reads it from there with one coalesced load into
+// LDS, then moves its own problem into scalar registers (a 1.2 KB by-value kernel argument read
+// field by field by 16k workgroups is slower and bloats every wave's prologue).
+#include <cstdlib>
+
 #include "e3k_common.h"
 
 namespace e3k {
@@ -26,181 +44,447 @@ constexpr int GEMM_MAXP = 8;
 struct GemmBatch {
   int n;
   int tile_start[GEMM_MAXP + 1];
-  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec)
-  int splits[GEMM_MAXP]; // wgrad only
+  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad)
+  int aux[GEMM_MAXP];    // wgrad: row splits; smallk: column tiles per block
   e3k_gemm_problem p[GEMM_MAXP];
 };
+constexpr int GB_WORDS = sizeof(GemmBatch) / 4;
+static_assert(sizeof(GemmBatch) % 4 == 0 && sizeof(e3k_gemm_problem) % 4 == 0, "word-copyable descriptors");
 
-constexpr int BM = 128, BN = 64, BK = 32;
+constexpr int BN = 64, BK = 32;
 constexpr int LDA = BK + 1;
 constexpr int LDB = BN;
 constexpr int XU = 64;          // outer mode: channels of X kept per super-step
 constexpr int LDX = XU + 1;
 constexpr int VMAX = 32;        // outer mode: max attrs width
 constexpr int LDV = VMAX + 1;
+constexpr int SK_KMAX = 64;     // small-K kernel: max K
+constexpr int SK_LDA = SK_KMAX + 1;
+constexpr int SK_CT = 8;        // small-K kernel: column tiles per block
 
-__device__ __forceinline__ void find_problem(const GemmBatch& gb, int bid, int& pi, int& local) {
-  pi = 0;
-#pragma unroll
-  for (int i = 1; i < GEMM_MAXP; ++i)
-    if (i < gb.n && bid >= gb.tile_start[i]) pi = i;
-  local = bid - gb.tile_start[pi];
+#ifdef E3K_STAMPS
+__device__ unsigned long long e3k_dbg_buf[1 << 20];
+#define STAMP_DECL unsigned long long st_last = __builtin_readcyclecounter(), st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define STAMP(i)                                                  \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    st_acc[i] += now_ - st_last;                                  \
+    st_last = now_;                                               \
+  } while (0)
+#define STAMP_FLUSH()                                                                             \
+  do {                                                                                            \
+    if ((threadIdx.x & 63) == 0) {                                                                \
+      const size_t slot = ((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;                      \
+      if (slot + 8 <= (1u << 20))                                                                 \
+        for (int i_ = 0; i_ < 8; ++i_) e3k_dbg_buf[slot + i_] = st_acc[i_];                       \
+    }                                                                                             \
+  } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_FLUSH()
+#endif
+
+__global__ void upload_batch_kernel(const GemmBatch gb, GemmBatch* __restrict__ dst) {
+  const int* src = reinterpret_cast<const int*>(&gb);
+  int* d = reinterpret_cast<int*>(dst);
+  for (int i = threadIdx.x; i < GB_WORDS; i += blockDim.x) d[i] = src[i];
 }
 
-__device__ __forceinline__ void stage_b(const e3k_gemm_problem& P, int bmode, int k0, int n0, float* Bs) {
+struct BlockProblem {
+  e3k_gemm_problem P;
+  int flags, aux, local;
+};
+
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch* gb, int* lds /* GB_WORDS */) {
+  const int* src = reinterpret_cast<const int*>(gb);
+  for (int i = threadIdx.x; i < GB_WORDS; i += 256) lds[i] = src[i];
+  __syncthreads();
+  const GemmBatch* b = reinterpret_cast<const GemmBatch*>(lds);
+  const int n = uniform(b->n);
+  int pi = 0;
+  for (int i = 1; i < GEMM_MAXP; ++i)
+    if (i < n && (int)blockIdx.x >= uniform(b->tile_start[i])) pi = i;
+  BlockProblem out;
+  out.local = blockIdx.x - uniform(b->tile_start[pi]);
+  out.flags = uniform(b->flags[pi]);
+  out.aux = uniform(b->aux[pi]);
+  union {
+    e3k_gemm_problem p;
+    int w[sizeof(e3k_gemm_problem) / 4];
+  } u;
+  const int* pw = reinterpret_cast<const int*>(&b->p[pi]);
+#pragma unroll
+  for (int i = 0; i < (int)(sizeof(e3k_gemm_problem) / 4); ++i) u.w[i] = uniform(pw[i]);
+  out.P = u.p;
+  return out;
+}
+
+struct BRegs {
+  float4 v[2];
+};
+
+// B tile (BK x BN) global -> registers (vector modes only; issued early, written to LDS late)
+__device__ __forceinline__ void load_b_regs(const e3k_gemm_problem& P, int bmode, int k0, int n0, BRegs& r) {
   const int t = threadIdx.x;
   if (bmode == 1) {
-    // rows of B contiguous along n: float4 loads, 16-byte LDS stores
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
       const int k = (t >> 4) + 16 * pass, nq = (t & 15) * 4;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < P.K && n0 + nq < P.N) v = *reinterpret_cast<const float4*>(P.B + (int64_t)(k0 + k) * P.b_k + (n0 + nq));
-      *reinterpret_cast<float4*>(Bs + k * LDB + nq) = v;
+      r.v[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k0 + k < P.K && n0 + nq < P.N)
+        r.v[pass] = *reinterpret_cast<const float4*>(P.B + (int64_t)(k0 + k) * P.b_k + (n0 + nq));
     }
-  } else if (bmode == 2) {
-    // B^T view: contiguous along k
+  } else {  // bmode == 2: B^T view, contiguous along k
     const int n = t & 63, kq = (t >> 6) * 8;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
       const int k = kq + 4 * h;
-      if (n0 + n < P.N && k0 + k < P.K) v = *reinterpret_cast<const float4*>(P.B + (int64_t)(n0 + n) * P.b_n + (k0 + k));
-      Bs[(k + 0) * LDB + n] = v.x;
-      Bs[(k + 1) * LDB + n] = v.y;
-      Bs[(k + 2) * LDB + n] = v.z;
-      Bs[(k + 3) * LDB + n] = v.w;
+      r.v[h] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n0 + n < P.N && k0 + k < P.K) r.v[h] = *reinterpret_cast<const float4*>(P.B + (int64_t)(n0 + n) * P.b_n + (k0 + k));
+    }
+  }
+}
+
+__device__ __forceinline__ void store_b_regs(int bmode, const BRegs& r, float* Bs) {
+  const int t = threadIdx.x;
+  if (bmode == 1) {
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int k = (t >> 4) + 16 * pass, nq = (t & 15) * 4;
+      *reinterpret_cast<float4*>(Bs + k * LDB + nq) = r.v[pass];
     }
   } else {
-    const int n = t & 63, kb = t >> 6;
+    const int n = t & 63, kq = (t >> 6) * 8;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int k = kb + 4 * j;
-      float v = 0.f;
-      if (n0 + n < P.N && k0 + k < P.K) v = P.B[(int64_t)(k0 + k) * P.b_k + (int64_t)(n0 + n) * P.b_n];
-      Bs[k * LDB + n] = v;
+    for (int h = 0; h < 2; ++h) {
+      const int k = kq + 4 * h;
+      Bs[(k + 0) * LDB + n] = r.v[h].x;
+      Bs[(k + 1) * LDB + n] = r.v[h].y;
+      Bs[(k + 2) * LDB + n] = r.v[h].z;
+      Bs[(k + 3) * LDB + n] = r.v[h].w;
     }
   }
 }
 
-__device__ __forceinline__ void epilogue(const e3k_gemm_problem& P, const f32x16 (&acc)[2], int row0, int n0) {
-  const int lane = threadIdx.x & 63, wr = threadIdx.x >> 6;
-  const int M = P.M1 * P.M2;
+// generic (scalar) B staging straight to LDS
+__device__ __forceinline__ void stage_b_scalar(const e3k_gemm_problem& P, int k0, int n0, float* Bs) {
+  const int t = threadIdx.x;
+  const int n = t & 63, kb = t >> 6;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + j * 32 + (lane & 31);
-    if (n >= P.N) continue;
-    const float bias = P.bias ? P.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int R = row0 + wr * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (R >= M) continue;
+  for (int j = 0; j < 8; ++j) {
+    const int k = kb + 4 * j;
+    float v = 0.f;
+    if (n0 + n < P.N && k0 + k < P.K) v = P.B[(int64_t)(k0 + k) * P.b_k + (int64_t)(n0 + n) * P.b_n];
+    Bs[k * LDB + n] = v;
+  }
+}
+
+// row tables of a tile: element offsets of its A and C rows (-1 = out of range); one integer
+// division per row per block instead of one per staged / stored element
+template <int ROWS>
+__device__ __forceinline__ void fill_row_tables(const e3k_gemm_problem& P, int row0, int M, long long* rowA,
+                                                long long* rowC) {
+  const int t = threadIdx.x;
+  if (t < ROWS) {
+    const int R = row0 + t;
+    long long oa = -1, oc = -1;
+    if (R < M) {
       const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-      float* c = P.C + (int64_t)r1 * P.c_r1 + (int64_t)r2 * P.c_r2 + (int64_t)n * P.c_n;
-      float v = P.alpha * acc[j][i] + bias;
-      if (P.accumulate) v += *c;
-      *c = v;
+      oa = (long long)r1 * P.a_r1 + (long long)r2 * P.a_r2;
+      oc = (long long)r1 * P.c_r1 + (long long)r2 * P.c_r2;
+    }
+    rowA[t] = oa;
+    rowC[t] = oc;
+  }
+}
+
+// stores NT 32x32 accumulators of one wave: rows wrow0.., columns ncol0 + 32*j
+template <int NT>
+__device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x16 (&acc)[NT], const long long* rowC,
+                                          int wrow0, int ncol0) {
+  const int lane = threadIdx.x & 63;
+  int n[NT];
+  bool ok[NT];
+  float bias[NT];
+  long long cn[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    n[j] = ncol0 + 32 * j + (lane & 31);
+    ok[j] = n[j] < P.N;
+    bias[j] = (P.bias && ok[j]) ? P.bias[n[j]] : 0.f;
+    cn[j] = (long long)n[j] * P.c_n;
+  }
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const long long off = rowC[wrow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)];
+    if (off < 0) continue;
+    float* c = P.C + off;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      if (ok[j]) {
+        float v = fmaf(P.alpha, acc[j][i], bias[j]);
+        if (P.accumulate) v += c[cn[j]];
+        c[cn[j]] = v;
+      }
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------
-// plain forward / dgrad
+// plain forward / dgrad, tile (32*WM) x 64 x 32
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
-  __shared__ float As[BM * LDA];
+template <int WM>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch* __restrict__ gb) {
+  constexpr int BM_ = 32 * WM;          // rows per tile
+  constexpr int WN = 4 / WM;            // waves along n
+  constexpr int NT = (BN / WN) / 32;    // accumulators per wave
+  constexpr int PASSES = BM_ / 32;      // float4 passes of the A staging
+  constexpr int TPR = 256 / BM_;        // threads per row in the scalar path
+  constexpr int KSEG = BK / TPR;
+  __shared__ float As[BM_ * LDA];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  int pi, local;
-  find_problem(gb, blockIdx.x, pi, local);
-  const e3k_gemm_problem& P = gb.p[pi];
-  const int flags = gb.flags[pi];
+  __shared__ long long rowA[BM_];
+  __shared__ long long rowC[BM_];
+  __shared__ int gbs[GB_WORDS];
+  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const e3k_gemm_problem& P = bp_.P;
+  const int flags = bp_.flags, local = bp_.local;
   const int M = P.M1 * P.M2;
   const int tiles_n = (P.N + BN - 1) / BN;
-  const int row0 = (local / tiles_n) * BM, n0 = (local % tiles_n) * BN;
-  const int t = threadIdx.x, lane = t & 63, wr = t >> 6;
+  const int row0 = (local / tiles_n) * BM_, n0 = (local % tiles_n) * BN;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w % WM, wn = w / WM;
 
-  f32x16 acc[2];
+  f32x16 acc[NT];
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
+  for (int j = 0; j < NT; ++j)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+  fill_row_tables<BM_>(P, row0, M, rowA, rowC);
+  __syncthreads();
+
   const bool avec = flags & 1;
   const int bmode = (flags >> 1) & 3;
-  // per-thread source rows (fixed over the K loop)
-  const float* arow[4];
-  if (avec) {
-#pragma unroll
-    for (int pass = 0; pass < 4; ++pass) {
-      const int R = row0 + (t >> 3) + 32 * pass;
-      if (R < M) {
-        const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-        arow[pass] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2;
-      } else {
-        arow[pass] = nullptr;
-      }
-    }
-  } else {
-    const int R = row0 + (t >> 1);
-    if (R < M) {
-      const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-      arow[0] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2;
-    } else {
-      arow[0] = nullptr;
-    }
-  }
-
-  for (int k0 = 0; k0 < P.K; k0 += BK) {
-    if (avec) {
-      const int kq = (t & 7) * 4;
-#pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (arow[pass] && k0 + kq < P.K) v = *reinterpret_cast<const float4*>(arow[pass] + k0 + kq);
-        float* d = As + ((t >> 3) + 32 * pass) * LDA + kq;
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-      }
-    } else {
-      const int kb = (t & 1) * 16;
-      float* d = As + (t >> 1) * LDA + kb;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = 0.f;
-        if (arow[0] && k0 + kb + j < P.K) v = arow[0][(int64_t)(k0 + kb + j) * P.a_k];
-        d[j] = v;
-      }
-    }
-    stage_b(P, bmode, k0, n0, Bs);
-    __syncthreads();
-    const float* ap = As + (wr * 32 + (lane & 31)) * LDA + (lane >> 5);
-    const float* bp = Bs + (lane >> 5) * LDB + (lane & 31);
+  const float* ap = As + (wm * 32 + (lane & 31)) * LDA + (lane >> 5);
+  const float* bp = Bs + (lane >> 5) * LDB + wn * (BN / WN) + (lane & 31);
+  auto mfma_tile = [&]() {
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const float a = ap[kk];
-      const float b0 = bp[kk * LDB], b1 = bp[kk * LDB + 32];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc[1], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB + 32 * j], acc[j], 0, 0, 0);
     }
-    __syncthreads();
+  };
+
+  if (avec && bmode != 0) {
+    const float* arow[PASSES];
+#pragma unroll
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const long long off = rowA[(t >> 3) + 32 * pass];
+      arow[pass] = off >= 0 ? P.A + off : nullptr;
+    }
+    const int kq = (t & 7) * 4;
+    float4 ra[PASSES];
+    BRegs rb;
+    auto gload = [&](int k0) {
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        ra[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arow[pass] && k0 + kq < P.K) ra[pass] = *reinterpret_cast<const float4*>(arow[pass] + k0 + kq);
+      }
+      load_b_regs(P, bmode, k0, n0, rb);
+    };
+    gload(0);
+    for (int k0 = 0; k0 < P.K; k0 += BK) {
+#pragma unroll
+      for (int pass = 0; pass < PASSES; ++pass) {
+        float* d = As + ((t >> 3) + 32 * pass) * LDA + kq;
+        d[0] = ra[pass].x; d[1] = ra[pass].y; d[2] = ra[pass].z; d[3] = ra[pass].w;
+      }
+      store_b_regs(bmode, rb, Bs);
+      __syncthreads();
+      if (k0 + BK < P.K) gload(k0 + BK);
+      mfma_tile();
+      __syncthreads();
+    }
+  } else {
+    const long long off = rowA[t / TPR];
+    const float* arow = off >= 0 ? P.A + off : nullptr;
+    const int kb = (t % TPR) * KSEG;
+    for (int k0 = 0; k0 < P.K; k0 += BK) {
+      float* d = As + (t / TPR) * LDA + kb;
+#pragma unroll
+      for (int j = 0; j < KSEG; ++j) {
+        float v = 0.f;
+        if (arow && k0 + kb + j < P.K) v = arow[(int64_t)(k0 + kb + j) * P.a_k];
+        d[j] = v;
+      }
+      if (bmode != 0) {
+        BRegs rb;
+        load_b_regs(P, bmode, k0, n0, rb);
+        store_b_regs(bmode, rb, Bs);
+      } else {
+        stage_b_scalar(P, k0, n0, Bs);
+      }
+      __syncthreads();
+      mfma_tile();
+      __syncthreads();
+    }
   }
-  epilogue(P, acc, row0, n0);
+  store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
+}
+
+// ---------------------------------------------------------------------------------------
+// small-K forward (K <= 64, A k-contiguous, B n-contiguous): A tile resident, walk column tiles
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch* __restrict__ gb) {
+  constexpr int BM_ = 128;
+  __shared__ float As[BM_ * SK_LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[SK_KMAX * LDB];
+  __shared__ long long rowA[BM_];
+  __shared__ long long rowC[BM_];
+  __shared__ int gbs[GB_WORDS];
+  STAMP_DECL
+  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  STAMP(0);
+  const e3k_gemm_problem& P = bp_.P;
+  const int local = bp_.local, ct = bp_.aux;
+  const int M = P.M1 * P.M2, K = P.K;
+  const int tiles_n = (P.N + BN - 1) / BN;
+  const int col_groups = (tiles_n + ct - 1) / ct;
+  const int row0 = (local / col_groups) * BM_;
+  const int tile_beg = (local % col_groups) * ct;
+  const int tile_end = (tile_beg + ct < tiles_n) ? tile_beg + ct : tiles_n;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int kpad = (K + 3) & ~3;  // K % 4 == 0 is a precondition of this kernel (float4 rows)
+
+  fill_row_tables<BM_>(P, row0, M, rowA, rowC);
+  __syncthreads();
+  // ---- A tile: 2 threads per row, each up to 8 float4
+  {
+    const long long off = rowA[t >> 1];
+    const float* arow = off >= 0 ? P.A + off : nullptr;
+    float* d = As + (t >> 1) * SK_LDA;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = ((t & 1) * 8 + j) * 4;
+      if (k < kpad) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (arow && k < K) v = *reinterpret_cast<const float4*>(arow + k);
+        d[k] = v.x; d[k + 1] = v.y; d[k + 2] = v.z; d[k + 3] = v.w;
+      }
+    }
+  }
+  // ---- B tile registers: K x 64 floats = up to 4 float4 per thread
+  float4 rb[4];
+  auto gload_b = [&](int n0) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int k = (t >> 4) + 16 * pass, nq = (t & 15) * 4;
+      rb[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (k < K && n0 + nq < P.N) rb[pass] = *reinterpret_cast<const float4*>(P.B + (int64_t)k * P.b_k + (n0 + nq));
+    }
+  };
+  const float* ap = As + (w * 32 + (lane & 31)) * SK_LDA + (lane >> 5);
+  const float* bp = Bs + (lane >> 5) * LDB + (lane & 31);
+  gload_b(tile_beg * BN);
+  STAMP(1);
+  for (int tile = tile_beg; tile < tile_end; ++tile) {
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int k = (t >> 4) + 16 * pass, nq = (t & 15) * 4;
+      if (k < kpad) *reinterpret_cast<float4*>(Bs + k * LDB + nq) = rb[pass];
+    }
+    STAMP(2);
+    __syncthreads();
+    STAMP(3);
+    if (tile + 1 < tile_end) gload_b((tile + 1) * BN);
+    f32x16 acc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    int kk = 0;
+    for (; kk + 16 <= kpad; kk += 16) {  // 16 MFMAs per trip, all fragment reads issued up front
+      float a[8], b0[8], b1[8];
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        a[s] = ap[kk + 2 * s];
+        b0[s] = bp[(kk + 2 * s) * LDB];
+        b1[s] = bp[(kk + 2 * s) * LDB + 32];
+      }
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc[1], 0, 0, 0);
+      }
+    }
+    for (; kk < kpad; kk += 2) {
+      const float a = ap[kk];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB + 32], acc[1], 0, 0, 0);
+    }
+    STAMP(4);
+    // ---- epilogue through LDS: the MFMA layout gives a lane one column (4-byte stores, 2 x 128 B per
+    // wave-instruction: store-issue bound, measured 13k cycles per tile vs 8k for the MFMAs); staged
+    // through the (now idle) B tile each lane stores 16 B and a wave-instruction covers 8 rows x 128 B.
+    __syncthreads();  // every wave is done reading Bs
+    {
+      float* cs = Bs + w * 1024;  // per-wave 32 x 32 staging
+      const int rsub = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cs[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[j][i];
+        // same wave wrote and reads: LDS ops of one wave complete in order, the compiler waits on lgkmcnt
+        const int n = tile * BN + 32 * j + c4;
+        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (P.bias && n < P.N) bias4 = *reinterpret_cast<const float4*>(P.bias + n);
+#pragma unroll
+        for (int rb = 0; rb < 4; ++rb) {
+          const int r = rb * 8 + rsub;
+          const float4 v = *reinterpret_cast<const float4*>(cs + r * 32 + c4);
+          const long long off = rowC[w * 32 + r];
+          if (off >= 0 && n < P.N) {
+            float4* dst = reinterpret_cast<float4*>(P.C + off + n);
+            float4 o = make_float4(fmaf(P.alpha, v.x, bias4.x), fmaf(P.alpha, v.y, bias4.y), fmaf(P.alpha, v.z, bias4.z),
+                                   fmaf(P.alpha, v.w, bias4.w));
+            if (P.accumulate) {
+              const float4 old = *dst;
+              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+            }
+            *dst = o;
+          }
+        }
+      }
+    }
+    STAMP(5);
+    __syncthreads();
+    STAMP(6);
+  }
+  STAMP_FLUSH();
 }
 
 // ---------------------------------------------------------------------------------------
 // outer-mode forward:  Aeff[(r1,r2), u*V+v] = X[(r1,r2),u] * attrs[r1,v]
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
-  __shared__ float Xs[BM * LDX];
-  __shared__ float Vs[BM * LDV];
+__global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch* __restrict__ gb) {
+  constexpr int BM_ = 128;
+  __shared__ float Xs[BM_ * LDX];
+  __shared__ float Vs[BM_ * LDV];
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
-  int pi, local;
-  find_problem(gb, blockIdx.x, pi, local);
-  const e3k_gemm_problem& P = gb.p[pi];
-  const int flags = gb.flags[pi];
+  __shared__ long long rowA[BM_];
+  __shared__ long long rowC[BM_];
+  __shared__ int gbs[GB_WORDS];
+  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const e3k_gemm_problem& P = bp_.P;
+  const int flags = bp_.flags, local = bp_.local;
   const int bmode = (flags >> 1) & 3;
   const int M = P.M1 * P.M2, V = P.V, U = P.K / P.V;
   const int tiles_n = (P.N + BN - 1) / BN;
-  const int row0 = (local / tiles_n) * BM, n0 = (local % tiles_n) * BN;
+  const int row0 = (local / tiles_n) * BM_, n0 = (local % tiles_n) * BN;
   const int t = threadIdx.x, lane = t & 63, wr = t >> 6;
 
   f32x16 acc[2];
@@ -209,6 +493,7 @@ __global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+  fill_row_tables<BM_>(P, row0, M, rowA, rowC);
   // attrs tile: row r -> attrs[r1(r), 0..V)
   {
     const int r = t >> 1, R = row0 + r;
@@ -223,36 +508,43 @@ __global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
       for (int j = 0; j < 16; ++j) Vs[r * LDV + vb + j] = 0.f;
     }
   }
-  const float* xrow = nullptr;
-  {
-    const int R = row0 + (t >> 1);
-    if (R < M) {
-      const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-      xrow = P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2;
-    }
-  }
+  __syncthreads();
+  const long long xoff = rowA[t >> 1];
+  const float* xrow = xoff >= 0 ? P.A + xoff : nullptr;
   const float* xp = Xs + (wr * 32 + (lane & 31)) * LDX;
   const float* vp = Vs + (wr * 32 + (lane & 31)) * LDV;
   const float* bp = Bs + (lane >> 5) * LDB + (lane & 31);
 
   for (int u0 = 0; u0 < U; u0 += XU) {
-    __syncthreads();  // previous super-step finished reading Xs
     {
+      // (the trailing barrier of the previous super-step guarantees nobody still reads Xs)
       const int ub = (t & 1) * 32;
       float* d = Xs + (t >> 1) * LDX + ub;
+      if (xrow && P.a_k == 1 && u0 + ub + 32 <= U && ((reinterpret_cast<uintptr_t>(xrow + u0 + ub) & 15) == 0)) {
+#pragma unroll
+        for (int j = 0; j < 32; j += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(xrow + u0 + ub + j);
+          d[j] = v.x; d[j + 1] = v.y; d[j + 2] = v.z; d[j + 3] = v.w;
+        }
+      } else {
 #pragma unroll 8
-      for (int j = 0; j < 32; ++j) {
-        float v = 0.f;
-        if (xrow && u0 + ub + j < U) v = xrow[(int64_t)(u0 + ub + j) * P.a_k];
-        d[j] = v;
+        for (int j = 0; j < 32; ++j) {
+          float v = 0.f;
+          if (xrow && u0 + ub + j < U) v = xrow[(int64_t)(u0 + ub + j) * P.a_k];
+          d[j] = v;
+        }
       }
     }
     const int uend = (u0 + XU < U) ? u0 + XU : U;
     const int kbeg = u0 * V, kend = uend * V;
+    BRegs rb;
+    if (bmode != 0) load_b_regs(P, bmode, kbeg, n0, rb);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      // rows of B beyond kend belong to the next super-step: their A operand is forced to zero below
+      if (bmode != 0) store_b_regs(bmode, rb, Bs);
+      else stage_b_scalar(P, k0, n0, Bs);
       __syncthreads();
-      stage_b(P, bmode, k0, n0, Bs);  // rows >= K are zero-filled; rows in [kend, K) belong to the next super-step
-      __syncthreads();
+      if (bmode != 0 && k0 + BK < kend) load_b_regs(P, bmode, k0 + BK, n0, rb);
       int kg = k0 + (lane >> 5);
       int u = kg / V, v = kg - u * V;
       u -= u0;
@@ -270,29 +562,51 @@ __global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
           ++u;
         }
       }
+      __syncthreads();
     }
   }
-  epilogue(P, acc, row0, n0);
+  store_acc<2>(P, acc, rowC, wr * 32, n0);
 }
 
 // ---------------------------------------------------------------------------------------
 // wgrad:  B[k, n] += alpha * sum_rows Aeff[row, k] * G[row, n]      (G passed in P.C)
 // ---------------------------------------------------------------------------------------
-constexpr int WK = 64, WN = 64, WR = 64;  // output tile 64x64, 64-row chunks
-constexpr int LDWA = WK + 4, LDWG = WN + 4;
+constexpr int WK = 64, WR = 64;  // output tile 64 k x (64*TN) n, 64-row chunks
+constexpr int LDWA = WK + 4;
 
-template <bool OUTER>
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
+// a row cursor that advances by WR rows per iteration without integer division
+struct RowCursor {
+  int R, r1, r2;
+  __device__ __forceinline__ void init(int row, int M2) {
+    R = row;
+    r1 = row / M2;
+    r2 = row - r1 * M2;
+  }
+  __device__ __forceinline__ void advance(int q, int rem, int M2) {
+    R += WR;
+    r1 += q;
+    r2 += rem;
+    if (r2 >= M2) {
+      r2 -= M2;
+      ++r1;
+    }
+  }
+};
+
+template <bool OUTER, int TN>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch* __restrict__ gb) {
+  constexpr int WN = 64 * TN;
+  constexpr int LDWG = WN + 4;
   __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
   __shared__ __attribute__((aligned(16))) float Gs[WR * LDWG];
   __shared__ float Vs[OUTER ? WR * LDV : 1];
-  int pi, local;
-  find_problem(gb, blockIdx.x, pi, local);
-  const e3k_gemm_problem& P = gb.p[pi];
-  const int flags = gb.flags[pi];
-  const int M = P.M1 * P.M2;
+  __shared__ int gbs[GB_WORDS];
+  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const e3k_gemm_problem& P = bp_.P;
+  const int flags = bp_.flags, local = bp_.local;
+  const int M = P.M1 * P.M2, M2 = P.M2;
   const int tiles_k = (P.K + WK - 1) / WK, tiles_n = (P.N + WN - 1) / WN;
-  const int splits = gb.splits[pi];
+  const int splits = bp_.aux;
   const int tile = local % (tiles_k * tiles_n), split = local / (tiles_k * tiles_n);
   const int k0 = (tile / tiles_n) * WK, n0 = (tile % tiles_n) * WN;
   const int chunk_rows = ((M + splits - 1) / splits + WR - 1) / WR * WR;
@@ -300,120 +614,155 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
   const int rend = (rbeg + chunk_rows < M) ? rbeg + chunk_rows : M;
   if (rbeg >= M) return;  // block-uniform: this split has no rows
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int wk = wv >> 1, wn = wv & 1;
+  const int wk = wv >> 1, wn = wv & 1;  // wave = 32 k x (32*TN) n
+  const int q64 = WR / M2, rem64 = WR - q64 * M2;
 
-  f32x16 acc;
+  f32x16 acc[TN];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
   const bool avec = flags & 1;
   const bool gvec = flags & 8;
-  // outer mode: this lane's k index -> (u, v), fixed for the whole loop
-  int V = 1, ulo = 0, uw = 0, lu = 0, lv = 0;
-  bool kvalid = true;
-  if constexpr (OUTER) {
-    V = P.V;
-    ulo = k0 / V;
-    const int klast = (k0 + WK - 1 < P.K - 1) ? k0 + WK - 1 : P.K - 1;
-    uw = klast / V - ulo + 1;  // <= WK/2 + 1 < LDWA
-    const int ki = k0 + wk * 32 + (lane & 31);
-    kvalid = ki < P.K;
-    lu = kvalid ? ki / V - ulo : 0;
-    lv = kvalid ? ki % V : 0;
-  }
+  const float* gp = Gs + (lane >> 5) * LDWG + wn * (32 * TN) + (lane & 31);
 
-  for (int r0 = rbeg; r0 < rend; r0 += WR) {
-    // ---- stage the operand chunk (rows r0 .. r0+63)
-    if constexpr (!OUTER) {
-      if (avec) {
+  if constexpr (!OUTER) {
+    if (avec && gvec) {
+      // fast path: both operands by 16-byte loads, one chunk ahead
+      RowCursor cur[4];
+#pragma unroll
+      for (int pass = 0; pass < 4; ++pass) cur[pass].init(rbeg + (t >> 4) + 16 * pass, M2);
+      const int cq = (t & 15) * 4;
+      float4 ra[4], rg[4 * TN];
+      auto gload = [&]() {
 #pragma unroll
         for (int pass = 0; pass < 4; ++pass) {
-          const int r = (t >> 4) + 16 * pass, kq = (t & 15) * 4, R = r0 + r;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (R < rend && k0 + kq < P.K) {
-            const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-            v = *reinterpret_cast<const float4*>(P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2 + k0 + kq);
+          ra[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) rg[pass * TN + j] = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (cur[pass].R < rend) {
+            if (k0 + cq < P.K)
+              ra[pass] = *reinterpret_cast<const float4*>(P.A + (int64_t)cur[pass].r1 * P.a_r1 + (int64_t)cur[pass].r2 * P.a_r2 + k0 + cq);
+            const float* grow = P.C + (int64_t)cur[pass].r1 * P.c_r1 + (int64_t)cur[pass].r2 * P.c_r2 + n0 + cq;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              if (n0 + cq + 64 * j < P.N) rg[pass * TN + j] = *reinterpret_cast<const float4*>(grow + 64 * j);
           }
-          *reinterpret_cast<float4*>(As + r * LDWA + kq) = v;
+          cur[pass].advance(q64, rem64, M2);
         }
-      } else {
-        const int r = t >> 2, kb = (t & 3) * 16, R = r0 + r;
-        const float* src = nullptr;
-        if (R < rend) {
-          const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-          src = P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2;
+      };
+      const float* ap = As + (lane >> 5) * LDWA + wk * 32 + (lane & 31);
+      gload();
+      for (int r0 = rbeg; r0 < rend; r0 += WR) {
+#pragma unroll
+        for (int pass = 0; pass < 4; ++pass) {
+          const int r = (t >> 4) + 16 * pass;
+          *reinterpret_cast<float4*>(As + r * LDWA + cq) = ra[pass];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) *reinterpret_cast<float4*>(Gs + r * LDWG + cq + 64 * j) = rg[pass * TN + j];
         }
+        __syncthreads();
+        if (r0 + WR < rend) gload();
+#pragma unroll 8
+        for (int rr = 0; rr < WR; rr += 2) {
+          const float a = ap[rr * LDWA];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[rr * LDWG + 32 * j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
+      }
+    } else {
+      RowCursor cur;
+      cur.init(rbeg + (t >> 2), M2);
+      const int cb = (t & 3) * 16;
+      const float* ap = As + (lane >> 5) * LDWA + wk * 32 + (lane & 31);
+      for (int r0 = rbeg; r0 < rend; r0 += WR) {
+        const bool ok = cur.R < rend;
+        const float* sa = P.A + (int64_t)cur.r1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
+        const float* sg = P.C + (int64_t)cur.r1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          float v = 0.f;
-          if (src && k0 + kb + j < P.K) v = src[(int64_t)(k0 + kb + j) * P.a_k];
-          As[r * LDWA + kb + j] = v;
+          float va = 0.f;
+          if (ok && k0 + cb + j < P.K) va = sa[(int64_t)(k0 + cb + j) * P.a_k];
+          As[(t >> 2) * LDWA + cb + j] = va;
         }
-      }
-    } else {
-      // X columns ulo .. ulo+uw-1 and the attrs row of each staged row
-      const int r = t >> 2, R = r0 + r;
-      const float* src = nullptr;
-      const float* asrc = nullptr;
-      if (R < rend) {
-        const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-        src = P.A + (int64_t)r1 * P.a_r1 + (int64_t)r2 * P.a_r2;
-        asrc = P.A2 + (int64_t)r1 * P.a2_r1;
-      }
-      for (int j = (t & 3); j < uw; j += 4) As[r * LDWA + j] = src ? src[(int64_t)(ulo + j) * P.a_k] : 0.f;
-      for (int j = (t & 3); j < V; j += 4) Vs[r * LDV + j] = asrc ? asrc[j] : 0.f;
-    }
-    if (gvec) {
 #pragma unroll
-      for (int pass = 0; pass < 4; ++pass) {
-        const int r = (t >> 4) + 16 * pass, nq = (t & 15) * 4, R = r0 + r;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (R < rend && n0 + nq < P.N) {
-          const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-          v = *reinterpret_cast<const float4*>(P.C + (int64_t)r1 * P.c_r1 + (int64_t)r2 * P.c_r2 + n0 + nq);
+        for (int j = 0; j < 16 * TN; ++j) {
+          float vg = 0.f;
+          const int c = (t & 3) * 16 * TN + j;
+          if (ok && n0 + c < P.N) vg = sg[(int64_t)(n0 + c) * P.c_n];
+          Gs[(t >> 2) * LDWG + c] = vg;
         }
-        *reinterpret_cast<float4*>(Gs + r * LDWG + nq) = v;
-      }
-    } else {
-      const int r = t >> 2, nb = (t & 3) * 16, R = r0 + r;
-      const float* src = nullptr;
-      if (R < rend) {
-        const int r1 = R / P.M2, r2 = R - r1 * P.M2;
-        src = P.C + (int64_t)r1 * P.c_r1 + (int64_t)r2 * P.c_r2;
-      }
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        float v = 0.f;
-        if (src && n0 + nb + j < P.N) v = src[(int64_t)(n0 + nb + j) * P.c_n];
-        Gs[r * LDWG + nb + j] = v;
-      }
-    }
-    __syncthreads();
-    const float* gp = Gs + (lane >> 5) * LDWG + wn * 32 + (lane & 31);
-    if constexpr (!OUTER) {
-      const float* ap = As + (lane >> 5) * LDWA + wk * 32 + (lane & 31);
+        cur.advance(q64, rem64, M2);
+        __syncthreads();
 #pragma unroll 8
-      for (int rr = 0; rr < WR; rr += 2) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[rr * LDWA], gp[rr * LDWG], acc, 0, 0, 0);
+        for (int rr = 0; rr < WR; rr += 2) {
+          const float a = ap[rr * LDWA];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[rr * LDWG + 32 * j], acc[j], 0, 0, 0);
+        }
+        __syncthreads();
       }
-    } else {
-      const float* ap = As + (lane >> 5) * LDWA + lu;
-      const float* vp = Vs + (lane >> 5) * LDV + lv;
+    }
+  } else {
+    // outer mode: this lane's k index -> (u, v), fixed for the whole loop
+    const int V = P.V;
+    const int ulo = k0 / V;
+    const int klast = (k0 + WK - 1 < P.K - 1) ? k0 + WK - 1 : P.K - 1;
+    const int uw = klast / V - ulo + 1;  // <= WK/2 + 1 < LDWA
+    const int ki = k0 + wk * 32 + (lane & 31);
+    const bool kvalid = ki < P.K;
+    const int lu = kvalid ? ki / V - ulo : 0;
+    const int lv = kvalid ? ki % V : 0;
+    RowCursor cur;
+    cur.init(rbeg + (t >> 2), M2);
+    const float* ap = As + (lane >> 5) * LDWA + lu;
+    const float* vp = Vs + (lane >> 5) * LDV + lv;
+    for (int r0 = rbeg; r0 < rend; r0 += WR) {
+      const bool ok = cur.R < rend;
+      const float* sx = P.A + (int64_t)cur.r1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
+      const float* sv = P.A2 + (int64_t)cur.r1 * P.a2_r1;
+      const float* sg = P.C + (int64_t)cur.r1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
+      for (int j = (t & 3); j < uw; j += 4) As[(t >> 2) * LDWA + j] = ok ? sx[(int64_t)(ulo + j) * P.a_k] : 0.f;
+      for (int j = (t & 3); j < V; j += 4) Vs[(t >> 2) * LDV + j] = ok ? sv[j] : 0.f;
+      const int cb = (t & 3) * 16 * TN;
+      if (gvec) {
+#pragma unroll
+        for (int j = 0; j < 16 * TN; j += 4) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (ok && n0 + cb + j < P.N) v = *reinterpret_cast<const float4*>(sg + n0 + cb + j);
+          *reinterpret_cast<float4*>(Gs + (t >> 2) * LDWG + cb + j) = v;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 16 * TN; ++j) {
+          float vg = 0.f;
+          if (ok && n0 + cb + j < P.N) vg = sg[(int64_t)(n0 + cb + j) * P.c_n];
+          Gs[(t >> 2) * LDWG + cb + j] = vg;
+        }
+      }
+      cur.advance(q64, rem64, M2);
+      __syncthreads();
 #pragma unroll 8
       for (int rr = 0; rr < WR; rr += 2) {
         const float a = kvalid ? ap[rr * LDWA] * vp[rr * LDV] : 0.f;
-        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[rr * LDWG], acc, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[rr * LDWG + 32 * j], acc[j], 0, 0, 0);
       }
+      __syncthreads();
     }
-    __syncthreads();
   }
   // ---- atomic accumulate into B
-  const int n = n0 + wn * 32 + (lane & 31);
-  if (n < P.N) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int k = k0 + wk * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-      if (k < P.K) atomicAdd(const_cast<float*>(P.B) + (int64_t)k * P.b_k + (int64_t)n * P.b_n, P.alpha * acc[i]);
+  for (int j = 0; j < TN; ++j) {
+    const int n = n0 + wn * (32 * TN) + 32 * j + (lane & 31);
+    if (n < P.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + wk * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (k < P.K) atomicAdd(const_cast<float*>(P.B) + (int64_t)k * P.b_k + (int64_t)n * P.b_n, P.alpha * acc[j][i]);
+      }
     }
   }
 }
@@ -480,6 +829,32 @@ __global__ __launch_bounds__(256) void fctp_reduce_kernel(const float* __restric
 namespace {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+// device ring of descriptor slots, one ring per device; a slot is reused after RING launches,
+// far beyond the depth of work a stream can have in flight
+constexpr int RING = 4096;
+struct Ring {
+  e3k::GemmBatch* base = nullptr;
+  unsigned next = 0;
+};
+Ring g_rings[16];
+
+e3k::GemmBatch* next_slot() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  Ring& r = g_rings[dev];
+  if (!r.base && hipMalloc(&r.base, sizeof(e3k::GemmBatch) * RING) != hipSuccess) return nullptr;
+  return r.base + (r.next++ % RING);
+}
+
+template <class K>
+int launch_batch(K kernel, const e3k::GemmBatch& gb, int blocks, hipStream_t st) {
+  e3k::GemmBatch* slot = next_slot();
+  if (!slot) return E3K_ERR_LAUNCH;
+  hipLaunchKernelGGL(e3k::upload_batch_kernel, dim3(1), dim3(320), 0, st, gb, slot);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, (const e3k::GemmBatch*)slot);
+  return E3K_OK;
+}
+
 int validate(const e3k_gemm_problem& P, bool wgrad) {
   if (P.M1 < 0 || P.M2 <= 0 || P.N <= 0 || P.K <= 0) return E3K_ERR_INVALID;
   if (!P.A || !P.B || !P.C) return E3K_ERR_INVALID;
@@ -489,43 +864,101 @@ int validate(const e3k_gemm_problem& P, bool wgrad) {
   return E3K_OK;
 }
 
-int a_flags(const e3k_gemm_problem& P) {
-  int f = 0;
-  if (P.V == 0 && P.a_k == 1 && P.K % 4 == 0 && P.a_r1 % 4 == 0 && P.a_r2 % 4 == 0 && aligned16(P.A)) f |= 1;
-  return f;
+bool a_vec(const e3k_gemm_problem& P) {
+  return P.V == 0 && P.a_k == 1 && P.K % 4 == 0 && P.a_r1 % 4 == 0 && (P.M2 == 1 || P.a_r2 % 4 == 0) && aligned16(P.A);
 }
+bool c_vec(const e3k_gemm_problem& P) {
+  return P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C) &&
+         (!P.bias || aligned16(P.bias));
+}
+int b_mode(const e3k_gemm_problem& P) {
+  if (P.b_n == 1 && P.N % 4 == 0 && P.b_k % 4 == 0 && aligned16(P.B)) return 1;
+  if (P.b_k == 1 && P.K % 4 == 0 && P.b_n % 4 == 0 && aligned16(P.B)) return 2;
+  return 0;
+}
+
+enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_KINDS };
+
+struct Batcher {
+  e3k::GemmBatch gb{};
+  int blocks = 0;
+  void reset() {
+    gb = e3k::GemmBatch{};
+    blocks = 0;
+  }
+};
 }  // namespace
 
 extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
+  if (n_problems > 64) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  for (int mode = 0; mode < 2; ++mode) {  // 0: plain, 1: outer
-    int i = 0;
-    while (i < n_problems) {
-      e3k::GemmBatch gb{};
-      int tiles = 0;
-      while (i < n_problems && gb.n < e3k::GEMM_MAXP) {
-        const e3k_gemm_problem& P = problems[i];
-        ++i;
-        const int rc = validate(P, false);
-        if (rc != E3K_OK) return rc;
-        if ((P.V > 0) != (mode == 1)) continue;
-        const int64_t M = (int64_t)P.M1 * P.M2;
-        if (M == 0) continue;
-        int f = a_flags(P);
-        if (P.b_n == 1 && P.N % 4 == 0 && P.b_k % 4 == 0 && aligned16(P.B)) f |= 1 << 1;
-        else if (P.b_k == 1 && P.K % 4 == 0 && P.b_n % 4 == 0 && aligned16(P.B)) f |= 2 << 1;
-        gb.p[gb.n] = P;
-        gb.flags[gb.n] = f;
-        gb.tile_start[gb.n] = tiles;
-        tiles += (int)((M + e3k::BM - 1) / e3k::BM) * ((P.N + e3k::BN - 1) / e3k::BN);
-        ++gb.n;
-      }
-      gb.tile_start[gb.n] = tiles;
-      if (!tiles) continue;
-      if (mode == 0) hipLaunchKernelGGL(e3k::gemm_kernel, dim3(tiles), dim3(256), 0, st, gb);
-      else hipLaunchKernelGGL(e3k::gemm_outer_kernel, dim3(tiles), dim3(256), 0, st, gb);
+  int kind[64];
+  int64_t plain_tiles128 = 0;
+  for (int i = 0; i < n_problems; ++i) {
+    const e3k_gemm_problem& P = problems[i];
+    const int rc = validate(P, false);
+    if (rc != E3K_OK) return rc;
+    const int64_t M = (int64_t)P.M1 * P.M2;
+    if (P.V > 0) kind[i] = FWD_OUTER;
+    else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= 1024) kind[i] = FWD_SMALLK;
+    else {
+      kind[i] = FWD_PLAIN;
+      plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
     }
+  }
+  // launches that would leave most of the 256 CUs without a third workgroup use 64-row tiles
+  const bool small_grid = plain_tiles128 < 3 * 256;
+  for (int k = 0; k < FWD_KINDS; ++k) {
+    Batcher b;
+    auto flush = [&]() -> int {
+      if (!b.blocks) {
+        b.reset();
+        return E3K_OK;
+      }
+      b.gb.tile_start[b.gb.n] = b.blocks;
+      int rc = E3K_OK;
+      switch (k) {
+        case FWD_PLAIN:
+          rc = small_grid ? launch_batch(e3k::gemm_kernel<2>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4>, b.gb, b.blocks, st);
+          break;
+        case FWD_SMALLK: rc = launch_batch(e3k::gemm_smallk_kernel, b.gb, b.blocks, st); break;
+        default: rc = launch_batch(e3k::gemm_outer_kernel, b.gb, b.blocks, st); break;
+      }
+      b.reset();
+      return rc;
+    };
+    for (int i = 0; i < n_problems; ++i) {
+      if (kind[i] != k) continue;
+      const e3k_gemm_problem& P = problems[i];
+      const int64_t M = (int64_t)P.M1 * P.M2;
+      if (M == 0) continue;
+      const int tiles_n = (P.N + e3k::BN - 1) / e3k::BN;
+      int64_t blocks;
+      int aux = 0;
+      if (k == FWD_SMALLK) {
+        static const int sk_ct = getenv("E3K_SK_CT") ? atoi(getenv("E3K_SK_CT")) : e3k::SK_CT;
+        aux = tiles_n < sk_ct ? tiles_n : sk_ct;
+        blocks = ((M + 127) / 128) * ((tiles_n + aux - 1) / aux);
+      } else if (k == FWD_PLAIN && small_grid) {
+        blocks = ((M + 63) / 64) * tiles_n;
+      } else {
+        blocks = ((M + 127) / 128) * tiles_n;
+      }
+      if (b.blocks + blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
+      e3k::GemmBatch& gb = b.gb;
+      gb.p[gb.n] = P;
+      gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1);
+      gb.aux[gb.n] = aux;
+      gb.tile_start[gb.n] = b.blocks;
+      b.blocks += (int)blocks;
+      if (++gb.n == e3k::GEMM_MAXP) {
+        const int rc = flush();
+        if (rc != E3K_OK) return rc;
+      }
+    }
+    const int rc = flush();
+    if (rc != E3K_OK) return rc;
   }
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -534,42 +967,67 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
 extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  for (int mode = 0; mode < 2; ++mode) {
-    int i = 0;
-    while (i < n_problems) {
-      e3k::GemmBatch gb{};
-      int blocks = 0;
-      while (i < n_problems && gb.n < e3k::GEMM_MAXP) {
-        const e3k_gemm_problem& P = problems[i];
-        ++i;
-        const int rc = validate(P, true);
-        if (rc != E3K_OK) return rc;
-        if ((P.V > 0) != (mode == 1)) continue;
-        const int64_t M = (int64_t)P.M1 * P.M2;
-        if (M == 0) continue;
-        int f = a_flags(P);
-        if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && P.c_r2 % 4 == 0 && aligned16(P.C)) f |= 8;
-        const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + e3k::WN - 1) / e3k::WN);
-        int64_t splits = (1024 + tiles - 1) / tiles;
-        const int64_t max_splits = (M + 4 * e3k::WR - 1) / (4 * e3k::WR);
-        if (splits > max_splits) splits = max_splits;
-        if (splits < 1) splits = 1;
-        gb.p[gb.n] = P;
-        gb.flags[gb.n] = f;
-        gb.splits[gb.n] = (int)splits;
-        gb.tile_start[gb.n] = blocks;
-        blocks += tiles * (int)splits;
-        ++gb.n;
+  for (int i = 0; i < n_problems; ++i) {
+    const int rc = validate(problems[i], true);
+    if (rc != E3K_OK) return rc;
+  }
+  for (int mode = 0; mode < 4; ++mode) {  // (outer?, 128-wide output tile?)
+    const bool outer = mode & 1;
+    const int tn = (mode & 2) ? 2 : 1;
+    Batcher b;
+    auto flush = [&]() -> int {
+      if (!b.blocks) {
+        b.reset();
+        return E3K_OK;
       }
-      gb.tile_start[gb.n] = blocks;
-      if (!blocks) continue;
-      if (mode == 0) hipLaunchKernelGGL(e3k::gemm_wgrad_kernel<false>, dim3(blocks), dim3(256), 0, st, gb);
-      else hipLaunchKernelGGL(e3k::gemm_wgrad_kernel<true>, dim3(blocks), dim3(256), 0, st, gb);
+      b.gb.tile_start[b.gb.n] = b.blocks;
+      int rc;
+      if (!outer) rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<false, 2>, b.gb, b.blocks, st)
+                               : launch_batch(e3k::gemm_wgrad_kernel<false, 1>, b.gb, b.blocks, st);
+      else rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<true, 2>, b.gb, b.blocks, st)
+                        : launch_batch(e3k::gemm_wgrad_kernel<true, 1>, b.gb, b.blocks, st);
+      b.reset();
+      return rc;
+    };
+    for (int i = 0; i < n_problems; ++i) {
+      const e3k_gemm_problem& P = problems[i];
+      if ((P.V > 0) != outer) continue;
+      if ((P.N >= 128 ? 2 : 1) != tn) continue;
+      const int64_t M = (int64_t)P.M1 * P.M2;
+      if (M == 0) continue;
+      int f = a_vec(P) ? 1 : 0;
+      if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C)) f |= 8;
+      const int wn = 64 * tn;
+      const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + wn - 1) / wn);
+      int64_t splits = (1024 + tiles - 1) / tiles;
+      const int64_t max_splits = (M + 4 * e3k::WR - 1) / (4 * e3k::WR);
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+      e3k::GemmBatch& gb = b.gb;
+      gb.p[gb.n] = P;
+      gb.flags[gb.n] = f;
+      gb.aux[gb.n] = (int)splits;
+      gb.tile_start[gb.n] = b.blocks;
+      b.blocks += tiles * (int)splits;
+      if (++gb.n == e3k::GEMM_MAXP) {
+        const int rc = flush();
+        if (rc != E3K_OK) return rc;
+      }
     }
+    const int rc = flush();
+    if (rc != E3K_OK) return rc;
   }
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
+
+#ifdef E3K_STAMPS
+extern "C" int e3k_debug_stamps(unsigned long long* out, int n) {
+  if (hipDeviceSynchronize() != hipSuccess) return E3K_ERR_LAUNCH;
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(e3k::e3k_dbg_buf), sizeof(unsigned long long) * n) != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+#endif
 
 extern "C" int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream) {
   if (rows < 0 || cols <= 0 || !out) return E3K_ERR_INVALID;

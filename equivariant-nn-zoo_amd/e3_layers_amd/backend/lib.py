@@ -15,7 +15,7 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
-LIB_PATH = os.path.join(CSRC_DIR, "libe3k.so")
+LIB_PATH = os.environ.get("E3K_LIB", os.path.join(CSRC_DIR, "libe3k.so"))  # E3K_LIB: debug builds only
 
 TP_MAXQ = 8
 
