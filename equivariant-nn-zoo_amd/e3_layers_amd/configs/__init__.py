@@ -1,4 +1,4 @@
 from .config_dict import ConfigDict
-from . import config_energy, config_energy_force, config_diffusion
+from . import config_energy, config_energy_force, config_diffusion, config_diffusion_CA
 
-__all__ = ["ConfigDict", "config_energy", "config_energy_force", "config_diffusion"]
+__all__ = ["ConfigDict", "config_energy", "config_energy_force", "config_diffusion", "config_diffusion_CA"]

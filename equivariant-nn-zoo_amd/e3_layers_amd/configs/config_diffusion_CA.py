@@ -1,0 +1,73 @@
+"""Residue-level (C-alpha) protein score network — the model tree of
+``e3_layers/configs/config_diffusion_CA.py:66-194`` (BASELINE.json configs[4] names it
+"config_diffusion_protein", which the reference does not register).
+n_dim 64, l_max 2, 8 layers, 32 radial / 32 node-attr channels, avg_num_neighbors 100,
+LayerNormalization on, relative-position encoding of same-chain residue pairs, time encoding.
+Dataset preprocessing (mask/crop, HDF5) is out of scope; ``criteria`` is the edge rule of :58-64.
+"""
+from functools import partial
+
+import torch
+
+from ..data import computeEdgeIndex, computeEdgeVector
+from ..nn import Broadcast, Concat, PointwiseLinear, RadialBasisEncoding, RelativePositionEncoding, symmetricCutoff
+from ..utils import getScaler, insertAfter, replace
+from .config_dict import ConfigDict
+from .layer_configs import featureModel
+
+
+def criteria(data, edge_index):
+    """same chain and |i - j| < 5, or a 2 % random subset (CPU generator, as the reference)."""
+    mask = (data["chain_id"][edge_index[0]] == data["chain_id"][edge_index[1]]).view(-1)
+    mask = torch.logical_and(mask, (edge_index[0] - edge_index[1]).abs() < 5)
+    extra = torch.rand((edge_index.shape[1],)).to(mask.device)
+    return torch.logical_or(mask, extra < 0.02)
+
+
+def get_config(spec="", l_max=2, num_layers=8, n_dim=64):
+    config = ConfigDict()
+    data, model = ConfigDict(), ConfigDict()
+    config.data_config, config.model_config = data, model
+    config.diffusion_keys = {"CA": 3}
+    config.update(dict(learning_rate=2e-3, batch_size=4, grad_acc=4, grad_clid_norm=1.0))
+
+    model.n_dim, model.l_max, model.r_max, model.num_layers = n_dim, l_max, 5.0, num_layers
+    model.edge_radial, model.node_attrs, model.jit = "32x0e", "32x0e", True
+    num_types = 21
+    data.std = 25.83
+    data.scaler = getScaler([("CA", ("shift", "mean")), ("CA", ("scale", 1 / data.std))])
+    data.inverse_scaler = getScaler([("CA", ("scale", data.std))])
+
+    features = "+".join(f"{model.n_dim}x{l}e+{model.n_dim}x{l}o" for l in range(model.l_max + 1))
+    lc = featureModel(n_dim=model.n_dim, l_max=model.l_max, edge_spherical="1x0e+1x1o+1x2e",
+                      node_attrs=model.node_attrs, edge_radial=model.edge_radial, num_types=num_types,
+                      num_layers=model.num_layers, r_max=model.r_max, avg_num_neighbors=100, normalize=True)
+    lc.layers = replace(lc.layers, "edge_vector", ("edge_vector", partial(computeEdgeVector, key="CA")))
+    rel_radial = {"module": RadialBasisEncoding, "r_max": 150, "cutoff": symmetricCutoff, "trainable": True,
+                  "one_over_r": False}
+    relative_position = ("relative_position", {"module": RelativePositionEncoding, "segment": ("1x0e", "chain_id"),
+                                               "id": ("1x0e", "id"), "irreps_out": (model.edge_radial, "rel_pos_embed"),
+                                               "radial_encoding": rel_radial})
+    concat1 = ("concat1", {"module": Concat, "rel_pos": (model.edge_radial, "rel_pos_embed"),
+                           "edge_radial": (model.edge_radial, "edge_radial"),
+                           "irreps_out": (model.edge_radial, "edge_radial")})
+    lc.layers = [relative_position] + list(lc.layers)
+    lc.layers = insertAfter(lc.layers, "radial_basis", concat1)
+    time_encoding = ("time_encoding", {"module": RadialBasisEncoding, "r_max": 1.0, "trainable": True,
+                                       "irreps_in": ("1x0e", "t"), "one_over_r": False,
+                                       "irreps_out": (f"{model.n_dim}x0e", "time_encoding")})
+    lc.layers = insertAfter(lc.layers, "embedding", time_encoding)
+    graph2node = ("graph2node", {"module": Broadcast, "irreps_in": (f"{model.n_dim}x0e", "time_encoding"),
+                                 "irreps_out": (f"{model.n_dim}x0e", "time_encoding"), "to": "node"})
+    lc.layers = insertAfter(lc.layers, "time_encoding", graph2node)
+    concat2 = ("concat2", {"module": Concat, "node_attrs": (model.node_attrs, "node_attrs"),
+                           "time_encoding": (f"{model.n_dim}x0e", "time_encoding"),
+                           "irreps_out": (model.node_attrs, "node_attrs")})
+    lc.layers = insertAfter(lc.layers, "graph2node", concat2)
+    for key in config.diffusion_keys:
+        lc.layers = list(lc.layers) + [(f"score_{key}", {"module": PointwiseLinear,
+                                                         "irreps_in": (features, "node_features"),
+                                                         "irreps_out": ("1x1o", f"score_{key}")})]
+    lc.layers = [("edge_index", partial(computeEdgeIndex, r_max=8.0 / data.std, key="CA", criteria=criteria))] + list(lc.layers)
+    model.update(lc)
+    return config

@@ -62,3 +62,50 @@ def synth_qm9(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max
     """A Batch with pos, species, total_energy, edge_index (cutoff r_max), _n_nodes, _n_edges."""
     lst, attrs = synth_qm9_list(seed, n_mol, shifts, r_max)
     return Batch.from_data_list(lst, dict(attrs))
+
+
+def synth_qm9_diffusion(seed: int, n_mol: int, std: float = 1.4) -> Batch:
+    """Inputs of the small-molecule score network (``e3_layers/configs/config_diffusion.py``):
+    positions scaled by 1/std (:43-44), fully connected graphs (``r_max=9999`` preprocess, :50),
+    a bond type in {0..3} per edge (0 = no bond beyond 1.7 A) and a diffusion time per graph."""
+    lst, attrs = synth_qm9_list(seed, n_mol, None, r_max=None)
+    gen = torch.Generator(device="cpu").manual_seed(seed + 7919)
+    attrs = dict(attrs)
+    attrs["bond_type"] = ("edge", "1x0e")
+    attrs["t"] = ("graph", "1x0e")
+    for s in lst:
+        s["pos"] = s["pos"] / std
+        new, _ = computeEdgeIndex(s, dict(attrs), r_max=9999.0)
+        ei = new["edge_index"]
+        s["edge_index"] = ei
+        d = (s["pos"][ei[0]] - s["pos"][ei[1]]).norm(dim=1) * std
+        bonded = d < 1.7
+        kind = torch.randint(1, 4, (ei.shape[1],), generator=gen)
+        s["bond_type"] = torch.where(bonded, kind, torch.zeros_like(kind)).view(-1, 1).long()
+        s["t"] = torch.rand(1, 1, generator=gen) * (1.0 - 1e-5) + 1e-5
+        s.pop("total_energy")
+    attrs.pop("total_energy")
+    return Batch.from_data_list(lst, attrs)
+
+
+def synth_protein(seed: int, n_prot: int, n_res: int = 384, std: float = 25.83, n_chains: int = 2) -> Batch:
+    """Inputs of the residue-level score network (``config_diffusion_CA``): per protein a C-alpha
+    random walk with 3.8 A steps split into ``n_chains`` chains, residue types in [0, 21), residue
+    index ``id``, ``chain_id``, a diffusion time per graph; CA centred and scaled by 1/std as the
+    config's scaler does.  No edges: the model's first layer (computeEdgeIndex) builds them."""
+    gen = torch.Generator(device="cpu").manual_seed(seed)
+    attrs = {"CA": ("node", "1x1o"), "species": ("node", "1x0e"), "chain_id": ("node", "1x0e"), "id": ("node", "1x0e"),
+             "t": ("graph", "1x0e")}
+    lst = []
+    for _ in range(n_prot):
+        steps = torch.randn(n_res, 3, generator=gen)
+        steps = 3.8 * steps / steps.norm(dim=1, keepdim=True)
+        ca = torch.cumsum(steps, 0)
+        ca = (ca - ca.mean(0, keepdim=True)) / std
+        chain = (torch.arange(n_res) * n_chains // n_res).view(-1, 1)
+        lst.append({"CA": ca.float(), "species": torch.randint(0, 21, (n_res, 1), generator=gen),
+                    "chain_id": chain.long(), "id": torch.arange(n_res).view(-1, 1),
+                    "t": torch.rand(1, 1, generator=gen) * (1.0 - 1e-5) + 1e-5, "_n_nodes": torch.tensor([[n_res]])})
+    b = Batch.from_data_list(lst, attrs)
+    b.attrs.pop("_n_edges", None)
+    return b

@@ -1,0 +1,75 @@
+"""The ~40 lines of VP-SDE arithmetic that drive the diffusion score networks (host-side torch
+plumbing).  Same formulas as ``e3_layers/run/sde_utils.py``:
+``VPSDE.marginal`` (:54-66), ``get_score_fn`` (:176-187), the loss of ``get_sde_loss_fn``
+(:143-171).  The head key is ``score_{key}`` as those functions expect; a model that emits the
+shipped config's plain ``score`` key is mapped onto it.
+"""
+from __future__ import annotations
+
+from typing import Dict, Tuple
+
+import torch
+
+
+class VPSDE:
+    def __init__(self, diffusion_keys: Dict[str, int], beta_min: float = 0.1, beta_max: float = 20.0, N: int = 1000):
+        self.beta_0, self.beta_1, self.N = beta_min, beta_max, N
+        self.irreps = dict(diffusion_keys)
+
+    @property
+    def T(self) -> float:
+        return 1.0
+
+    def log_mean_coeff(self, t: torch.Tensor) -> torch.Tensor:
+        return -0.25 * t ** 2 * (self.beta_1 - self.beta_0) - 0.5 * t * self.beta_0
+
+    def std(self, batch) -> torch.Tensor:
+        t = batch["t"][batch.nodeSegment()]
+        return torch.sqrt(1.0 - torch.exp(2.0 * self.log_mean_coeff(t)))
+
+    def marginal(self, batch, return_std: bool = False, generator=None):
+        """x_t = exp(log_mean) x_0 + std z per diffused key, with the per-graph time broadcast to nodes."""
+        if return_std:
+            return self.std(batch)
+        t = batch["t"][batch.nodeSegment()]
+        lm = self.log_mean_coeff(t)
+        std = torch.sqrt(1.0 - torch.exp(2.0 * lm))
+        zs = {}
+        for key in self.irreps:
+            x = batch[key]
+            z = torch.randn(x.shape, device=x.device, dtype=x.dtype, generator=generator)
+            batch[key] = torch.exp(lm) * x + std * z
+            zs[key] = z
+        return batch, {"zs": zs, "std": std}
+
+
+def get_score_fn(sde: VPSDE, model, train: bool = False):
+    def score_fn(batch):
+        model.train(train)
+        result = model(batch)
+        std = sde.std(batch)
+        for key in sde.irreps:
+            name = f"score_{key}"
+            raw = result[name] if name in result else result["score"]
+            result[name] = -raw / std - batch[key]
+        return result
+
+    return score_fn
+
+
+def sde_loss(sde: VPSDE, model, batch, eps: float = 1e-5, train: bool = True, generator=None) -> Tuple[torch.Tensor, dict]:
+    """mean over graphs/nodes of (score * std + z)^2, t ~ U(eps, 1) per graph."""
+    dev = batch["_n_nodes"].device
+    t = torch.rand(len(batch), device=dev, generator=generator) * (sde.T - eps) + eps
+    pert = batch.clone()
+    pert.attrs["t"] = ("graph", "1x0e")
+    pert["t"] = t
+    pert, misc = sde.marginal(pert, generator=generator)
+    scores = get_score_fn(sde, model, train)(pert)
+    losses = {}
+    for key in sde.irreps:
+        err = torch.square(scores[f"score_{key}"] * misc["std"] + misc["zs"][key])
+        losses[key] = err.reshape(err.shape[0], -1).mean(dim=-1).mean()
+    total = sum(losses.values())
+    losses["total"] = total
+    return total, losses
