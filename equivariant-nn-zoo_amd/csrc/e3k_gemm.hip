@@ -28,10 +28,9 @@
 //                       split over blocks, 64-row chunks staged in natural row-major order (both MFMA
 //                       operands conflict-free), fp32 atomics on the small output.
 //
-// Descriptors: up to 8 problems per launch.  The batch is uploaded once per launch into a device
-// ring by a one-block kernel and every workgroup reads it from there with one coalesced load into
-// LDS, then moves its own problem into scalar registers (a 1.2 KB by-value kernel argument read
-// field by field by 16k workgroups is slower and bloats every wave's prologue).
+// Descriptors: up to 8 problems per launch, passed by value (1.2 KB of kernel arguments); every
+// workgroup copies the batch into LDS with one coalesced read and moves its own problem into
+// scalar registers, instead of re-reading kernel-argument fields all over the kernel.
 #include <cstdlib>
 
 #include "e3k_common.h"
@@ -85,19 +84,13 @@ __device__ unsigned long long e3k_dbg_buf[1 << 20];
 #define STAMP_FLUSH()
 #endif
 
-__global__ void upload_batch_kernel(const GemmBatch gb, GemmBatch* __restrict__ dst) {
-  const int* src = reinterpret_cast<const int*>(&gb);
-  int* d = reinterpret_cast<int*>(dst);
-  for (int i = threadIdx.x; i < GB_WORDS; i += blockDim.x) d[i] = src[i];
-}
-
 struct BlockProblem {
   e3k_gemm_problem P;
   int flags, aux, local;
 };
 
-__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch* gb, int* lds /* GB_WORDS */) {
-  const int* src = reinterpret_cast<const int*>(gb);
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int* lds /* GB_WORDS */) {
+  const int* src = reinterpret_cast<const int*>(&gb);
   for (int i = threadIdx.x; i < GB_WORDS; i += 256) lds[i] = src[i];
   __syncthreads();
   const GemmBatch* b = reinterpret_cast<const GemmBatch*>(lds);
@@ -235,7 +228,7 @@ __device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x1
 // plain forward / dgrad, tile (32*WM) x 64 x 32
 // ---------------------------------------------------------------------------------------
 template <int WM>
-__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch* __restrict__ gb) {
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   constexpr int BM_ = 32 * WM;          // rows per tile
   constexpr int WN = 4 / WM;            // waves along n
   constexpr int NT = (BN / WN) / 32;    // accumulators per wave
@@ -339,7 +332,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch* __restrict__
 // ---------------------------------------------------------------------------------------
 // small-K forward (K <= 64, A k-contiguous, B n-contiguous): A tile resident, walk column tiles
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch* __restrict__ gb) {
+__global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
   constexpr int BM_ = 128;
   __shared__ float As[BM_ * SK_LDA];
   __shared__ __attribute__((aligned(16))) float Bs[SK_KMAX * LDB];
@@ -470,7 +463,7 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch* __res
 // ---------------------------------------------------------------------------------------
 // outer-mode forward:  Aeff[(r1,r2), u*V+v] = X[(r1,r2),u] * attrs[r1,v]
 // ---------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch* __restrict__ gb) {
+__global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
   constexpr int BM_ = 128;
   __shared__ float Xs[BM_ * LDX];
   __shared__ float Vs[BM_ * LDV];
@@ -594,7 +587,7 @@ struct RowCursor {
 };
 
 template <bool OUTER, int TN>
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch* __restrict__ gb) {
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
   constexpr int WN = 64 * TN;
   constexpr int LDWG = WN + 4;
   __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
@@ -829,29 +822,9 @@ __global__ __launch_bounds__(256) void fctp_reduce_kernel(const float* __restric
 namespace {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
-// device ring of descriptor slots, one ring per device; a slot is reused after RING launches,
-// far beyond the depth of work a stream can have in flight
-constexpr int RING = 4096;
-struct Ring {
-  e3k::GemmBatch* base = nullptr;
-  unsigned next = 0;
-};
-Ring g_rings[16];
-
-e3k::GemmBatch* next_slot() {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
-  Ring& r = g_rings[dev];
-  if (!r.base && hipMalloc(&r.base, sizeof(e3k::GemmBatch) * RING) != hipSuccess) return nullptr;
-  return r.base + (r.next++ % RING);
-}
-
 template <class K>
 int launch_batch(K kernel, const e3k::GemmBatch& gb, int blocks, hipStream_t st) {
-  e3k::GemmBatch* slot = next_slot();
-  if (!slot) return E3K_ERR_LAUNCH;
-  hipLaunchKernelGGL(e3k::upload_batch_kernel, dim3(1), dim3(320), 0, st, gb, slot);
-  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, (const e3k::GemmBatch*)slot);
+  hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, gb);
   return E3K_OK;
 }
 

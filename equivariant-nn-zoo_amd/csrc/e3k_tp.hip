@@ -255,24 +255,46 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int d = uniform(a.nbr[e]);
-    YRegs yc;
-    load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
-    const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
-    const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
-    static_for<0, S::NQ>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      constexpr int L2 = S::L2[Q], L3 = S::L3[Q];
-      if (mask & (1u << Q)) {
-        float gk[2 * L3 + 1];
+  if (beg < end) {
+    // software pipeline: the gathers of edge t+1 are in flight while edge t is consumed
+    float gn[S::TOTAL], wn[S::NQ];
+    YRegs yn;
+    auto issue = [&](int t) {
+      const int e = uniform(a.perm[t]);
+      const int d = uniform(a.nbr[e]);
+      load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
+      const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
+      const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
+      static_for<0, S::NQ>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+        if (mask & (1u << Q)) {
 #pragma unroll
-        for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = active ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
-        const float wv = active ? wr[g.w_off[Q]] * g.coeff[Q] : 0.0f;
-        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wv, gx);
-      }
-    });
+          for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
+          wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
+        }
+      });
+    };
+    issue(beg);
+    for (int t = beg; t < end; ++t) {
+      float gc[S::TOTAL], wc[S::NQ];
+      YRegs yc = yn;
+#pragma unroll
+      for (int i = 0; i < S::TOTAL; ++i) gc[i] = gn[i];
+#pragma unroll
+      for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
+      if (t + 1 < end) issue(t + 1);
+      static_for<0, S::NQ>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+        if (mask & (1u << Q)) {
+          float gk[2 * L3 + 1];
+#pragma unroll
+          for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gc[OFF + k];
+          CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wc[Q] * g.coeff[Q], gx);
+        }
+      });
+    }
   }
   if (active) {
     float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off + u;
