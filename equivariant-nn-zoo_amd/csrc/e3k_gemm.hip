@@ -183,7 +183,9 @@ __device__ __forceinline__ void fill_row_tables(const e3k_gemm_problem& P, int r
     const int R = row0 + t;
     long long oa = -1, oc = -1;
     if (R < M) {
-      const int r1 = R / P.M2, r2 = R - r1 * P.M2;
+      int r1 = R / P.M2;
+      const int r2 = R - r1 * P.M2;
+      if (P.row_index) r1 = P.row_index[r1];
       oa = (long long)r1 * P.a_r1 + (long long)r2 * P.a_r2;
       oc = (long long)r1 * P.c_r1 + (long long)r2 * P.c_r2;
     }
@@ -492,7 +494,8 @@ __global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
     const int r = t >> 1, R = row0 + r;
     const int vb = (t & 1) * 16;
     if (R < M) {
-      const int r1 = R / P.M2;
+      int r1 = R / P.M2;
+      if (P.row_index) r1 = P.row_index[r1];
       const float* src = P.A2 + (int64_t)r1 * P.a2_r1;
 #pragma unroll
       for (int j = 0; j < 16; ++j) Vs[r * LDV + vb + j] = (vb + j < V) ? src[vb + j] : 0.f;
@@ -635,9 +638,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) rg[pass * TN + j] = make_float4(0.f, 0.f, 0.f, 0.f);
           if (cur[pass].R < rend) {
+            const int n1 = P.row_index ? P.row_index[cur[pass].r1] : cur[pass].r1;
             if (k0 + cq < P.K)
-              ra[pass] = *reinterpret_cast<const float4*>(P.A + (int64_t)cur[pass].r1 * P.a_r1 + (int64_t)cur[pass].r2 * P.a_r2 + k0 + cq);
-            const float* grow = P.C + (int64_t)cur[pass].r1 * P.c_r1 + (int64_t)cur[pass].r2 * P.c_r2 + n0 + cq;
+              ra[pass] = *reinterpret_cast<const float4*>(P.A + (int64_t)n1 * P.a_r1 + (int64_t)cur[pass].r2 * P.a_r2 + k0 + cq);
+            const float* grow = P.C + (int64_t)n1 * P.c_r1 + (int64_t)cur[pass].r2 * P.c_r2 + n0 + cq;
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               if (n0 + cq + 64 * j < P.N) rg[pass * TN + j] = *reinterpret_cast<const float4*>(grow + 64 * j);
@@ -672,8 +676,9 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
       const float* ap = As + (lane >> 5) * LDWA + wk * 32 + (lane & 31);
       for (int r0 = rbeg; r0 < rend; r0 += WR) {
         const bool ok = cur.R < rend;
-        const float* sa = P.A + (int64_t)cur.r1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
-        const float* sg = P.C + (int64_t)cur.r1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
+        const int n1 = (ok && P.row_index) ? P.row_index[cur.r1] : cur.r1;
+        const float* sa = P.A + (int64_t)n1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
+        const float* sg = P.C + (int64_t)n1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           float va = 0.f;
@@ -714,9 +719,10 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
     const float* vp = Vs + (lane >> 5) * LDV + lv;
     for (int r0 = rbeg; r0 < rend; r0 += WR) {
       const bool ok = cur.R < rend;
-      const float* sx = P.A + (int64_t)cur.r1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
-      const float* sv = P.A2 + (int64_t)cur.r1 * P.a2_r1;
-      const float* sg = P.C + (int64_t)cur.r1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
+      const int n1 = (ok && P.row_index) ? P.row_index[cur.r1] : cur.r1;
+      const float* sx = P.A + (int64_t)n1 * P.a_r1 + (int64_t)cur.r2 * P.a_r2;
+      const float* sv = P.A2 + (int64_t)n1 * P.a2_r1;
+      const float* sg = P.C + (int64_t)n1 * P.c_r1 + (int64_t)cur.r2 * P.c_r2;
       for (int j = (t & 3); j < uw; j += 4) As[(t >> 2) * LDWA + j] = ok ? sx[(int64_t)(ulo + j) * P.a_k] : 0.f;
       for (int j = (t & 3); j < V; j += 4) Vs[(t >> 2) * LDV + j] = ok ? sv[j] : 0.f;
       const int cb = (t & 3) * 16 * TN;

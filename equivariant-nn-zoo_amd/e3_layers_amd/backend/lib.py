@@ -23,6 +23,7 @@ TP_MAXQ = 8
 class GemmProblem(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("A2", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
+        ("row_index", C.c_void_p),
         ("M1", C.c_int32), ("M2", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("V", C.c_int32), ("accumulate", C.c_int32),
         ("a_r1", C.c_int64), ("a_r2", C.c_int64), ("a_k", C.c_int64),

@@ -318,6 +318,120 @@ def fctp(x, attrs, weight, spec: FctpSpec):
 
 
 # --------------------------------------------------------------------------------------
+# Self-connection over *keyed* node attributes: rows of node_attrs that carry the same integer key
+# (structurally identical rows, e.g. attrs = Linear(one_hot(species))) share the contracted weight
+# M[t] = sum_v attrs_t[v] W[:, v, :], so the self-connection becomes one small GEMM per key group
+# with K = mul_in instead of K = mul_in * V  (V = 20x fewer FLOPs for config_energy).
+# --------------------------------------------------------------------------------------
+@dataclass
+class RowGroups:
+    """Nodes grouped by key: ``perm`` (int32 [N], node ids sorted by key, stable), ``starts`` /
+    ``counts`` (host lists, one entry per key value), ``reps`` (int64 [K], a representative node per
+    key, 0 for empty groups)."""
+    perm: torch.Tensor
+    starts: List[int]
+    counts: List[int]
+    reps: torch.Tensor
+
+
+class GroupedLinearFn(torch.autograd.Function):
+    """out[n, w, k] = alpha * sum_u M[key(n)][u, w] x[n, u, k] per instruction; M is
+    [K, sum_j U_j * W_j] with instruction j's block at column offset ``m_off[j]``."""
+
+    @staticmethod
+    def forward(ctx, x, m, groups: RowGroups, spec: "FctpSpec", m_off: Tuple[int, ...]):
+        L.require_cuda(x, m)
+        x, m = L.f32c(x), L.f32c(m)
+        rows = x.shape[0]
+        ld_m = m.shape[1]
+        y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
+        for r, group in enumerate(spec.rounds("i_out")):
+            probs = []
+            for ins in group:
+                j = spec.instr.index(ins)
+                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+                for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
+                    if cnt == 0:
+                        continue
+                    p = L.GemmProblem()
+                    p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(m, t * ld_m + m_off[j]), _addr(y, ins.out_off), None
+                    p.row_index = groups.perm.data_ptr() + 4 * start
+                    p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_out, ins.mul_in, 0
+                    p.accumulate = 1 if r > 0 else 0
+                    p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
+                    p.b_k, p.b_n = ins.mul_out, 1
+                    p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+                    p.alpha = ins.alpha
+                    probs.append(p)
+            _run_gemm_chunks(probs)
+        ctx.save_for_backward(x, m)
+        ctx.groups, ctx.spec, ctx.m_off = groups, spec, m_off
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gy):
+        x, m = ctx.saved_tensors
+        groups, spec, m_off = ctx.groups, ctx.spec, ctx.m_off
+        gy = L.f32c(gy)
+        rows, ld_m = x.shape[0], m.shape[1]
+        gx = gm = None
+        if ctx.needs_input_grad[0]:
+            gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
+            for r, group in enumerate(spec.rounds("i_in")):
+                probs = []
+                for ins in group:
+                    j = spec.instr.index(ins)
+                    a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+                    c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+                    for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
+                        if cnt == 0:
+                            continue
+                        p = L.GemmProblem()
+                        p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(m, t * ld_m + m_off[j]), _addr(gx, ins.in_off), None
+                        p.row_index = groups.perm.data_ptr() + 4 * start
+                        p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_in, ins.mul_out, 0
+                        p.accumulate = 1 if r > 0 else 0
+                        p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
+                        p.b_k, p.b_n = 1, ins.mul_out
+                        p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
+                        p.alpha = ins.alpha
+                        probs.append(p)
+                _run_gemm_chunks(probs)
+        if ctx.needs_input_grad[1]:
+            gm = torch.zeros_like(m)
+            probs = []
+            for j, ins in enumerate(spec.instr):
+                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+                for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
+                    if cnt == 0:
+                        continue
+                    p = L.GemmProblem()
+                    p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gm, t * ld_m + m_off[j]), _addr(gy, ins.out_off), None
+                    p.row_index = groups.perm.data_ptr() + 4 * start
+                    p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_out, ins.mul_in, 0
+                    p.accumulate = 1
+                    p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
+                    p.b_k, p.b_n = ins.mul_out, 1
+                    p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+                    p.alpha = ins.alpha
+                    probs.append(p)
+            _run_gemm_chunks(probs, wgrad=True)
+        return gx, gm, None, None, None
+
+
+def _run_gemm_chunks(problems, wgrad: bool = False, chunk: int = 64) -> None:
+    for i in range(0, len(problems), chunk):
+        _run_gemm(problems[i:i + chunk], wgrad=wgrad)
+
+
+def grouped_linear(x, m, groups: RowGroups, spec: "FctpSpec", m_off: Sequence[int]):
+    return GroupedLinearFn.apply(x, m, groups, spec, tuple(int(v) for v in m_off))
+
+
+# --------------------------------------------------------------------------------------
 # fused uvu tensor product + destination reduce
 # --------------------------------------------------------------------------------------
 class TpPlan:

@@ -28,6 +28,64 @@ from ..utils.utils import act_output_parity, act_second_moment_const, activation
 TP_L1MAX, TP_L2MAX, TP_L3MAX = 3, 2, 3
 
 
+# ---- row keys -----------------------------------------------------------------------------
+# A tensor produced row-wise from a categorical input carries ``_e3k_key = (index int64 [rows],
+# n_keys)``: rows with equal keys are the same function of the same inputs, hence identical.
+_KEY_CAP = 1 << 20
+
+
+def get_row_key(t):
+    return getattr(t, "_e3k_key", None)
+
+
+def set_row_key(t, index, n_keys: int):
+    if index is not None and 0 < n_keys <= _KEY_CAP:
+        t._e3k_key = (index, int(n_keys))
+    return t
+
+
+def combine_row_keys(tensors):
+    """Key of a row-wise function of several keyed tensors (None if any is unkeyed or too many combinations)."""
+    index, n = None, 1
+    for t in tensors:
+        k = get_row_key(t)
+        if k is None:
+            return None
+        index = k[0] if index is None else index * k[1] + k[0]
+        n *= k[1]
+        if n > _KEY_CAP:
+            return None
+    return (index, n) if index is not None else None
+
+
+_groups_cache: Dict[int, tuple] = {}
+
+
+def row_groups(index: torch.Tensor, n_keys: int) -> "ops.RowGroups":
+    """Group rows by key (stable sort); memoised per key tensor so the five layers of a forward and
+    the backward share one sort and one small device->host copy of the group sizes."""
+    import weakref
+
+    hit = _groups_cache.get(id(index))
+    if hit is not None and hit[0]() is index and hit[1] == n_keys:
+        return hit[2]
+    idx = index.reshape(-1)
+    perm = torch.argsort(idx, stable=True)
+    counts_dev = torch.bincount(idx, minlength=n_keys)
+    counts = counts_dev.tolist()
+    starts, pos = [], 0
+    for c in counts:
+        starts.append(pos)
+        pos += c
+    starts_dev = torch.tensor(starts, device=idx.device, dtype=torch.long).clamp(max=max(idx.numel() - 1, 0))
+    reps = perm[starts_dev]
+    groups = ops.RowGroups(perm.to(torch.int32), starts, counts, reps)
+    if len(_groups_cache) > 16:
+        _groups_cache.clear()
+    _groups_cache[id(index)] = (weakref.ref(index), n_keys, groups)
+    return groups
+
+
 def irreps_blocks(irreps: Irreps) -> List[Tuple[int, int, int]]:
     """(offset, mul, 2l+1) per entry."""
     out, pos = [], 0
@@ -146,9 +204,32 @@ class FullyConnectedTensorProduct(nn.Module):
                                   all(o in cov_o for o in range(len(self.irreps_out))),
                                   all(i in cov_i for i in range(len(self.irreps_in1))))
 
+    # keyed attrs: use the per-key contracted weights when there are few keys and many rows
+    KEY_MAX = 64
+    KEY_MIN_ROWS = 256
+
     def forward(self, x_cf, attrs):
         """x in the channel-fastest layout -> output in the channel-fastest layout."""
+        key = get_row_key(attrs)
+        if key is not None and key[1] <= self.KEY_MAX and x_cf.shape[0] >= self.KEY_MIN_ROWS:
+            return self._forward_keyed(x_cf, attrs, key)
         return ops.fctp(x_cf, attrs, self.weight, self._spec)
+
+    def _forward_keyed(self, x_cf, attrs, key):
+        groups = row_groups(key[0], key[1])
+        v = self._spec.v
+        a_rep = attrs.index_select(0, groups.reps)                     # [K, V] one row per key
+        parts, m_off, pos = [], [], 0
+        for ins in self._spec.instr:                                     # W_j [U, V, Wout] -> [V, U*Wout]
+            w = self.weight[ins.w_off: ins.w_off + ins.mul_in * v * ins.mul_out]
+            parts.append(w.view(ins.mul_in, v, ins.mul_out).permute(1, 0, 2).reshape(v, ins.mul_in * ins.mul_out))
+            m_off.append(pos)
+            pos += ins.mul_in * ins.mul_out
+        wv = torch.cat(parts, dim=1)                                     # [V, sum U*Wout]
+        # M[t] = sum_v attrs_t[v] W[:, v, :]: a [K<=64, V] x [V, ~1e5] product (and, backward, a
+        # [K, ~1e5] x [~1e5, V] one) -- a few MFLOP of plain library GEMM, left to torch/rocBLAS
+        m = a_rep @ wv
+        return ops.grouped_linear(x_cf, m, groups, self._spec, m_off)
 
 
 class Gate(nn.Module):

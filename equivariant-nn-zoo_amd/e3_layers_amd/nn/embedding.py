@@ -15,6 +15,7 @@ from torch import Tensor, nn
 from ..backend import ops
 from ..o3 import Irreps
 from ..utils.utils import build
+from .core import set_row_key
 from .sequential import Module
 
 
@@ -106,7 +107,9 @@ class Broadcast(Module):
     def forward(self, data, attrs):
         assert attrs["input"][0] == "graph"
         seg = data["_node_segment"] if self.to_kind == "node" else data["_edge_segment"]
-        return {"output": data["input"][seg]}, {"output": (self.to_kind, self.irreps_out["output"])}
+        out = data["input"][seg]
+        set_row_key(out, seg, data["input"].shape[0])   # rows of one graph are identical
+        return {"output": out}, {"output": (self.to_kind, self.irreps_out["output"])}
 
 
 class OneHotEncoding(Module):
@@ -120,6 +123,7 @@ class OneHotEncoding(Module):
     def forward(self, data, attrs):
         idx = data["input"].squeeze(-1)
         one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
+        set_row_key(one_hot, idx, self.num_types)   # rows are a function of the type index only
         return {"one_hot": one_hot}, {"one_hot": (attrs["input"][0], self.irreps_out["one_hot"])}
 
 

@@ -11,7 +11,7 @@ from torch import Tensor
 from ..backend import ops
 from ..backend.graph import build_topology
 from ..o3 import Irreps
-from .core import Linear, UVUTensorProduct, irreps_blocks
+from .core import Linear, UVUTensorProduct, combine_row_keys, get_row_key, irreps_blocks, set_row_key
 from .sequential import Module
 
 
@@ -23,6 +23,9 @@ class PointwiseLinear(Module):
 
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
         out = self.linear(data["input"])
+        key = get_row_key(data["input"])
+        if key is not None:
+            set_row_key(out, *key)      # a row-wise map keeps rows with equal keys equal
         return {"output": out}, {"output": (attrs["input"][0], self.irreps_out["output"])}
 
 
@@ -82,4 +85,8 @@ class Concat(Module):
     def forward(self, data, attrs):
         keys = list(self.irreps_in.keys())
         x = torch.cat([data[k] for k in keys], dim=1)
-        return {"output": self.linear(x)}, {"output": (attrs[keys[0]][0], self.irreps_out["output"])}
+        out = self.linear(x)
+        key = combine_row_keys([data[k] for k in keys])
+        if key is not None:
+            set_row_key(out, *key)
+        return {"output": out}, {"output": (attrs[keys[0]][0], self.irreps_out["output"])}

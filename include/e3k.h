@@ -57,6 +57,8 @@ typedef struct {
   const float* B;
   float* C;
   const float* bias;
+  const int32_t* row_index; /* optional: r1 := row_index[r1] for the A, A2 and C rows (grouped GEMM over a
+                               gathered subset of nodes); M1 = length of the list */
   int32_t M1, M2, N, K;
   int32_t V;
   int32_t accumulate;

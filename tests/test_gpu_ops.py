@@ -363,3 +363,40 @@ def test_pooling(dev):
         (g,) = _grads(y, [xin], torch.ones_like(y))
         expect = torch.ones(11, 1) if reduce == "sum" else (1.0 / n_nodes.view(-1)[seg].double()).view(-1, 1)
         assert rel_err(g, expect) < TOL
+
+
+def test_fctp_keyed_attrs_matches_generic_and_oracle(dev):
+    """Self-connection over keyed node attributes (rows = table[species]): the per-key contracted
+    path equals the generic outer-product path and the oracle; parameter gradients agree, and the
+    attrs gradient summed per key agrees (it is deposited on each key's representative row)."""
+    from e3_layers_amd.nn import FullyConnectedTensorProduct
+    from e3_layers_amd.nn.core import set_row_key
+
+    torch.manual_seed(11)
+    in1, in2, out = "32x0e+32x1o+32x2e+16x0o", "20x0e", "48x0e+32x0e+32x1o+32x2e+16x0o"
+    tp = FullyConnectedTensorProduct(in1, in2, out).to(dev)
+    ref = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    ref.load_state_dict({k: v.cpu() for k, v in tp.state_dict().items()})
+    rows, n_types = 700, 7
+    species = torch.randint(0, n_types - 1, (rows,))          # the last type never occurs: empty group
+    table = torch.randn(n_types, 20, dtype=torch.float64)
+    x = torch.randn(rows, tp.irreps_in1.dim, dtype=torch.float64)
+    a = table[species]
+    xin = to_cf(x, in1).float().to(dev).requires_grad_(True)
+    ain = a.float().to(dev).requires_grad_(True)
+    set_row_key(ain, species.to(dev), n_types)
+    y = tp(xin, ain)                                           # keyed path
+    xr, ar = x.clone().requires_grad_(True), a.clone().requires_grad_(True)
+    yr = ref(xr, ar)
+    assert rel_err(from_cf(y.cpu(), out), yr) < TOL
+    ain2 = a.float().to(dev).requires_grad_(True)              # no key: generic path
+    y2 = tp(xin, ain2)
+    assert rel_err(y, y2) < TOL
+    seed = torch.randn_like(yr)
+    gx, ga, gw = _grads(y, [xin, ain, tp.weight], to_cf(seed, out).float().to(dev))
+    rx, ra, rw = _grads(yr, [xr, ar, ref.weight], seed)
+    assert rel_err(from_cf(gx.cpu(), in1), rx) < GTOL
+    assert rel_err(gw, rw) < GTOL
+    per_key = torch.zeros(n_types, 20, dtype=torch.float64).index_add_(0, species, ra)
+    got = torch.zeros(n_types, 20, dtype=torch.float64).index_add_(0, species, ga.cpu().double())
+    assert rel_err(got, per_key) < GTOL
