@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
     ap.add_argument("--lmax", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) in one HIP graph and replay it; the "
+                         "roofline block then comes from an eager pass after the timed region")
     ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU-baseline sample")
     return ap.parse_args()
 
@@ -96,10 +99,16 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # one process per GPU; E3K_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
+    backend = os.environ.get("E3K_DIST_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     if args.gpus != world and rank == 0:
         print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
@@ -116,7 +125,7 @@ def main():
     model = build(tree).to(dev)
     broadcast_parameters(model)
     flat = FlatGradients(model.parameters())
-    opt = torch.optim.Adam(flat.params, lr=cfg.learning_rate)
+    opt = torch.optim.Adam(flat.params, lr=cfg.learning_rate, capturable=args.graph)
 
     # every rank owns its own 256 molecules (weak scaling); seeded per rank, resident in HBM
     batch = synth_qm9(1000 + rank, args.batch, config_energy.QM9_SHIFTS).to(dev)
@@ -138,16 +147,39 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    run = step
+    graph = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                step()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = step()
+
+        def run():
+            graph.replay()
+            return static_loss
+
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
-    ops.PROFILE_TP = []
+    ops.PROFILE_TP = [] if graph is None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     elapsed = time.perf_counter() - t0
     records, ops.PROFILE_TP = ops.PROFILE_TP, None
+    if graph is not None:  # per-kernel events cannot be read back from a replayed graph: eager pass for the roofline block
+        ops.PROFILE_TP = []
+        for _ in range(min(args.steps, 5)):
+            step()
+        torch.cuda.synchronize()
+        records, ops.PROFILE_TP = ops.PROFILE_TP, None
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -180,7 +212,7 @@ def main():
             "config": {
                 "workload": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU "
                             f"(rank 0: N={n_nodes} nodes, E={n_edges} edges), fwd + 1e3*MSE + bwd + Adam",
-                "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
+                "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}", "launch": "hip-graph replay" if graph is not None else "eager",
                 "parameters": countParameters(model), "final_loss": round(float(loss.detach()), 4),
             },
             "roofline": roofline,

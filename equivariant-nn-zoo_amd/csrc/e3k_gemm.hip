@@ -110,6 +110,11 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int* 
 #pragma unroll
   for (int i = 0; i < (int)(sizeof(e3k_gemm_problem) / 4); ++i) u.w[i] = uniform(pw[i]);
   out.P = u.p;
+  if (out.P.row_index && out.P.group_dev) {  // device-side {start, count} of this key group
+    const int start = uniform(out.P.group_dev[0]), count = uniform(out.P.group_dev[1]);
+    out.P.row_index += start;
+    out.P.M1 = count < out.P.M1 ? count : out.P.M1;
+  }
   return out;
 }
 
@@ -248,6 +253,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   const int M = P.M1 * P.M2;
   const int tiles_n = (P.N + BN - 1) / BN;
   const int row0 = (local / tiles_n) * BM_, n0 = (local % tiles_n) * BN;
+  if (row0 >= M) return;  // block-uniform: surplus workgroup of a device-sized group
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w % WM, wn = w / WM;
 
@@ -350,6 +356,7 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
   const int tiles_n = (P.N + BN - 1) / BN;
   const int col_groups = (tiles_n + ct - 1) / ct;
   const int row0 = (local / col_groups) * BM_;
+  if (row0 >= M) return;  // block-uniform: surplus workgroup of a device-sized group
   const int tile_beg = (local % col_groups) * ct;
   const int tile_end = (tile_beg + ct < tiles_n) ? tile_beg + ct : tiles_n;
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -1007,6 +1014,30 @@ extern "C" int e3k_debug_stamps(unsigned long long* out, int n) {
   return E3K_OK;
 }
 #endif
+
+extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
+                                const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
+                                void* stream) {
+  if (n_templates < 0 || n_keys <= 0 || !perm || !groups_dev || (n_templates && !templates)) return E3K_ERR_INVALID;
+  e3k_gemm_problem buf[64];
+  int n = 0;
+  for (int i = 0; i < n_templates; ++i) {
+    for (int t = 0; t < n_keys; ++t) {
+      e3k_gemm_problem p = templates[i];
+      p.B = p.B + (int64_t)t * b_key_stride;
+      p.row_index = perm;
+      p.group_dev = groups_dev + 2 * t;
+      buf[n++] = p;
+      if (n == 64) {
+        const int rc = wgrad ? e3k_gemm_wgrad(buf, n, stream) : e3k_gemm(buf, n, stream);
+        if (rc != E3K_OK) return rc;
+        n = 0;
+      }
+    }
+  }
+  if (n) return wgrad ? e3k_gemm_wgrad(buf, n, stream) : e3k_gemm(buf, n, stream);
+  return E3K_OK;
+}
 
 extern "C" int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream) {
   if (rows < 0 || cols <= 0 || !out) return E3K_ERR_INVALID;

@@ -23,7 +23,7 @@ TP_MAXQ = 8
 class GemmProblem(C.Structure):
     _fields_ = [
         ("A", C.c_void_p), ("A2", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p), ("bias", C.c_void_p),
-        ("row_index", C.c_void_p),
+        ("row_index", C.c_void_p), ("group_dev", C.c_void_p),
         ("M1", C.c_int32), ("M2", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("V", C.c_int32), ("accumulate", C.c_int32),
         ("a_r1", C.c_int64), ("a_r2", C.c_int64), ("a_k", C.c_int64),
@@ -62,6 +62,7 @@ SIGNATURES = {
     "e3k_tp_limits": (None, [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "e3k_gemm": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
     "e3k_gemm_wgrad": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
+    "e3k_gemm_grouped": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),

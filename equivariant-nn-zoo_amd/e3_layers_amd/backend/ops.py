@@ -325,13 +325,65 @@ def fctp(x, attrs, weight, spec: FctpSpec):
 # --------------------------------------------------------------------------------------
 @dataclass
 class RowGroups:
-    """Nodes grouped by key: ``perm`` (int32 [N], node ids sorted by key, stable), ``starts`` /
-    ``counts`` (host lists, one entry per key value), ``reps`` (int64 [K], a representative node per
-    key, 0 for empty groups)."""
+    """Nodes grouped by key, all on the device (no host sync): ``perm`` (int32 [N], node ids sorted
+    by key, stable), ``bounds`` (int32 [K, 2] = {start, count} per key), ``reps`` (int64 [K], one
+    representative node per key; arbitrary for empty groups), ``n_keys``."""
     perm: torch.Tensor
-    starts: List[int]
-    counts: List[int]
+    bounds: torch.Tensor
     reps: torch.Tensor
+    n_keys: int
+
+
+def _grouped_templates(x, m_like, y, spec, m_off, ld_m, mode: str):
+    """One template problem per instruction; e3k_gemm_grouped expands them over the keys."""
+    rows = x.shape[0]
+    out = []
+    for j, ins in enumerate(spec.instr):
+        in_r2, in_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+        out_r2, out_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+        p = L.GemmProblem()
+        p.bias, p.A2, p.V = None, None, 0
+        p.M1, p.M2 = rows, ins.dim
+        p.alpha = ins.alpha
+        if mode == "fwd":      # y = x . M
+            p.A, p.B, p.C = _addr(x, ins.in_off), _addr(m_like, m_off[j]), _addr(y, ins.out_off)
+            p.N, p.K = ins.mul_out, ins.mul_in
+            p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
+            p.b_k, p.b_n = ins.mul_out, 1
+            p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
+        elif mode == "dgrad":  # gx = gy . M^T      (x := gy, y := gx)
+            p.A, p.B, p.C = _addr(x, ins.out_off), _addr(m_like, m_off[j]), _addr(y, ins.in_off)
+            p.N, p.K = ins.mul_in, ins.mul_out
+            p.a_r1, p.a_r2, p.a_k = spec.d_out, out_r2, out_n
+            p.b_k, p.b_n = 1, ins.mul_out
+            p.c_r1, p.c_r2, p.c_n = spec.d_in, in_r2, in_k
+        else:                  # wgrad: gm += x^T . gy   (y := gy)
+            p.A, p.B, p.C = _addr(x, ins.in_off), _addr(m_like, m_off[j]), _addr(y, ins.out_off)
+            p.N, p.K = ins.mul_out, ins.mul_in
+            p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
+            p.b_k, p.b_n = ins.mul_out, 1
+            p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
+        out.append((ins, p))
+    return out
+
+
+def _run_grouped(templates, groups: RowGroups, ld_m: int, wgrad: bool, key: str):
+    """Launch rounds so that no two problems of one launch write the same block."""
+    seen: Dict[int, int] = {}
+    rounds: List[List] = []
+    for ins, p in templates:
+        k = getattr(ins, key) if key else id(p)
+        r = seen.get(k, 0)
+        seen[k] = r + 1
+        while len(rounds) <= r:
+            rounds.append([])
+        p.accumulate = 1 if (r > 0 or wgrad) else 0
+        rounds[r].append(p)
+    lib = L.load()
+    for grp in rounds:
+        arr = (L.GemmProblem * len(grp))(*grp)
+        L.check(lib.e3k_gemm_grouped(arr, len(grp), L.ptr(groups.perm), L.ptr(groups.bounds), groups.n_keys, ld_m,
+                                     int(wgrad), L.stream_ptr()), "e3k_gemm_grouped")
 
 
 class GroupedLinearFn(torch.autograd.Function):
@@ -342,29 +394,10 @@ class GroupedLinearFn(torch.autograd.Function):
     def forward(ctx, x, m, groups: RowGroups, spec: "FctpSpec", m_off: Tuple[int, ...]):
         L.require_cuda(x, m)
         x, m = L.f32c(x), L.f32c(m)
-        rows = x.shape[0]
-        ld_m = m.shape[1]
+        rows, ld_m = x.shape[0], m.shape[1]
+        # rows of absent keys do not exist, every node belongs to exactly one key: full coverage
         y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
-        for r, group in enumerate(spec.rounds("i_out")):
-            probs = []
-            for ins in group:
-                j = spec.instr.index(ins)
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
-                    if cnt == 0:
-                        continue
-                    p = L.GemmProblem()
-                    p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(m, t * ld_m + m_off[j]), _addr(y, ins.out_off), None
-                    p.row_index = groups.perm.data_ptr() + 4 * start
-                    p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_out, ins.mul_in, 0
-                    p.accumulate = 1 if r > 0 else 0
-                    p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
-                    p.b_k, p.b_n = ins.mul_out, 1
-                    p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                    p.alpha = ins.alpha
-                    probs.append(p)
-            _run_gemm_chunks(probs)
+        _run_grouped(_grouped_templates(x, m, y, spec, m_off, ld_m, "fwd"), groups, ld_m, False, "i_out")
         ctx.save_for_backward(x, m)
         ctx.groups, ctx.spec, ctx.m_off = groups, spec, m_off
         return y
@@ -379,52 +412,11 @@ class GroupedLinearFn(torch.autograd.Function):
         gx = gm = None
         if ctx.needs_input_grad[0]:
             gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
-            for r, group in enumerate(spec.rounds("i_in")):
-                probs = []
-                for ins in group:
-                    j = spec.instr.index(ins)
-                    a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                    c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                    for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
-                        if cnt == 0:
-                            continue
-                        p = L.GemmProblem()
-                        p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(m, t * ld_m + m_off[j]), _addr(gx, ins.in_off), None
-                        p.row_index = groups.perm.data_ptr() + 4 * start
-                        p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_in, ins.mul_out, 0
-                        p.accumulate = 1 if r > 0 else 0
-                        p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
-                        p.b_k, p.b_n = 1, ins.mul_out
-                        p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
-                        p.alpha = ins.alpha
-                        probs.append(p)
-                _run_gemm_chunks(probs)
+            _run_grouped(_grouped_templates(gy, m, gx, spec, m_off, ld_m, "dgrad"), groups, ld_m, False, "i_in")
         if ctx.needs_input_grad[1]:
             gm = torch.zeros_like(m)
-            probs = []
-            for j, ins in enumerate(spec.instr):
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                for t, (start, cnt) in enumerate(zip(groups.starts, groups.counts)):
-                    if cnt == 0:
-                        continue
-                    p = L.GemmProblem()
-                    p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gm, t * ld_m + m_off[j]), _addr(gy, ins.out_off), None
-                    p.row_index = groups.perm.data_ptr() + 4 * start
-                    p.M1, p.M2, p.N, p.K, p.V = cnt, ins.dim, ins.mul_out, ins.mul_in, 0
-                    p.accumulate = 1
-                    p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
-                    p.b_k, p.b_n = ins.mul_out, 1
-                    p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                    p.alpha = ins.alpha
-                    probs.append(p)
-            _run_gemm_chunks(probs, wgrad=True)
+            _run_grouped(_grouped_templates(x, gm, gy, spec, m_off, ld_m, "wgrad"), groups, ld_m, True, "")
         return gx, gm, None, None, None
-
-
-def _run_gemm_chunks(problems, wgrad: bool = False, chunk: int = 64) -> None:
-    for i in range(0, len(problems), chunk):
-        _run_gemm(problems[i:i + chunk], wgrad=wgrad)
 
 
 def grouped_linear(x, m, groups: RowGroups, spec: "FctpSpec", m_off: Sequence[int]):

@@ -62,8 +62,9 @@ _groups_cache: Dict[int, tuple] = {}
 
 
 def row_groups(index: torch.Tensor, n_keys: int) -> "ops.RowGroups":
-    """Group rows by key (stable sort); memoised per key tensor so the five layers of a forward and
-    the backward share one sort and one small device->host copy of the group sizes."""
+    """Group rows by key with device-side ops only (stable sort, scatter-add counts, cumsum): no host
+    synchronisation, so a forward can be captured in a HIP graph.  Memoised per key tensor so the
+    layers of one forward (and their backward) share one sort."""
     import weakref
 
     hit = _groups_cache.get(id(index))
@@ -71,15 +72,11 @@ def row_groups(index: torch.Tensor, n_keys: int) -> "ops.RowGroups":
         return hit[2]
     idx = index.reshape(-1)
     perm = torch.argsort(idx, stable=True)
-    counts_dev = torch.bincount(idx, minlength=n_keys)
-    counts = counts_dev.tolist()
-    starts, pos = [], 0
-    for c in counts:
-        starts.append(pos)
-        pos += c
-    starts_dev = torch.tensor(starts, device=idx.device, dtype=torch.long).clamp(max=max(idx.numel() - 1, 0))
-    reps = perm[starts_dev]
-    groups = ops.RowGroups(perm.to(torch.int32), starts, counts, reps)
+    counts = torch.zeros(n_keys, dtype=torch.long, device=idx.device).scatter_add_(0, idx, torch.ones_like(idx))
+    starts = torch.cumsum(counts, 0) - counts
+    reps = perm[starts.clamp(max=max(idx.numel() - 1, 0))]
+    bounds = torch.stack([starts, counts], dim=1).to(torch.int32).contiguous()
+    groups = ops.RowGroups(perm.to(torch.int32), bounds, reps, n_keys)
     if len(_groups_cache) > 16:
         _groups_cache.clear()
     _groups_cache[id(index)] = (weakref.ref(index), n_keys, groups)

@@ -59,6 +59,9 @@ typedef struct {
   const float* bias;
   const int32_t* row_index; /* optional: r1 := row_index[r1] for the A, A2 and C rows (grouped GEMM over a
                                gathered subset of nodes); M1 = length of the list */
+  const int32_t* group_dev; /* optional, with row_index: DEVICE pair {start, count}; the list is
+                               row_index[start .. start+count) and M1 is only an upper bound of count
+                               (grids are sized from M1, surplus workgroups exit) -- no host sync needed */
   int32_t M1, M2, N, K;
   int32_t V;
   int32_t accumulate;
@@ -75,6 +78,13 @@ int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream);
 /* Weight gradient ("TN"):  B[k, n] += alpha * sum_{r1,r2} Aeff[r1,r2,k] * C[r1,r2,n]
  * (C is read as the incoming gradient, B is accumulated with fp32 atomics; the caller zeroes B). */
 int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream);
+
+/* Grouped launch over key groups: every template problem is expanded into n_keys problems, one per
+ * key t, with  B += t * b_key_stride,  row_index = perm,  group_dev = groups_dev + 2*t  and M1 kept as the
+ * (host-known) upper bound of the group size.  wgrad != 0 runs e3k_gemm_wgrad semantics (B accumulated).
+ * Used by the keyed self-connection: rows = nodes sorted by the key of their attribute row. */
+int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
+                     const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad, void* stream);
 
 /* Column sums: out[n] += sum_r G[r*ld + n]   (bias gradients) */
 int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream);
