@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) in one HIP graph and replay it; the "
                          "roofline block then comes from an eager pass after the timed region")
-    ap.add_argument("--cpu-sample", type=int, default=32, help="molecules in the CPU-baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=96, help="molecules in the CPU-baseline sample")
     return ap.parse_args()
 
 
@@ -193,9 +193,19 @@ def main():
         tot_bytes += e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
     n_launch = max(len(records), 1)
     achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+    # HBM bytes per launch from the PMC counters cannot be read in-process; they come from the committed
+    # rocprofv3 --pmc passes over this same command (profiles/, tools/collect_profiles.sh) when the
+    # workload matches, else null
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "r01_tp_fwd_traffic.json")
+    if os.path.exists(tfile) and args.batch == 256 and args.lmax == 2:
+        try:
+            traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"])
+        except Exception:
+            traffic = None
     roofline = {
         "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "kernel": "e3k::tp_fwd_kernel", "launches": len(records),
         "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "avg_launch_algorithmic_MB": round(tot_bytes / n_launch / 1e6, 2),
     }
