@@ -125,6 +125,7 @@ def main():
     model = build(tree).to(dev)
     broadcast_parameters(model)
     flat = FlatGradients(model.parameters())
+    flat.enable_direct_accumulation()
     opt = torch.optim.Adam(flat.params, lr=cfg.learning_rate, capturable=args.graph)
 
     # every rank owns its own 256 molecules (weak scaling); seeded per rank, resident in HBM

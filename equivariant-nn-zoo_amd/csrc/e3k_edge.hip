@@ -228,30 +228,43 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
                                                           int64_t E, const float* __restrict__ bw, int nb, float r_max,
                                                           float r_min, float p, int one_over_r, int kind,
                                                           float* __restrict__ g_r, float* __restrict__ g_w) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const bool valid = e < E;
-  const float rv = valid ? r[e] : 1.0f;
+  // grid-stride over edges; the frequency gradients are summed per thread first, so the whole launch
+  // issues (waves x n_basis) atomics instead of (E / 64 x n_basis)
   const float delta = r_max - r_min, pref = 2.0f / delta;
-  float c, dc;
-  cutoff_eval(rv, r_max, p, kind, c, dc);
-  const float inv_r = one_over_r ? 1.0f / rv : 1.0f;
-  float gr = 0.f;
-  for (int n = 0; n < nb; ++n) {
-    const float w = bw[n];
-    const float arg = w * rv / delta;
-    float sn, cs;
-    sincosf(arg, &sn, &cs);
-    const float g = valid ? g_out[e * nb + n] : 0.f;
-    // out = pref * sin(arg) * inv_r * c
-    float dbasis = pref * cs * (w / delta) * inv_r;
-    if (one_over_r) dbasis -= pref * sn * inv_r * inv_r;
-    gr = fmaf(g, dbasis * c + pref * sn * inv_r * dc, gr);
-    if (g_w) {
-      const float gw = wave_sum(g * pref * cs * (rv / delta) * inv_r * c);
-      if ((threadIdx.x & 63) == 0) atomicAdd(g_w + n, gw);
+  float acc[RB_MAXB];
+#pragma unroll
+  for (int n = 0; n < RB_MAXB; ++n) acc[n] = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    const float rv = r[e];
+    float c, dc;
+    cutoff_eval(rv, r_max, p, kind, c, dc);
+    const float inv_r = one_over_r ? 1.0f / rv : 1.0f;
+    float gr = 0.f;
+#pragma unroll
+    for (int n = 0; n < RB_MAXB; ++n) {
+      if (n < nb) {
+        const float w = bw[n];
+        float sn, cs;
+        sincosf(w * rv / delta, &sn, &cs);
+        const float g = g_out[e * nb + n];
+        // out = pref * sin(arg) * inv_r * c
+        float dbasis = pref * cs * (w / delta) * inv_r;
+        if (one_over_r) dbasis -= pref * sn * inv_r * inv_r;
+        gr = fmaf(g, dbasis * c + pref * sn * inv_r * dc, gr);
+        acc[n] = fmaf(g, pref * cs * (rv / delta) * inv_r * c, acc[n]);
+      }
+    }
+    if (g_r) g_r[e] = gr;
+  }
+  if (g_w) {
+#pragma unroll
+    for (int n = 0; n < RB_MAXB; ++n) {
+      if (n < nb) {
+        const float tot = wave_sum(acc[n]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(g_w + n, tot);
+      }
     }
   }
-  if (g_r && valid) g_r[e] = gr;
 }
 
 }  // namespace e3k
@@ -350,7 +363,9 @@ extern "C" int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t 
   if (cutoff_kind < 0 || cutoff_kind > 1) return E3K_ERR_INVALID;
   if (E == 0) return E3K_OK;
   if (!r || !g_out || !bessel_w || (!g_r && !g_w)) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::radial_bwd_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r,
+  int64_t blocks = (E + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(e3k::radial_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r,
                      g_out, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w);
   E3K_CHECK_LAUNCH();
   return E3K_OK;

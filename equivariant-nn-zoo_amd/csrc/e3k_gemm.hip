@@ -118,6 +118,11 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int* 
   return out;
 }
 
+__device__ __forceinline__ float epilogue_act(const e3k_gemm_problem& P, float v) {
+  if (P.act == 1) v = P.act_cst * (fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))) - 0.6931471805599453f);  // shifted softplus
+  return v;
+}
+
 struct BRegs {
   float4 v[2];
 };
@@ -225,7 +230,7 @@ __device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x1
       if (ok[j]) {
         float v = fmaf(P.alpha, acc[j][i], bias[j]);
         if (P.accumulate) v += c[cn[j]];
-        c[cn[j]] = v;
+        c[cn[j]] = epilogue_act(P, v);
       }
     }
   }
@@ -457,6 +462,7 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
               const float4 old = *dst;
               o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
             }
+            o.x = epilogue_act(P, o.x); o.y = epilogue_act(P, o.y); o.z = epilogue_act(P, o.z); o.w = epilogue_act(P, o.w);
             *dst = o;
           }
         }
@@ -846,7 +852,8 @@ int validate(const e3k_gemm_problem& P, bool wgrad) {
   if (!P.A || !P.B || !P.C) return E3K_ERR_INVALID;
   if (P.V < 0 || P.V > e3k::VMAX) return E3K_ERR_UNSUPPORTED;
   if (P.V > 0 && (!P.A2 || P.K % P.V != 0)) return E3K_ERR_INVALID;
-  if (wgrad && P.bias) return E3K_ERR_INVALID;
+  if (wgrad && (P.bias || P.act)) return E3K_ERR_INVALID;
+  if (P.act < 0 || P.act > 1) return E3K_ERR_INVALID;
   return E3K_OK;
 }
 

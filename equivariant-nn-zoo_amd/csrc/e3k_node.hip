@@ -55,6 +55,14 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     gx[i] = gy[i] * cst * act_df(act, x[i]);
 }
 
+__global__ __launch_bounds__(256) void act_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ gy,
+                                                           int64_t n, float cst, float* __restrict__ gx) {
+  // ssp: y = cst*(softplus(x) - ln 2)  =>  cst*sigmoid(x) = cst*(1 - 0.5*exp(-y/cst))
+  const float inv = 1.0f / cst;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
+    gx[i] = gy[i] * cst * (1.0f - 0.5f * expf(-y[i] * inv));
+}
+
 // ---------------------------------------------------------------------------------------
 // relayout
 // ---------------------------------------------------------------------------------------
@@ -262,6 +270,17 @@ extern "C" int e3k_act_bwd(const float* x, const float* g_y, int64_t n, int32_t 
   if (n == 0) return E3K_OK;
   if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::act_bwd_kernel, dim3(e3k::grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g_y, n, act, cst,
+                     g_x);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_act_bwd_from_output(const float* y, const float* g_y, int64_t n, int32_t act, float cst,
+                                       float* g_x, void* stream) {
+  if (n < 0 || act != 1 || !(cst > 0.f)) return E3K_ERR_INVALID;
+  if (n == 0) return E3K_OK;
+  if (!y || !g_y || !g_x) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::act_bwd_out_kernel, dim3(e3k::grid_for(n)), dim3(256), 0, (hipStream_t)stream, y, g_y, n, cst,
                      g_x);
   E3K_CHECK_LAUNCH();
   return E3K_OK;

@@ -30,7 +30,7 @@ class GemmProblem(C.Structure):
         ("a2_r1", C.c_int64),
         ("b_k", C.c_int64), ("b_n", C.c_int64),
         ("c_r1", C.c_int64), ("c_r2", C.c_int64), ("c_n", C.c_int64),
-        ("alpha", C.c_float), ("_pad", C.c_int32),
+        ("alpha", C.c_float), ("act", C.c_int32), ("act_cst", C.c_float), ("_pad", C.c_int32),
     ]
 
 
@@ -78,6 +78,7 @@ SIGNATURES = {
     "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
+    "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_relayout": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _P, _P]),
     "e3k_gate_fwd": (C.c_int, [_P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
     "e3k_gate_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),

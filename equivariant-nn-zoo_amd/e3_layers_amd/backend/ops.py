@@ -23,6 +23,56 @@ from .graph import GraphTopo
 # fused TP+reduce forward kernel (HIP events on the launching stream); None = no profiling.
 PROFILE_TP = None
 
+# Independent backward kernels of one op (e.g. grad-wrt-weights streams grad_w to HBM while
+# grad-wrt-x gathers from L2/MALL; dgrad and wgrad of a GEMM read the same gradient) are issued on
+# two HIP streams so that they overlap; the side stream is joined before the op returns.
+import os as _os
+OVERLAP_STREAMS = int(_os.environ.get("E3K_OVERLAP", "0"))  # 0 off (default), 1 TP backward only, 2 also GEMM dgrad/wgrad
+_side_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class _Fork:
+    """with _Fork(dev) as f: f.side(lambda: ...); ...main work...   -> joins on exit."""
+
+    def __init__(self, device):
+        self.device = device
+        self.used = False
+
+    def __enter__(self):
+        self.cur = torch.cuda.current_stream(self.device)
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        st = _side_streams.get(idx)
+        if st is None:
+            st = _side_streams[idx] = torch.cuda.Stream(device=self.device)
+        self.st = st
+        return self
+
+    def side(self, fn):
+        if not OVERLAP_STREAMS or torch.cuda.is_current_stream_capturing():
+            return fn()
+        self.st.wait_stream(self.cur)
+        with torch.cuda.stream(self.st):
+            out = fn()
+        self.used = True
+        return out
+
+    def __exit__(self, *exc):
+        if self.used:
+            self.cur.wait_stream(self.st)
+        return False
+
+
+# Gradient sink: run/parallel.FlatGradients registers (data_ptr, numel) -> view of its flat gradient
+# buffer for every parameter.  A backward that finds its weight there accumulates the weight
+# gradient straight into the (pre-zeroed) flat buffer and returns None for it: no zero-fill of a
+# temporary and no autograd "+=" per parameter.
+GRAD_SINK: Dict[Tuple[int, int], torch.Tensor] = {}
+
+
+def _sink_for(t: torch.Tensor):
+    return GRAD_SINK.get((t.data_ptr(), t.numel())) if GRAD_SINK else None
+
+
 ACT_IDS = {None: 0, "identity": 0, "ssp": 1, "silu": 2, "tanhlu": 3, "tanh": 4, "abs": 5}
 
 
@@ -94,13 +144,15 @@ class StridedLinearFn(torch.autograd.Function):
     """y[rows, d_out] = (base +) sum over instructions  alpha * x_block @ W_block  (+ bias)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, base, spec: LinearSpec, scale: float):
+    def forward(ctx, x, weight, bias, base, spec: LinearSpec, scale: float, act: int = 0, act_cst: float = 1.0):
         L.require_cuda(x, weight)
         x = L.f32c(x)
         weight = L.f32c(weight)
         rows = x.shape[0]
         assert x.shape[1] == spec.d_in, (x.shape, spec.d_in)
         if base is not None:
+            if act:
+                raise NotImplementedError("fused activation cannot accumulate into a base tensor")
             y = base
             ctx.mark_dirty(base)
         elif spec.out_covered:
@@ -130,57 +182,87 @@ class StridedLinearFn(torch.autograd.Function):
                 p.b_k, p.b_n = ins.mul_out, 1
                 p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
                 p.alpha = ins.alpha * scale
+                if act:
+                    p.act, p.act_cst = act, act_cst
                 probs.append(p)
             _run_gemm(probs)
+        if act and len(spec.rounds("i_out")) != 1:
+            raise NotImplementedError("fused activation needs single-round linears")
         for off, mul, boff in spec.bias_blocks:  # biased block without any incoming path
             if bias is not None and off not in done_bias:
                 y[:, off:off + mul] += bias[boff:boff + mul]
-        ctx.save_for_backward(x, weight)
+        if act:
+            ctx.save_for_backward(x, weight, y)
+        else:
+            ctx.save_for_backward(x, weight)
+        ctx.act, ctx.act_cst = act, act_cst
         ctx.spec, ctx.scale, ctx.has_bias, ctx.has_base = spec, scale, bias is not None, base is not None
         return y
 
     @staticmethod
     @once_differentiable
     def backward(ctx, gy):
-        x, weight = ctx.saved_tensors
+        if ctx.act:
+            x, weight, y = ctx.saved_tensors
+            gy = L.f32c(gy)
+            gz = torch.empty_like(gy)
+            L.check(L.load().e3k_act_bwd_from_output(L.ptr(y), L.ptr(gy), gy.numel(), ctx.act, ctx.act_cst, L.ptr(gz),
+                                                     L.stream_ptr()), "e3k_act_bwd_from_output")
+            gy = gz
+        else:
+            x, weight = ctx.saved_tensors
         spec: LinearSpec = ctx.spec
         scale = ctx.scale
         gy = L.f32c(gy)
         rows = x.shape[0]
         gx = gw = gb = None
-        if ctx.needs_input_grad[0]:
-            gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
-            for r, group in enumerate(spec.rounds("i_in")):
-                probs = []
-                for ins in group:
-                    a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                    c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                    p = L.GemmProblem()
-                    p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(gx, ins.in_off), None
-                    p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_in, ins.mul_out, 0
-                    p.accumulate = 1 if r > 0 else 0
-                    p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
-                    p.b_k, p.b_n = 1, ins.mul_out  # W^T
-                    p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
-                    p.alpha = ins.alpha * scale
-                    probs.append(p)
-                _run_gemm(probs)
-        if ctx.needs_input_grad[1]:
-            gw = torch.zeros_like(weight)
-            probs = []
-            for ins in spec.instr:
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                p = L.GemmProblem()
-                p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
-                p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
-                p.accumulate = 1
-                p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
-                p.b_k, p.b_n = ins.mul_out, 1
-                p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                p.alpha = ins.alpha * scale
-                probs.append(p)
-            _run_gemm(probs, wgrad=True)
+        with _Fork(x.device) as fork:
+            sunk = False
+            if ctx.needs_input_grad[1]:
+                gw = _sink_for(weight)
+                sunk = gw is not None
+                if not sunk:
+                    gw = torch.zeros_like(weight)
+
+                def _wgrad():
+                    probs = []
+                    for ins in spec.instr:
+                        a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+                        c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+                        p = L.GemmProblem()
+                        p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
+                        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
+                        p.accumulate = 1
+                        p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
+                        p.b_k, p.b_n = ins.mul_out, 1
+                        p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+                        p.alpha = ins.alpha * scale
+                        probs.append(p)
+                    _run_gemm(probs, wgrad=True)
+
+                if OVERLAP_STREAMS >= 2 and ctx.needs_input_grad[0] and rows * spec.d_out >= (1 << 22):
+                    fork.side(_wgrad)   # big enough for the overlap to pay for the stream join
+                else:
+                    _wgrad()
+            if ctx.needs_input_grad[0]:
+                gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
+                for r, group in enumerate(spec.rounds("i_in")):
+                    probs = []
+                    for ins in group:
+                        a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+                        c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+                        p = L.GemmProblem()
+                        p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(gx, ins.in_off), None
+                        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_in, ins.mul_out, 0
+                        p.accumulate = 1 if r > 0 else 0
+                        p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
+                        p.b_k, p.b_n = 1, ins.mul_out  # W^T
+                        p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
+                        p.alpha = ins.alpha * scale
+                        probs.append(p)
+                    _run_gemm(probs)
+        if sunk:
+            gw = None   # already accumulated into the flat gradient buffer
         if ctx.has_bias and ctx.needs_input_grad[2]:
             nb = sum(m for _, m, _ in spec.bias_blocks)
             gb = torch.zeros(nb, device=x.device, dtype=torch.float32)
@@ -188,11 +270,17 @@ class StridedLinearFn(torch.autograd.Function):
             for off, mul, boff in spec.bias_blocks:
                 L.check(lib.e3k_colsum(_addr(gy, off), rows, mul, spec.d_out, _addr(gb, boff), L.stream_ptr()), "e3k_colsum")
         gbase = gy if (ctx.has_base and ctx.needs_input_grad[3]) else None
-        return gx, gw, gb, gbase, None, None
+        return gx, gw, gb, gbase, None, None, None, None
 
 
-def strided_linear(x, weight, bias, spec: LinearSpec, base=None, scale: float = 1.0):
-    return StridedLinearFn.apply(x, weight, bias, base, spec, float(scale))
+def strided_linear(x, weight, bias, spec: LinearSpec, base=None, scale: float = 1.0, act: Optional[str] = None,
+                   act_cst: float = 1.0):
+    """``act='ssp'`` fuses ``act_cst * ssp(.)`` into the GEMM epilogue (radial MLP layers)."""
+    if act is None:
+        return StridedLinearFn.apply(x, weight, bias, base, spec, float(scale))
+    if act != "ssp":
+        return activation(StridedLinearFn.apply(x, weight, bias, base, spec, float(scale)), act, act_cst)
+    return StridedLinearFn.apply(x, weight, bias, base, spec, float(scale), 1, float(act_cst))
 
 
 # --------------------------------------------------------------------------------------
@@ -290,8 +378,12 @@ class FctpFn(torch.autograd.Function):
                     "e3k_fctp_reduce_bwd",
                 )
                 seen_in.add(ins.i_in)
+        sunk = False
         if ctx.needs_input_grad[2]:
-            gw = torch.zeros_like(weight)
+            gw = _sink_for(weight)
+            sunk = gw is not None
+            if not sunk:
+                gw = torch.zeros_like(weight)
             probs = []
             for ins in spec.instr:
                 a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
@@ -310,6 +402,8 @@ class FctpFn(torch.autograd.Function):
             gx = None
         if not ctx.needs_input_grad[1]:
             ga = None
+        if sunk:
+            gw = None
         return gx, ga, gw, None
 
 
@@ -489,18 +583,20 @@ class TpFn(torch.autograd.Function):
         n, e = x.shape[0], sh.shape[0]
         lib = L.load()
         gx = gsh = gw = None
-        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            gw = torch.empty_like(w)
-            if ctx.needs_input_grad[1]:
-                gsh = torch.zeros_like(sh)
-            L.check(lib.e3k_tp_bwd_w(plan.handle(x.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
-                                     L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
-                                     L.stream_ptr()), "e3k_tp_bwd_w")
-        if ctx.needs_input_grad[0]:
-            gx = torch.zeros_like(x)
-            L.check(lib.e3k_tp_bwd_x(plan.handle(x.device), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
-                                     L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()),
-                    "e3k_tp_bwd_x")
+        handle = plan.handle(x.device)
+        with _Fork(x.device) as fork:
+            if ctx.needs_input_grad[0]:
+                gx = torch.zeros_like(x)
+                fork.side(lambda: L.check(
+                    lib.e3k_tp_bwd_x(handle, L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst), L.ptr(topo.src_ptr),
+                                     L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x"))
+            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+                gw = torch.empty_like(w)
+                if ctx.needs_input_grad[1]:
+                    gsh = torch.zeros_like(sh)
+                L.check(lib.e3k_tp_bwd_w(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
+                                         L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
+                                         L.stream_ptr()), "e3k_tp_bwd_w")
         if not ctx.needs_input_grad[2]:
             gw = None
         return gx, gsh, gw, None, None

@@ -152,6 +152,8 @@ class _FCLayer(nn.Module):
                                     "e3nn", "e3nn", [], True, True, h_in * h_out)
 
     def forward(self, x):
+        # (a fused activation epilogue exists -- strided_linear(..., act="ssp") -- but measured slower here: the
+        # transcendental lands in the store phase that already bounds the small-K GEMM)
         y = ops.strided_linear(x, self.weight.view(-1), None, self._spec)
         return ops.activation(y, self.act, self.cst) if self.act else y
 

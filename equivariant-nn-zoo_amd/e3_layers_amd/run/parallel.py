@@ -59,9 +59,25 @@ class FlatGradients:
         ref = self.params[0]
         self.buffer = torch.zeros(total, dtype=ref.dtype, device=ref.device)
         off = 0
+        self._sink = {}
         for p in self.params:
             p.grad = self.buffer[off:off + p.numel()].view_as(p)
+            self._sink[(p.data_ptr(), p.numel())] = self.buffer[off:off + p.numel()]
             off += p.numel()
+
+    def enable_direct_accumulation(self) -> None:
+        """Let the HIP weight-gradient kernels add straight into this buffer (it must be zeroed with
+        ``zero()`` before every backward; each parameter must feed exactly the op that owns it)."""
+        if self.buffer.is_cuda:
+            from ..backend import ops
+
+            ops.GRAD_SINK.update(self._sink)
+
+    def disable_direct_accumulation(self) -> None:
+        from ..backend import ops
+
+        for k in self._sink:
+            ops.GRAD_SINK.pop(k, None)
 
     def zero(self) -> None:
         self.buffer.zero_()

@@ -70,6 +70,8 @@ typedef struct {
   int64_t b_k, b_n;
   int64_t c_r1, c_r2, c_n;
   float alpha;
+  int32_t act;   /* 0 none; 1: C = act_cst * ssp(alpha*A.B + bias) fused into the epilogue (radial MLP layers) */
+  float act_cst; /* second-moment normalisation constant of the activation */
   int32_t _pad;
 } e3k_gemm_problem;
 
@@ -169,6 +171,10 @@ int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const
 /* activation ids: 0 identity, 1 ssp, 2 silu, 3 tanhlu, 4 tanh, 5 abs */
 int e3k_act_fwd(const float* x, int64_t n, int32_t act, float cst, float* y, void* stream);
 int e3k_act_bwd(const float* x, const float* g_y, int64_t n, int32_t act, float cst, float* g_x, void* stream);
+/* same derivative from the OUTPUT y = cst*act(x) (act = 1 ssp only: cst*sigmoid(x) = cst*(1 - 0.5*exp(-y/cst))),
+ * so a fused linear+activation layer keeps only its output */
+int e3k_act_bwd_from_output(const float* y, const float* g_y, int64_t n, int32_t act, float cst, float* g_x,
+                            void* stream);
 
 /* layout change of a feature row: blocks (off, mul, dim=2l+1); to_cf=1: [mul][dim] -> [dim][mul]. */
 typedef struct {

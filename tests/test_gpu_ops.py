@@ -400,3 +400,35 @@ def test_fctp_keyed_attrs_matches_generic_and_oracle(dev):
     per_key = torch.zeros(n_types, 20, dtype=torch.float64).index_add_(0, species, ra)
     got = torch.zeros(n_types, 20, dtype=torch.float64).index_add_(0, species, ga.cpu().double())
     assert rel_err(got, per_key) < GTOL
+
+
+def test_fused_activation_epilogue_and_grad_sink(dev):
+    """strided_linear(act='ssp') == linear followed by the activation kernel (values and gradients);
+    with a registered gradient sink the weight gradient lands in the flat buffer instead of a temporary."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.run.parallel import FlatGradients
+    from e3_layers_amd.utils import act_second_moment_const
+
+    torch.manual_seed(12)
+    rows, k, n = 2000, 64, 192
+    spec = ops.LinearSpec(k, n, [ops.LinInstr(0, 0, k, n, 1, 0, 0.125)], "e3nn", "e3nn", [], True, True, k * n)
+    x = torch.randn(rows, k, device=dev, requires_grad=True)
+    w = torch.nn.Parameter(torch.randn(k * n, device=dev))
+    cst = act_second_moment_const("ssp")
+    seed = torch.randn(rows, n, device=dev)
+    y_f = ops.strided_linear(x, w, None, spec, act="ssp", act_cst=cst)
+    y_u = ops.activation(ops.strided_linear(x, w, None, spec), "ssp", cst)
+    assert rel_err(y_f, y_u) < 1e-6
+    gf = _grads(y_f, [x, w], seed)
+    gu = _grads(y_u, [x, w], seed)
+    assert rel_err(gf[0], gu[0]) < 1e-5 and rel_err(gf[1], gu[1]) < 1e-5
+    (gw_plain,) = _grads(ops.strided_linear(x, w, None, spec), [w], seed)
+    flat = FlatGradients([w])
+    flat.enable_direct_accumulation()
+    try:
+        flat.zero()
+        ops.strided_linear(x, w, None, spec).backward(seed)
+    finally:
+        flat.disable_direct_accumulation()
+    assert rel_err(flat.buffer, gw_plain) < 1e-5        # accumulated in place by the wgrad kernel
+    assert rel_err(w.grad, gw_plain) < 1e-5             # .grad is a view of the same buffer
