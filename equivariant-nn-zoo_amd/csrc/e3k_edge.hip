@@ -90,11 +90,51 @@ __device__ __forceinline__ float sh_norm_factor(int l, int normalization) {
   return 1.0f;
 }
 
-// evaluates degree l into out[0..2l]; returns count
+// First-order dual number (value, derivative along ONE direction): the double-backward kernels run the
+// same formulas on Du instead of float, which yields Jacobian-vector and Hessian-vector products.
+struct Du {
+  float v, e;
+  __device__ __forceinline__ Du(float a = 0.f, float b = 0.f) : v(a), e(b) {}
+};
+__device__ __forceinline__ Du operator+(const Du& a, const Du& b) { return {a.v + b.v, a.e + b.e}; }
+__device__ __forceinline__ Du operator-(const Du& a, const Du& b) { return {a.v - b.v, a.e - b.e}; }
+__device__ __forceinline__ Du operator*(const Du& a, const Du& b) { return {a.v * b.v, fmaf(a.v, b.e, a.e * b.v)}; }
+__device__ __forceinline__ Du operator*(float s, const Du& a) { return {s * a.v, s * a.e}; }
+__device__ __forceinline__ Du operator/(const Du& a, const Du& b) {
+  const float q = a.v / b.v;
+  return {q, (a.e - q * b.e) / b.v};
+}
+__device__ __forceinline__ Du du_sqrt(const Du& a) {
+  const float s = sqrtf(a.v);
+  return {s, s > 0.f ? 0.5f * a.e / s : 0.f};
+}
+__device__ __forceinline__ Du du_sin(const Du& a) { return {sinf(a.v), cosf(a.v) * a.e}; }
+__device__ __forceinline__ Du du_cos(const Du& a) { return {cosf(a.v), -sinf(a.v) * a.e}; }
+__device__ __forceinline__ Du du_pow(const Du& a, float p) {   // a^p, a >= 0
+  const float pm1 = (a.v != 0.f) ? powf(a.v, p - 1.0f) : 0.f;
+  return {pm1 * a.v, p * pm1 * a.e};
+}
+
+// value + gradient whose four entries are themselves duals
+struct D3u {
+  Du v, dx, dy, dz;
+};
+__device__ __forceinline__ D3u operator*(const D3u& a, const D3u& b) {
+  return {a.v * b.v, a.v * b.dx + a.dx * b.v, a.v * b.dy + a.dy * b.v, a.v * b.dz + a.dz * b.v};
+}
+__device__ __forceinline__ D3u operator+(const D3u& a, const D3u& b) { return {a.v + b.v, a.dx + b.dx, a.dy + b.dy, a.dz + b.dz}; }
+__device__ __forceinline__ D3u operator-(const D3u& a, const D3u& b) { return {a.v - b.v, a.dx - b.dx, a.dy - b.dy, a.dz - b.dz}; }
+__device__ __forceinline__ D3u operator*(float s, const D3u& a) { return {s * a.v, s * a.dx, s * a.dy, s * a.dz}; }
+
+__device__ __forceinline__ void set_one(D3& o) { o = {1.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ void set_one(D3u& o) { o = {Du(1.f), Du(), Du(), Du()}; }
+
+// evaluates degree l into out[0..2l]; returns count   (D3 = float duals, D3u = second-order)
+template <class D3>
 __device__ __forceinline__ int sh_eval(int l, const D3& x, const D3& y, const D3& z, D3* out) {
   const float s3 = 1.7320508075688772f, s5 = 2.23606797749979f, s15 = 3.872983346207417f, s7 = 2.6457513110645907f;
   if (l == 0) {
-    out[0] = {1.f, 0.f, 0.f, 0.f};
+    set_one(out[0]);
     return 1;
   }
   if (l == 1) {
@@ -176,6 +216,57 @@ __global__ __launch_bounds__(256) void sph_harm_kernel(const float* __restrict__
     g_vec[3 * e] = gx;
     g_vec[3 * e + 1] = gy;
     g_vec[3 * e + 2] = gz;
+  }
+}
+
+// Backward of sph_harm_kernel<true>: g_vec = f(vec, g_sh) received the cotangent t = g_hat [E,3].
+//   g_gsh[e,k] = d/d eps  sh_k(vec + eps t)                    (Jacobian-vector product)
+//   g_vec2[e]  = d/d eps  f(vec + eps t, g_sh)                 (Hessian-vector product; the Hessian is symmetric)
+// Both fall out of ONE evaluation of the forward+backward formulas on dual numbers.
+__global__ __launch_bounds__(256) void sph_harm_bwd2_kernel(const float* __restrict__ vec, const float* __restrict__ g_sh,
+                                                             const float* __restrict__ g_hat, int64_t E, ShArgs sa,
+                                                             int dim, float* __restrict__ g_gsh,
+                                                             float* __restrict__ g_vec2) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const Du vx(vec[3 * e], g_hat[3 * e]), vy(vec[3 * e + 1], g_hat[3 * e + 1]), vz(vec[3 * e + 2], g_hat[3 * e + 2]);
+  Du ux = vx, uy = vy, uz = vz, inv(1.f);
+  if (sa.normalize) {
+    const Du r = du_sqrt(vx * vx + vy * vy + vz * vz);
+    inv = (r.v > 1e-12f) ? Du(1.f) / r : Du(1e12f);
+    ux = ux * inv;
+    uy = uy * inv;
+    uz = uz * inv;
+  }
+  const D3u x{ux, Du(1.f), Du(), Du()}, y{uy, Du(), Du(1.f), Du()}, z{uz, Du(), Du(), Du(1.f)};
+  int off = 0;
+  Du gx, gy, gz;
+  for (int i = 0; i < sa.n_ls; ++i) {
+    const int l = sa.ls[i];
+    D3u out[7];
+    const int cnt = sh_eval(l, x, y, z, out);
+    const float nf = sh_norm_factor(l, sa.normalization);
+    for (int m = 0; m < cnt; ++m) {
+      if (g_gsh) g_gsh[e * dim + off + m] = nf * out[m].v.e;
+      if (g_vec2) {
+        const float g = nf * g_sh[e * dim + off + m];
+        gx = gx + g * out[m].dx;
+        gy = gy + g * out[m].dy;
+        gz = gz + g * out[m].dz;
+      }
+    }
+    off += cnt;
+  }
+  if (g_vec2) {
+    if (sa.normalize) {
+      const Du dot = gx * ux + gy * uy + gz * uz;
+      gx = (gx - ux * dot) * inv;
+      gy = (gy - uy * dot) * inv;
+      gz = (gz - uz * dot) * inv;
+    }
+    g_vec2[3 * e] = gx.e;
+    g_vec2[3 * e + 1] = gy.e;
+    g_vec2[3 * e + 2] = gz.e;
   }
 }
 
@@ -267,6 +358,81 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
   }
 }
 
+// cutoff envelope on duals (same two kinds as cutoff_eval); c only — its derivative comes from the dual part
+__device__ __forceinline__ void cutoff_du(const Du& r, float r_max, float p, int kind, Du& c, Du& dc) {
+  const Du x = (1.0f / r_max) * r;
+  if (kind == 1) {
+    if (fabsf(x.v) < 1.0f) {
+      const Du q = x * x - Du(1.0f);
+      c = q * q;
+      dc = (4.0f / r_max) * (q * x);
+    } else {
+      c = Du();
+      dc = Du();
+    }
+    return;
+  }
+  if (x.v < 1.0f) {
+    const Du xp = du_pow(x, p), xpm1 = du_pow(x, p - 1.0f);
+    const float c0 = (p + 1.0f) * (p + 2.0f) * 0.5f, c1 = p * (p + 2.0f), c2 = p * (p + 1.0f) * 0.5f;
+    c = Du(1.0f) - c0 * xp + c1 * (xp * x) - c2 * (xp * x * x);
+    dc = (1.0f / r_max) * ((-c0 * p) * xpm1 + (c1 * (p + 1.0f)) * xp - (c2 * (p + 2.0f)) * (xp * x));
+  } else {
+    c = Du();
+    dc = Du();
+  }
+}
+
+// Backward of radial_bwd_kernel: (g_r, g_w) = f(r, w, g_out) received cotangents (hat_r [E], hat_w [nb]).
+//   g_gout[e,n] = d/d eps out_n(r_e + eps hat_r_e, w_n + eps hat_w_n)
+//   g_r2, g_w2  = d/d eps f(r + eps hat_r, w + eps hat_w, g_out)
+__global__ __launch_bounds__(256) void radial_bwd2_kernel(const float* __restrict__ r, const float* __restrict__ g_out,
+                                                           const float* __restrict__ hat_r,
+                                                           const float* __restrict__ hat_w, int64_t E,
+                                                           const float* __restrict__ bw, int nb, float r_max,
+                                                           float r_min, float p, int one_over_r, int kind,
+                                                           float* __restrict__ g_gout, float* __restrict__ g_r2,
+                                                           float* __restrict__ g_w2) {
+  const float delta = r_max - r_min, pref = 2.0f / delta;
+  float acc[RB_MAXB];
+#pragma unroll
+  for (int n = 0; n < RB_MAXB; ++n) acc[n] = 0.f;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
+    const Du rv(r[e], hat_r ? hat_r[e] : 0.f);
+    Du c, dc;
+    cutoff_du(rv, r_max, p, kind, c, dc);
+    const Du inv_r = one_over_r ? Du(1.0f) / rv : Du(1.0f);
+    float gr = 0.f;
+#pragma unroll
+    for (int n = 0; n < RB_MAXB; ++n) {
+      if (n < nb) {
+        const Du w(bw[n], hat_w ? hat_w[n] : 0.f);
+        const Du arg = (1.0f / delta) * (w * rv);
+        const Du sn = du_sin(arg), cs = du_cos(arg);
+        const Du out = pref * (sn * inv_r * c);
+        if (g_gout) g_gout[e * nb + n] = out.e;
+        const float g = g_out[e * nb + n];
+        Du dbasis = (pref / delta) * (cs * w * inv_r);
+        if (one_over_r) dbasis = dbasis - pref * (sn * inv_r * inv_r);
+        const Du d_r = dbasis * c + pref * (sn * inv_r * dc);
+        const Du d_w = (pref / delta) * (cs * rv * inv_r * c);
+        gr = fmaf(g, d_r.e, gr);
+        acc[n] = fmaf(g, d_w.e, acc[n]);
+      }
+    }
+    if (g_r2) g_r2[e] = gr;
+  }
+  if (g_w2) {
+#pragma unroll
+    for (int n = 0; n < RB_MAXB; ++n) {
+      if (n < nb) {
+        const float tot = wave_sum(acc[n]);
+        if ((threadIdx.x & 63) == 0) atomicAdd(g_w2 + n, tot);
+      }
+    }
+  }
+}
+
 }  // namespace e3k
 
 extern "C" int e3k_edge_vector_fwd(const float* pos, const int32_t* src, const int32_t* dst, int64_t E,
@@ -343,6 +509,22 @@ extern "C" int e3k_sph_harm_bwd(const float* vec, const float* g_sh, int64_t E, 
   return E3K_OK;
 }
 
+extern "C" int e3k_sph_harm_bwd2(const float* vec, const float* g_sh, const float* g_hat, int64_t E, const int32_t* ls,
+                                 int32_t n_ls, int32_t normalize, int32_t normalization, float* g_gsh, float* g_vec,
+                                 void* stream) {
+  e3k::ShArgs sa{};
+  int dim = 0;
+  const int rc = make_sh_args(ls, n_ls, normalize, normalization, sa, dim);
+  if (rc != E3K_OK) return rc;
+  if (E < 0) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!vec || !g_hat || (!g_gsh && !g_vec) || (g_vec && !g_sh)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::sph_harm_bwd2_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, vec,
+                     g_sh, g_hat, E, sa, dim, g_gsh, g_vec);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
 extern "C" int e3k_radial_basis_fwd(const float* r, int64_t E, const float* bessel_w, int32_t n_basis, float r_max,
                                     float r_min, float p, int32_t one_over_r, int32_t cutoff_kind, float* out,
                                     void* stream) {
@@ -367,6 +549,22 @@ extern "C" int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t 
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(e3k::radial_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r,
                      g_out, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_radial_basis_bwd2(const float* r, const float* g_out, const float* hat_r, const float* hat_w,
+                                     int64_t E, const float* bessel_w, int32_t n_basis, float r_max, float r_min,
+                                     float p, int32_t one_over_r, int32_t cutoff_kind, float* g_gout, float* g_r,
+                                     float* g_w, void* stream) {
+  if (E < 0 || n_basis <= 0 || n_basis > e3k::RB_MAXB || !(r_max > r_min)) return E3K_ERR_INVALID;
+  if (cutoff_kind < 0 || cutoff_kind > 1) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!r || !g_out || !bessel_w || (!hat_r && !hat_w) || (!g_gout && !g_r && !g_w)) return E3K_ERR_INVALID;
+  int64_t blocks = (E + 255) / 256;
+  if (blocks > 512) blocks = 512;
+  hipLaunchKernelGGL(e3k::radial_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, g_out, hat_r,
+                     hat_w, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_gout, g_r, g_w);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -44,6 +44,30 @@ __device__ __forceinline__ float act_df(int id, float x) {
   }
 }
 
+// second derivative (double backward: force training differentiates the backward pass once more)
+__device__ __forceinline__ float act_d2f(int id, float x) {
+  switch (id) {
+    case 1: {
+      const float s = sigmoidf_(x);
+      return s * (1.0f - s);
+    }
+    case 2: {
+      const float s = sigmoidf_(x);
+      return s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s));
+    }
+    case 3: {
+      const float th = tanhf(x), sech2 = 1.0f - th * th;
+      const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
+      return 2.0f * sech2 * (sg - th * fabsf(x));
+    }
+    case 4: {
+      const float th = tanhf(x);
+      return -2.0f * th * (1.0f - th * th);
+    }
+    default: return 0.0f;
+  }
+}
+
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int act, float cst,
                                                        float* __restrict__ y) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
@@ -53,6 +77,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
                                                        int64_t n, int act, float cst, float* __restrict__ gx) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
     gx[i] = gy[i] * cst * act_df(act, x[i]);
+}
+
+// backward of act_bwd: gx = gy*cst*act'(x) with cotangent gh  ->  g_gy = gh*cst*act'(x), g_x = gh*gy*cst*act''(x)
+__global__ __launch_bounds__(256) void act_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                        const float* __restrict__ gh, int64_t n, int act, float cst,
+                                                        float* __restrict__ g_gy, float* __restrict__ g_x) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const float xv = x[i], h = gh[i] * cst;
+    if (g_gy) g_gy[i] = h * act_df(act, xv);
+    if (g_x) g_x[i] = h * gy[i] * act_d2f(act, xv);
+  }
 }
 
 __global__ __launch_bounds__(256) void act_bwd_out_kernel(const float* __restrict__ y, const float* __restrict__ gy,
@@ -166,6 +201,80 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       }
     }
     gx[i] = v;
+  }
+}
+
+// backward of gate_bwd (cotangent gh on gx): g_gy = (d y / d x) gh  — one thread per OUTPUT element
+__global__ __launch_bounds__(256) void gate_bwd2_gy_kernel(const float* __restrict__ x, const float* __restrict__ gh,
+                                                            int64_t rows, int in_dim, int out_dim, GateArgs ga,
+                                                            float* __restrict__ g_gy) {
+  const int64_t total = rows * out_dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / out_dim;
+    const int c = (int)(i - r * out_dim);
+    const float* xr = x + r * in_dim;
+    const float* hr = gh + r * in_dim;
+    float v = 0.f;
+    for (int k = 0; k < ga.n; ++k) {
+      const e3k_gate_seg& s = ga.s[k];
+      const int rel = c - s.out_off;
+      if (rel >= 0 && rel < s.mul * s.dim) {
+        if (s.kind == 0) {
+          v = hr[s.in_off + rel] * s.cst * act_df(s.act, xr[s.in_off + rel]);
+        } else {
+          const int u = rel / s.dim, m = rel - u * s.dim;
+          const float gt = xr[s.gate_off + u];
+          const int xi = s.in_off + m * s.mul + u;
+          v = hr[xi] * (s.cst * act_f(s.act, gt)) + hr[s.gate_off + u] * xr[xi] * (s.cst * act_df(s.act, gt));
+        }
+        break;
+      }
+    }
+    g_gy[i] = v;
+  }
+}
+
+// ... and g_x = d/dx <gh, gate_bwd(x, gy)> — one thread per INPUT element
+__global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           const float* __restrict__ gh, int64_t rows, int in_dim,
+                                                           int out_dim, GateArgs ga, float* __restrict__ g_x) {
+  const int64_t total = rows * in_dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / in_dim;
+    const int c = (int)(i - r * in_dim);
+    const float* xr = x + r * in_dim;
+    const float* hr = gh + r * in_dim;
+    const float* gr = gy + r * out_dim;
+    float v = 0.f;
+    for (int k = 0; k < ga.n; ++k) {
+      const e3k_gate_seg& s = ga.s[k];
+      if (s.kind == 0) {
+        const int rel = c - s.in_off;
+        if (rel >= 0 && rel < s.mul) {
+          v = hr[c] * gr[s.out_off + rel] * s.cst * act_d2f(s.act, xr[c]);
+          break;
+        }
+      } else {
+        const int relg = c - s.gate_off;
+        if (relg >= 0 && relg < s.mul) {
+          float dgh = 0.f, dgx = 0.f;   // sum_m gy*gh_gated, sum_m gy*x_gated
+          for (int m = 0; m < s.dim; ++m) {
+            const float g = gr[s.out_off + relg * s.dim + m];
+            dgh = fmaf(g, hr[s.in_off + m * s.mul + relg], dgh);
+            dgx = fmaf(g, xr[s.in_off + m * s.mul + relg], dgx);
+          }
+          v = s.cst * (dgh * act_df(s.act, xr[c]) + hr[c] * dgx * act_d2f(s.act, xr[c]));
+          break;
+        }
+        const int rel = c - s.in_off;
+        if (rel >= 0 && rel < s.mul * s.dim) {
+          const int m = rel / s.mul, u = rel - m * s.mul;
+          v = hr[s.gate_off + u] * gr[s.out_off + u * s.dim + m] * (s.cst * act_df(s.act, xr[s.gate_off + u]));
+          break;
+        }
+      }
+    }
+    g_x[i] = v;
   }
 }
 
@@ -286,6 +395,17 @@ extern "C" int e3k_act_bwd_from_output(const float* y, const float* g_y, int64_t
   return E3K_OK;
 }
 
+extern "C" int e3k_act_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t n, int32_t act, float cst,
+                            float* g_gy, float* g_x, void* stream) {
+  if (n < 0 || act < 0 || act > 5) return E3K_ERR_INVALID;
+  if (n == 0) return E3K_OK;
+  if (!x || !g_hat || (!g_gy && !g_x) || (g_x && !g_y)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::act_bwd2_kernel, dim3(e3k::grid_for(n)), dim3(256), 0, (hipStream_t)stream, x, g_y, g_hat, n,
+                     act, cst, g_gy, g_x);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
 namespace {
 int make_blocks(const e3k_block* blocks, int32_t n_blocks, int32_t row_dim, e3k::BlockArgs& ba) {
   if (n_blocks < 0 || n_blocks > e3k::MAXBLK || (n_blocks && !blocks)) return E3K_ERR_INVALID;
@@ -349,6 +469,28 @@ extern "C" int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int3
   hipLaunchKernelGGL(e3k::gate_bwd_kernel, dim3(e3k::grid_for(rows * in_dim)), dim3(256), 0, (hipStream_t)stream, x, g_y,
                      rows, in_dim, out_dim, ga, g_x);
   E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t rows, int32_t in_dim,
+                             int32_t out_dim, const e3k_gate_seg* segs, int32_t n_segs, float* g_gy, float* g_x,
+                             void* stream) {
+  e3k::GateArgs ga{};
+  const int rc = make_gate(segs, n_segs, ga);
+  if (rc != E3K_OK) return rc;
+  if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!x || !g_hat || (!g_gy && !g_x) || (g_x && !g_y)) return E3K_ERR_INVALID;
+  if (g_gy) {
+    hipLaunchKernelGGL(e3k::gate_bwd2_gy_kernel, dim3(e3k::grid_for(rows * out_dim)), dim3(256), 0, (hipStream_t)stream,
+                       x, g_hat, rows, in_dim, out_dim, ga, g_gy);
+    E3K_CHECK_LAUNCH();
+  }
+  if (g_x) {
+    hipLaunchKernelGGL(e3k::gate_bwd2_x_kernel, dim3(e3k::grid_for(rows * in_dim)), dim3(256), 0, (hipStream_t)stream, x,
+                       g_y, g_hat, rows, in_dim, out_dim, ga, g_x);
+    E3K_CHECK_LAUNCH();
+  }
   return E3K_OK;
 }
 

@@ -69,8 +69,10 @@ SIGNATURES = {
     "e3k_edge_vector_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
     "e3k_sph_harm_fwd": (C.c_int, [_P, _I64, C.POINTER(_I32), _I32, _I32, _I32, _P, _P]),
     "e3k_sph_harm_bwd": (C.c_int, [_P, _P, _I64, C.POINTER(_I32), _I32, _I32, _I32, _P, _P]),
+    "e3k_sph_harm_bwd2": (C.c_int, [_P, _P, _P, _I64, C.POINTER(_I32), _I32, _I32, _I32, _P, _P, _P]),
     "e3k_radial_basis_fwd": (C.c_int, [_P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P]),
     "e3k_radial_basis_bwd": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P]),
+    "e3k_radial_basis_bwd2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P, _P]),
     "e3k_tp_plan_create": (C.c_int, [C.POINTER(TpGroup), _I32, _I32, _I32, _I32, _I32, C.POINTER(_P)]),
     "e3k_tp_plan_destroy": (None, [_P]),
     "e3k_tp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
@@ -79,9 +81,11 @@ SIGNATURES = {
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
+    "e3k_act_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P, _P, _P]),
     "e3k_relayout": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _P, _P]),
     "e3k_gate_fwd": (C.c_int, [_P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
     "e3k_gate_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
+    "e3k_gate_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P, _P]),
     "e3k_layernorm_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
     "e3k_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
     "e3k_segment_sum": (C.c_int, [_P, _P, _I64, _I32, _I32, _P, _P]),

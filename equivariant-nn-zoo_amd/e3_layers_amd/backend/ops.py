@@ -2,9 +2,15 @@
 
 Every op here is ``torch.autograd.Function`` glue: it allocates outputs with torch, fills the
 C structs of ``include/e3k.h`` with raw device pointers and enqueues the HIP kernels on the
-current stream.  Backward passes call the matching backward kernels; they are *once
-differentiable* (double backward — force training, ``e3_layers/nn/output.py:42`` with
-``create_graph=True`` — is not built yet and fails loudly).
+current stream.  Backward passes call the matching backward kernels.
+
+Double backward (force training: ``GradientOutput`` differentiates with ``create_graph=True``,
+``e3_layers/nn/output.py:42-50``, and the loss on the forces is differentiated again): when a
+backward runs with grad mode enabled it is expressed through further ``autograd.Function``s
+(``*DgradFn``, ``*WgradFn``, ``TpBwdXFn``, ``ActBwdFn`` ...) whose own backward passes reuse the same
+kernels with the operands' roles exchanged (every contraction here is multilinear) or the
+``*_bwd2`` kernels (activations, gate, spherical harmonics, radial basis).  Third derivatives are
+not built and fail loudly.
 """
 from __future__ import annotations
 
@@ -76,6 +82,14 @@ def _sink_for(t: torch.Tensor):
 ACT_IDS = {None: 0, "identity": 0, "ssp": 1, "silu": 2, "tanhlu": 3, "tanh": 4, "abs": 5}
 
 
+def _c(t):
+    """Contiguous fp32 through *differentiable* torch ops, applied before ``Function.apply`` so that the
+    tensors a Function saves are its true inputs (double backward differentiates through them)."""
+    if t is None or (t.dtype == torch.float32 and t.is_contiguous()):
+        return t
+    return t.float().contiguous()
+
+
 def _addr(t: torch.Tensor, elem_off: int = 0) -> int:
     return t.data_ptr() + 4 * int(elem_off)
 
@@ -140,6 +154,96 @@ class LinearSpec:
         return out
 
 
+def _lin_fwd_raw(x, weight, bias, y, spec: LinearSpec, scale: float, accumulate: bool, act: int = 0, act_cst: float = 1.0):
+    """y (+)= sum over instructions alpha*scale * x_block @ W_block (+ bias); raw launch, no autograd."""
+    rows = x.shape[0]
+    bias_at = {}
+    if bias is not None:
+        for off, mul, boff in spec.bias_blocks:
+            bias_at[off] = _addr(bias, boff)
+    done_bias = set()
+    rounds = spec.rounds("i_out")
+    if act and len(rounds) != 1:
+        raise NotImplementedError("fused activation needs single-round linears")
+    for r, group in enumerate(rounds):
+        probs = []
+        for ins in group:
+            a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+            c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+            p = L.GemmProblem()
+            p.A, p.A2, p.B, p.C = _addr(x, ins.in_off), None, _addr(weight, ins.w_off), _addr(y, ins.out_off)
+            p.bias = None
+            if r == 0 and ins.out_off in bias_at:
+                p.bias = bias_at[ins.out_off]
+                done_bias.add(ins.out_off)
+            p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
+            p.accumulate = 1 if (r > 0 or accumulate) else 0
+            p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
+            p.b_k, p.b_n = ins.mul_out, 1
+            p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+            p.alpha = ins.alpha * scale
+            if act:
+                p.act, p.act_cst = act, act_cst
+            probs.append(p)
+        _run_gemm(probs)
+    for off, mul, boff in spec.bias_blocks:  # biased block without any incoming path
+        if bias is not None and off not in done_bias:
+            y[:, off:off + mul] += bias[boff:boff + mul]
+
+
+def _lin_dgrad_raw(gy, weight, spec: LinearSpec, scale: float):
+    """gx = sum over instructions alpha*scale * gy_block @ W_block^T."""
+    rows = gy.shape[0]
+    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
+    for r, group in enumerate(spec.rounds("i_in")):
+        probs = []
+        for ins in group:
+            a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+            c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+            p = L.GemmProblem()
+            p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(gx, ins.in_off), None
+            p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_in, ins.mul_out, 0
+            p.accumulate = 1 if r > 0 else 0
+            p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
+            p.b_k, p.b_n = 1, ins.mul_out  # W^T
+            p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
+            p.alpha = ins.alpha * scale
+            probs.append(p)
+        _run_gemm(probs)
+    return gx
+
+
+def _lin_wgrad_raw(x, gy, gw, spec: LinearSpec, scale: float) -> None:
+    """gw += alpha*scale * x_block^T @ gy_block per instruction (gw pre-zeroed or a gradient sink)."""
+    rows = x.shape[0]
+    probs = []
+    for ins in spec.instr:
+        a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+        c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+        p = L.GemmProblem()
+        p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
+        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
+        p.accumulate = 1
+        p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
+        p.b_k, p.b_n = ins.mul_out, 1
+        p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+        p.alpha = ins.alpha * scale
+        probs.append(p)
+    _run_gemm(probs, wgrad=True)
+
+
+def _bias_grad_diff(gy, spec: LinearSpec):
+    """Differentiable bias gradient (double-backward mode only): column sums of the biased blocks."""
+    blocks = sorted(spec.bias_blocks, key=lambda b: b[2])
+    pos = 0
+    parts = []
+    for off, mul, boff in blocks:
+        assert boff == pos, "bias blocks must tile the bias vector"
+        parts.append(gy[:, off:off + mul].sum(0))
+        pos += mul
+    return torch.cat(parts)
+
+
 class StridedLinearFn(torch.autograd.Function):
     """y[rows, d_out] = (base +) sum over instructions  alpha * x_block @ W_block  (+ bias)."""
 
@@ -159,38 +263,9 @@ class StridedLinearFn(torch.autograd.Function):
             y = torch.empty(rows, spec.d_out, device=x.device, dtype=torch.float32)
         else:
             y = torch.zeros(rows, spec.d_out, device=x.device, dtype=torch.float32)
-        bias_at = {}
         if bias is not None:
             bias = L.f32c(bias)
-            for off, mul, boff in spec.bias_blocks:
-                bias_at[off] = _addr(bias, boff)
-        done_bias = set()
-        for r, group in enumerate(spec.rounds("i_out")):
-            probs = []
-            for ins in group:
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                p = L.GemmProblem()
-                p.A, p.A2, p.B, p.C = _addr(x, ins.in_off), None, _addr(weight, ins.w_off), _addr(y, ins.out_off)
-                p.bias = None
-                if r == 0 and ins.out_off in bias_at:
-                    p.bias = bias_at[ins.out_off]
-                    done_bias.add(ins.out_off)
-                p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
-                p.accumulate = 1 if (r > 0 or base is not None) else 0
-                p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
-                p.b_k, p.b_n = ins.mul_out, 1
-                p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                p.alpha = ins.alpha * scale
-                if act:
-                    p.act, p.act_cst = act, act_cst
-                probs.append(p)
-            _run_gemm(probs)
-        if act and len(spec.rounds("i_out")) != 1:
-            raise NotImplementedError("fused activation needs single-round linears")
-        for off, mul, boff in spec.bias_blocks:  # biased block without any incoming path
-            if bias is not None and off not in done_bias:
-                y[:, off:off + mul] += bias[boff:boff + mul]
+        _lin_fwd_raw(x, weight, bias, y, spec, scale, base is not None, act, act_cst)
         if act:
             ctx.save_for_backward(x, weight, y)
         else:
@@ -200,8 +275,19 @@ class StridedLinearFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
+        spec: LinearSpec = ctx.spec
+        scale = ctx.scale
+        if torch.is_grad_enabled():   # double backward: stay differentiable
+            if ctx.act:
+                raise NotImplementedError("double backward through a fused linear+activation layer is not built; "
+                                          "use the unfused layers (default)")
+            x, weight = ctx.saved_tensors
+            gx = LinearDgradFn.apply(gy, weight, spec, scale) if ctx.needs_input_grad[0] else None
+            gw = LinearWgradFn.apply(x, gy, spec, scale, weight.numel()).view_as(weight) if ctx.needs_input_grad[1] else None
+            gb = _bias_grad_diff(gy, spec) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+            gbase = gy if (ctx.has_base and ctx.needs_input_grad[3]) else None
+            return gx, gw, gb, gbase, None, None, None, None
         if ctx.act:
             x, weight, y = ctx.saved_tensors
             gy = L.f32c(gy)
@@ -211,8 +297,6 @@ class StridedLinearFn(torch.autograd.Function):
             gy = gz
         else:
             x, weight = ctx.saved_tensors
-        spec: LinearSpec = ctx.spec
-        scale = ctx.scale
         gy = L.f32c(gy)
         rows = x.shape[0]
         gx = gw = gb = None
@@ -223,44 +307,12 @@ class StridedLinearFn(torch.autograd.Function):
                 sunk = gw is not None
                 if not sunk:
                     gw = torch.zeros_like(weight)
-
-                def _wgrad():
-                    probs = []
-                    for ins in spec.instr:
-                        a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                        c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                        p = L.GemmProblem()
-                        p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
-                        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
-                        p.accumulate = 1
-                        p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
-                        p.b_k, p.b_n = ins.mul_out, 1
-                        p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                        p.alpha = ins.alpha * scale
-                        probs.append(p)
-                    _run_gemm(probs, wgrad=True)
-
                 if OVERLAP_STREAMS >= 2 and ctx.needs_input_grad[0] and rows * spec.d_out >= (1 << 22):
-                    fork.side(_wgrad)   # big enough for the overlap to pay for the stream join
+                    fork.side(lambda: _lin_wgrad_raw(x, gy, gw, spec, scale))   # big enough to pay for the stream join
                 else:
-                    _wgrad()
+                    _lin_wgrad_raw(x, gy, gw, spec, scale)
             if ctx.needs_input_grad[0]:
-                gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
-                for r, group in enumerate(spec.rounds("i_in")):
-                    probs = []
-                    for ins in group:
-                        a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                        c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                        p = L.GemmProblem()
-                        p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(gx, ins.in_off), None
-                        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_in, ins.mul_out, 0
-                        p.accumulate = 1 if r > 0 else 0
-                        p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
-                        p.b_k, p.b_n = 1, ins.mul_out  # W^T
-                        p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
-                        p.alpha = ins.alpha * scale
-                        probs.append(p)
-                    _run_gemm(probs)
+                gx = _lin_dgrad_raw(gy, weight, spec, scale)
         if sunk:
             gw = None   # already accumulated into the flat gradient buffer
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -273,9 +325,49 @@ class StridedLinearFn(torch.autograd.Function):
         return gx, gw, gb, gbase, None, None, None, None
 
 
+class LinearDgradFn(torch.autograd.Function):
+    """gx = dgrad(gy, W); bilinear, so its backward is again (forward, wgrad) with roles exchanged."""
+
+    @staticmethod
+    def forward(ctx, gy, weight, spec: LinearSpec, scale: float):
+        gy, weight = L.f32c(gy), L.f32c(weight)
+        ctx.save_for_backward(gy, weight)
+        ctx.spec, ctx.scale = spec, scale
+        return _lin_dgrad_raw(gy, weight, spec, scale)
+
+    @staticmethod
+    def backward(ctx, h):   # h: cotangent of gx, shaped like x
+        gy, weight = ctx.saved_tensors
+        g_gy = StridedLinearFn.apply(h, weight, None, None, ctx.spec, ctx.scale) if ctx.needs_input_grad[0] else None
+        g_w = LinearWgradFn.apply(h, gy, ctx.spec, ctx.scale, weight.numel()) if ctx.needs_input_grad[1] else None
+        return g_gy, g_w, None, None
+
+
+class LinearWgradFn(torch.autograd.Function):
+    """gw = wgrad(x, gy); its backward: g_x = dgrad(gy, h), g_gy = forward(x, h) for the cotangent h of gw."""
+
+    @staticmethod
+    def forward(ctx, x, gy, spec: LinearSpec, scale: float, w_numel: int):
+        x, gy = L.f32c(x), L.f32c(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.spec, ctx.scale = spec, scale
+        gw = torch.zeros(w_numel, device=x.device, dtype=torch.float32)
+        _lin_wgrad_raw(x, gy, gw, spec, scale)
+        return gw
+
+    @staticmethod
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        h = h.reshape(-1)
+        g_x = LinearDgradFn.apply(gy, h, ctx.spec, ctx.scale) if ctx.needs_input_grad[0] else None
+        g_gy = StridedLinearFn.apply(x, h, None, None, ctx.spec, ctx.scale) if ctx.needs_input_grad[1] else None
+        return g_x, g_gy, None, None, None
+
+
 def strided_linear(x, weight, bias, spec: LinearSpec, base=None, scale: float = 1.0, act: Optional[str] = None,
                    act_cst: float = 1.0):
     """``act='ssp'`` fuses ``act_cst * ssp(.)`` into the GEMM epilogue (radial MLP layers)."""
+    x, weight, bias = _c(x), _c(weight), _c(bias)
     if act is None:
         return StridedLinearFn.apply(x, weight, bias, base, spec, float(scale))
     if act != "ssp":
@@ -343,10 +435,18 @@ class FctpFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         x, attrs, weight = ctx.saved_tensors
         spec: FctpSpec = ctx.spec
+        if torch.is_grad_enabled():
+            # double backward of the un-keyed self-connection: differentiate a torch restatement of the
+            # same trilinear form on the device (rare path — keyed node attributes take GroupedLinearFn)
+            wrt = [t for t, need in zip((x, attrs, weight), ctx.needs_input_grad[:3]) if need]
+            with torch.enable_grad():
+                y = _fctp_composed(x, attrs, weight, spec)
+                grads = list(torch.autograd.grad(y, wrt, gy, create_graph=True, allow_unused=True))
+            out = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:3]]
+            return out[0], out[1], out[2], None
         gy = L.f32c(gy)
         rows = x.shape[0]
         lib = L.load()
@@ -407,8 +507,23 @@ class FctpFn(torch.autograd.Function):
         return gx, ga, gw, None
 
 
+def _fctp_composed(x, attrs, weight, spec: FctpSpec):
+    """torch-op restatement of FctpFn.forward (same layouts), used only to build a double-backward graph."""
+    rows = x.shape[0]
+    y = torch.zeros(rows, spec.d_out, device=x.device, dtype=x.dtype)
+    for ins in spec.instr:
+        xb = x[:, ins.in_off:ins.in_off + ins.mul_in * ins.dim]
+        xb = xb.reshape(rows, ins.dim, ins.mul_in) if spec.in_layout == "cf" else xb.reshape(rows, ins.mul_in, ins.dim).transpose(1, 2)
+        wb = weight.reshape(-1)[ins.w_off:ins.w_off + ins.mul_in * spec.v * ins.mul_out].reshape(ins.mul_in, spec.v, ins.mul_out)
+        ob = ins.alpha * torch.einsum("nku,nv,uvw->nkw", xb, attrs, wb)
+        if spec.out_layout != "cf":
+            ob = ob.transpose(1, 2)
+        y[:, ins.out_off:ins.out_off + ins.mul_out * ins.dim] += ob.reshape(rows, -1)
+    return y
+
+
 def fctp(x, attrs, weight, spec: FctpSpec):
-    return FctpFn.apply(x, attrs, weight, spec)
+    return FctpFn.apply(_c(x), _c(attrs), _c(weight), spec)
 
 
 # --------------------------------------------------------------------------------------
@@ -480,41 +595,88 @@ def _run_grouped(templates, groups: RowGroups, ld_m: int, wgrad: bool, key: str)
                                      int(wgrad), L.stream_ptr()), "e3k_gemm_grouped")
 
 
+def _grp_fwd_raw(x, m, groups, spec, m_off):
+    rows, ld_m = x.shape[0], m.shape[1]
+    # rows of absent keys do not exist, every node belongs to exactly one key: full coverage
+    y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
+    _run_grouped(_grouped_templates(x, m, y, spec, m_off, ld_m, "fwd"), groups, ld_m, False, "i_out")
+    return y
+
+
+def _grp_dgrad_raw(gy, m, groups, spec, m_off):
+    rows, ld_m = gy.shape[0], m.shape[1]
+    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
+    _run_grouped(_grouped_templates(gy, m, gx, spec, m_off, ld_m, "dgrad"), groups, ld_m, False, "i_in")
+    return gx
+
+
+def _grp_wgrad_raw(x, gy, m_shape, groups, spec, m_off):
+    gm = torch.zeros(m_shape, device=x.device, dtype=torch.float32)
+    _run_grouped(_grouped_templates(x, gm, gy, spec, m_off, m_shape[1], "wgrad"), groups, m_shape[1], True, "")
+    return gm
+
+
 class GroupedLinearFn(torch.autograd.Function):
     """out[n, w, k] = alpha * sum_u M[key(n)][u, w] x[n, u, k] per instruction; M is
-    [K, sum_j U_j * W_j] with instruction j's block at column offset ``m_off[j]``."""
+    [K, sum_j U_j * W_j] with instruction j's block at column offset ``m_off[j]``.  Bilinear in
+    (x, M): forward / dgrad / wgrad are closed under differentiation (double backward)."""
 
     @staticmethod
     def forward(ctx, x, m, groups: RowGroups, spec: "FctpSpec", m_off: Tuple[int, ...]):
         L.require_cuda(x, m)
         x, m = L.f32c(x), L.f32c(m)
-        rows, ld_m = x.shape[0], m.shape[1]
-        # rows of absent keys do not exist, every node belongs to exactly one key: full coverage
-        y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
-        _run_grouped(_grouped_templates(x, m, y, spec, m_off, ld_m, "fwd"), groups, ld_m, False, "i_out")
         ctx.save_for_backward(x, m)
         ctx.groups, ctx.spec, ctx.m_off = groups, spec, m_off
-        return y
+        return _grp_fwd_raw(x, m, groups, spec, m_off)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         x, m = ctx.saved_tensors
-        groups, spec, m_off = ctx.groups, ctx.spec, ctx.m_off
+        a = (ctx.groups, ctx.spec, ctx.m_off)
+        if torch.is_grad_enabled():
+            gx = GroupedDgradFn.apply(gy, m, *a) if ctx.needs_input_grad[0] else None
+            gm = GroupedWgradFn.apply(x, gy, tuple(m.shape), *a) if ctx.needs_input_grad[1] else None
+            return gx, gm, None, None, None
         gy = L.f32c(gy)
-        rows, ld_m = x.shape[0], m.shape[1]
-        gx = gm = None
-        if ctx.needs_input_grad[0]:
-            gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
-            _run_grouped(_grouped_templates(gy, m, gx, spec, m_off, ld_m, "dgrad"), groups, ld_m, False, "i_in")
-        if ctx.needs_input_grad[1]:
-            gm = torch.zeros_like(m)
-            _run_grouped(_grouped_templates(x, gm, gy, spec, m_off, ld_m, "wgrad"), groups, ld_m, True, "")
+        gx = _grp_dgrad_raw(gy, m, *a) if ctx.needs_input_grad[0] else None
+        gm = _grp_wgrad_raw(x, gy, tuple(m.shape), *a) if ctx.needs_input_grad[1] else None
         return gx, gm, None, None, None
 
 
+class GroupedDgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gy, m, groups, spec, m_off):
+        gy, m = L.f32c(gy), L.f32c(m)
+        ctx.save_for_backward(gy, m)
+        ctx.a = (groups, spec, m_off)
+        return _grp_dgrad_raw(gy, m, groups, spec, m_off)
+
+    @staticmethod
+    def backward(ctx, h):
+        gy, m = ctx.saved_tensors
+        g_gy = GroupedLinearFn.apply(h, m, *ctx.a) if ctx.needs_input_grad[0] else None
+        g_m = GroupedWgradFn.apply(h, gy, tuple(m.shape), *ctx.a) if ctx.needs_input_grad[1] else None
+        return g_gy, g_m, None, None, None
+
+
+class GroupedWgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gy, m_shape, groups, spec, m_off):
+        x, gy = L.f32c(x), L.f32c(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.a = (groups, spec, m_off)
+        return _grp_wgrad_raw(x, gy, m_shape, groups, spec, m_off)
+
+    @staticmethod
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        g_x = GroupedDgradFn.apply(gy, h, *ctx.a) if ctx.needs_input_grad[0] else None
+        g_gy = GroupedLinearFn.apply(x, h, *ctx.a) if ctx.needs_input_grad[1] else None
+        return g_x, g_gy, None, None, None, None
+
+
 def grouped_linear(x, m, groups: RowGroups, spec: "FctpSpec", m_off: Sequence[int]):
-    return GroupedLinearFn.apply(x, m, groups, spec, tuple(int(v) for v in m_off))
+    return GroupedLinearFn.apply(_c(x), _c(m), groups, spec, tuple(int(v) for v in m_off))
 
 
 # --------------------------------------------------------------------------------------
@@ -551,59 +713,146 @@ class TpPlan:
             pass
 
 
+def _tp_fwd_raw(x, sh, w, topo: GraphTopo, plan: TpPlan):
+    n, e = x.shape[0], sh.shape[0]
+    assert x.shape[1] == plan.d_in and sh.shape[1] == plan.d_sh and w.shape == (e, plan.w_numel)
+    assert topo.num_nodes == n and topo.num_edges == e
+    out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
+    handle = plan.handle(x.device)
+    prof = PROFILE_TP
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    L.check(L.load().e3k_tp_fwd(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
+                                L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, n, e, plan))
+    return out
+
+
+def _tp_bwd_x_raw(sh, w, g_out, topo: GraphTopo, plan: TpPlan):
+    n, e = topo.num_nodes, topo.num_edges
+    gx = torch.zeros(n, plan.d_in, device=sh.device, dtype=torch.float32)
+    L.check(L.load().e3k_tp_bwd_x(plan.handle(sh.device), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
+                                  L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x")
+    return gx
+
+
+def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool):
+    n, e = topo.num_nodes, topo.num_edges
+    gw = torch.empty(e, plan.w_numel, device=x.device, dtype=torch.float32)
+    gsh = torch.zeros(e, plan.d_sh, device=x.device, dtype=torch.float32) if want_sh else None
+    L.check(L.load().e3k_tp_bwd_w(plan.handle(x.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
+                                  L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
+                                  L.stream_ptr()), "e3k_tp_bwd_w")
+    return gw, gsh
+
+
 class TpFn(torch.autograd.Function):
+    """out[n] = sum over edges into n of TP(x[src], sh, w): trilinear in (x, sh, w).  With
+    F = <g, TP(x, sh, w)> every derivative of every order is one of three kernels — forward (contract
+    nothing), bwd_x (leave x open), bwd_w (leave w and sh open) — with operands exchanged."""
+
     @staticmethod
     def forward(ctx, x, sh, w, topo: GraphTopo, plan: TpPlan):
         L.require_cuda(x, sh, w)
         x, sh, w = L.f32c(x), L.f32c(sh), L.f32c(w)
-        n, e = x.shape[0], sh.shape[0]
-        assert x.shape[1] == plan.d_in and sh.shape[1] == plan.d_sh and w.shape == (e, plan.w_numel)
-        assert topo.num_nodes == n and topo.num_edges == e
-        out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
-        handle = plan.handle(x.device)
-        prof = PROFILE_TP
-        if prof is not None:
-            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            ev0.record()
-        L.check(L.load().e3k_tp_fwd(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
-                                    L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd")
-        if prof is not None:
-            ev1.record()
-            prof.append((ev0, ev1, n, e, plan))
         ctx.save_for_backward(x, sh, w)
         ctx.topo, ctx.plan = topo, plan
-        return out
+        return _tp_fwd_raw(x, sh, w, topo, plan)
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g_out):
         x, sh, w = ctx.saved_tensors
         topo, plan = ctx.topo, ctx.plan
+        need_x, need_sh, need_w = ctx.needs_input_grad[:3]
+        if torch.is_grad_enabled():
+            gx = TpBwdXFn.apply(sh, w, g_out, topo, plan) if need_x else None
+            gw = gsh = None
+            if need_sh or need_w:
+                gw, gsh = TpBwdWFn.apply(x, sh, w, g_out, topo, plan, bool(need_sh))
+            return gx, (gsh if need_sh else None), (gw if need_w else None), None, None
         g_out = L.f32c(g_out)
-        n, e = x.shape[0], sh.shape[0]
-        lib = L.load()
         gx = gsh = gw = None
-        handle = plan.handle(x.device)
         with _Fork(x.device) as fork:
-            if ctx.needs_input_grad[0]:
-                gx = torch.zeros_like(x)
-                fork.side(lambda: L.check(
-                    lib.e3k_tp_bwd_x(handle, L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst), L.ptr(topo.src_ptr),
-                                     L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x"))
-            if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-                gw = torch.empty_like(w)
-                if ctx.needs_input_grad[1]:
-                    gsh = torch.zeros_like(sh)
-                L.check(lib.e3k_tp_bwd_w(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
-                                         L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
-                                         L.stream_ptr()), "e3k_tp_bwd_w")
-        if not ctx.needs_input_grad[2]:
+            if need_x:
+                gx = fork.side(lambda: _tp_bwd_x_raw(sh, w, g_out, topo, plan))
+            if need_sh or need_w:
+                gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, bool(need_sh))
+        if not need_w:
             gw = None
         return gx, gsh, gw, None, None
 
 
+class TpBwdXFn(torch.autograd.Function):
+    """gx = dF/dx (sh, w, g)."""
+
+    @staticmethod
+    def forward(ctx, sh, w, g_out, topo: GraphTopo, plan: TpPlan):
+        sh, w, g_out = L.f32c(sh), L.f32c(w), L.f32c(g_out)
+        ctx.save_for_backward(sh, w, g_out)
+        ctx.topo, ctx.plan = topo, plan
+        return _tp_bwd_x_raw(sh, w, g_out, topo, plan)
+
+    @staticmethod
+    def backward(ctx, h):   # h ~ x
+        sh, w, g_out = ctx.saved_tensors
+        topo, plan = ctx.topo, ctx.plan
+        need_sh, need_w, need_g = ctx.needs_input_grad[:3]
+        g_g = TpFn.apply(h, sh, w, topo, plan) if need_g else None
+        g_w = g_sh = None
+        if need_sh or need_w:
+            g_w, g_sh = TpBwdWFn.apply(h, sh, w, g_out, topo, plan, bool(need_sh))
+        return (g_sh if need_sh else None), (g_w if need_w else None), g_g, None, None
+
+
+class TpBwdWFn(torch.autograd.Function):
+    """(gw, gsh) = (dF/dw, dF/dsh) (x, sh, w, g);  gw does not depend on w, gsh does not depend on sh."""
+
+    @staticmethod
+    def forward(ctx, x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool):
+        x, sh, w, g_out = L.f32c(x), L.f32c(sh), L.f32c(w), L.f32c(g_out)
+        ctx.save_for_backward(x, sh, w, g_out)
+        ctx.topo, ctx.plan, ctx.want_sh = topo, plan, want_sh
+        ctx.set_materialize_grads(False)
+        gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, want_sh)
+        if gsh is None:
+            gsh = torch.zeros(0, device=x.device)
+            ctx.mark_non_differentiable(gsh)
+        return gw, gsh
+
+    @staticmethod
+    def backward(ctx, hw, hsh):   # hw ~ w, hsh ~ sh
+        x, sh, w, g_out = ctx.saved_tensors
+        topo, plan = ctx.topo, ctx.plan
+        need_x, need_sh, need_w, need_g = ctx.needs_input_grad[:4]
+        if not ctx.want_sh:
+            hsh = None
+        t = (topo, plan)
+        g_x = g_sh = g_w = g_g = None
+
+        def acc(a, b):
+            return b if a is None else a + b
+        if hw is not None:      # term <g, TP(x, sh, hw)>
+            if need_x:
+                g_x = acc(g_x, TpBwdXFn.apply(sh, hw, g_out, *t))
+            if need_g:
+                g_g = acc(g_g, TpFn.apply(x, sh, hw, *t))
+            if need_sh:
+                g_sh = acc(g_sh, TpBwdWFn.apply(x, sh, hw, g_out, *t, True)[1])
+        if hsh is not None:     # term <g, TP(x, hsh, w)>
+            if need_x:
+                g_x = acc(g_x, TpBwdXFn.apply(hsh, w, g_out, *t))
+            if need_g:
+                g_g = acc(g_g, TpFn.apply(x, hsh, w, *t))
+            if need_w:
+                g_w = acc(g_w, TpBwdWFn.apply(x, hsh, w, g_out, *t, False)[0])
+        return g_x, g_sh, g_w, g_g, None, None, None
+
+
 def tp_uvu_scatter(x, sh, w, topo: GraphTopo, plan: TpPlan):
-    return TpFn.apply(x, sh, w, topo, plan)
+    return TpFn.apply(_c(x), _c(sh), _c(w), topo, plan)
 
 
 # --------------------------------------------------------------------------------------
@@ -621,17 +870,44 @@ class ActFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
-        gy = L.f32c(gy)
-        gx = torch.empty_like(x)
-        L.check(L.load().e3k_act_bwd(L.ptr(x), L.ptr(gy), x.numel(), ctx.act_id, ctx.cst, L.ptr(gx), L.stream_ptr()), "e3k_act_bwd")
-        return gx, None, None
+        if torch.is_grad_enabled():
+            return ActBwdFn.apply(x, gy, ctx.act_id, ctx.cst), None, None
+        return _act_bwd_raw(x, L.f32c(gy), ctx.act_id, ctx.cst), None, None
+
+
+def _act_bwd_raw(x, gy, act_id, cst):
+    gx = torch.empty_like(x)
+    L.check(L.load().e3k_act_bwd(L.ptr(x), L.ptr(gy), x.numel(), act_id, cst, L.ptr(gx), L.stream_ptr()), "e3k_act_bwd")
+    return gx
+
+
+class ActBwdFn(torch.autograd.Function):
+    """gx = gy * cst * act'(x), differentiable once more (e3k_act_bwd2: act'')."""
+
+    @staticmethod
+    def forward(ctx, x, gy, act_id: int, cst: float):
+        x, gy = L.f32c(x), L.f32c(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.act_id, ctx.cst = act_id, cst
+        return _act_bwd_raw(x, gy, act_id, cst)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        h = L.f32c(h)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_gy = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        if g_x is not None or g_gy is not None:
+            L.check(L.load().e3k_act_bwd2(L.ptr(x), L.ptr(gy), L.ptr(h), x.numel(), ctx.act_id, ctx.cst, L.ptr(g_gy),
+                                          L.ptr(g_x), L.stream_ptr()), "e3k_act_bwd2")
+        return g_x, g_gy, None, None
 
 
 def activation(x, name: str, cst: float):
-    return ActFn.apply(x, ACT_IDS[name], float(cst))
+    return ActFn.apply(_c(x), ACT_IDS[name], float(cst))
 
 
 def _blocks(blocks: Sequence[Tuple[int, int, int]]):
@@ -653,13 +929,8 @@ class RelayoutFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
-    def backward(ctx, gy):
-        gy = L.f32c(gy)
-        gx = torch.empty_like(gy)
-        L.check(L.load().e3k_relayout(L.ptr(gy), gy.shape[0], gy.shape[1], _blocks(ctx.blocks), len(ctx.blocks),
-                                      int(not ctx.to_cf), L.ptr(gx), L.stream_ptr()), "e3k_relayout")
-        return gx, None, None
+    def backward(ctx, gy):   # a permutation: its backward is the inverse permutation (any order of derivative)
+        return RelayoutFn.apply(gy, ctx.blocks, not ctx.to_cf), None, None
 
 
 def relayout(x, blocks: Sequence[Tuple[int, int, int]], to_cf: bool):
@@ -667,7 +938,7 @@ def relayout(x, blocks: Sequence[Tuple[int, int, int]], to_cf: bool):
     blocks = tuple(b for b in blocks if b[1] > 1 and b[2] > 1)
     if not blocks:
         return x
-    return RelayoutFn.apply(x, blocks, to_cf)
+    return RelayoutFn.apply(_c(x), blocks, to_cf)
 
 
 @dataclass
@@ -697,19 +968,45 @@ class GateFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return GateBwdFn.apply(x, gy, ctx.spec), None
+        return _gate_bwd_raw(x, L.f32c(gy), ctx.spec), None
+
+
+def _gate_bwd_raw(x, gy, spec: GateSpec):
+    gx = torch.empty_like(x)
+    L.check(L.load().e3k_gate_bwd(L.ptr(x), L.ptr(gy), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(),
+                                  len(spec.segs), L.ptr(gx), L.stream_ptr()), "e3k_gate_bwd")
+    return gx
+
+
+class GateBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gy, spec: GateSpec):
+        x, gy = L.f32c(x), L.f32c(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.spec = spec
+        return _gate_bwd_raw(x, gy, spec)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
         spec = ctx.spec
-        gy = L.f32c(gy)
-        gx = torch.empty_like(x)
-        L.check(L.load().e3k_gate_bwd(L.ptr(x), L.ptr(gy), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(),
-                                      len(spec.segs), L.ptr(gx), L.stream_ptr()), "e3k_gate_bwd")
-        return gx, None
+        h = L.f32c(h)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_gy = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
+        if g_x is not None or g_gy is not None:
+            L.check(L.load().e3k_gate_bwd2(L.ptr(x), L.ptr(gy), L.ptr(h), x.shape[0], spec.in_dim, spec.out_dim,
+                                           spec.c_array(), len(spec.segs), L.ptr(g_gy), L.ptr(g_x), L.stream_ptr()),
+                    "e3k_gate_bwd2")
+        return g_x, g_gy, None
 
 
 def gate(x, spec: GateSpec):
-    return GateFn.apply(x, spec)
+    return GateFn.apply(_c(x), spec)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -726,9 +1023,25 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, gy):
         x, std, inv = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            # double backward: differentiate a torch restatement on the device (no shipped config combines
+            # LayerNormalization with GradientOutput training; kept correct rather than fast)
+            with torch.enable_grad():
+                parts, pos = [], 0
+                for k, (off, mul, dim) in enumerate(ctx.blocks):
+                    assert off == pos, "normalisation blocks must tile the row"
+                    xb = x[:, off:off + mul * dim]
+                    parts.append(xb * torch.rsqrt(xb.pow(2).sum(1, keepdim=True) / mul + 1e-6) * std[k])
+                    pos += mul * dim
+                y = torch.cat(parts, 1)
+                wrt = [t for t, need in zip((x, std), ctx.needs_input_grad[:2]) if need]
+                grads = list(torch.autograd.grad(y, wrt, gy[:, :pos], create_graph=True))
+            out = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:2]]
+            if out[0] is not None and pos < x.shape[1]:
+                out[0] = torch.cat([out[0][:, :pos], gy.new_zeros(x.shape[0], x.shape[1] - pos)], 1)
+            return out[0], out[1], None
         gy = L.f32c(gy)
         gx = torch.empty_like(x)
         gstd = torch.zeros_like(std)
@@ -739,7 +1052,7 @@ class LayerNormFn(torch.autograd.Function):
 
 
 def layer_norm(x, std, blocks):
-    return LayerNormFn.apply(x, std, tuple(blocks))
+    return LayerNormFn.apply(_c(x), _c(std), tuple(blocks))
 
 
 class SegmentSumFn(torch.autograd.Function):
@@ -756,8 +1069,7 @@ class SegmentSumFn(torch.autograd.Function):
         return out
 
     @staticmethod
-    @once_differentiable
-    def backward(ctx, g):
+    def backward(ctx, g):   # torch ops only: differentiable to any order
         ptr, seg_index = ctx.saved_tensors
         if ctx.mean:
             cnt = (ptr[1:] - ptr[:-1]).clamp(min=1).to(g.dtype).view(-1, 1)
@@ -766,7 +1078,7 @@ class SegmentSumFn(torch.autograd.Function):
 
 
 def segment_sum(x, ptr, seg_index, mean=False):
-    return SegmentSumFn.apply(x, ptr, seg_index, bool(mean))
+    return SegmentSumFn.apply(_c(x), ptr, seg_index, bool(mean))
 
 
 # --------------------------------------------------------------------------------------
@@ -787,10 +1099,17 @@ class EdgeVectorFn(torch.autograd.Function):
         return vec, length
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g_vec, g_len):
         vec, length = ctx.saved_tensors
         topo = ctx.topo
+        if torch.is_grad_enabled():
+            # d len = vec/len . d vec (elementwise torch ops), then the linear scatter dst(+) / src(-)
+            gv = g_vec
+            if g_len is not None:
+                f = torch.where(length > 0, g_len / length.clamp_min(1e-30), torch.zeros_like(length))
+                gl = f.unsqueeze(1) * vec
+                gv = gl if gv is None else gv + gl
+            return EdgeScatterFn.apply(gv, topo, ctx.n), None
         g_vec = L.f32c(g_vec) if g_vec is not None else None
         g_len = L.f32c(g_len) if g_len is not None else None
         g_pos = torch.empty(ctx.n, 3, device=vec.device, dtype=torch.float32)
@@ -800,8 +1119,26 @@ class EdgeVectorFn(torch.autograd.Function):
         return g_pos, None
 
 
+class EdgeScatterFn(torch.autograd.Function):
+    """g_pos[n] = sum_{dst(e)=n} gv[e] - sum_{src(e)=n} gv[e]  (adjoint of the edge-vector gather)."""
+
+    @staticmethod
+    def forward(ctx, gv, topo: GraphTopo, n: int):
+        gv = L.f32c(gv)
+        g_pos = torch.empty(n, 3, device=gv.device, dtype=torch.float32)
+        L.check(L.load().e3k_edge_vector_bwd(L.ptr(gv), None, None, None, L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm),
+                                             L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, L.ptr(g_pos),
+                                             L.stream_ptr()), "e3k_edge_vector_bwd")
+        ctx.topo = topo
+        return g_pos
+
+    @staticmethod
+    def backward(ctx, h):   # h ~ pos: gather h[dst] - h[src]
+        return EdgeVectorFn.apply(h, ctx.topo)[0], None, None
+
+
 def edge_vector(pos, topo: GraphTopo):
-    return EdgeVectorFn.apply(pos, topo)
+    return EdgeVectorFn.apply(_c(pos), topo)
 
 
 class SphHarmFn(torch.autograd.Function):
@@ -820,53 +1157,141 @@ class SphHarmFn(torch.autograd.Function):
         return sh
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g_sh):
         (vec,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return SphHarmBwdFn.apply(vec, g_sh, ctx.cfg), None, None, None
+        return _sph_bwd_raw(vec, L.f32c(g_sh), ctx.cfg), None, None, None
+
+
+def _sph_bwd_raw(vec, g_sh, cfg):
+    ls, normalize, normalization = cfg
+    rows = vec.numel() // 3
+    g_vec = torch.empty_like(vec)
+    arr = (C.c_int32 * len(ls))(*ls)
+    L.check(L.load().e3k_sph_harm_bwd(L.ptr(vec), L.ptr(g_sh), rows, arr, len(ls), int(normalize), normalization,
+                                      L.ptr(g_vec), L.stream_ptr()), "e3k_sph_harm_bwd")
+    return g_vec
+
+
+class SphHarmBwdFn(torch.autograd.Function):
+    """g_vec = J(vec)^T g_sh; its backward (e3k_sph_harm_bwd2) evaluates the same polynomials on dual numbers."""
+
+    @staticmethod
+    def forward(ctx, vec, g_sh, cfg):
+        vec, g_sh = L.f32c(vec), L.f32c(g_sh)
+        ctx.save_for_backward(vec, g_sh)
+        ctx.cfg = cfg
+        return _sph_bwd_raw(vec, g_sh, cfg)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        vec, g_sh = ctx.saved_tensors
         ls, normalize, normalization = ctx.cfg
-        g_sh = L.f32c(g_sh)
+        h = L.f32c(h)
         rows = vec.numel() // 3
-        g_vec = torch.empty_like(vec)
-        arr = (C.c_int32 * len(ls))(*ls)
-        L.check(L.load().e3k_sph_harm_bwd(L.ptr(vec), L.ptr(g_sh), rows, arr, len(ls), int(normalize), normalization,
-                                          L.ptr(g_vec), L.stream_ptr()), "e3k_sph_harm_bwd")
-        return g_vec, None, None, None
+        g_vec = torch.empty_like(vec) if ctx.needs_input_grad[0] else None
+        g_gsh = torch.empty_like(g_sh) if ctx.needs_input_grad[1] else None
+        if g_vec is not None or g_gsh is not None:
+            arr = (C.c_int32 * len(ls))(*ls)
+            L.check(L.load().e3k_sph_harm_bwd2(L.ptr(vec), L.ptr(g_sh), L.ptr(h), rows, arr, len(ls), int(normalize),
+                                               normalization, L.ptr(g_gsh), L.ptr(g_vec), L.stream_ptr()),
+                    "e3k_sph_harm_bwd2")
+        return g_vec, g_gsh, None
 
 
 NORMALIZATIONS = {"component": 0, "integral": 1, "norm": 2}
 
 
 def spherical_harmonics(vec, ls: Sequence[int], normalize: bool, normalization: str):
-    return SphHarmFn.apply(vec, tuple(int(l) for l in ls), bool(normalize), NORMALIZATIONS[normalization])
+    return SphHarmFn.apply(_c(vec), tuple(int(l) for l in ls), bool(normalize), NORMALIZATIONS[normalization])
 
 
 class RadialBasisFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, r, bessel_w, r_max, r_min, p, one_over_r, cutoff_kind):
         L.require_cuda(r, bessel_w)
-        r, bessel_w = L.f32c(r).view(-1), L.f32c(bessel_w)
+        r_shape = r.shape
+        assert r.dim() == 1, "radial_basis() flattens r before apply (saved tensors must be the true inputs)"
+        r, bessel_w = L.f32c(r), L.f32c(bessel_w)
         e, nb = r.numel(), bessel_w.numel()
         out = torch.empty(e, nb, device=r.device, dtype=torch.float32)
         L.check(L.load().e3k_radial_basis_fwd(L.ptr(r), e, L.ptr(bessel_w), nb, r_max, r_min, p, int(one_over_r),
                                               cutoff_kind, L.ptr(out), L.stream_ptr()), "e3k_radial_basis_fwd")
         ctx.save_for_backward(r, bessel_w)
         ctx.cfg = (r_max, r_min, p, int(one_over_r), cutoff_kind)
+        ctx.r_shape = r_shape
         return out
 
     @staticmethod
-    @once_differentiable
     def backward(ctx, g_out):
         r, bessel_w = ctx.saved_tensors
+        need_r, need_w = ctx.needs_input_grad[:2]
+        if torch.is_grad_enabled():
+            g_r, g_w = RadialBasisBwdFn.apply(r, bessel_w, g_out, ctx.cfg, bool(need_r), bool(need_w))
+        else:
+            g_r, g_w = _radial_bwd_raw(r, bessel_w, L.f32c(g_out), ctx.cfg, need_r, need_w)
+        if g_r is not None and ctx.r_shape != g_r.shape:
+            g_r = g_r.view(ctx.r_shape)
+        return (g_r if need_r else None), (g_w if need_w else None), None, None, None, None, None
+
+
+def _radial_bwd_raw(r, bessel_w, g_out, cfg, need_r, need_w):
+    r_max, r_min, p, one_over_r, kind = cfg
+    g_r = torch.empty_like(r) if need_r else None
+    g_w = torch.zeros_like(bessel_w) if need_w else None
+    if g_r is not None or g_w is not None:
+        L.check(L.load().e3k_radial_basis_bwd(L.ptr(r), L.ptr(g_out), r.numel(), L.ptr(bessel_w), bessel_w.numel(),
+                                              r_max, r_min, p, one_over_r, kind, L.ptr(g_r), L.ptr(g_w),
+                                              L.stream_ptr()), "e3k_radial_basis_bwd")
+    return g_r, g_w
+
+
+class RadialBasisBwdFn(torch.autograd.Function):
+    """(g_r, g_w) of the radial basis; its backward is e3k_radial_basis_bwd2 (dual numbers)."""
+
+    @staticmethod
+    def forward(ctx, r, bessel_w, g_out, cfg, need_r: bool, need_w: bool):
+        r, bessel_w, g_out = L.f32c(r), L.f32c(bessel_w), L.f32c(g_out)
+        ctx.save_for_backward(r, bessel_w, g_out)
+        ctx.cfg, ctx.flags = cfg, (need_r, need_w)
+        ctx.set_materialize_grads(False)
+        g_r, g_w = _radial_bwd_raw(r, bessel_w, g_out, cfg, need_r, need_w)
+        dead = []
+        if g_r is None:
+            g_r = torch.zeros(0, device=r.device)
+            dead.append(g_r)
+        if g_w is None:
+            g_w = torch.zeros(0, device=r.device)
+            dead.append(g_w)
+        if dead:
+            ctx.mark_non_differentiable(*dead)
+        return g_r, g_w
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, hr, hw):
+        r, bessel_w, g_out = ctx.saved_tensors
         r_max, r_min, p, one_over_r, kind = ctx.cfg
-        g_out = L.f32c(g_out)
+        if not ctx.flags[0]:
+            hr = None
+        if not ctx.flags[1]:
+            hw = None
+        if hr is None and hw is None:
+            return None, None, None, None, None, None
+        hr = L.f32c(hr).view(-1) if hr is not None else None
+        hw = L.f32c(hw) if hw is not None else None
         g_r = torch.empty_like(r) if ctx.needs_input_grad[0] else None
         g_w = torch.zeros_like(bessel_w) if ctx.needs_input_grad[1] else None
-        if g_r is not None or g_w is not None:
-            L.check(L.load().e3k_radial_basis_bwd(L.ptr(r), L.ptr(g_out), r.numel(), L.ptr(bessel_w), bessel_w.numel(),
-                                                  r_max, r_min, p, one_over_r, kind, L.ptr(g_r), L.ptr(g_w),
-                                                  L.stream_ptr()), "e3k_radial_basis_bwd")
-        return g_r, g_w, None, None, None, None, None
+        g_go = torch.empty_like(g_out) if ctx.needs_input_grad[2] else None
+        if g_r is not None or g_w is not None or g_go is not None:
+            L.check(L.load().e3k_radial_basis_bwd2(L.ptr(r), L.ptr(g_out), L.ptr(hr), L.ptr(hw), r.numel(),
+                                                   L.ptr(bessel_w), bessel_w.numel(), r_max, r_min, p, one_over_r, kind,
+                                                   L.ptr(g_go), L.ptr(g_r), L.ptr(g_w), L.stream_ptr()),
+                    "e3k_radial_basis_bwd2")
+        return g_r, g_w, g_go, None, None, None
 
 
 def radial_basis(r, bessel_w, r_max, r_min, p, one_over_r, cutoff_kind):
-    return RadialBasisFn.apply(r, bessel_w, float(r_max), float(r_min), float(p), bool(one_over_r), int(cutoff_kind))
+    return RadialBasisFn.apply(_c(r).reshape(-1), _c(bessel_w), float(r_max), float(r_min), float(p), bool(one_over_r), int(cutoff_kind))

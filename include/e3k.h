@@ -116,6 +116,11 @@ int e3k_sph_harm_fwd(const float* vec, int64_t E, const int32_t* ls, int32_t n_l
                      int32_t normalization, float* sh, void* stream);
 int e3k_sph_harm_bwd(const float* vec, const float* g_sh, int64_t E, const int32_t* ls, int32_t n_ls,
                      int32_t normalize, int32_t normalization, float* g_vec, void* stream);
+/* double backward: g_hat [E,3] is the cotangent of e3k_sph_harm_bwd's g_vec.
+ * g_gsh [E,dim] = J(vec) g_hat;  g_vec [E,3] = d/dvec <g_hat, sph_harm_bwd(vec, g_sh)>  (either may be NULL). */
+int e3k_sph_harm_bwd2(const float* vec, const float* g_sh, const float* g_hat, int64_t E, const int32_t* ls,
+                      int32_t n_ls, int32_t normalize, int32_t normalization, float* g_gsh, float* g_vec,
+                      void* stream);
 
 /* cutoff_kind: 0 polynomial (p), 1 symmetric (x^2-1)^2 */
 int e3k_radial_basis_fwd(const float* r, int64_t E, const float* bessel_w, int32_t n_basis, float r_max, float r_min,
@@ -123,6 +128,13 @@ int e3k_radial_basis_fwd(const float* r, int64_t E, const float* bessel_w, int32
 int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t E, const float* bessel_w, int32_t n_basis,
                          float r_max, float r_min, float p, int32_t one_over_r, int32_t cutoff_kind, float* g_r,
                          float* g_w, void* stream);
+/* double backward: hat_r [E] / hat_w [n_basis] are the cotangents of e3k_radial_basis_bwd's g_r / g_w (either
+ * may be NULL = zero).  g_gout [E,n_basis] = d out along (hat_r, hat_w); g_r [E] written, g_w [n_basis]
+ * ACCUMULATED (caller zeroes): the second derivatives contracted with g_out.  Outputs may be NULL. */
+int e3k_radial_basis_bwd2(const float* r, const float* g_out, const float* hat_r, const float* hat_w, int64_t E,
+                          const float* bessel_w, int32_t n_basis, float r_max, float r_min, float p,
+                          int32_t one_over_r, int32_t cutoff_kind, float* g_gout, float* g_r, float* g_w,
+                          void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Fused 'uvu' tensor product + destination reduce.
@@ -175,6 +187,11 @@ int e3k_act_bwd(const float* x, const float* g_y, int64_t n, int32_t act, float 
  * so a fused linear+activation layer keeps only its output */
 int e3k_act_bwd_from_output(const float* y, const float* g_y, int64_t n, int32_t act, float cst, float* g_x,
                             void* stream);
+/* double backward (GradientOutput with create_graph=True, e3_layers/nn/output.py:42-50 — force training):
+ * e3k_act_bwd computed g_x = g_y*cst*act'(x); given the cotangent g_hat of that g_x,
+ *   g_gy = g_hat*cst*act'(x)   and   g_x = g_hat*g_y*cst*act''(x)   (either output may be NULL). */
+int e3k_act_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t n, int32_t act, float cst,
+                 float* g_gy, float* g_x, void* stream);
 
 /* layout change of a feature row: blocks (off, mul, dim=2l+1); to_cf=1: [mul][dim] -> [dim][mul]. */
 typedef struct {
@@ -198,6 +215,10 @@ int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_t out_dim, 
                  int32_t n_segs, float* y, void* stream);
 int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int32_t in_dim, int32_t out_dim,
                  const e3k_gate_seg* segs, int32_t n_segs, float* g_x, void* stream);
+/* double backward of the gate: g_hat [rows,in_dim] is the cotangent of e3k_gate_bwd's g_x;
+ * g_gy [rows,out_dim] = (dy/dx) g_hat,  g_x [rows,in_dim] = d/dx <g_hat, gate_bwd(x, g_y)>  (either may be NULL). */
+int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t rows, int32_t in_dim, int32_t out_dim,
+                  const e3k_gate_seg* segs, int32_t n_segs, float* g_gy, float* g_x, void* stream);
 
 /* per-irreps-block RMS normalisation (LayerNormalization, nn/pointwise.py:32-51), e3nn layout */
 int e3k_layernorm_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,

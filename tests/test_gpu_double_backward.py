@@ -1,0 +1,278 @@
+"""GPU parity of the DOUBLE backward (force training: ``GradientOutput`` with ``create_graph=True``,
+e3_layers/nn/output.py:42-50, then the loss on the gradient is differentiated again).  Each op's
+second-order path — the ``*_bwd2`` kernels and the re-used forward/backward kernels with operands
+exchanged — is compared with torch's own double backward through the float64 oracle."""
+import pytest
+import torch
+
+from oracle import e3ref
+from tests.util import batch_to_oracle, from_cf, oracle_like, rel_err, to_cf
+
+pytestmark = pytest.mark.gpu
+
+TOL2 = 5e-5   # second derivatives in fp32 against float64
+
+
+def _second_order(y, ins, yr, rins, dev, tol=TOL2, names=None):
+    """S = sum_i <dL/d in_i, c_i> with L = <y, seed>; compare dS/d in_j for every j."""
+    gen = torch.Generator().manual_seed(1234)
+    seed = torch.randn(yr.shape, dtype=torch.float64, generator=gen)
+    g = torch.autograd.grad(y, ins, seed.float().to(dev), create_graph=True, allow_unused=True)
+    r = torch.autograd.grad(yr, rins, seed, create_graph=True, allow_unused=True)
+    s_dev, s_ref = 0.0, 0.0
+    for gi, ri in zip(g, r):
+        assert (gi is None) == (ri is None)
+        if ri is None:
+            continue
+        assert rel_err(gi, ri) < tol
+        c = torch.randn(ri.shape, dtype=torch.float64, generator=gen)
+        s_dev = s_dev + (gi * c.float().to(dev)).sum()
+        s_ref = s_ref + (ri * c).sum()
+    gg = torch.autograd.grad(s_dev, ins, allow_unused=True)
+    rr = torch.autograd.grad(s_ref, rins, allow_unused=True)
+    for k, (a, b) in enumerate(zip(gg, rr)):
+        label = names[k] if names else k
+        if b is None or float(b.abs().max()) == 0.0:
+            assert a is None or float(a.abs().max()) < 1e-6, label
+            continue
+        assert a is not None, label
+        err = rel_err(a, b)
+        assert err < tol, (label, err)
+
+
+def _leaf(t, dev):
+    return t.float().to(dev).requires_grad_(True)
+
+
+def test_linear_double_backward(dev):
+    from e3_layers_amd.nn import Linear
+
+    torch.manual_seed(0)
+    ir_in, ir_out = "8x0e+4x1o+3x1o+5x2e+2x0o", "6x0e+7x1o+2x2e+3x3o+5x0e"
+    lin = Linear(ir_in, ir_out, biases=True).to(dev)
+    ref = e3ref.Linear(ir_in, ir_out, biases=True).double()
+    ref.load_state_dict({k: v.cpu() for k, v in lin.state_dict().items()})
+    x = torch.randn(200, lin.irreps_in.dim, dtype=torch.float64)
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    y = from_cf(lin(to_cf(xin, ir_in), in_layout="cf", out_layout="cf"), ir_out)
+    _second_order(y, [xin, lin.weight], ref(xr), [xr, ref.weight], dev, names=["x", "weight"])
+
+
+def test_radial_mlp_double_backward(dev):
+    from e3_layers_amd.nn import FullyConnectedNet
+    from e3_layers_amd.utils import activations
+
+    torch.manual_seed(1)
+    hs = [8, 64, 64, 96]
+    net = FullyConnectedNet(hs, activations["ssp"]).to(dev)
+    ref = e3ref.FullyConnectedNet(hs, "ssp").double()
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(500, 8, dtype=torch.float64)
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    _second_order(net(xin), [xin] + list(net.parameters()), ref(xr), [xr] + list(ref.parameters()), dev)
+
+
+@pytest.mark.parametrize("act", ["ssp", "silu", "tanhlu", "tanh"])
+def test_activation_double_backward(dev, act):
+    from e3_layers_amd.backend import ops
+
+    torch.manual_seed(2)
+    x = torch.randn(3000, dtype=torch.float64) * 2.0
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    y = ops.activation(xin, act, 1.3)
+    yr = 1.3 * e3ref.ACTIVATIONS[act](xr)
+    assert rel_err(y, yr) < 1e-5
+    # a non-trivial upstream so that the gy operand of the backward carries a graph too
+    _second_order(y * y, [xin], yr * yr, [xr], dev)
+
+
+def test_gate_double_backward(dev):
+    from e3_layers_amd.nn import Gate
+
+    torch.manual_seed(4)
+    args = ("8x0e+8x0o", ["silu", "tanhlu"], "4x0e+6x0e+5x0e", ["silu", "silu", "silu"], "4x1o+6x2e+5x1e")
+    g, ref = Gate(*args), e3ref.Gate(*args)
+    x = torch.randn(100, g.irreps_in.dim, dtype=torch.float64)
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    y, yr = g(to_cf(xin, g.irreps_in)), ref(xr)
+    _second_order(y * y, [xin], yr * yr, [xr], dev)
+
+
+@pytest.mark.parametrize("ls", [[0, 1, 2], [0, 1, 2, 3]])
+@pytest.mark.parametrize("normalize", [True, False])
+def test_spherical_harmonics_double_backward(dev, ls, normalize):
+    from e3_layers_amd.backend import ops
+
+    torch.manual_seed(5)
+    v = torch.randn(400, 3, dtype=torch.float64) * 1.5
+    vin, vr = _leaf(v, dev), v.clone().requires_grad_(True)
+    y = ops.spherical_harmonics(vin, ls, normalize, "component")
+    yr = e3ref.spherical_harmonics(ls, vr, normalize, "component")
+    _second_order(y * y, [vin], yr * yr, [vr], dev, tol=1e-4 if not normalize else TOL2)
+
+
+@pytest.mark.parametrize("one_over_r,cutoff", [(True, "_poly_cutoff"), (False, "_poly_cutoff"), (False, "symmetricCutoff")])
+def test_radial_basis_double_backward(dev, one_over_r, cutoff):
+    from e3_layers_amd import nn as pnn
+
+    torch.manual_seed(6)
+    mod = pnn.RadialBasisEncoding(4.0, True, "8x0e", cutoff=getattr(pnn, cutoff), one_over_r=one_over_r).to(dev)
+    ref = e3ref.RadialBasisEncoding(4.0, True, "8x0e", cutoff=cutoff, one_over_r=one_over_r).double()
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    r = torch.rand(600, dtype=torch.float64) * 4.2 + 0.5   # includes r > r_max
+    if cutoff == "symmetricCutoff":
+        r = r - 2.5
+    rin, rr = _leaf(r, dev), r.clone().requires_grad_(True)
+    y = mod({"input": rin}, {"input": ("edge", "1x0e")})[0]["radial_embedding"]
+    yr = ref({"input": rr}, {"input": ("edge", "1x0e")})[0]["radial_embedding"]
+    _second_order(y * y, [rin, mod.basis.bessel_weights], yr * yr, [rr, ref.basis.bessel_weights], dev, tol=2e-4,
+                  names=["r", "bessel_weights"])
+
+
+def _random_graph(n_nodes, avg_deg, seed):
+    gen = torch.Generator().manual_seed(seed)
+    e = n_nodes * avg_deg
+    src = torch.randint(n_nodes, (e,), generator=gen)
+    dst = torch.randint(n_nodes, (e,), generator=gen)
+    dst[dst == src] = (dst[dst == src] + 1) % n_nodes
+    dst[dst == 0] = 1
+    src[src == n_nodes - 1] = 2
+    return torch.stack([src, dst])
+
+
+def test_edge_vector_double_backward(dev):
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+
+    torch.manual_seed(7)
+    n = 40
+    ei = _random_graph(n, 8, 7)
+    ei = ei[:, ei[0] != ei[1]]      # the second derivative of |v| at v = 0 is undefined (NaN in torch too)
+    pos = torch.randn(n, 3, dtype=torch.float64)
+    pin, pr = _leaf(pos, dev), pos.clone().requires_grad_(True)
+    vec, length = ops.edge_vector(pin, build_topology(ei.to(dev), n))
+    vr = pr[ei[1]] - pr[ei[0]]
+    lr = torch.linalg.norm(vr, dim=-1)
+    y = vec * vec * length.unsqueeze(1) + length.unsqueeze(1) ** 3
+    yr = vr * vr * lr.unsqueeze(1) + lr.unsqueeze(1) ** 3
+    _second_order(y, [pin], yr, [pr], dev)
+
+
+@pytest.mark.parametrize("left,out", [
+    ("16x0e+16x1o+16x2e", "16x0e+16x1o+16x2e+16x1e+16x3o"),
+    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
+])
+def test_tp_double_backward(dev, left, out):
+    """All nine second-order blocks of the trilinear fused product (x, sh, w) + the node-side Linear."""
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(8)
+    sh_ir = "1x0e+1x1o+1x2e"
+    n = 29
+    ei = _random_graph(n, 6, 11)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    ref = e3ref.TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).double()
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(n, mod.tp.irreps_in1.dim, dtype=torch.float64)
+    sh = e3ref.spherical_harmonics([0, 1, 2], torch.randn(e, 3, dtype=torch.float64))
+    w = torch.randn(e, mod.tp.weight_numel, dtype=torch.float64)
+    xin, shin, win = _leaf(x, dev), _leaf(sh, dev), _leaf(w, dev)
+    mid = mod.tp.fused(to_cf(xin, left), shin, win, build_topology(ei.to(dev), n))
+    y = mod.linear(mid, in_layout="cf", out_layout="e3nn")
+    xr, shr, wr = (t.clone().requires_grad_(True) for t in (x, sh, w))
+    yr = e3ref.scatter(ref(left=xr[ei[0]], right=shr, weight=wr), ei[1], dim_size=n)
+    _second_order(y, [xin, shin, win, mod.linear.weight], yr, [xr, shr, wr, ref.linear.weight], dev,
+                  names=["x", "sh", "w", "linear.weight"])
+
+
+@pytest.mark.parametrize("keyed", [True, False])
+def test_self_connection_double_backward(dev, keyed):
+    from e3_layers_amd.nn import FullyConnectedTensorProduct
+    from e3_layers_amd.nn.core import set_row_key
+
+    torch.manual_seed(11)
+    in1, in2, out = "32x0e+32x1o+16x2e", "20x0e", "48x0e+32x1o+16x2e"
+    tp = FullyConnectedTensorProduct(in1, in2, out).to(dev)
+    ref = e3ref.FullyConnectedTensorProduct(in1, in2, out).double()
+    ref.load_state_dict({k: v.cpu() for k, v in tp.state_dict().items()})
+    rows, n_types = 400, 5
+    species = torch.randint(0, n_types, (rows,))
+    table = torch.randn(n_types, 20, dtype=torch.float64)
+    x = torch.randn(rows, tp.irreps_in1.dim, dtype=torch.float64)
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    tin, tr = _leaf(table, dev), table.clone().requires_grad_(True)
+    ain = tin[species.to(dev)]
+    if keyed:
+        set_row_key(ain, species.to(dev), n_types)
+    y = from_cf(tp(to_cf(xin, in1), ain), out)
+    yr = ref(xr, tr[species])
+    _second_order(y, [xin, tin, tp.weight], yr, [xr, tr, ref.weight], dev, names=["x", "attr table", "weight"])
+
+
+def test_layer_norm_and_pooling_double_backward(dev):
+    from e3_layers_amd import nn as pnn
+
+    torch.manual_seed(9)
+    ir = "8x0e+8x1o+4x2e"
+    mod = pnn.LayerNormalization(ir, ir).to(dev)
+    ref = e3ref.LayerNormalization(ir, ir).double()
+    with torch.no_grad():
+        mod.std.uniform_(0.5, 1.5)
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(64, 52, dtype=torch.float64)
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    y = mod({"input": xin}, {})[0]["output"]
+    yr = ref({"input": xr}, {})[0]["output"]
+    _second_order(y, [xin, mod.std], yr, [xr, ref.std], dev)
+
+    n_nodes = torch.tensor([[3], [1], [5], [2]])
+    seg = torch.repeat_interleave(torch.arange(4), n_nodes.view(-1))
+    x = torch.randn(11, 1, dtype=torch.float64)
+    pool = pnn.Pooling("1x0e", "1x0e", "mean")
+    xin, xr = _leaf(x, dev), x.clone().requires_grad_(True)
+    y = pool({"input": xin * xin, "_n_nodes": n_nodes.to(dev), "_node_segment": seg.to(dev)}, {"input": ("node", "1x0e")})[0]["output"]
+    yr = e3ref.scatter(xr * xr, seg, dim_size=4, reduce="mean")
+    _second_order(y * y, [xin], yr * yr, [xr], dev)
+
+
+def test_force_training_step_matches_oracle(dev):
+    """Energy+force model in TRAINING mode: loss = MSE(forces) + MSE(total energy); the parameter
+    gradients (d/dtheta of dE/dpos — the double backward through every kernel) against the oracle."""
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.utils import build
+
+    cfg = featureModel(n_dim=16, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+                       num_types=10, num_layers=3, r_max=4.0)
+    cfg = addForceOutput(addEnergyOutput(cfg, None, output_key="energy_total"), y="energy_total")
+    torch.manual_seed(0)
+    prod = build(cfg).to(dev).train()
+    orc = e3ref.build(cfg)
+    orc.load_state_dict({k.replace("func.", "func.mods.", 1): v.cpu() for k, v in prod.state_dict().items()})
+    orc = orc.double().train()
+    batch = synth_qm9(7, 4)
+    gen = torch.Generator().manual_seed(5)
+    f_target = torch.randn(batch["pos"].shape, dtype=torch.float64, generator=gen)
+    e_target = torch.randn(4, 1, dtype=torch.float64, generator=gen)
+    out = prod(batch.clone().to(dev))
+    loss = ((out["forces"] - f_target.float().to(dev)) ** 2).mean() + ((out["energy_total"] - e_target.float().to(dev)) ** 2).mean()
+    loss.backward()
+    data, attrs = batch_to_oracle(batch)
+    o, _ = orc(data, attrs)
+    loss_r = ((o["forces"] - f_target) ** 2).mean() + ((o["energy_total"] - e_target) ** 2).mean()
+    loss_r.backward()
+    assert rel_err(out["forces"], o["forces"]) < 5e-5
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-4 * abs(float(loss_r.detach()))
+    ref_params = dict(orc.named_parameters())
+    checked = 0
+    for name, p in prod.named_parameters():
+        rp = ref_params[name.replace("func.", "func.mods.", 1)]
+        if rp.grad is None or float(rp.grad.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        err = rel_err(p.grad, rp.grad)
+        assert err < 2e-4, (name, err)
+        checked += 1
+    assert checked >= 10
