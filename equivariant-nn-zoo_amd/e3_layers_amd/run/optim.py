@@ -1,0 +1,107 @@
+"""Fused training-step plumbing on the flat parameter vector.
+
+Stands in for the reference's per-step sequence ``clip_grad_norm_`` → ``optim.step()`` →
+``ema.update()`` (``e3_layers/run/trainer.py:374-386``; diffusion variant with the
+non-finite-gradient skip ``e3_layers/run/sde_utils.py:233-248``).  Parameters, gradients, both
+Adam moments and the EMA shadow live in five flat fp32 buffers; one ``e3k_adam_ema_step`` call
+(a gradient-norm reduction, a one-thread tick that derives the step-dependent scalars on the
+device, and one streaming update kernel) replaces ≈10 multi-tensor launches and touches each
+parameter's 28-36 bytes exactly once.  Step count and bias corrections are device state, so the
+whole step can be captured in a HIP graph.
+
+Semantics follow ``torch.optim.Adam`` (amsgrad off, decoupled=False weight decay) and
+``torch_ema.ExponentialMovingAverage`` (``decay=min(decay, (1+k)/(10+k))`` with ``use_num_updates``).
+"""
+from __future__ import annotations
+
+from contextlib import contextmanager
+from typing import Iterable, Optional, Tuple
+
+import torch
+
+from ..backend import lib as L
+from .parallel import FlatGradients, flat_layout
+
+
+class FusedAdamEMA:
+    def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
+                 eps: float = 1e-8, weight_decay: float = 0.0, ema_decay: Optional[float] = None,
+                 ema_use_num_updates: bool = True, max_grad_norm: Optional[float] = None, skip_nonfinite: bool = False):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        L.require_cuda(*self.params)
+        dev = self.params[0].device
+        self.offsets, total = flat_layout(self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, off in zip(self.params, self.offsets):
+                self.flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = self.flat[off:off + p.numel()].view_as(p)      # parameters become views of the flat vector
+        self.grads = FlatGradients(self.params)                      # after the re-pointing: sink keys use the new addresses
+        assert self.grads.offsets == self.offsets
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.ema = self.flat.clone() if ema_decay is not None else None
+        self.state = torch.zeros(16, dtype=torch.float32, device=dev)
+        self.lr, self.betas, self.eps, self.weight_decay = float(lr), (float(betas[0]), float(betas[1])), float(eps), float(weight_decay)
+        self.ema_decay = float(ema_decay) if ema_decay is not None else 0.0
+        self.ema_use_num_updates = bool(ema_use_num_updates)
+        self.max_grad_norm = float(max_grad_norm) if (max_grad_norm is not None and max_grad_norm < float("inf")) else 0.0
+        self.skip_nonfinite = bool(skip_nonfinite)
+
+    # ------------------------------------------------------------------ step
+    def zero_grad(self) -> None:
+        self.grads.zero()
+
+    @torch.no_grad()
+    def step(self) -> None:
+        """(all-reduce of the flat gradient is the caller's: ``self.grads.all_reduce_mean()``)"""
+        L.check(L.load().e3k_adam_ema_step(
+            L.ptr(self.flat), L.ptr(self.grads.buffer), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
+            self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.ema_decay,
+            int(self.ema_use_num_updates), self.max_grad_norm, int(self.skip_nonfinite), L.ptr(self.state),
+            L.stream_ptr()), "e3k_adam_ema_step")
+
+    # ------------------------------------------------------------------ introspection (each is a device->host sync)
+    @property
+    def steps_taken(self) -> int:
+        return int(self.state[0].item())
+
+    @property
+    def last_grad_norm(self) -> float:
+        """Total gradient norm seen by the last step (only computed when clipping / skipping is on)."""
+        return float(self.state[7].item())
+
+    # ------------------------------------------------------------------ EMA weights (validation / checkpoints)
+    @contextmanager
+    def average_parameters(self):
+        """``with opt.average_parameters(): validate(model)`` — torch_ema's context manager
+        (``e3_layers/run/trainer.py:438-439``): parameters hold the EMA inside, are restored after."""
+        if self.ema is None:
+            yield
+            return
+        saved = self.flat.clone()
+        self.flat.copy_(self.ema)
+        try:
+            yield
+        finally:
+            self.flat.copy_(saved)
+
+    def state_dict(self) -> dict:
+        return {"flat": self.flat.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+                "ema": None if self.ema is None else self.ema.clone(), "state": self.state.clone(),
+                "hyper": dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
+                              ema_decay=self.ema_decay, ema_use_num_updates=self.ema_use_num_updates,
+                              max_grad_norm=self.max_grad_norm, skip_nonfinite=self.skip_nonfinite)}
+
+    def load_state_dict(self, sd: dict) -> None:
+        with torch.no_grad():
+            self.flat.copy_(sd["flat"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            if self.ema is not None and sd.get("ema") is not None:
+                self.ema.copy_(sd["ema"])
+            self.state.copy_(sd["state"])
+        for k, v in sd.get("hyper", {}).items():
+            setattr(self, k, v)

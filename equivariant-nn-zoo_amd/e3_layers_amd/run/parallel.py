@@ -50,20 +50,34 @@ def shard_batch(batch, rank: int, world_size: int):
     return batch[mine]
 
 
+FLAT_ALIGN = 64   # floats: every parameter's slice starts on a 256-byte boundary (16-byte vector loads stay legal)
+
+
+def flat_layout(params: Sequence[torch.Tensor], align: int = FLAT_ALIGN):
+    """Offsets of each tensor in a flat buffer and the buffer length (padding slots stay zero)."""
+    offs, off = [], 0
+    for p in params:
+        offs.append(off)
+        off += -(-p.numel() // align) * align
+    return offs, off
+
+
 class FlatGradients:
     """Points every ``p.grad`` at a slice of one contiguous buffer."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
         self.params = [p for p in params if p.requires_grad]
-        total = sum(p.numel() for p in self.params)
+        self.offsets, total = flat_layout(self.params)
         ref = self.params[0]
         self.buffer = torch.zeros(total, dtype=ref.dtype, device=ref.device)
-        off = 0
         self._sink = {}
-        for p in self.params:
+        for p, off in zip(self.params, self.offsets):
             p.grad = self.buffer[off:off + p.numel()].view_as(p)
             self._sink[(p.data_ptr(), p.numel())] = self.buffer[off:off + p.numel()]
-            off += p.numel()
+
+    def gather(self) -> torch.Tensor:
+        """The gradients without the alignment padding, concatenated in parameter order."""
+        return torch.cat([self.buffer[o:o + p.numel()] for p, o in zip(self.params, self.offsets)])
 
     def enable_direct_accumulation(self) -> None:
         """Let the HIP weight-gradient kernels add straight into this buffer (it must be zeroed with

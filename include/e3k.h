@@ -231,6 +231,22 @@ int e3k_layernorm_bwd(const float* x, const float* g_y, const float* inv_norm, i
 int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t dim, int32_t mean, float* out,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Training-step plumbing on the flat parameter vector.
+ * Replaces clip_grad_norm_ + optim.step() + ema.update() (e3_layers/run/trainer.py:374-386) and the variant that
+ * skips the optimizer step on a non-finite gradient (e3_layers/run/sde_utils.py:233-248): torch.optim.Adam
+ * (amsgrad off) and torch_ema.ExponentialMovingAverage semantics, one pass over HBM.
+ *   param, grad, exp_avg, exp_avg_sq, ema (NULL = no EMA): flat fp32 [n], 16-byte aligned.
+ *   max_grad_norm <= 0: no clipping.  skip_nonfinite: leave param / moments untouched when the gradient norm is
+ *   not finite (the EMA still updates, as in the reference).
+ *   state: DEVICE float[16], zero-initialised once by the caller; holds the step count, bias corrections, clip
+ *   coefficient, skip flag, gradient norm ([7]) and the EMA update count — so a captured HIP graph replays
+ *   correctly. */
+int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t n,
+                      float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
+                      int32_t ema_use_num_updates, float max_grad_norm, int32_t skip_nonfinite, float* state,
+                      void* stream);
+
 #ifdef __cplusplus
 }
 #endif

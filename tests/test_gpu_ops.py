@@ -430,5 +430,61 @@ def test_fused_activation_epilogue_and_grad_sink(dev):
         ops.strided_linear(x, w, None, spec).backward(seed)
     finally:
         flat.disable_direct_accumulation()
-    assert rel_err(flat.buffer, gw_plain) < 1e-5        # accumulated in place by the wgrad kernel
+    assert rel_err(flat.gather(), gw_plain) < 1e-5        # accumulated in place by the wgrad kernel
     assert rel_err(w.grad, gw_plain) < 1e-5             # .grad is a view of the same buffer
+
+
+@pytest.mark.parametrize("ema,clip,wd", [(None, None, 0.0), (0.999, 0.5, 0.0), (0.99, None, 0.01)])
+def test_fused_adam_ema_matches_torch(dev, ema, clip, wd):
+    """e3k_adam_ema_step == clip_grad_norm_ + torch.optim.Adam.step + torch_ema update (the reference's
+    trainer.py:374-386 sequence), run in float64 on the CPU, over 12 steps of seeded gradients."""
+    from e3_layers_amd.run.optim import FusedAdamEMA
+
+    torch.manual_seed(13)
+    shapes = [(64, 33), (7,), (1000,), (5, 5, 3)]          # offsets that need padding
+    ps = [torch.nn.Parameter(torch.randn(s, device=dev)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().cpu().double().clone()) for p in ps]
+    opt = FusedAdamEMA(ps, lr=1e-2, weight_decay=wd, ema_decay=ema, max_grad_norm=clip)
+    ropt = torch.optim.Adam(ref, lr=1e-2, weight_decay=wd)
+    shadow = [p.detach().clone() for p in ref]
+    gen = torch.Generator().manual_seed(99)
+    for k in range(1, 13):
+        opt.zero_grad()
+        for p, r in zip(ps, ref):
+            g = torch.randn(r.shape, dtype=torch.float64, generator=gen) * (3.0 if k % 4 == 0 else 0.1)
+            p.grad.copy_(g.float().to(dev))
+            r.grad = g.float().double()
+        if clip is not None:
+            torch.nn.utils.clip_grad_norm_(ref, clip)
+        ropt.step()
+        opt.step()
+        if ema is not None:
+            d = min(ema, (1 + k) / (10 + k))
+            for s, r in zip(shadow, ref):
+                s.sub_((1 - d) * (s - r.detach()))
+    for p, r in zip(ps, ref):
+        assert rel_err(p, r) < 1e-5
+    assert opt.steps_taken == 12
+    if ema is not None:
+        with opt.average_parameters():
+            for p, s in zip(ps, shadow):
+                assert rel_err(p, s) < 1e-5
+        for p, r in zip(ps, ref):
+            assert rel_err(p, r) < 1e-5               # restored
+
+
+def test_fused_adam_skips_nonfinite_gradient(dev):
+    from e3_layers_amd.run.optim import FusedAdamEMA
+
+    p = torch.nn.Parameter(torch.randn(300, device=dev))
+    opt = FusedAdamEMA([p], lr=1e-2, skip_nonfinite=True, ema_decay=0.9)
+    before = p.detach().clone()
+    opt.zero_grad()
+    p.grad.fill_(1.0)
+    p.grad[17] = float("nan")
+    opt.step()
+    assert torch.equal(p.detach(), before) and opt.steps_taken == 0
+    p.grad.fill_(1.0)
+    opt.step()
+    assert opt.steps_taken == 1 and not torch.equal(p.detach(), before)
+    assert abs(opt.last_grad_norm - 300 ** 0.5) < 1e-3
