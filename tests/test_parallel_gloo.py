@@ -55,7 +55,7 @@ def _worker(rank, world, port, ret):
     flat.all_reduce_mean()
     n_graphs = torch.tensor([len(mine)])
     dist.all_reduce(n_graphs)
-    ret[rank] = (flat.buffer.clone(), [p.detach().clone() for p in model.parameters()], int(n_graphs), len(mine))
+    ret[rank] = (flat.gather(), [p.detach().clone() for p in model.parameters()], int(n_graphs), len(mine))
     dist.destroy_process_group()
 
 
