@@ -433,6 +433,66 @@ __global__ __launch_bounds__(256) void radial_bwd2_kernel(const float* __restric
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// radius graph (computeEdgeIndex, e3_layers/data/compute_edge.py:38-113) on the device
+// One wave per source node i walks its own graph's nodes 64 at a time; a ballot compacts the kept
+// pairs in ascending j, so the edge list comes out in the reference's order — graphs concatenated,
+// (i, j) lexicographic inside a graph — without a sort.  Two passes (count, exclusive scan on the host
+// side with torch.cumsum, fill).  Distance test exactly as the reference states it: fp32
+// sqrt(dx^2 + dy^2 + dz^2) < r_max, strict, no fused multiply-add.
+// ---------------------------------------------------------------------------------------
+template <bool FILL>
+__global__ __launch_bounds__(256) void radius_graph_kernel(const float* __restrict__ pos,
+                                                            const int32_t* __restrict__ g_start,
+                                                            const int32_t* __restrict__ g_end, int64_t N, float r_max,
+                                                            const int32_t* __restrict__ old_ptr,
+                                                            const int32_t* __restrict__ old_dst,
+                                                            int32_t* __restrict__ counts,
+                                                            const int64_t* __restrict__ offsets,
+                                                            int64_t* __restrict__ edge_index, int64_t E) {
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= N) return;
+  const int lane = threadIdx.x & 63;
+  const int beg = g_start[i], end = g_end[i];
+  const float px = pos[3 * i], py = pos[3 * i + 1], pz = pos[3 * i + 2];
+  const int ob = old_ptr ? old_ptr[i] : 0, oe = old_ptr ? old_ptr[i + 1] : 0;
+  const int64_t off = FILL ? offsets[i] : 0;
+  int cnt = 0;
+  for (int j0 = beg; j0 < end; j0 += 64) {
+    const int j = j0 + lane;
+    bool keep = false;
+    if (j < end) {
+      if (j != i) {
+        const float dx = __fsub_rn(px, pos[3 * (int64_t)j]);
+        const float dy = __fsub_rn(py, pos[3 * (int64_t)j + 1]);
+        const float dz = __fsub_rn(pz, pos[3 * (int64_t)j + 2]);
+        const float d2 = __fadd_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)), __fmul_rn(dz, dz));
+        keep = __fsqrt_rn(d2) < r_max;
+      }
+      if (!keep && oe > ob) {   // pre-existing edges stay (binary search in i's sorted old neighbours)
+        int lo = ob, hi = oe;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (old_dst[mid] < j) lo = mid + 1; else hi = mid;
+        }
+        keep = lo < oe && old_dst[lo] == j;
+      }
+    }
+    const unsigned long long mask = __ballot(keep);
+    if constexpr (FILL) {
+      if (keep) {
+        const int64_t at = off + cnt + __popcll(mask & ((1ull << lane) - 1ull));
+        edge_index[at] = i;
+        edge_index[E + at] = j;
+      }
+    }
+    cnt += __popcll(mask);
+  }
+  if constexpr (!FILL) {
+    if (lane == 0) counts[i] = cnt;
+  }
+}
+
 }  // namespace e3k
 
 extern "C" int e3k_edge_vector_fwd(const float* pos, const int32_t* src, const int32_t* dst, int64_t E,
@@ -565,6 +625,31 @@ extern "C" int e3k_radial_basis_bwd2(const float* r, const float* g_out, const f
   if (blocks > 512) blocks = 512;
   hipLaunchKernelGGL(e3k::radial_bwd2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, g_out, hat_r,
                      hat_w, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_gout, g_r, g_w);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_radius_graph_count(const float* pos, const int32_t* graph_start, const int32_t* graph_end, int64_t N,
+                                      float r_max, const int32_t* old_ptr, const int32_t* old_dst, int32_t* counts,
+                                      void* stream) {
+  if (N < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!pos || !graph_start || !graph_end || !counts || (old_ptr && !old_dst)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::radius_graph_kernel<false>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pos,
+                     graph_start, graph_end, N, r_max, old_ptr, old_dst, counts, (const int64_t*)nullptr,
+                     (int64_t*)nullptr, (int64_t)0);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_radius_graph_fill(const float* pos, const int32_t* graph_start, const int32_t* graph_end, int64_t N,
+                                     float r_max, const int32_t* old_ptr, const int32_t* old_dst, const int64_t* offsets,
+                                     int64_t E, int64_t* edge_index, void* stream) {
+  if (N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0 || E == 0) return E3K_OK;
+  if (!pos || !graph_start || !graph_end || !offsets || !edge_index || (old_ptr && !old_dst)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::radius_graph_kernel<true>, dim3((unsigned)((N + 3) / 4)), dim3(256), 0, (hipStream_t)stream, pos,
+                     graph_start, graph_end, N, r_max, old_ptr, old_dst, (int32_t*)nullptr, offsets, edge_index, E);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -8,9 +8,13 @@ topology the fused convolution needs (``backend/graph.py``).
 ``computeEdgeIndex`` mirrors ``e3_layers/data/compute_edge.py:38-113`` with the intent recorded
 in SURVEY.md appendix C: per graph all ordered pairs in (src slow, dst fast) order, keep
 ``|pos_src - pos_dst| < r_max`` (strict, fp32) or ``criteria``, drop self loops, keep
-pre-existing edges and carry their edge attributes (zero rows for new edges).  It is host-side
-integer plumbing written with vectorised torch ops (no per-graph Python scan); the edge order is
-bit-identical to the reference's when run on the same device type.
+pre-existing edges and carry their edge attributes (zero rows for new edges).  On CPU tensors
+(dataset preprocessing, as in the reference) it is vectorised torch integer plumbing; on device
+tensors without a ``criteria`` callback it runs the two-pass HIP radius-graph kernels
+(``e3k_radius_graph_count/fill``: one wave per source node, ballot compaction keeps the
+reference's edge order without a sort) — the per-step edge rebuild of the sampling loop
+(``e3_layers/run/sde_sampling.py:237-242``) then never leaves the GPU.  ``criteria`` callbacks are
+arbitrary Python over the candidate list and keep the torch path on whichever device holds the data.
 """
 from __future__ import annotations
 
@@ -19,6 +23,7 @@ from typing import Dict, Tuple
 import torch
 from torch import Tensor
 
+from ..backend import lib as L
 from ..backend import ops
 from ..backend.graph import get_topology
 
@@ -56,8 +61,62 @@ def _all_pairs(n_nodes: Tensor, device) -> Tensor:
     return torch.stack([src, dst]).to(device)
 
 
+_STALE = ("_edge_segment", "_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
+          "edge_vector", "edge_length")
+
+
+def _radius_graph_device(data, attrs, pos: Tensor, r_max: float):
+    """HIP path: edge_index [2,E] int64 in the reference's order, `_n_edges`, carried-over edge attributes."""
+    dev = pos.device
+    pos = L.f32c(pos.detach())
+    n = data["_n_nodes"].reshape(-1).to(dev)
+    total = pos.shape[0]
+    n_graphs = n.numel()
+    gid = torch.repeat_interleave(torch.arange(n_graphs, device=dev), n, output_size=total)
+    ends = torch.cumsum(n, 0)
+    g_end = ends[gid].to(torch.int32)
+    g_start = (ends - n)[gid].to(torch.int32)
+    old_ptr = old_dst = old_id = None
+    if "edge_index" in data:
+        old = data["edge_index"].to(dev)
+        if old.numel() and not bool((gid[old[0]] == gid[old[1]]).all()):
+            raise ValueError("an existing edge connects two different graphs")
+        old_id = old[0] * total + old[1]
+        order = torch.argsort(old_id)
+        old_dst = old[1][order].to(torch.int32).contiguous()
+        old_ptr = torch.zeros(total + 1, dtype=torch.int32, device=dev)
+        old_ptr[1:] = torch.cumsum(torch.bincount(old[0], minlength=total), 0).to(torch.int32)
+    lib = L.load()
+    counts = torch.empty(total, dtype=torch.int32, device=dev)
+    L.check(lib.e3k_radius_graph_count(L.ptr(pos), L.ptr(g_start), L.ptr(g_end), total, float(r_max), L.ptr(old_ptr),
+                                       L.ptr(old_dst), L.ptr(counts), L.stream_ptr()), "e3k_radius_graph_count")
+    incl = torch.cumsum(counts, 0, dtype=torch.int64)
+    offsets = (incl - counts).contiguous()
+    n_edge = int(incl[-1].item()) if total else 0          # the one host sync: the size of the output
+    edge_index = torch.empty(2, n_edge, dtype=torch.int64, device=dev)
+    L.check(lib.e3k_radius_graph_fill(L.ptr(pos), L.ptr(g_start), L.ptr(g_end), total, float(r_max), L.ptr(old_ptr),
+                                      L.ptr(old_dst), L.ptr(offsets), n_edge, L.ptr(edge_index), L.stream_ptr()),
+            "e3k_radius_graph_fill")
+    if old_id is not None:
+        where = torch.searchsorted(edge_index[0] * total + edge_index[1], old_id)
+        for k in list(attrs.keys()):
+            if attrs[k][0] == "edge" and k in data:
+                prev = data[k].to(dev)
+                fresh = torch.zeros((n_edge,) + tuple(prev.shape[1:]), dtype=prev.dtype, device=dev)
+                fresh[where] = prev
+                data[k] = fresh
+    per_graph = torch.zeros(n_graphs, dtype=torch.int64, device=dev).index_add_(0, gid, counts.to(torch.int64))
+    attrs["_n_edges"] = ("graph", "1x0e")
+    data["_n_edges"] = per_graph.view(-1, 1)
+    for k in _STALE:
+        data.pop(k, None)
+    return {"edge_index": edge_index}, attrs
+
+
 def computeEdgeIndex(data, attrs, r_max: float = None, key: str = "pos", criteria=None):
     pos = torch.as_tensor(data[key], dtype=torch.get_default_dtype())
+    if pos.is_cuda and criteria is None and r_max is not None:
+        return _radius_graph_device(data, attrs, pos, r_max)
     n_nodes = data["_n_nodes"]
     total = int(n_nodes.sum())
     cand = _all_pairs(n_nodes, pos.device)
@@ -89,8 +148,6 @@ def computeEdgeIndex(data, attrs, r_max: float = None, key: str = "pos", criteri
     attrs["_n_edges"] = ("graph", "1x0e")
     data["_n_edges"] = n_edges
     # stale per-edge caches belong to the old edge set
-    for k in ("_edge_segment", "_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
-              "edge_vector", "edge_length"):
-        if k in data:
-            data.pop(k)
+    for k in _STALE:
+        data.pop(k, None)
     return {"edge_index": edge_index}, attrs

@@ -232,6 +232,21 @@ int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t d
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radius graph on the device.
+ * Replaces computeEdgeIndex (e3_layers/data/compute_edge.py:38-113) for the criteria-free case: per graph all
+ * ordered pairs (i, j), i != j, with fp32 sqrt(|pos_i - pos_j|^2) < r_max (strict), in the reference's order
+ * (graphs concatenated, i slow, j fast); pre-existing edges (old_ptr [N+1] CSR by source with old_dst ascending
+ * inside a row; NULL = none) are kept whatever their length.
+ *   graph_start / graph_end [N]: first node / one-past-last node of the graph node i belongs to.
+ *   pass 1 writes counts [N] (kept pairs per source); the caller scans them (exclusive, int64) into offsets [N];
+ *   pass 2 writes edge_index int64 [2, E] (row 0 sources, row 1 destinations), E = total count. */
+int e3k_radius_graph_count(const float* pos, const int32_t* graph_start, const int32_t* graph_end, int64_t N,
+                           float r_max, const int32_t* old_ptr, const int32_t* old_dst, int32_t* counts, void* stream);
+int e3k_radius_graph_fill(const float* pos, const int32_t* graph_start, const int32_t* graph_end, int64_t N,
+                          float r_max, const int32_t* old_ptr, const int32_t* old_dst, const int64_t* offsets, int64_t E,
+                          int64_t* edge_index, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Training-step plumbing on the flat parameter vector.
  * Replaces clip_grad_norm_ + optim.step() + ema.update() (e3_layers/run/trainer.py:374-386) and the variant that
  * skips the optimizer step on a non-finite gradient (e3_layers/run/sde_utils.py:233-248): torch.optim.Adam

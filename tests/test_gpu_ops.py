@@ -488,3 +488,49 @@ def test_fused_adam_skips_nonfinite_gradient(dev):
     opt.step()
     assert opt.steps_taken == 1 and not torch.equal(p.detach(), before)
     assert abs(opt.last_grad_norm - 300 ** 0.5) < 1e-3
+
+
+@pytest.mark.parametrize("r_max", [2.0, 4.0, 9999.0])
+def test_radius_graph_kernel_bit_exact(dev, r_max):
+    """Device computeEdgeIndex == the oracle's (and the CPU path's) edge list, bit for bit: same edges, same
+    (graph, i, j) order, same per-graph counts — including graphs of 1 atom, > 64 atoms (several ballot rounds)
+    and a pair sitting exactly on the cutoff (strict '<')."""
+    from e3_layers_amd.data import computeEdgeIndex
+
+    g = torch.Generator().manual_seed(0)
+    n_nodes = [4, 1, 29, 150, 3, 70]
+    pos = torch.randn(sum(n_nodes), 3, generator=g) * 2.5
+    pos[1] = pos[0] + torch.tensor([2.0, 0.0, 0.0])
+    nn_ = torch.tensor(n_nodes).view(-1, 1)
+    odata = {"pos": pos.clone(), "_n_nodes": nn_.clone()}
+    ref, _ = e3ref.compute_edge_index(odata, {}, r_max=r_max)
+    ddata = {"pos": pos.to(dev), "_n_nodes": nn_.to(dev)}
+    out, attrs = computeEdgeIndex(ddata, {}, r_max=r_max)
+    assert out["edge_index"].is_cuda and out["edge_index"].dtype == torch.int64
+    assert torch.equal(out["edge_index"].cpu(), ref["edge_index"])
+    assert torch.equal(ddata["_n_edges"].cpu(), odata["_n_edges"])
+    assert attrs["_n_edges"] == ("graph", "1x0e")
+
+
+def test_radius_graph_kernel_keeps_existing_edges(dev):
+    """Pre-existing (bond) edges longer than the cutoff survive and their attributes land on the new rows."""
+    from e3_layers_amd.data import computeEdgeIndex
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    pos = torch.tensor([[0.0, 0, 0], [1.0, 0, 0], [5.0, 0, 0], [0.0, 0, 0], [0.5, 0, 0]])
+    n_nodes = torch.tensor([[3], [2]])
+    old = torch.tensor([[2, 0], [0, 2]])                      # unsorted on purpose
+    bond = torch.tensor([[9.0], [7.0]])
+    data = {"pos": pos.to(dev), "_n_nodes": n_nodes.to(dev), "edge_index": old.to(dev), "bond": bond.to(dev)}
+    out, _ = computeEdgeIndex(data, {"bond": ("edge", "1x0e")}, r_max=1.5)
+    assert out["edge_index"].tolist() == [[0, 0, 1, 2, 3, 4], [1, 2, 0, 0, 4, 3]]
+    assert data["bond"].view(-1).tolist() == [0.0, 7.0, 0.0, 9.0, 0.0, 0.0]
+    assert data["_n_edges"].view(-1).tolist() == [4, 2]
+    # a realistic batch: the device list equals the list the CPU preprocessing produced
+    batch = synth_qm9(3, 40)
+    data = {"pos": batch["pos"].to(dev), "_n_nodes": batch["_n_nodes"].to(dev)}
+    out, _ = computeEdgeIndex(data, {}, r_max=4.0)
+    assert torch.equal(out["edge_index"].cpu(), batch["edge_index"])
+    bad = {"pos": pos.to(dev), "_n_nodes": n_nodes.to(dev), "edge_index": torch.tensor([[0], [4]], device=dev)}
+    with pytest.raises(ValueError, match="different graphs"):
+        computeEdgeIndex(bad, {}, r_max=1.5)
