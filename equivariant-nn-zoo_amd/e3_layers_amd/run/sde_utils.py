@@ -1,7 +1,7 @@
-"""The ~40 lines of VP-SDE arithmetic that drive the diffusion score networks (host-side torch
-plumbing).  Same formulas as ``e3_layers/run/sde_utils.py``:
-``VPSDE.marginal`` (:54-66), ``get_score_fn`` (:176-187), the loss of ``get_sde_loss_fn``
-(:143-171).  The head key is ``score_{key}`` as those functions expect; a model that emits the
+"""The VP-SDE arithmetic that drives the diffusion score networks (host-side torch plumbing on
+device tensors).  Same formulas as ``e3_layers/run/sde_utils.py``:
+``VPSDE.marginal`` (:54-66), ``VPSDE.sde`` (:68-81), ``prior_sampling`` (:83-86), ``reverse`` (:88-123),
+``get_score_fn`` (:176-187), the loss of ``get_sde_loss_fn`` (:143-171).  The head key is ``score_{key}`` as those functions expect; a model that emits the
 shipped config's plain ``score`` key is mapped onto it.
 """
 from __future__ import annotations
@@ -15,6 +15,8 @@ class VPSDE:
     def __init__(self, diffusion_keys: Dict[str, int], beta_min: float = 0.1, beta_max: float = 20.0, N: int = 1000):
         self.beta_0, self.beta_1, self.N = beta_min, beta_max, N
         self.irreps = dict(diffusion_keys)
+        self.discrete_betas = torch.linspace(beta_min / N, beta_max / N, N)
+        self.alphas = 1.0 - self.discrete_betas
 
     @property
     def T(self) -> float:
@@ -41,6 +43,53 @@ class VPSDE:
             batch[key] = torch.exp(lm) * x + std * z
             zs[key] = z
         return batch, {"zs": zs, "std": std}
+
+
+def _randn(like: torch.Tensor, generator=None, noise_fn=None) -> torch.Tensor:
+    if noise_fn is not None:
+        return noise_fn(like.shape).to(like.device, like.dtype)
+    return torch.randn(like.shape, device=like.device, dtype=like.dtype, generator=generator)
+
+
+def _node_t(batch) -> torch.Tensor:
+    return batch["t"].reshape(-1, 1)[batch.nodeSegment()]
+
+
+def vpsde_sde(sde: VPSDE, batch, dt=None, generator=None, noise_fn=None):
+    """One Euler-Maruyama step of the FORWARD SDE dx = -beta/2 x dt + sqrt(beta) dw (``VPSDE.sde`` :68-81);
+    called with ``dt = -1/N`` by the reverse sampler."""
+    if dt is None:
+        dt = 1.0 / sde.N
+    t = _node_t(batch)
+    beta_t = sde.beta_0 + t * (sde.beta_1 - sde.beta_0)
+    diffusion = torch.sqrt(beta_t)
+    for key in sde.irreps:
+        x = batch[key]
+        x_mean = x + (-0.5 * beta_t * x) * dt
+        batch[key] = x_mean + diffusion * (abs(dt) ** 0.5) * _randn(x, generator, noise_fn)
+    return batch
+
+
+def prior_sampling(sde: VPSDE, batch, generator=None, noise_fn=None):
+    """x_T ~ N(0, 1) per diffused key (:83-86), drawn on the batch's device."""
+    dev = batch["_n_nodes"].device
+    n = batch["_node_segment"].shape[0] if "_node_segment" in batch else int(batch["_n_nodes"].sum())
+    for key, dim in sde.irreps.items():
+        batch[key] = _randn(torch.empty(n, dim, device=dev), generator, noise_fn)
+    return batch
+
+
+def reverse_step(sde: VPSDE, score_fn, batch, generator=None, noise_fn=None):
+    """One step of the reverse-time SDE (``RSDE.sde`` :104-119): forward-SDE Euler step with ``dt = -1/N``,
+    then ``x -= dt * beta_t * score``."""
+    scores = score_fn(batch)
+    t = _node_t(batch)
+    beta_t = sde.beta_0 + t * (sde.beta_1 - sde.beta_0)
+    dt = -1.0 / sde.N
+    batch = vpsde_sde(sde, batch, dt, generator, noise_fn)
+    for key in sde.irreps:
+        batch[key] = batch[key] - dt * beta_t * scores[f"score_{key}"]
+    return batch
 
 
 def get_score_fn(sde: VPSDE, model, train: bool = False):
