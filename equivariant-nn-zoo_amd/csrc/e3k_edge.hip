@@ -315,6 +315,7 @@ __global__ __launch_bounds__(256) void radial_fwd_kernel(const float* __restrict
   for (int n = 0; n < nb; ++n) out[e * nb + n] = sinf(bw[n] * rv / delta) * scale;
 }
 
+template <int MAXB>   // compile-time bound of the (unrolled) basis loop: 8 / 16 / 32 / 64
 __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict__ r, const float* __restrict__ g_out,
                                                           int64_t E, const float* __restrict__ bw, int nb, float r_max,
                                                           float r_min, float p, int one_over_r, int kind,
@@ -322,9 +323,9 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
   // grid-stride over edges; the frequency gradients are summed per thread first, so the whole launch
   // issues (waves x n_basis) atomics instead of (E / 64 x n_basis)
   const float delta = r_max - r_min, pref = 2.0f / delta;
-  float acc[RB_MAXB];
+  float acc[MAXB];
 #pragma unroll
-  for (int n = 0; n < RB_MAXB; ++n) acc[n] = 0.f;
+  for (int n = 0; n < MAXB; ++n) acc[n] = 0.f;
   for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < E; e += (int64_t)gridDim.x * 256) {
     const float rv = r[e];
     float c, dc;
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
     const float inv_r = one_over_r ? 1.0f / rv : 1.0f;
     float gr = 0.f;
 #pragma unroll
-    for (int n = 0; n < RB_MAXB; ++n) {
+    for (int n = 0; n < MAXB; ++n) {
       if (n < nb) {
         const float w = bw[n];
         float sn, cs;
@@ -349,7 +350,7 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
   }
   if (g_w) {
 #pragma unroll
-    for (int n = 0; n < RB_MAXB; ++n) {
+    for (int n = 0; n < MAXB; ++n) {
       if (n < nb) {
         const float tot = wave_sum(acc[n]);
         if ((threadIdx.x & 63) == 0) atomicAdd(g_w + n, tot);
@@ -607,8 +608,14 @@ extern "C" int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t 
   if (!r || !g_out || !bessel_w || (!g_r && !g_w)) return E3K_ERR_INVALID;
   int64_t blocks = (E + 255) / 256;
   if (blocks > 512) blocks = 512;
-  hipLaunchKernelGGL(e3k::radial_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r,
-                     g_out, E, bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w);
+#define E3K_RB_LAUNCH(MB)                                                                                            \
+  hipLaunchKernelGGL(e3k::radial_bwd_kernel<MB>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, g_out, E, \
+                     bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w)
+  if (n_basis <= 8) E3K_RB_LAUNCH(8);
+  else if (n_basis <= 16) E3K_RB_LAUNCH(16);
+  else if (n_basis <= 32) E3K_RB_LAUNCH(32);
+  else E3K_RB_LAUNCH(64);
+#undef E3K_RB_LAUNCH
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

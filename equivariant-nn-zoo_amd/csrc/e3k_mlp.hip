@@ -1,0 +1,302 @@
+// Fused hidden chain of the radial MLP for gfx950:  x[E,k0] -> (linear -> normalised activation) x L -> h[E,H]
+// in ONE launch forward and ONE launch backward.
+//
+// Replaces (paths relative to /root/reference) the hidden layers of
+//   e3nn.nn.FullyConnectedNet([n_radial, H, ..., H, weight_numel], act)   e3_layers/nn/message_passing.py:74-79,93
+// (the last, linear layer H -> weight_numel stays a GEMM: e3k_gemm small-K kernel).  Unfused, every hidden layer is
+// a [E,64]x[64,64] GEMM + an activation pass forward and dgrad + wgrad + activation-backward passes backward:
+// ~20 launches per convolution that each stream [E,H] through HBM twice.  Here a 64-edge tile stays in LDS through
+// the whole chain; only the pre-activations z_l (needed by the backward) and the final h touch HBM, once.
+//
+// Matrix work on v_mfma_f32_32x32x2_f32 (exact fp32): block = 4 waves = 2x2 tiles of 32x32 over a 64-row x H tile.
+// Backward: per tile   gz_l = g (.) cst act'(z_l);  gW_l += alpha_l prev_l^T gz_l (accumulated in registers over all the
+// tiles of a persistent block, one atomic add per element at the end);  g <- alpha_l gz_l W_l^T;  prev_l = cst act(z_{l-1})
+// is formed on the fly from the saved pre-activation when the MFMA operand is read.
+#include <cstdlib>
+
+#include "e3k_act.h"
+#include "e3k_common.h"
+
+namespace e3k {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int MLP_MAXL = 4;
+constexpr int MLP_BM = 64;     // rows (edges) per tile
+constexpr int MLP_LD = 68;     // LDS row stride of the [64][<=64] tiles (16-byte aligned rows)
+constexpr int MLP_LDW = 65;    // weight tile row stride (conflict-free column reads for the transposed operand)
+
+struct MlpArgs {
+  const float* x;
+  int64_t E;
+  int k0, h, n_layers, act;
+  float cst;
+  const float* w[MLP_MAXL];
+  float alpha[MLP_MAXL];
+  float* z[MLP_MAXL];   // forward: pre-activations out (NULL: not kept); backward: in
+  float* out;           // forward: h_{L-1}
+  const float* g;       // backward: gradient wrt out
+  float* gw[MLP_MAXL];  // backward: accumulated with atomics (NULL: not needed)
+  float* gx;            // backward: [E,k0] or NULL
+};
+
+__device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
+
+// rows x cols tile, global row-major (ld = cols) -> LDS (row stride MLP_LD); rows beyond E and columns beyond cols
+// up to cols_pad are zero-filled
+__device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t row0, int64_t E, int cols, int cols_pad,
+                                          float* dst) {
+  const int t = threadIdx.x;
+  if ((cols & 3) == 0 && cols_pad == cols) {
+    const int c4n = cols >> 2;
+    for (int idx = t; idx < MLP_BM * c4n; idx += 256) {
+      const int r = idx / c4n, c = (idx - r * c4n) * 4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row0 + r < E) v = *reinterpret_cast<const float4*>(src + (row0 + r) * cols + c);
+      *reinterpret_cast<float4*>(dst + r * MLP_LD + c) = v;
+    }
+  } else {
+    for (int idx = t; idx < MLP_BM * cols_pad; idx += 256) {
+      const int r = idx / cols_pad, c = idx - r * cols_pad;
+      dst[r * MLP_LD + c] = (row0 + r < E && c < cols) ? src[(row0 + r) * cols + c] : 0.f;
+    }
+  }
+}
+
+// W [k_real x h] row-major -> LDS [k_pad][MLP_LDW], rows >= k_real zero
+__device__ __forceinline__ void load_weight(const float* __restrict__ w, int k_real, int k_pad, int h, float* dst) {
+  const int sh = h == 64 ? 6 : 5;   // h is 32 or 64
+  for (int idx = threadIdx.x; idx < k_pad * h; idx += 256) {
+    const int k = idx >> sh, n = idx & (h - 1);
+    dst[k * MLP_LDW + n] = k < k_real ? w[idx] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
+  __shared__ __attribute__((aligned(16))) float As[MLP_BM * MLP_LD];
+  __shared__ float Ws[64 * MLP_LDW];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;
+  const int h = a.h, kp0 = (a.k0 + 1) & ~1;
+  const bool col_ok = wn * 32 < h;
+  const int64_t row0 = (int64_t)blockIdx.x * MLP_BM;
+  load_tile(a.x, row0, a.E, a.k0, kp0, As);
+  for (int l = 0; l < a.n_layers; ++l) {
+    const int k_real = l == 0 ? a.k0 : h, K = l == 0 ? kp0 : h;
+    load_weight(a.w[l], k_real, K, h, Ws);
+    __syncthreads();
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (col_ok) {
+      const float* ap = As + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5);
+      const float* bp = Ws + (lane >> 5) * MLP_LDW + wn * 32 + (lane & 31);
+#pragma unroll 8
+      for (int kk = 0; kk < K; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * MLP_LDW], acc, 0, 0, 0);
+    }
+    __syncthreads();   // every wave is done with this layer's operands
+    if (col_ok) {
+      const float al = a.alpha[l];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) As[(wm * 32 + acc_row(i, lane)) * MLP_LD + wn * 32 + (lane & 31)] = al * acc[i];
+    }
+    __syncthreads();
+    // row-major pass over the tile: keep z_l, activate in place, emit the last layer's activations
+    const int c4n = h >> 2, hs = h == 64 ? 4 : 3;
+    const bool last = l == a.n_layers - 1;
+    for (int idx = t; idx < MLP_BM * c4n; idx += 256) {
+      const int r = idx >> hs, c = (idx & (c4n - 1)) * 4;
+      float4 v = *reinterpret_cast<float4*>(As + r * MLP_LD + c);
+      const bool ok = row0 + r < a.E;
+      if (ok && a.z[l]) *reinterpret_cast<float4*>(a.z[l] + (row0 + r) * h + c) = v;
+      v.x = a.cst * act_f(a.act, v.x);
+      v.y = a.cst * act_f(a.act, v.y);
+      v.z = a.cst * act_f(a.act, v.z);
+      v.w = a.cst * act_f(a.act, v.w);
+      if (last) {
+        if (ok) *reinterpret_cast<float4*>(a.out + (row0 + r) * h + c) = v;
+      } else {
+        *reinterpret_cast<float4*>(As + r * MLP_LD + c) = v;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, int n_tiles) {
+  __shared__ __attribute__((aligned(16))) float Gs[MLP_BM * MLP_LD];   // gradient wrt h_l, then gz_l
+  __shared__ __attribute__((aligned(16))) float Ds[MLP_BM * MLP_LD];   // cst act'(z_l)
+  __shared__ __attribute__((aligned(16))) float Hs[MLP_BM * MLP_LD];   // layer input: h_{l-1} = cst act(z_{l-1}) or x
+  __shared__ float Ws[64 * MLP_LDW];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  const int wm = w & 1, wn = w >> 1;   // dgrad / wgrad tile coordinates (rows or k block, column block)
+  const int h = a.h, kp0 = (a.k0 + 1) & ~1;
+  const int hs = h == 64 ? 4 : 3;      // log2(h / 4): float4 columns per row
+  const int c4n = h >> 2;
+  const int L = a.n_layers;
+
+  f32x16 accw[MLP_MAXL];
+#pragma unroll
+  for (int l = 0; l < MLP_MAXL; ++l)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) accw[l][i] = 0.f;
+
+  // every elementwise pass maps thread t to the same tile elements, so a thread only ever re-reads what it wrote
+  // itself: the passes need no barrier between them
+  for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = (int64_t)tile * MLP_BM;
+    for (int idx = t; idx < MLP_BM * c4n; idx += 256) {
+      const int r = idx >> hs, c = (idx & (c4n - 1)) * 4;
+      float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), z4 = g4;
+      if (row0 + r < a.E) {
+        g4 = *reinterpret_cast<const float4*>(a.g + (row0 + r) * h + c);
+        z4 = *reinterpret_cast<const float4*>(a.z[L - 1] + (row0 + r) * h + c);
+      }
+      *reinterpret_cast<float4*>(Gs + r * MLP_LD + c) = g4;
+      *reinterpret_cast<float4*>(Ds + r * MLP_LD + c) =
+          make_float4(a.cst * act_df(a.act, z4.x), a.cst * act_df(a.act, z4.y), a.cst * act_df(a.act, z4.z), a.cst * act_df(a.act, z4.w));
+    }
+#pragma unroll
+    for (int li = 0; li < MLP_MAXL; ++li) {
+      const int l = L - 1 - li;
+      if (l < 0) break;
+      const int k_real = l == 0 ? a.k0 : h, K = l == 0 ? kp0 : h;   // input width of layer l
+      // gz = g (.) cst act'(z_l); then this layer's input and the next iteration's derivative factors
+      const float* zprev = l > 0 ? a.z[l - 1] : nullptr;
+      for (int idx = t; idx < MLP_BM * c4n; idx += 256) {
+        const int r = idx >> hs, c = (idx & (c4n - 1)) * 4;
+        float4 g4 = *reinterpret_cast<float4*>(Gs + r * MLP_LD + c);
+        const float4 d4 = *reinterpret_cast<const float4*>(Ds + r * MLP_LD + c);
+        g4.x *= d4.x; g4.y *= d4.y; g4.z *= d4.z; g4.w *= d4.w;
+        *reinterpret_cast<float4*>(Gs + r * MLP_LD + c) = g4;
+        if (zprev) {
+          float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (row0 + r < a.E) z4 = *reinterpret_cast<const float4*>(zprev + (row0 + r) * h + c);
+          *reinterpret_cast<float4*>(Hs + r * MLP_LD + c) =
+              make_float4(a.cst * act_f(a.act, z4.x), a.cst * act_f(a.act, z4.y), a.cst * act_f(a.act, z4.z), a.cst * act_f(a.act, z4.w));
+          *reinterpret_cast<float4*>(Ds + r * MLP_LD + c) =
+              make_float4(a.cst * act_df(a.act, z4.x), a.cst * act_df(a.act, z4.y), a.cst * act_df(a.act, z4.z), a.cst * act_df(a.act, z4.w));
+        }
+      }
+      if (l == 0) load_tile(a.x, row0, a.E, a.k0, kp0, Hs);
+      load_weight(a.w[l], k_real, K, h, Ws);
+      __syncthreads();
+      // wgrad: gW_l[k, n] += sum_rows input[row, k] gz[row, n]; wave tile (k block wm, n block wn)
+      if (a.gw[l] && wm * 32 < K && wn * 32 < h) {
+        const float* pp = Hs + (lane >> 5) * MLP_LD + wm * 32 + (lane & 31);
+        const float* gp = Gs + (lane >> 5) * MLP_LD + wn * 32 + (lane & 31);
+        const bool kin = wm * 32 + (lane & 31) < K;
+#pragma unroll 8
+        for (int rr = 0; rr < MLP_BM; rr += 2)
+          accw[li] = __builtin_amdgcn_mfma_f32_32x32x2f32(kin ? pp[rr * MLP_LD] : 0.f, gp[rr * MLP_LD], accw[li], 0, 0, 0);
+      }
+      // dgrad: g_prev[row, k] = alpha_l sum_n gz[row, n] W_l[k, n]; wave tile (row block wm, k block wn)
+      const bool need_d = l > 0 || a.gx;
+      f32x16 accd;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) accd[i] = 0.f;
+      const bool d_ok = need_d && wn * 32 < K;
+      if (d_ok) {
+        const float* gp = Gs + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5);
+        const float* wp = Ws + (wn * 32 + (lane & 31)) * MLP_LDW + (lane >> 5);
+        const bool kin = wn * 32 + (lane & 31) < K;
+#pragma unroll 8
+        for (int nn = 0; nn < h; nn += 2) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[nn], kin ? wp[nn] : 0.f, accd, 0, 0, 0);
+      }
+      __syncthreads();   // everyone is done reading Gs / Hs / Ws
+      if (d_ok) {
+        const float al = a.alpha[l];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) Gs[(wm * 32 + acc_row(i, lane)) * MLP_LD + wn * 32 + (lane & 31)] = al * accd[i];
+      }
+      __syncthreads();   // Gs now holds the gradient wrt this layer's input
+    }
+    if (a.gx) {
+      for (int idx = t; idx < MLP_BM * a.k0; idx += 256) {
+        const int r = idx / a.k0, c = idx - r * a.k0;
+        if (row0 + r < a.E) a.gx[(row0 + r) * a.k0 + c] = Gs[r * MLP_LD + c];
+      }
+      __syncthreads();   // the next tile overwrites Gs
+    }
+  }
+  // one atomic add per weight element and block
+#pragma unroll
+  for (int li = 0; li < MLP_MAXL; ++li) {
+    const int l = L - 1 - li;
+    if (l < 0) break;
+    const int k_real = l == 0 ? a.k0 : h;
+    if (!a.gw[l] || wn * 32 >= h) continue;
+    const int n = wn * 32 + (lane & 31);
+    const float al = a.alpha[l];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int k = wm * 32 + acc_row(i, lane);
+      if (k < k_real) atomicAdd(a.gw[l] + k * h + n, al * accw[li][i]);
+    }
+  }
+}
+
+}  // namespace e3k
+
+namespace {
+int fill_args(e3k::MlpArgs& a, const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
+              const float* const* weights, const float* alphas, int32_t act, float cst) {
+  if (E < 0 || k0 <= 0 || k0 > 64 || (h != 32 && h != 64) || n_layers < 1 || n_layers > e3k::MLP_MAXL) return E3K_ERR_UNSUPPORTED;
+  if (act < 0 || act > 5 || !weights || !alphas || !x) return E3K_ERR_INVALID;
+  a.x = x;
+  a.E = E;
+  a.k0 = k0;
+  a.h = h;
+  a.n_layers = n_layers;
+  a.act = act;
+  a.cst = cst;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!weights[l]) return E3K_ERR_INVALID;
+    a.w[l] = weights[l];
+    a.alpha[l] = alphas[l];
+  }
+  return E3K_OK;
+}
+}  // namespace
+
+extern "C" int e3k_mlp_hidden_fwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
+                                  const float* const* weights, const float* alphas, int32_t act, float cst,
+                                  float* const* z, float* out, void* stream) {
+  e3k::MlpArgs a{};
+  const int rc = fill_args(a, x, E, k0, h, n_layers, weights, alphas, act, cst);
+  if (rc != E3K_OK) return rc;
+  if (E == 0) return E3K_OK;
+  if (!out) return E3K_ERR_INVALID;
+  for (int l = 0; l < n_layers; ++l) a.z[l] = z ? z[l] : nullptr;
+  a.out = out;
+  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
+  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::mlp_hidden_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
+                                  const float* const* weights, const float* alphas, int32_t act, float cst,
+                                  const float* const* z, const float* g_out, float* const* g_weights, float* g_x,
+                                  void* stream) {
+  e3k::MlpArgs a{};
+  const int rc = fill_args(a, x, E, k0, h, n_layers, weights, alphas, act, cst);
+  if (rc != E3K_OK) return rc;
+  if (E == 0) return E3K_OK;
+  if (!z || !g_out) return E3K_ERR_INVALID;
+  for (int l = 0; l < n_layers; ++l) {
+    if (!z[l]) return E3K_ERR_INVALID;
+    a.z[l] = const_cast<float*>(z[l]);
+    a.gw[l] = g_weights ? g_weights[l] : nullptr;
+  }
+  a.g = g_out;
+  a.gx = g_x;
+  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
+  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
+  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 512;
+  int64_t blocks = tiles < max_blocks ? tiles : max_blocks;   // persistent: two workgroups per CU share the weight-gradient atomics
+  hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}

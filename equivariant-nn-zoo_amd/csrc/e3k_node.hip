@@ -7,66 +7,9 @@
 //   LayerNormalization                           e3_layers/nn/pointwise.py:32-51
 //   Pooling (scatter over _node_segment)         e3_layers/nn/output.py:66-74
 #include "e3k_common.h"
+#include "e3k_act.h"
 
 namespace e3k {
-
-// activation ids: 0 identity, 1 ssp, 2 silu, 3 tanhlu, 4 tanh, 5 abs  (e3_layers/utils/utils.py:64-84)
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
-
-__device__ __forceinline__ float act_f(int id, float x) {
-  switch (id) {
-    case 1: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x))) - 0.6931471805599453f;
-    case 2: return x * sigmoidf_(x);
-    case 3: return tanhf(x) * fabsf(x);
-    case 4: return tanhf(x);
-    case 5: return fabsf(x);
-    default: return x;
-  }
-}
-__device__ __forceinline__ float act_df(int id, float x) {
-  switch (id) {
-    case 1: return sigmoidf_(x);
-    case 2: {
-      const float s = sigmoidf_(x);
-      return s * (1.0f + x * (1.0f - s));
-    }
-    case 3: {
-      const float th = tanhf(x);
-      const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-      return (1.0f - th * th) * fabsf(x) + th * sg;
-    }
-    case 4: {
-      const float th = tanhf(x);
-      return 1.0f - th * th;
-    }
-    case 5: return (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-    default: return 1.0f;
-  }
-}
-
-// second derivative (double backward: force training differentiates the backward pass once more)
-__device__ __forceinline__ float act_d2f(int id, float x) {
-  switch (id) {
-    case 1: {
-      const float s = sigmoidf_(x);
-      return s * (1.0f - s);
-    }
-    case 2: {
-      const float s = sigmoidf_(x);
-      return s * (1.0f - s) * (2.0f + x * (1.0f - 2.0f * s));
-    }
-    case 3: {
-      const float th = tanhf(x), sech2 = 1.0f - th * th;
-      const float sg = (x > 0.f) ? 1.f : ((x < 0.f) ? -1.f : 0.f);
-      return 2.0f * sech2 * (sg - th * fabsf(x));
-    }
-    case 4: {
-      const float th = tanhf(x);
-      return -2.0f * th * (1.0f - th * th);
-    }
-    default: return 0.0f;
-  }
-}
 
 __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int act, float cst,
                                                        float* __restrict__ y) {

@@ -73,6 +73,9 @@ SIGNATURES = {
     "e3k_radial_basis_fwd": (C.c_int, [_P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P]),
     "e3k_radial_basis_bwd": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P]),
     "e3k_radial_basis_bwd2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P, _P]),
+    "e3k_mlp_hidden_fwd": (C.c_int, [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_F), _I32, _F, C.POINTER(_P), _P, _P]),
+    "e3k_mlp_hidden_bwd": (C.c_int, [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_F), _I32, _F, C.POINTER(_P), _P,
+                                     C.POINTER(_P), _P, _P]),
     "e3k_radius_graph_count": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _P]),
     "e3k_radius_graph_fill": (C.c_int, [_P, _P, _P, _I64, _F, _P, _P, _P, _I64, _P, _P]),
     "e3k_tp_plan_create": (C.c_int, [C.POINTER(TpGroup), _I32, _I32, _I32, _I32, _I32, C.POINTER(_P)]),

@@ -94,13 +94,24 @@ def _addr(t: torch.Tensor, elem_off: int = 0) -> int:
     return t.data_ptr() + 4 * int(elem_off)
 
 
+# tools/gemm_profile.py sets this to a list: (start_event, end_event, wgrad, [(M1, M2, N, K, V), ...]) per launch group
+PROFILE_GEMM = None
+
+
 def _run_gemm(problems: List[L.GemmProblem], wgrad: bool = False) -> None:
     if not problems:
         return
     arr = (L.GemmProblem * len(problems))(*problems)
     lib = L.load()
     fn = lib.e3k_gemm_wgrad if wgrad else lib.e3k_gemm
+    prof = PROFILE_GEMM
+    if prof is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     L.check(fn(arr, len(problems), L.stream_ptr()), "e3k_gemm_wgrad" if wgrad else "e3k_gemm")
+    if prof is not None:
+        ev1.record()
+        prof.append((ev0, ev1, wgrad, [(p.M1, p.M2, p.N, p.K, p.V) for p in problems]))
 
 
 def _layout_strides(layout: str, mul: int, dim: int) -> Tuple[int, int]:
@@ -373,6 +384,91 @@ def strided_linear(x, weight, bias, spec: LinearSpec, base=None, scale: float = 
     if act != "ssp":
         return activation(StridedLinearFn.apply(x, weight, bias, base, spec, float(scale)), act, act_cst)
     return StridedLinearFn.apply(x, weight, bias, base, spec, float(scale), 1, float(act_cst))
+
+
+# --------------------------------------------------------------------------------------
+# fused hidden chain of the radial MLP
+# --------------------------------------------------------------------------------------
+def mlp_hidden_supported(k0: int, hs: Sequence[int], act: Optional[str]) -> bool:
+    """Shapes the fused kernels take: input width <= 64, 1-4 hidden layers of one width 32 or 64."""
+    return (0 < k0 <= 64 and 1 <= len(hs) <= 4 and len(set(hs)) == 1 and hs[0] in (32, 64)
+            and act in ACT_IDS and act is not None)
+
+
+def _ptr_array(tensors):
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
+def _mlp_unfused(x, weights, alphas, act: str, cst: float):
+    """The same chain through the per-layer ops (used to build a double-backward graph)."""
+    cur = x
+    for w, al in zip(weights, alphas):
+        k, n = w.shape
+        spec = LinearSpec(k, n, [LinInstr(0, 0, k, n, 1, 0, al)], "e3nn", "e3nn", [], True, True, k * n)
+        cur = activation(strided_linear(cur, w.reshape(-1), None, spec), act, cst)
+    return cur
+
+
+class MlpHiddenFn(torch.autograd.Function):
+    """h = (act o linear)^L (x): one launch forward, one backward (csrc/e3k_mlp.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, alphas: Tuple[float, ...], act: str, cst: float, *weights):
+        L.require_cuda(x, *weights)
+        x = L.f32c(x)
+        weights = tuple(L.f32c(w) for w in weights)
+        e, k0 = x.shape
+        h, n = weights[0].shape[1], len(weights)
+        need_grad = any(ctx.needs_input_grad)
+        out = torch.empty(e, h, device=x.device, dtype=torch.float32)
+        zs = [torch.empty(e, h, device=x.device, dtype=torch.float32) for _ in range(n)] if need_grad else []
+        L.check(L.load().e3k_mlp_hidden_fwd(L.ptr(x), e, k0, h, n, _ptr_array(weights), (C.c_float * n)(*alphas), ACT_IDS[act],
+                                            cst, _ptr_array(zs) if zs else None, L.ptr(out), L.stream_ptr()),
+                "e3k_mlp_hidden_fwd")
+        ctx.save_for_backward(x, *weights, *zs)
+        ctx.cfg = (alphas, act, cst, n)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        alphas, act, cst, n = ctx.cfg
+        saved = ctx.saved_tensors
+        x, weights, zs = saved[0], saved[1:1 + n], saved[1 + n:]
+        if torch.is_grad_enabled():   # double backward: differentiate the per-layer ops instead
+            wrt = [t for t, need in zip((x,) + tuple(weights), (ctx.needs_input_grad[0],) + tuple(ctx.needs_input_grad[4:])) if need]
+            with torch.enable_grad():
+                y = _mlp_unfused(x, weights, alphas, act, cst)
+                grads = list(torch.autograd.grad(y, wrt, g, create_graph=True, allow_unused=True))
+            gx = grads.pop(0) if ctx.needs_input_grad[0] else None
+            gws = [grads.pop(0) if need else None for need in ctx.needs_input_grad[4:]]
+            return (gx, None, None, None, *gws)
+        g = L.f32c(g)
+        e, k0 = x.shape
+        h = weights[0].shape[1]
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gws, ret = [], []
+        for w, need in zip(weights, ctx.needs_input_grad[4:]):
+            if not need:
+                gws.append(None)
+                ret.append(None)
+                continue
+            sink = _sink_for(w)
+            if sink is not None:
+                gws.append(sink)
+                ret.append(None)
+            else:
+                buf = torch.zeros_like(w)
+                gws.append(buf)
+                ret.append(buf)
+        L.check(L.load().e3k_mlp_hidden_bwd(L.ptr(x), e, k0, h, n, _ptr_array(weights), (C.c_float * n)(*alphas), ACT_IDS[act],
+                                            cst, _ptr_array(zs), L.ptr(g), _ptr_array(gws), L.ptr(gx), L.stream_ptr()),
+                "e3k_mlp_hidden_bwd")
+        return (gx, None, None, None, *ret)
+
+
+def mlp_hidden(x, weights: Sequence[torch.Tensor], alphas: Sequence[float], act: str, cst: float):
+    """weights[l]: [k_l, h] parameters (2-D); returns the activations of the last hidden layer."""
+    return MlpHiddenFn.apply(_c(x), tuple(float(a) for a in alphas), act, float(cst), *[_c(w) for w in weights])
 
 
 # --------------------------------------------------------------------------------------

@@ -149,6 +149,17 @@ class Data:
         out.device = self.device
         return out
 
+    def view(self):
+        """A new container over the SAME tensors (new key dict, new attrs dict).  The network only ever adds keys
+        to the batch it is given and never writes into an input tensor, so a training step that wants to keep its
+        input batch pristine needs this, not ``clone()``'s ~50 device copies (``out = self.model(data.clone())``,
+        e3_layers/run/trainer.py:365, copies every tensor each step)."""
+        out = self.__class__.__new__(self.__class__)
+        out.attrs = copy.deepcopy(self.attrs)
+        out.data = dict(self.data)
+        out.device = self.device
+        return out
+
     def __repr__(self):
         shapes = {k: (tuple(v.shape), str(v.dtype).replace("torch.", "")) for k, v in self.data.items()}
         return f"{self.__class__.__name__}(attrs={self.attrs}, tensors={shapes})"

@@ -13,6 +13,7 @@ Layouts: "e3nn" = block [mul][2l+1] (what the data dict carries), "cf" = block [
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -171,6 +172,19 @@ class FullyConnectedNet(nn.Sequential):
         for k, v in layers.items():
             self.add_module(k, v)
         self.hs = hs
+        self.act_name = name
+        # hidden chain in one launch (csrc/e3k_mlp.hip) when the widths fit; E3K_FUSED_MLP=0 keeps the per-layer ops
+        self.fused_hidden = (len(hs) >= 3 and name is not None and os.environ.get("E3K_FUSED_MLP", "1") != "0"
+                             and ops.mlp_hidden_supported(hs[0], hs[1:-1], name))
+
+    def forward(self, x):
+        if not self.fused_hidden or not x.is_cuda:
+            return super().forward(x)
+        layers = list(self.children())
+        hidden, last = layers[:-1], layers[-1]
+        h = ops.mlp_hidden(x, [m.weight for m in hidden], [1.0 / math.sqrt(m.h_in) for m in hidden], self.act_name,
+                           hidden[0].cst)
+        return last(h)
 
 
 class FullyConnectedTensorProduct(nn.Module):

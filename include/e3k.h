@@ -232,6 +232,22 @@ int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t d
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused hidden chain of the radial MLP.
+ * Replaces the hidden layers of e3nn.nn.FullyConnectedNet([n_radial, H, ..., H, weight_numel], act)
+ * (e3_layers/nn/message_passing.py:74-79, call :93): per layer l < n_layers
+ *     z_l = alphas[l] * (prev @ W_l),   h_l = cst * act(z_l),   prev = x for l = 0, else h_{l-1}
+ * x [E,k0] (k0 <= 64), W_0 [k0,h], W_l [h,h] row-major, h in {32, 64}, n_layers <= 4; out = h_{n_layers-1} [E,h].
+ * `weights`, `z`, `g_weights` are HOST arrays of n_layers device pointers.
+ *   forward : z[l] [E,h] receive the pre-activations the backward needs (z or any z[l] may be NULL: inference).
+ *   backward: g_out = gradient wrt out; g_weights[l] (same shapes as W_l) are ACCUMULATED with atomics
+ *             (caller zeroes; NULL entries / NULL array are skipped); g_x [E,k0] written when not NULL. */
+int e3k_mlp_hidden_fwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers, const float* const* weights,
+                       const float* alphas, int32_t act, float cst, float* const* z, float* out, void* stream);
+int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers, const float* const* weights,
+                       const float* alphas, int32_t act, float cst, const float* const* z, const float* g_out,
+                       float* const* g_weights, float* g_x, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radius graph on the device.
  * Replaces computeEdgeIndex (e3_layers/data/compute_edge.py:38-113) for the criteria-free case: per graph all
  * ordered pairs (i, j), i != j, with fp32 sqrt(|pos_i - pos_j|^2) < r_max (strict), in the reference's order

@@ -65,6 +65,7 @@ def test_radial_mlp_double_backward(dev):
     torch.manual_seed(1)
     hs = [8, 64, 64, 96]
     net = FullyConnectedNet(hs, activations["ssp"]).to(dev)
+    assert net.fused_hidden      # the fused chain's backward rebuilds the per-layer graph under create_graph
     ref = e3ref.FullyConnectedNet(hs, "ssp").double()
     ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
     x = torch.randn(500, 8, dtype=torch.float64)

@@ -534,3 +534,46 @@ def test_radius_graph_kernel_keeps_existing_edges(dev):
     bad = {"pos": pos.to(dev), "_n_nodes": n_nodes.to(dev), "edge_index": torch.tensor([[0], [4]], device=dev)}
     with pytest.raises(ValueError, match="different graphs"):
         computeEdgeIndex(bad, {}, r_max=1.5)
+
+
+@pytest.mark.parametrize("hs,act,rows", [([8, 64, 64, 64, 96], "ssp", 1234), ([32, 32, 32, 40], "silu", 130),
+                                         ([6, 64, 20], "ssp", 1), ([8, 32, 32, 32, 32, 24], "ssp", 777)])
+def test_fused_radial_mlp_hidden_chain(dev, hs, act, rows, monkeypatch):
+    """The one-launch hidden chain (csrc/e3k_mlp.hip) == the oracle's FullyConnectedNet and == the per-layer
+    kernels (E3K_FUSED_MLP=0), values and every gradient; ragged row counts, input widths 6/8/32, 1-4 hidden layers."""
+    from e3_layers_amd.nn import FullyConnectedNet
+    from e3_layers_amd.utils import activations
+
+    torch.manual_seed(21)
+    net = FullyConnectedNet(hs, activations[act]).to(dev)
+    assert net.fused_hidden
+    ref = e3ref.FullyConnectedNet(hs, act).double()
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(rows, hs[0], dtype=torch.float64)
+    xin, xr = x.float().to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    y, yr = net(xin), ref(xr)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    params = list(net.parameters())
+    g = _grads(y, [xin] + params, seed.float().to(dev))
+    r = _grads(yr, [xr] + list(ref.parameters()), seed)
+    for a, b in zip(g, r):
+        assert rel_err(a, b) < GTOL
+    net.fused_hidden = False                      # per-layer kernels on the same parameters
+    y2 = net(xin)
+    g2 = _grads(y2, [xin] + params, seed.float().to(dev))
+    assert rel_err(y, y2) < 1e-6
+    for a, b in zip(g, g2):
+        assert rel_err(a, b) < 1e-5
+    with torch.no_grad():                         # inference: no pre-activations kept
+        net.fused_hidden = True
+        assert rel_err(net(xin), yr) < TOL
+
+
+def test_fused_radial_mlp_falls_back_for_other_widths(dev):
+    from e3_layers_amd.nn import FullyConnectedNet
+    from e3_layers_amd.utils import activations
+
+    assert not FullyConnectedNet([8, 16, 16, 30], activations["ssp"]).fused_hidden      # width 16: per-layer path
+    assert not FullyConnectedNet([8, 64, 32, 30], activations["ssp"]).fused_hidden      # mixed widths
+    assert not FullyConnectedNet([8, 30], None).fused_hidden

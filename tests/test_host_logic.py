@@ -175,6 +175,11 @@ def test_batch_from_data_list_and_back():
     assert b["pos"][0, 0] == 0
     b["extra"] = [1.0, 2.0]
     assert isinstance(b["extra"], torch.Tensor)
+    v = b.view()                                    # same tensors, independent key / attrs dicts
+    v["new_key"] = torch.zeros(5, 1)
+    v.attrs["new_key"] = ("node", "1x0e")
+    assert "new_key" not in b and "new_key" not in b.attrs and v["pos"].data_ptr() == b["pos"].data_ptr()
+    assert len(v) == len(b) and v["_node_segment"] is b["_node_segment"]
 
 
 def test_data_autoreshape_by_irreps():
