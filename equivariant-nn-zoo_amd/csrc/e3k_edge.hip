@@ -349,13 +349,18 @@ __global__ __launch_bounds__(256) void radial_bwd_kernel(const float* __restrict
     if (g_r) g_r[e] = gr;
   }
   if (g_w) {
+    // the block's four waves meet in LDS: one atomic per basis function and block (same-address atomics from
+    // every wave of the launch serialise)
+    __shared__ float part[4][MAXB];
 #pragma unroll
     for (int n = 0; n < MAXB; ++n) {
       if (n < nb) {
         const float tot = wave_sum(acc[n]);
-        if ((threadIdx.x & 63) == 0) atomicAdd(g_w + n, tot);
+        if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6][n] = tot;
       }
     }
+    __syncthreads();
+    if ((int)threadIdx.x < nb) atomicAdd(g_w + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
   }
 }
 
@@ -607,7 +612,7 @@ extern "C" int e3k_radial_basis_bwd(const float* r, const float* g_out, int64_t 
   if (E == 0) return E3K_OK;
   if (!r || !g_out || !bessel_w || (!g_r && !g_w)) return E3K_ERR_INVALID;
   int64_t blocks = (E + 255) / 256;
-  if (blocks > 512) blocks = 512;
+  if (blocks > 256) blocks = 256;
 #define E3K_RB_LAUNCH(MB)                                                                                            \
   hipLaunchKernelGGL(e3k::radial_bwd_kernel<MB>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, r, g_out, E, \
                      bessel_w, n_basis, r_max, r_min, p, one_over_r, cutoff_kind, g_r, g_w)

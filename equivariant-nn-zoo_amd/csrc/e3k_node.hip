@@ -222,6 +222,117 @@ __global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restric
 }
 
 // ---------------------------------------------------------------------------------------
+// keyed self-connection weights:  M[t, (j,u,w)] = sum_v a[t,v] W_j[u,v,w]
+// (W_j stored [U][V][Wout] as e3nn's 'uvw' weights; one thread per column (j,u,w), coalesced along w)
+// ---------------------------------------------------------------------------------------
+constexpr int KW_MAXI = 16, KW_MAXV = 32, KW_MAXK = 64;
+struct KwArgs {
+  int n, K, V;
+  int64_t ld_m, total;
+  e3k_kw_instr ins[KW_MAXI];
+};
+
+__device__ __forceinline__ const float* kw_locate(const KwArgs& ka, int64_t c, const float* W, int& wout) {
+  int j = 0;
+  for (int i = 1; i < ka.n; ++i)
+    if (c >= ka.ins[i].m_off) j = i;
+  const e3k_kw_instr& in = ka.ins[j];
+  const int local = (int)(c - in.m_off);
+  const int u = local / in.w_out, w = local - u * in.w_out;
+  wout = in.w_out;
+  return W + in.w_off + (int64_t)u * ka.V * in.w_out + w;
+}
+
+template <int MODE>   // 0: M = a . W    1: gW (+)= a^T . gM    (MODE 1: `M` is gM, `Wout_` is gW)
+__global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restrict__ a, const float* __restrict__ W,
+                                                             KwArgs ka, float* __restrict__ M, float* __restrict__ Wout_,
+                                                             int accumulate) {
+  __shared__ float as[KW_MAXK * KW_MAXV];
+  for (int i = threadIdx.x; i < ka.K * ka.V; i += 256) as[i] = a[i];
+  __syncthreads();
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ka.total) return;
+  int wout;
+  const float* base = kw_locate(ka, c, W, wout);
+  if constexpr (MODE == 0) {
+    float wv[KW_MAXV];
+#pragma unroll
+    for (int v = 0; v < KW_MAXV; ++v) wv[v] = v < ka.V ? base[(int64_t)v * wout] : 0.f;
+    for (int t = 0; t < ka.K; ++t) {
+      float acc = 0.f;
+#pragma unroll
+      for (int v = 0; v < KW_MAXV; ++v)
+        if (v < ka.V) acc = fmaf(as[t * ka.V + v], wv[v], acc);
+      M[(int64_t)t * ka.ld_m + c] = acc;
+    }
+  } else {
+    float gv[KW_MAXV];
+#pragma unroll
+    for (int v = 0; v < KW_MAXV; ++v) gv[v] = 0.f;
+    for (int t = 0; t < ka.K; ++t) {
+      const float g = M[(int64_t)t * ka.ld_m + c];
+#pragma unroll
+      for (int v = 0; v < KW_MAXV; ++v)
+        if (v < ka.V) gv[v] = fmaf(as[t * ka.V + v], g, gv[v]);
+    }
+    float* dst = Wout_ + (base - W);
+#pragma unroll
+    for (int v = 0; v < KW_MAXV; ++v)
+      if (v < ka.V) dst[(int64_t)v * wout] = accumulate ? dst[(int64_t)v * wout] + gv[v] : gv[v];
+  }
+}
+
+// ga[t,v] += sum_c gM[t,c] W[c,v]  (c over all ~1e5 columns): a [K x C] x [C x V] product with a tiny output.
+// Stage 1: a block stages 256 columns of gM ([K][256]) and of W ([V][256]) in LDS with coalesced loads; thread
+// (t, v) then owns one output and walks the 256 columns with 16-byte LDS reads; the block's K*V partials go to a
+// workspace row.  Stage 2: one block sums the workspace rows into ga (no same-address atomics: they serialised).
+constexpr int KWA_COLS = 256, KWA_KT = 16;
+__global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* __restrict__ gM, const float* __restrict__ W,
+                                                                   KwArgs ka, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
+  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+  const int t_id = threadIdx.x;
+  const int64_t c = (int64_t)blockIdx.x * KWA_COLS + t_id;
+  const bool ok = c < ka.total;
+  {
+    int wout = 1;
+    const float* base = ok ? kw_locate(ka, c, W, wout) : W;
+    for (int v = 0; v < ka.V; ++v) wsm[v][t_id] = ok ? base[(int64_t)v * wout] : 0.f;
+  }
+  float* out = ws + (int64_t)blockIdx.x * ka.K * ka.V;
+  for (int t0 = 0; t0 < ka.K; t0 += KWA_KT) {
+    const int kt = (ka.K - t0 < KWA_KT) ? ka.K - t0 : KWA_KT;
+    __syncthreads();   // previous chunk's readers are done (and wsm is complete on the first trip)
+    for (int t = 0; t < kt; ++t) gs[t][t_id] = ok ? gM[(int64_t)(t0 + t) * ka.ld_m + c] : 0.f;
+    __syncthreads();
+    for (int o = t_id; o < kt * ka.V; o += 256) {
+      const int t = o / ka.V, v = o - t * ka.V;
+      const float4* g4 = reinterpret_cast<const float4*>(gs[t]);
+      const float4* w4 = reinterpret_cast<const float4*>(wsm[v]);
+      float acc = 0.f;
+#pragma unroll 8
+      for (int q = 0; q < KWA_COLS / 4; ++q) {
+        const float4 g = g4[q], w = w4[q];
+        acc = fmaf(g.x, w.x, acc);
+        acc = fmaf(g.y, w.y, acc);
+        acc = fmaf(g.z, w.z, acc);
+        acc = fmaf(g.w, w.w, acc);
+      }
+      out[(t0 + t) * ka.V + v] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void keyed_weights_bwd_a_reduce_kernel(const float* __restrict__ ws, int n_rows, int n,
+                                                                          float* __restrict__ ga) {
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < n; o += gridDim.x * 256) {
+    float acc = 0.f;
+    for (int r = 0; r < n_rows; ++r) acc += ws[(int64_t)r * n + o];
+    ga[o] += acc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // per-block RMS normalisation: one wave per row
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t rows, int row_dim,
@@ -432,6 +543,72 @@ extern "C" int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_ha
   if (g_x) {
     hipLaunchKernelGGL(e3k::gate_bwd2_x_kernel, dim3(e3k::grid_for(rows * in_dim)), dim3(256), 0, (hipStream_t)stream, x,
                        g_y, g_hat, rows, in_dim, out_dim, ga, g_x);
+    E3K_CHECK_LAUNCH();
+  }
+  return E3K_OK;
+}
+
+namespace {
+int make_kw(const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys, int32_t V, int64_t ld_m, e3k::KwArgs& ka) {
+  if (!instr || n_instr <= 0 || n_instr > e3k::KW_MAXI || n_keys <= 0 || n_keys > e3k::KW_MAXK || V <= 0 ||
+      V > e3k::KW_MAXV)
+    return E3K_ERR_UNSUPPORTED;
+  ka.n = n_instr;
+  ka.K = n_keys;
+  ka.V = V;
+  ka.ld_m = ld_m;
+  int64_t pos = 0;
+  for (int i = 0; i < n_instr; ++i) {
+    if (instr[i].u <= 0 || instr[i].w_out <= 0 || instr[i].m_off != pos) return E3K_ERR_INVALID;   // columns are packed
+    ka.ins[i] = instr[i];
+    pos += (int64_t)instr[i].u * instr[i].w_out;
+  }
+  ka.total = pos;
+  if (ld_m < pos) return E3K_ERR_INVALID;
+  return E3K_OK;
+}
+}  // namespace
+
+extern "C" int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_kw_instr* instr, int32_t n_instr,
+                                     int32_t n_keys, int32_t V, int64_t ld_m, float* M, void* stream) {
+  e3k::KwArgs ka{};
+  const int rc = make_kw(instr, n_instr, n_keys, V, ld_m, ka);
+  if (rc != E3K_OK) return rc;
+  if (!a || !W || !M) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::keyed_weights_kernel<0>, dim3((unsigned)((ka.total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, a, W, ka, M, (float*)nullptr, 0);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int64_t e3k_keyed_weights_bwd_workspace(const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys, int32_t V) {
+  if (!instr || n_instr <= 0 || n_keys <= 0 || V <= 0) return 0;
+  int64_t total = 0;
+  for (int i = 0; i < n_instr; ++i) total += (int64_t)instr[i].u * instr[i].w_out;
+  return ((total + e3k::KWA_COLS - 1) / e3k::KWA_COLS) * n_keys * V;
+}
+
+extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float* g_M, const e3k_kw_instr* instr,
+                                     int32_t n_instr, int32_t n_keys, int32_t V, int64_t ld_m, float* g_a, float* g_W,
+                                     int32_t accumulate_w, float* workspace, void* stream) {
+  e3k::KwArgs ka{};
+  const int rc = make_kw(instr, n_instr, n_keys, V, ld_m, ka);
+  if (rc != E3K_OK) return rc;
+  if (!a || !W || !g_M || (!g_a && !g_W)) return E3K_ERR_INVALID;
+  if (g_W) {
+    hipLaunchKernelGGL(e3k::keyed_weights_kernel<1>, dim3((unsigned)((ka.total + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, a, W, ka, const_cast<float*>(g_M), g_W, accumulate_w);
+    E3K_CHECK_LAUNCH();
+  }
+  if (g_a) {
+    if (!workspace) return E3K_ERR_INVALID;
+    const int64_t blocks = (ka.total + e3k::KWA_COLS - 1) / e3k::KWA_COLS;
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_M, W,
+                       ka, workspace);
+    E3K_CHECK_LAUNCH();
+    const int n = n_keys * V;
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, workspace, (int)blocks, n, g_a);
     E3K_CHECK_LAUNCH();
   }
   return E3K_OK;

@@ -43,6 +43,10 @@ class TpGroup(C.Structure):
     ]
 
 
+class KwInstr(C.Structure):
+    _fields_ = [("w_off", C.c_int64), ("m_off", C.c_int64), ("u", C.c_int32), ("w_out", C.c_int32)]
+
+
 class Block(C.Structure):
     _fields_ = [("off", C.c_int32), ("mul", C.c_int32), ("dim", C.c_int32), ("_pad", C.c_int32)]
 
@@ -73,6 +77,9 @@ SIGNATURES = {
     "e3k_radial_basis_fwd": (C.c_int, [_P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P]),
     "e3k_radial_basis_bwd": (C.c_int, [_P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P]),
     "e3k_radial_basis_bwd2": (C.c_int, [_P, _P, _P, _P, _I64, _P, _I32, _F, _F, _F, _I32, _I32, _P, _P, _P, _P]),
+    "e3k_keyed_weights_fwd": (C.c_int, [_P, _P, C.POINTER(KwInstr), _I32, _I32, _I32, _I64, _P, _P]),
+    "e3k_keyed_weights_bwd_workspace": (C.c_int64, [C.POINTER(KwInstr), _I32, _I32, _I32]),
+    "e3k_keyed_weights_bwd": (C.c_int, [_P, _P, _P, C.POINTER(KwInstr), _I32, _I32, _I32, _I64, _P, _P, _I32, _P, _P]),
     "e3k_mlp_hidden_fwd": (C.c_int, [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_F), _I32, _F, C.POINTER(_P), _P, _P]),
     "e3k_mlp_hidden_bwd": (C.c_int, [_P, _I64, _I32, _I32, _I32, C.POINTER(_P), C.POINTER(_F), _I32, _F, C.POINTER(_P), _P,
                                      C.POINTER(_P), _P, _P]),

@@ -639,6 +639,75 @@ class RowGroups:
     n_keys: int
 
 
+def _kw_array(spec: "FctpSpec", m_off):
+    arr = (L.KwInstr * len(spec.instr))()
+    for i, (ins, mo) in enumerate(zip(spec.instr, m_off)):
+        arr[i].w_off, arr[i].m_off, arr[i].u, arr[i].w_out = ins.w_off, int(mo), ins.mul_in, ins.mul_out
+    return arr
+
+
+def _keyed_weights_composed(a_rep, weight, spec: "FctpSpec"):
+    """torch restatement of KeyedWeightsFn.forward (double-backward graph only)."""
+    parts = []
+    for ins in spec.instr:
+        w = weight.reshape(-1)[ins.w_off: ins.w_off + ins.mul_in * spec.v * ins.mul_out]
+        parts.append(torch.einsum("tv,uvw->tuw", a_rep, w.reshape(ins.mul_in, spec.v, ins.mul_out)).reshape(a_rep.shape[0], -1))
+    return torch.cat(parts, dim=1)
+
+
+class KeyedWeightsFn(torch.autograd.Function):
+    """M[t, (j,u,w)] = sum_v a_rep[t,v] W_j[u,v,w]: the per-key contracted self-connection weights, read straight from
+    the e3nn-ordered flat weight (no permuted copies), one launch; backward two launches."""
+
+    @staticmethod
+    def forward(ctx, a_rep, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
+        L.require_cuda(a_rep, weight)
+        a_rep, weight = L.f32c(a_rep), L.f32c(weight)
+        k = a_rep.shape[0]
+        m = torch.empty(k, ld_m, device=a_rep.device, dtype=torch.float32)
+        L.check(L.load().e3k_keyed_weights_fwd(L.ptr(a_rep), L.ptr(weight), _kw_array(spec, m_off), len(spec.instr), k, spec.v,
+                                               ld_m, L.ptr(m), L.stream_ptr()), "e3k_keyed_weights_fwd")
+        ctx.save_for_backward(a_rep, weight)
+        ctx.cfg = (spec, m_off, ld_m)
+        return m
+
+    @staticmethod
+    def backward(ctx, gm):
+        a_rep, weight = ctx.saved_tensors
+        spec, m_off, ld_m = ctx.cfg
+        need_a, need_w = ctx.needs_input_grad[:2]
+        if torch.is_grad_enabled():
+            wrt = [t for t, need in zip((a_rep, weight), (need_a, need_w)) if need]
+            with torch.enable_grad():
+                grads = list(torch.autograd.grad(_keyed_weights_composed(a_rep, weight, spec), wrt, gm, create_graph=True))
+            return (grads.pop(0) if need_a else None), (grads.pop(0) if need_w else None), None, None, None
+        gm = L.f32c(gm)
+        ga = torch.zeros_like(a_rep) if need_a else None
+        gw = ret_w = None
+        acc = 0
+        if need_w:
+            gw = _sink_for(weight)
+            if gw is not None:
+                acc = 1
+            else:
+                covered = sum(i.mul_in * spec.v * i.mul_out for i in spec.instr) == weight.numel()
+                gw = ret_w = (torch.empty_like(weight) if covered else torch.zeros_like(weight))
+        if ga is not None or gw is not None:
+            lib, arr = L.load(), _kw_array(spec, m_off)
+            work = None
+            if ga is not None:
+                n_work = lib.e3k_keyed_weights_bwd_workspace(arr, len(spec.instr), a_rep.shape[0], spec.v)
+                work = torch.empty(n_work, device=a_rep.device, dtype=torch.float32)
+            L.check(lib.e3k_keyed_weights_bwd(L.ptr(a_rep), L.ptr(weight), L.ptr(gm), arr, len(spec.instr), a_rep.shape[0], spec.v,
+                                              ld_m, L.ptr(ga), L.ptr(gw), acc, L.ptr(work), L.stream_ptr()),
+                    "e3k_keyed_weights_bwd")
+        return ga, ret_w, None, None, None
+
+
+def keyed_weights(a_rep, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: int):
+    return KeyedWeightsFn.apply(_c(a_rep), _c(weight), spec, tuple(int(v) for v in m_off), int(ld_m))
+
+
 def _grouped_templates(x, m_like, y, spec, m_off, ld_m, mode: str):
     """One template problem per instruction; e3k_gemm_grouped expands them over the keys."""
     rows = x.shape[0]

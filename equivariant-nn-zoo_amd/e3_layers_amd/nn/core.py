@@ -232,16 +232,12 @@ class FullyConnectedTensorProduct(nn.Module):
         groups = row_groups(key[0], key[1])
         v = self._spec.v
         a_rep = attrs.index_select(0, groups.reps)                     # [K, V] one row per key
-        parts, m_off, pos = [], [], 0
-        for ins in self._spec.instr:                                     # W_j [U, V, Wout] -> [V, U*Wout]
-            w = self.weight[ins.w_off: ins.w_off + ins.mul_in * v * ins.mul_out]
-            parts.append(w.view(ins.mul_in, v, ins.mul_out).permute(1, 0, 2).reshape(v, ins.mul_in * ins.mul_out))
+        m_off, pos = [], 0
+        for ins in self._spec.instr:
             m_off.append(pos)
             pos += ins.mul_in * ins.mul_out
-        wv = torch.cat(parts, dim=1)                                     # [V, sum U*Wout]
-        # M[t] = sum_v attrs_t[v] W[:, v, :]: a [K<=64, V] x [V, ~1e5] product (and, backward, a
-        # [K, ~1e5] x [~1e5, V] one) -- a few MFLOP of plain library GEMM, left to torch/rocBLAS
-        m = a_rep @ wv
+        # M[t] = sum_v attrs_t[v] W[:, v, :], one launch reading the e3nn-ordered ('uvw') flat weight in place
+        m = ops.keyed_weights(a_rep, self.weight, self._spec, m_off, pos)
         return ops.grouped_linear(x_cf, m, groups, self._spec, m_off)
 
 

@@ -232,6 +232,27 @@ int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t d
                     void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Keyed self-connection weights (see e3k_gemm_grouped): rows of node_attrs that carry the same key share
+ *     M[t, (j,u,w)] = sum_v a[t,v] * W_j[u,v,w]
+ * with W_j the [U][V][Wout] weight block of instruction j of FullyConnectedTensorProduct(x, node_attrs)
+ * (e3_layers/nn/message_passing.py:81-87, e3nn 'uvw' weight order) at element offset w_off of the flat weight,
+ * and its U*Wout columns at m_off of M (columns packed in instruction order, row stride ld_m).
+ * a [n_keys, V] (n_keys <= 64, V <= 32).  backward: g_a [n_keys,V] ACCUMULATED (caller zeroes), g_W flat like W:
+ * written (accumulate_w = 0) or added to (accumulate_w = 1); either may be NULL.  g_a needs a device `workspace` of
+ * e3k_keyed_weights_bwd_workspace(...) floats (per-block partial sums, reduced by a second launch — same-address
+ * atomics from every block serialise).  `instr` is a HOST array. */
+typedef struct {
+  int64_t w_off, m_off;
+  int32_t u, w_out;
+} e3k_kw_instr;
+int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys,
+                          int32_t V, int64_t ld_m, float* M, void* stream);
+int64_t e3k_keyed_weights_bwd_workspace(const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys, int32_t V);
+int e3k_keyed_weights_bwd(const float* a, const float* W, const float* g_M, const e3k_kw_instr* instr, int32_t n_instr,
+                          int32_t n_keys, int32_t V, int64_t ld_m, float* g_a, float* g_W, int32_t accumulate_w,
+                          float* workspace, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused hidden chain of the radial MLP.
  * Replaces the hidden layers of e3nn.nn.FullyConnectedNet([n_radial, H, ..., H, weight_numel], act)
  * (e3_layers/nn/message_passing.py:74-79, call :93): per layer l < n_layers
