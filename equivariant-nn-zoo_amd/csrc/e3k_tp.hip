@@ -25,6 +25,14 @@
 #include "e3k_common.h"
 #include "e3k_cg_gen.h"
 
+#ifndef E3K_TP_FWD_PIPE
+#define E3K_TP_FWD_PIPE 0    // 1: loads of edge t+1 issued before edge t is consumed; costs a second register set, and
+                             // occupancy buys more here: measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
+#endif
+#ifndef E3K_TP_BWDX_PIPE
+#define E3K_TP_BWDX_PIPE 0   // same trade for the backward wrt x: 495 vs 498 us (l_max 2), 1005 vs 1131 us (l_max 3)
+#endif
+
 static_assert(E3K_MAXQ == E3K_TP_MAXQ, "e3k.h and e3k_cg_gen.h disagree on the slot count");
 static_assert(E3K_L2MAX == 2, "YRegs below is written for sh degrees 0..2");
 
@@ -88,7 +96,16 @@ __device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, c
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-template <int L1>
+// visits the path slots whose output degree the plan can contain: slots with l3 > L3MAX are compiled out, so an
+// l_max = 2 model carries no accumulators for l3 = 3 outputs (14 of the 36 registers of an l1 = 2 group)
+template <class S, int L3MAX, class F>
+__device__ __forceinline__ void slot_for(F&& f) {
+  static_for<0, S::NQ>([&](auto qc) {
+    if constexpr (S::L3[decltype(qc)::value] <= L3MAX) f(qc);
+  });
+}
+
+template <int L1, int L3MAX>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -112,12 +129,19 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 #pragma unroll
       for (int i = 0; i < D1; ++i) xn[i] = active ? xr[i * mul] : 0.0f;
       const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
-      static_for<0, S::NQ>([&](auto qc) {
+      slot_for<S, L3MAX>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         if (mask & (1u << Q)) wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
       });
       load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
     };
+#if !E3K_TP_FWD_PIPE
+    for (int t = beg; t < end; ++t) {
+      issue(t);
+      float (&xc)[D1] = xn;
+      float (&wc)[S::NQ] = wn;
+      YRegs& yc = yn;
+#else
     issue(beg);
     for (int t = beg; t < end; ++t) {
       float xc[D1], wc[S::NQ];
@@ -127,7 +151,8 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 #pragma unroll
       for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
       if (t + 1 < end) issue(t + 1);
-      static_for<0, S::NQ>([&](auto qc) {
+#endif
+      slot_for<S, L3MAX>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -142,7 +167,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
   }
   if (active) {
     float* __restrict__ orow = a.out + (int64_t)node * a.d_mid + u;
-    static_for<0, S::NQ>([&](auto qc) {
+    slot_for<S, L3MAX>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
       if (mask & (1u << Q)) {
@@ -156,7 +181,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
-template <int L1, bool WITH_SH>
+template <int L1, bool WITH_SH, int L3MAX>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -168,7 +193,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
   float go[S::TOTAL];
   {
     const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid + u;
-    static_for<0, S::NQ>([&](auto qc) {
+    slot_for<S, L3MAX>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
 #pragma unroll
@@ -196,7 +221,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 #pragma unroll
       for (int j = 0; j < 5; ++j) gy.y2[j] = 0.0f;
     }
-    static_for<0, S::NQ>([&](auto qc) {
+    slot_for<S, L3MAX>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
       if (mask & (1u << Q)) {
@@ -243,7 +268,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
-template <int L1>
+template <int L1, int L3MAX>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -265,7 +290,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
       const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
       const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
-      static_for<0, S::NQ>([&](auto qc) {
+      slot_for<S, L3MAX>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -275,6 +300,13 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
         }
       });
     };
+#if !E3K_TP_BWDX_PIPE
+    for (int t = beg; t < end; ++t) {
+      issue(t);
+      float (&gc)[S::TOTAL] = gn;
+      float (&wc)[S::NQ] = wn;
+      YRegs& yc = yn;
+#else
     issue(beg);
     for (int t = beg; t < end; ++t) {
       float gc[S::TOTAL], wc[S::NQ];
@@ -284,7 +316,8 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
 #pragma unroll
       for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
       if (t + 1 < end) issue(t + 1);
-      static_for<0, S::NQ>([&](auto qc) {
+#endif
+      slot_for<S, L3MAX>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -316,38 +349,39 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   const e3k_tp_group& g = groups[uniform(gcv.x)];                              \
   const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
 
+// MAXL = largest input degree of the plan: the register allocation of a kernel is the maximum over the branches of
+// the degree switch, so an l_max = 2 model must not carry the l1 = 3 body (63 accumulators) it never runs.
+template <int MAXL, int L3MAX>
 __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  switch (g.l1) {
-    case 0: tp_fwd_body<0>(a, g, node, u); break;
-    case 1: tp_fwd_body<1>(a, g, node, u); break;
-    case 2: tp_fwd_body<2>(a, g, node, u); break;
-    default: tp_fwd_body<3>(a, g, node, u); break;
-  }
+  const int l1 = g.l1;
+  if (l1 == 0) tp_fwd_body<0, L3MAX>(a, g, node, u);
+  if constexpr (MAXL >= 1) { if (l1 == 1) tp_fwd_body<1, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 2) { if (l1 == 2) tp_fwd_body<2, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 3) { if (l1 == 3) tp_fwd_body<3, L3MAX>(a, g, node, u); }
 }
 
-template <bool WITH_SH>
+template <bool WITH_SH, int MAXL, int L3MAX>
 __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  switch (g.l1) {
-    case 0: tp_bwd_w_body<0, WITH_SH>(a, g, node, u); break;
-    case 1: tp_bwd_w_body<1, WITH_SH>(a, g, node, u); break;
-    case 2: tp_bwd_w_body<2, WITH_SH>(a, g, node, u); break;
-    default: tp_bwd_w_body<3, WITH_SH>(a, g, node, u); break;
-  }
+  const int l1 = g.l1;
+  if (l1 == 0) tp_bwd_w_body<0, WITH_SH, L3MAX>(a, g, node, u);
+  if constexpr (MAXL >= 1) { if (l1 == 1) tp_bwd_w_body<1, WITH_SH, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 2) { if (l1 == 2) tp_bwd_w_body<2, WITH_SH, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 3) { if (l1 == 3) tp_bwd_w_body<3, WITH_SH, L3MAX>(a, g, node, u); }
 }
 
+template <int MAXL, int L3MAX>
 __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  switch (g.l1) {
-    case 0: tp_bwd_x_body<0>(a, g, node, u); break;
-    case 1: tp_bwd_x_body<1>(a, g, node, u); break;
-    case 2: tp_bwd_x_body<2>(a, g, node, u); break;
-    default: tp_bwd_x_body<3>(a, g, node, u); break;
-  }
+  const int l1 = g.l1;
+  if (l1 == 0) tp_bwd_x_body<0, L3MAX>(a, g, node, u);
+  if constexpr (MAXL >= 1) { if (l1 == 1) tp_bwd_x_body<1, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 2) { if (l1 == 2) tp_bwd_x_body<2, L3MAX>(a, g, node, u); }
+  if constexpr (MAXL >= 3) { if (l1 == 3) tp_bwd_x_body<3, L3MAX>(a, g, node, u); }
 }
 
 }  // namespace e3k
@@ -360,6 +394,8 @@ struct e3k_tp_plan {
   e3k_tp_group* d_groups;
   int2* d_gc;     // (group, 64-channel chunk) work list, all degrees
   int32_t n_gc;
+  int32_t max_l1; // largest input degree among the groups (selects the kernel instantiation)
+  int32_t max_l3; // largest output degree any group's mask enables
 };
 
 extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
@@ -367,6 +403,24 @@ extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
   if (l2max) *l2max = E3K_L2MAX;
   if (l3max) *l3max = E3K_L3MAX;
 }
+
+namespace {
+template <int L1>
+int max_l3_of(unsigned mask) {
+  int m = 0;
+  for (int q = 0; q < e3k::Slots<L1>::NQ; ++q)
+    if ((mask & (1u << q)) && e3k::Slots<L1>::L3[q] > m) m = e3k::Slots<L1>::L3[q];
+  return m;
+}
+int plan_max_l3(const e3k_tp_group& g) {
+  switch (g.l1) {
+    case 0: return max_l3_of<0>(g.mask);
+    case 1: return max_l3_of<1>(g.mask);
+    case 2: return max_l3_of<2>(g.mask);
+    default: return max_l3_of<3>(g.mask);
+  }
+}
+}  // namespace
 
 extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, int32_t d_in, int32_t d_sh,
                                   int32_t w_numel, int32_t d_mid, e3k_tp_plan** out) {
@@ -408,6 +462,12 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
       return E3K_ERR_LAUNCH;
     }
     p->n_gc = cnt;
+    p->max_l1 = 0;
+    p->max_l3 = 0;
+    for (int i = 0; i < n_groups; ++i) {
+      p->max_l1 = groups[i].l1 > p->max_l1 ? groups[i].l1 : p->max_l1;
+      p->max_l3 = plan_max_l3(groups[i]) > p->max_l3 ? plan_max_l3(groups[i]) : p->max_l3;
+    }
   }
   *out = p;
   return E3K_OK;
@@ -432,20 +492,26 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-  switch (kind) {
-    case TP_FWD:
-      hipLaunchKernelGGL(e3k::tp_fwd_kernel, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
-      break;
-    case TP_BWD_W:
-      hipLaunchKernelGGL(e3k::tp_bwd_w_kernel<false>, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
-      break;
-    case TP_BWD_W_SH:
-      hipLaunchKernelGGL(e3k::tp_bwd_w_kernel<true>, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
-      break;
-    case TP_BWD_X:
-      hipLaunchKernelGGL(e3k::tp_bwd_x_kernel, grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
-      break;
+#define E3K_TP_LAUNCH(ML, L3)                                                                                           \
+  switch (kind) {                                                                                                   \
+    case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_W:                                                                                                  \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
+      break;                                                                                                        \
+    case TP_BWD_W_SH:                                                                                               \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
+      break;                                                                                                        \
+    case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
   }
+  // two instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3
+  const bool low = p->max_l3 <= p->max_l1;
+  switch (p->max_l1) {
+    case 0: if (low) { E3K_TP_LAUNCH(0, 0) } else { E3K_TP_LAUNCH(0, 3) } break;
+    case 1: if (low) { E3K_TP_LAUNCH(1, 1) } else { E3K_TP_LAUNCH(1, 3) } break;
+    case 2: if (low) { E3K_TP_LAUNCH(2, 2) } else { E3K_TP_LAUNCH(2, 3) } break;
+    default: E3K_TP_LAUNCH(3, 3) break;
+  }
+#undef E3K_TP_LAUNCH
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
