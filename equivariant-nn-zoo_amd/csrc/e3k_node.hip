@@ -323,13 +323,15 @@ __global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* _
   }
 }
 
+// one block per 4 outputs: each wave sums its output's column of the workspace with 64 rows in flight
 __global__ __launch_bounds__(256) void keyed_weights_bwd_a_reduce_kernel(const float* __restrict__ ws, int n_rows, int n,
                                                                           float* __restrict__ ga) {
-  for (int o = blockIdx.x * 256 + threadIdx.x; o < n; o += gridDim.x * 256) {
-    float acc = 0.f;
-    for (int r = 0; r < n_rows; ++r) acc += ws[(int64_t)r * n + o];
-    ga[o] += acc;
-  }
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (o >= n) return;
+  float acc = 0.f;
+  for (int r = lane; r < n_rows; r += 64) acc += ws[(int64_t)r * n + o];
+  acc = wave_sum(acc);
+  if (lane == 0) ga[o] += acc;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -607,7 +609,7 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
                        ka, workspace);
     E3K_CHECK_LAUNCH();
     const int n = n_keys * V;
-    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, workspace, (int)blocks, n, g_a);
     E3K_CHECK_LAUNCH();
   }
