@@ -24,7 +24,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int MLP_MAXL = 4;
 constexpr int MLP_BM = 64;     // rows (edges) per tile
 constexpr int MLP_LD = 68;     // LDS row stride of the [64][<=64] tiles (16-byte aligned rows)
-constexpr int MLP_LDW = 65;    // weight tile row stride (conflict-free column reads for the transposed operand)
 
 struct MlpArgs {
   const float* x;
@@ -63,18 +62,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
   }
 }
 
-// W [k_real x h] row-major -> LDS [k_pad][MLP_LDW], rows >= k_real zero
-__device__ __forceinline__ void load_weight(const float* __restrict__ w, int k_real, int k_pad, int h, float* dst) {
-  const int sh = h == 64 ? 6 : 5;   // h is 32 or 64
-  for (int idx = threadIdx.x; idx < k_pad * h; idx += 256) {
-    const int k = idx >> sh, n = idx & (h - 1);
-    dst[k * MLP_LDW + n] = k < k_real ? w[idx] : 0.f;
-  }
-}
-
 __global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
   __shared__ __attribute__((aligned(16))) float As[MLP_BM * MLP_LD];
-  __shared__ float Ws[64 * MLP_LDW];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
   const int h = a.h, kp0 = (a.k0 + 1) & ~1;
@@ -83,16 +72,25 @@ __global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
   load_tile(a.x, row0, a.E, a.k0, kp0, As);
   for (int l = 0; l < a.n_layers; ++l) {
     const int k_real = l == 0 ? a.k0 : h, K = l == 0 ? kp0 : h;
-    load_weight(a.w[l], k_real, K, h, Ws);
-    __syncthreads();
+    const int KH = K >> 1;
+    // B operand straight from global memory (the weights are L2 resident) in MFMA operand order, with the
+    // contraction index permuted so that lane half hh owns k = hh*K/2 + s: no weight tile in LDS, no staging pass
+    float bw[32];
+    {
+      const float* wl = a.w[l] + wn * 32 + (lane & 31);
+      const int kb = (lane >> 5) * KH;
+#pragma unroll
+      for (int sI = 0; sI < 32; ++sI) bw[sI] = (col_ok && sI < KH && kb + sI < k_real) ? wl[(kb + sI) * h] : 0.f;
+    }
+    __syncthreads();   // the A tile (input or previous activations) is complete
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     if (col_ok) {
-      const float* ap = As + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5);
-      const float* bp = Ws + (lane >> 5) * MLP_LDW + wn * 32 + (lane & 31);
-#pragma unroll 8
-      for (int kk = 0; kk < K; kk += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[kk], bp[kk * MLP_LDW], acc, 0, 0, 0);
+      const float* ap = As + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5) * KH;
+#pragma unroll
+      for (int sI = 0; sI < 32; ++sI)
+        if (sI < KH) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[sI], bw[sI], acc, 0, 0, 0);
     }
     __syncthreads();   // every wave is done with this layer's operands
     if (col_ok) {
@@ -123,21 +121,21 @@ __global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, int n_tiles) {
+template <int NL>   // number of hidden layers: one register-resident weight-gradient tile each
+__global__ __launch_bounds__(256, 3) void mlp_hidden_bwd_kernel(const MlpArgs a, int n_tiles) {
   __shared__ __attribute__((aligned(16))) float Gs[MLP_BM * MLP_LD];   // gradient wrt h_l, then gz_l
   __shared__ __attribute__((aligned(16))) float Ds[MLP_BM * MLP_LD];   // cst act'(z_l)
   __shared__ __attribute__((aligned(16))) float Hs[MLP_BM * MLP_LD];   // layer input: h_{l-1} = cst act(z_{l-1}) or x
-  __shared__ float Ws[64 * MLP_LDW];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;   // dgrad / wgrad tile coordinates (rows or k block, column block)
   const int h = a.h, kp0 = (a.k0 + 1) & ~1;
   const int hs = h == 64 ? 4 : 3;      // log2(h / 4): float4 columns per row
   const int c4n = h >> 2;
-  const int L = a.n_layers;
+  constexpr int L = NL;
 
-  f32x16 accw[MLP_MAXL];
+  f32x16 accw[NL];
 #pragma unroll
-  for (int l = 0; l < MLP_MAXL; ++l)
+  for (int l = 0; l < NL; ++l)
 #pragma unroll
     for (int i = 0; i < 16; ++i) accw[l][i] = 0.f;
 
@@ -157,9 +155,8 @@ __global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, in
           make_float4(a.cst * act_df(a.act, z4.x), a.cst * act_df(a.act, z4.y), a.cst * act_df(a.act, z4.z), a.cst * act_df(a.act, z4.w));
     }
 #pragma unroll
-    for (int li = 0; li < MLP_MAXL; ++li) {
+    for (int li = 0; li < NL; ++li) {
       const int l = L - 1 - li;
-      if (l < 0) break;
       const int k_real = l == 0 ? a.k0 : h, K = l == 0 ? kp0 : h;   // input width of layer l
       // gz = g (.) cst act'(z_l); then this layer's input and the next iteration's derivative factors
       const float* zprev = l > 0 ? a.z[l - 1] : nullptr;
@@ -179,7 +176,22 @@ __global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, in
         }
       }
       if (l == 0) load_tile(a.x, row0, a.E, a.k0, kp0, Hs);
-      load_weight(a.w[l], k_real, K, h, Ws);
+      // dgrad B operand W_l[k][n] straight from global memory: lane (k, hh) owns n = hh*h/2 + s, a contiguous run
+      const bool need_d = l > 0 || a.gx;
+      const bool d_ok = need_d && wn * 32 < K;
+      const int NH = h >> 1;
+      float bd[32];
+      {
+        const int krow = wn * 32 + (lane & 31);
+        const bool kin = d_ok && krow < k_real;
+        const float* wl = a.w[l] + krow * h + (lane >> 5) * NH;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (kin && 4 * q < NH) v = *reinterpret_cast<const float4*>(wl + 4 * q);
+          bd[4 * q] = v.x; bd[4 * q + 1] = v.y; bd[4 * q + 2] = v.z; bd[4 * q + 3] = v.w;
+        }
+      }
       __syncthreads();
       // wgrad: gW_l[k, n] += sum_rows input[row, k] gz[row, n]; wave tile (k block wm, n block wn)
       if (a.gw[l] && wm * 32 < K && wn * 32 < h) {
@@ -191,19 +203,16 @@ __global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, in
           accw[li] = __builtin_amdgcn_mfma_f32_32x32x2f32(kin ? pp[rr * MLP_LD] : 0.f, gp[rr * MLP_LD], accw[li], 0, 0, 0);
       }
       // dgrad: g_prev[row, k] = alpha_l sum_n gz[row, n] W_l[k, n]; wave tile (row block wm, k block wn)
-      const bool need_d = l > 0 || a.gx;
       f32x16 accd;
 #pragma unroll
       for (int i = 0; i < 16; ++i) accd[i] = 0.f;
-      const bool d_ok = need_d && wn * 32 < K;
       if (d_ok) {
-        const float* gp = Gs + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5);
-        const float* wp = Ws + (wn * 32 + (lane & 31)) * MLP_LDW + (lane >> 5);
-        const bool kin = wn * 32 + (lane & 31) < K;
-#pragma unroll 8
-        for (int nn = 0; nn < h; nn += 2) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[nn], kin ? wp[nn] : 0.f, accd, 0, 0, 0);
+        const float* gp = Gs + (wm * 32 + (lane & 31)) * MLP_LD + (lane >> 5) * NH;
+#pragma unroll
+        for (int sI = 0; sI < 32; ++sI)
+          if (sI < NH) accd = __builtin_amdgcn_mfma_f32_32x32x2f32(gp[sI], bd[sI], accd, 0, 0, 0);
       }
-      __syncthreads();   // everyone is done reading Gs / Hs / Ws
+      __syncthreads();   // everyone is done reading Gs / Hs
       if (d_ok) {
         const float al = a.alpha[l];
 #pragma unroll
@@ -221,9 +230,8 @@ __global__ __launch_bounds__(256) void mlp_hidden_bwd_kernel(const MlpArgs a, in
   }
   // one atomic add per weight element and block
 #pragma unroll
-  for (int li = 0; li < MLP_MAXL; ++li) {
+  for (int li = 0; li < NL; ++li) {
     const int l = L - 1 - li;
-    if (l < 0) break;
     const int k_real = l == 0 ? a.k0 : h;
     if (!a.gw[l] || wn * 32 >= h) continue;
     const int n = wn * 32 + (lane & 31);
@@ -294,9 +302,14 @@ extern "C" int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t
   a.gx = g_x;
   const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
   if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
-  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 512;
+  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 768;
   int64_t blocks = tiles < max_blocks ? tiles : max_blocks;   // persistent: two workgroups per CU share the weight-gradient atomics
-  hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles);
+  switch (n_layers) {
+    case 1: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
+    case 2: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
+    case 3: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
+    default: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
+  }
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
