@@ -33,12 +33,14 @@ rd = sum(bf["tp_fwd"]) / n * 1024 * cal_f
 wr = sum(bw["tp_fwd"]) / len(bw["tp_fwd"]) * 1024 * cal_w
 under = json.load(open(os.path.join(SRC, "bench_under_rocprof.json")))
 rows = list(csv.DictReader(open(stats)))
-tp = next(r for r in rows if "tp_fwd_kernel" in r["Name"])
+tp_rows = [r for r in rows if "tp_fwd_kernel" in r["Name"]]   # one instantiation per (max l1, max l3) of a plan
+tp_calls = sum(int(r["Calls"]) for r in tp_rows)
+tp = {"AverageNs": sum(float(r["TotalDurationNs"]) for r in tp_rows) / tp_calls}
 out = {
     "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over bench.py (default workload), MI355X; "
               "calibrated on a known 1 GiB dword-per-lane stream in tools/pmc_probe.py (FETCH_SIZE reads 1/2 on gfx950)",
     "workload": under["config"]["workload"],
-    "kernel": "e3k::tp_fwd_kernel",
+    "kernel": "e3k::tp_fwd_kernel (all instantiations: " + ", ".join(r["Name"].split("(")[0].replace("void ", "") + " x" + r["Calls"] for r in tp_rows) + ")",
     "launches_sampled": n,
     "calibration": {"fetch_factor": cal_f, "write_factor": cal_w},
     "hbm_read_bytes_per_launch": rd, "hbm_write_bytes_per_launch": wr, "traffic_bytes_per_launch": rd + wr,
