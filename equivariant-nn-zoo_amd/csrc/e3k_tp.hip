@@ -22,6 +22,8 @@
 // (CSR by source) and accumulates grad_x in registers.
 #include <type_traits>
 
+#include <cstdlib>
+
 #include "e3k_common.h"
 #include "e3k_cg_gen.h"
 
@@ -98,14 +100,20 @@ __device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, c
 // ------------------------------------------------------------------------------------------
 // visits the path slots whose output degree the plan can contain: slots with l3 > L3MAX are compiled out, so an
 // l_max = 2 model carries no accumulators for l3 = 3 outputs (14 of the 36 registers of an l1 = 2 group)
-template <class S, int L3MAX, class F>
-__device__ __forceinline__ void slot_for(F&& f) {
+// PART splits a group's slots between two waves (0: slots below the split point, 1: the rest, 2: all of them): at
+// l_max = 3 a group carries 27-36 accumulators; halving them takes the kernels from 3-4 to 6-7 waves per SIMD at the
+// price of gathering x[src] twice (an L2 hit).  Split points: l1 = 1 -> slot 4, l1 = 2 -> slot 4, l1 = 3 -> slot 3.
+template <int L1> struct SplitAt { static constexpr int Q = L1 == 3 ? 3 : 4; };
+template <class S, int L1, int L3MAX, int PART, class F>
+__device__ __forceinline__ void slot_for_part(F&& f) {
   static_for<0, S::NQ>([&](auto qc) {
-    if constexpr (S::L3[decltype(qc)::value] <= L3MAX) f(qc);
+    constexpr int Q = decltype(qc)::value;
+    constexpr bool in_part = PART == 2 || (PART == 0 ? Q < SplitAt<L1>::Q : Q >= SplitAt<L1>::Q);
+    if constexpr (S::L3[Q] <= L3MAX && in_part) f(qc);
   });
 }
 
-template <int L1, int L3MAX>
+template <int L1, int L3MAX, int PART>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -129,7 +137,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 #pragma unroll
       for (int i = 0; i < D1; ++i) xn[i] = active ? xr[i * mul] : 0.0f;
       const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
-      slot_for<S, L3MAX>([&](auto qc) {
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         if (mask & (1u << Q)) wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
       });
@@ -152,7 +160,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
       for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
       if (t + 1 < end) issue(t + 1);
 #endif
-      slot_for<S, L3MAX>([&](auto qc) {
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -167,7 +175,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
   }
   if (active) {
     float* __restrict__ orow = a.out + (int64_t)node * a.d_mid + u;
-    slot_for<S, L3MAX>([&](auto qc) {
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
       if (mask & (1u << Q)) {
@@ -181,7 +189,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
-template <int L1, bool WITH_SH, int L3MAX>
+template <int L1, bool WITH_SH, int L3MAX, int PART>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -193,7 +201,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
   float go[S::TOTAL];
   {
     const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid + u;
-    slot_for<S, L3MAX>([&](auto qc) {
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
 #pragma unroll
@@ -221,7 +229,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 #pragma unroll
       for (int j = 0; j < 5; ++j) gy.y2[j] = 0.0f;
     }
-    slot_for<S, L3MAX>([&](auto qc) {
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
       if (mask & (1u << Q)) {
@@ -268,7 +276,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX>
+template <int L1, int L3MAX, int PART>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -290,7 +298,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
       const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
       const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
-      slot_for<S, L3MAX>([&](auto qc) {
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -317,7 +325,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
       if (t + 1 < end) issue(t + 1);
 #endif
-      slot_for<S, L3MAX>([&](auto qc) {
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
         if (mask & (1u << Q)) {
@@ -332,7 +340,10 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   if (active) {
     float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off + u;
 #pragma unroll
-    for (int i = 0; i < D1; ++i) gxr[i * mul] = gx[i];
+    for (int i = 0; i < D1; ++i) {
+      if constexpr (PART == 2) gxr[i * mul] = gx[i];
+      else atomicAdd(gxr + i * mul, gx[i]);   // two waves per group, g_x pre-zeroed: a + b is order independent
+    }
   }
 }
 
@@ -347,42 +358,53 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   const int gci = uniform((int)(item % n_gc));                                 \
   const int2 gcv = gc[gci];                                                    \
   const e3k_tp_group& g = groups[uniform(gcv.x)];                              \
-  const int u = uniform(gcv.y) * 64 + (threadIdx.x & 63);
+  const int part = uniform(gcv.y) >> 16;                                        \
+  const int u = (uniform(gcv.y) & 0xffff) * 64 + (threadIdx.x & 63);
 
 // MAXL = largest input degree of the plan: the register allocation of a kernel is the maximum over the branches of
 // the degree switch, so an l_max = 2 model must not carry the l1 = 3 body (63 accumulators) it never runs.
-template <int MAXL, int L3MAX>
+#define E3K_TP_CASE(L, BODY, ...)                                                                    \
+  if constexpr (MAXL >= L) {                                                                         \
+    if (l1 == L) {                                                                                   \
+      if constexpr (!SPLIT) {                                                                        \
+        BODY<L, __VA_ARGS__, 2>(a, g, node, u);                                                      \
+      } else {                                                                                       \
+        if (part == 0) BODY<L, __VA_ARGS__, 0>(a, g, node, u);                                       \
+        else BODY<L, __VA_ARGS__, 1>(a, g, node, u);                                                 \
+      }                                                                                              \
+    }                                                                                                \
+  }
+// SPLIT kernels (l_max = 3 plans) only contain the half-group bodies: the full bodies would set the register count
+#define E3K_TP_DISPATCH(BODY, ...)                                                                   \
+  const int l1 = g.l1;                                                                               \
+  (void)part;                                                                                        \
+  if (l1 == 0) BODY<0, __VA_ARGS__, 2>(a, g, node, u);                                               \
+  E3K_TP_CASE(1, BODY, __VA_ARGS__)                                                                  \
+  E3K_TP_CASE(2, BODY, __VA_ARGS__)                                                                  \
+  E3K_TP_CASE(3, BODY, __VA_ARGS__)
+
+template <int MAXL, int L3MAX, bool SPLIT>
 __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  const int l1 = g.l1;
-  if (l1 == 0) tp_fwd_body<0, L3MAX>(a, g, node, u);
-  if constexpr (MAXL >= 1) { if (l1 == 1) tp_fwd_body<1, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 2) { if (l1 == 2) tp_fwd_body<2, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 3) { if (l1 == 3) tp_fwd_body<3, L3MAX>(a, g, node, u); }
+  E3K_TP_DISPATCH(tp_fwd_body, L3MAX)
 }
 
-template <bool WITH_SH, int MAXL, int L3MAX>
+template <bool WITH_SH, int MAXL, int L3MAX, bool SPLIT>
 __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  const int l1 = g.l1;
-  if (l1 == 0) tp_bwd_w_body<0, WITH_SH, L3MAX>(a, g, node, u);
-  if constexpr (MAXL >= 1) { if (l1 == 1) tp_bwd_w_body<1, WITH_SH, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 2) { if (l1 == 2) tp_bwd_w_body<2, WITH_SH, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 3) { if (l1 == 3) tp_bwd_w_body<3, WITH_SH, L3MAX>(a, g, node, u); }
+  E3K_TP_DISPATCH(tp_bwd_w_body, WITH_SH, L3MAX)
 }
 
-template <int MAXL, int L3MAX>
+template <int MAXL, int L3MAX, bool SPLIT>
 __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  const int l1 = g.l1;
-  if (l1 == 0) tp_bwd_x_body<0, L3MAX>(a, g, node, u);
-  if constexpr (MAXL >= 1) { if (l1 == 1) tp_bwd_x_body<1, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 2) { if (l1 == 2) tp_bwd_x_body<2, L3MAX>(a, g, node, u); }
-  if constexpr (MAXL >= 3) { if (l1 == 3) tp_bwd_x_body<3, L3MAX>(a, g, node, u); }
+  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX)
 }
+#undef E3K_TP_DISPATCH
+#undef E3K_TP_CASE
 
 }  // namespace e3k
 
@@ -396,6 +418,7 @@ struct e3k_tp_plan {
   int32_t n_gc;
   int32_t max_l1; // largest input degree among the groups (selects the kernel instantiation)
   int32_t max_l3; // largest output degree any group's mask enables
+  int32_t split;  // 1: groups with l1 >= 1 are walked by two waves (slot parts 0 / 1)
 };
 
 extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
@@ -411,6 +434,24 @@ int max_l3_of(unsigned mask) {
   for (int q = 0; q < e3k::Slots<L1>::NQ; ++q)
     if ((mask & (1u << q)) && e3k::Slots<L1>::L3[q] > m) m = e3k::Slots<L1>::L3[q];
   return m;
+}
+template <int L1>
+void slot_counts_of(unsigned mask, int& n_acc, int& lo, int& hi) {
+  using S = e3k::Slots<L1>;
+  for (int q = 0; q < S::NQ; ++q) {
+    if (!(mask & (1u << q))) continue;
+    const int d = 2 * S::L3[q] + 1;
+    n_acc += d;
+    if (q < e3k::SplitAt<L1>::Q) lo += d; else hi += d;
+  }
+}
+void plan_slot_counts(const e3k_tp_group& g, int& n_acc, int& lo, int& hi) {
+  switch (g.l1) {
+    case 0: slot_counts_of<0>(g.mask, n_acc, lo, hi); break;
+    case 1: slot_counts_of<1>(g.mask, n_acc, lo, hi); break;
+    case 2: slot_counts_of<2>(g.mask, n_acc, lo, hi); break;
+    default: slot_counts_of<3>(g.mask, n_acc, lo, hi); break;
+  }
 }
 int plan_max_l3(const e3k_tp_group& g) {
   switch (g.l1) {
@@ -448,13 +489,31 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     return E3K_ERR_LAUNCH;
   }
   {
+    // work list: (group, 64-channel chunk | part << 16).  A group whose enabled slots hold more than
+    // E3K_TP_SPLIT_ACC accumulators (l_max = 3 models) is walked by two waves, one per slot part.
+    static const int split_acc = getenv("E3K_TP_SPLIT_ACC") ? atoi(getenv("E3K_TP_SPLIT_ACC")) : 24;
+    int2* host = new int2[2 * 1024];
     int cnt = 0;
-    for (int i = 0; i < n_groups; ++i) cnt += (groups[i].mul + 63) / 64;
-    int2* host = new int2[cnt];
-    int k = 0;
-    for (int i = 0; i < n_groups; ++i)
-      for (int c = 0; c < (groups[i].mul + 63) / 64; ++c) host[k++] = make_int2(i, c);
-    hipError_t e1 = hipMalloc(&p->d_gc, sizeof(int2) * cnt);
+    bool any = false;
+    for (int i = 0; i < n_groups; ++i) {
+      int n_acc = 0, lo = 0, hi = 0;
+      plan_slot_counts(groups[i], n_acc, lo, hi);
+      if (groups[i].l1 >= 1 && n_acc > split_acc) any = true;
+    }
+    p->split = any ? 1 : 0;
+    for (int i = 0; i < n_groups; ++i) {
+      int n_acc = 0, lo = 0, hi = 0;
+      plan_slot_counts(groups[i], n_acc, lo, hi);
+      for (int c = 0; c < (groups[i].mul + 63) / 64 && cnt + 2 <= 2 * 1024; ++c) {
+        if (any && groups[i].l1 >= 1) {   // in a split plan every l1 >= 1 group goes by parts (empty parts are skipped)
+          if (lo > 0) host[cnt++] = make_int2(i, c | (0 << 16));
+          if (hi > 0) host[cnt++] = make_int2(i, c | (1 << 16));
+        } else {
+          host[cnt++] = make_int2(i, c | (2 << 16));
+        }
+      }
+    }
+    hipError_t e1 = hipMalloc(&p->d_gc, sizeof(int2) * (cnt ? cnt : 1));
     hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_gc, host, sizeof(int2) * cnt, hipMemcpyHostToDevice) : e1;
     delete[] host;
     if (e2 != hipSuccess) {
@@ -492,24 +551,26 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-#define E3K_TP_LAUNCH(ML, L3)                                                                                           \
+#define E3K_TP_LAUNCH(ML, L3, SP)                                                                                           \
   switch (kind) {                                                                                                   \
-    case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_W:                                                                                                  \
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
       break;                                                                                                        \
     case TP_BWD_W_SH:                                                                                               \
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
       break;                                                                                                        \
-    case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
   }
-  // two instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3
+  // instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3, the latter
+  // also in the split form (two waves per group)
   const bool low = p->max_l3 <= p->max_l1;
+  const bool sp = p->split != 0;
   switch (p->max_l1) {
-    case 0: if (low) { E3K_TP_LAUNCH(0, 0) } else { E3K_TP_LAUNCH(0, 3) } break;
-    case 1: if (low) { E3K_TP_LAUNCH(1, 1) } else { E3K_TP_LAUNCH(1, 3) } break;
-    case 2: if (low) { E3K_TP_LAUNCH(2, 2) } else { E3K_TP_LAUNCH(2, 3) } break;
-    default: E3K_TP_LAUNCH(3, 3) break;
+    case 0: if (low) { E3K_TP_LAUNCH(0, 0, false) } else { E3K_TP_LAUNCH(0, 3, false) } break;
+    case 1: if (low && !sp) { E3K_TP_LAUNCH(1, 1, false) } else if (!sp) { E3K_TP_LAUNCH(1, 3, false) } else { E3K_TP_LAUNCH(1, 3, true) } break;
+    case 2: if (low && !sp) { E3K_TP_LAUNCH(2, 2, false) } else if (!sp) { E3K_TP_LAUNCH(2, 3, false) } else { E3K_TP_LAUNCH(2, 3, true) } break;
+    default: if (!sp) { E3K_TP_LAUNCH(3, 3, false) } else { E3K_TP_LAUNCH(3, 3, true) } break;
   }
 #undef E3K_TP_LAUNCH
   E3K_CHECK_LAUNCH();
