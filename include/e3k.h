@@ -173,7 +173,9 @@ int e3k_tp_fwd(const e3k_tp_plan* plan, const float* x, const float* sh, const f
 int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out,
                  const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
                  float* g_w, float* g_sh, void* stream);
-/* g_x [N,d_in] written; CSR by source (src_ptr, src_perm), dst [E]. */
+/* g_x [N,d_in]: the CALLER ZERO-FILLS it; plans whose groups are walked by two waves (l_max = 3: more than 24
+ * accumulators per group) add their two partial sums with atomics (order independent), the others store.
+ * CSR by source (src_ptr, src_perm), dst [E]. */
 int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
