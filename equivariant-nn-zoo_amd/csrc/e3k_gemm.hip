@@ -1048,13 +1048,14 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
   int kind[64];
   int64_t plain_tiles128 = 0;
   static const int use_x3 = getenv("E3K_GEMM_X3") ? atoi(getenv("E3K_GEMM_X3")) : 0;
+  static const int64_t sk_min_rows = getenv("E3K_SK_MIN_ROWS") ? atoll(getenv("E3K_SK_MIN_ROWS")) : 1024;
   for (int i = 0; i < n_problems; ++i) {
     const e3k_gemm_problem& P = problems[i];
     const int rc = validate(P, false);
     if (rc != E3K_OK) return rc;
     const int64_t M = (int64_t)P.M1 * P.M2;
     if (P.V > 0) kind[i] = FWD_OUTER;
-    else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= 1024 && !(use_x3 & 2)) kind[i] = FWD_SMALLK;
+    else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows && !(use_x3 & 2)) kind[i] = FWD_SMALLK;
     else {
       kind[i] = (use_x3 && a_vec(P) && b_mode(P) != 0) ? FWD_X3 : FWD_PLAIN;
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
