@@ -362,24 +362,39 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
                                                              const float* __restrict__ inv_norm, int64_t rows,
                                                              int row_dim, BlockArgs ba, const float* __restrict__ stdv,
                                                              float* __restrict__ gx, float* __restrict__ g_std) {
-  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (r >= rows) return;
-  const int lane = threadIdx.x & 63;
-  for (int k = 0; k < ba.n; ++k) {
-    const e3k_block& b = ba.b[k];
-    const int len = b.mul * b.dim;
-    const float* xb = x + r * row_dim + b.off;
-    const float* gb = gy + r * row_dim + b.off;
-    float dot = 0.f;
-    for (int j = lane; j < len; j += 64) dot = fmaf(gb[j], xb[j], dot);
-    dot = wave_sum(dot);
-    const float inv = inv_norm[r * ba.n + k], s = stdv[k];
-    // y = s * x * inv, inv = (sum x^2 / mul + eps)^-1/2  =>  dx = s*inv*(g - x * dot * inv^2 / mul)
-    const float coef = dot * inv * inv / (float)b.mul;
-    float* gxb = gx + r * row_dim + b.off;
-    for (int j = lane; j < len; j += 64) gxb[j] = s * inv * (gb[j] - xb[j] * coef);
-    if (lane == 0) atomicAdd(g_std + k, dot * inv);
+  // one wave per row, rows grid-strided; the gradient of the per-block scale is summed per wave in registers, the
+  // block's four waves meet in LDS and issue one atomic per irrep block (one per ROW serialised on n_blocks addresses)
+  __shared__ float part[4][MAXBLK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float gs[MAXBLK];
+#pragma unroll
+  for (int k = 0; k < MAXBLK; ++k) gs[k] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += (int64_t)gridDim.x * 4) {
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k) {
+      if (k < ba.n) {
+        const e3k_block& b = ba.b[k];
+        const int len = b.mul * b.dim;
+        const float* xb = x + r * row_dim + b.off;
+        const float* gb = gy + r * row_dim + b.off;
+        float dot = 0.f;
+        for (int j = lane; j < len; j += 64) dot = fmaf(gb[j], xb[j], dot);
+        dot = wave_sum(dot);
+        const float inv = inv_norm[r * ba.n + k], sc = stdv[k];
+        // y = s * x * inv, inv = (sum x^2 / mul + eps)^-1/2  =>  dx = s*inv*(g - x * dot * inv^2 / mul)
+        const float coef = dot * inv * inv / (float)b.mul;
+        float* gxb = gx + r * row_dim + b.off;
+        for (int j = lane; j < len; j += 64) gxb[j] = sc * inv * (gb[j] - xb[j] * coef);
+        gs[k] += dot * inv;
+      }
+    }
   }
+#pragma unroll
+  for (int k = 0; k < MAXBLK; ++k)
+    if (k < ba.n && lane == 0) part[wv][k] = gs[k];
+  __syncthreads();
+  if ((int)threadIdx.x < ba.n)
+    atomicAdd(g_std + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -639,8 +654,10 @@ extern "C" int e3k_layernorm_bwd(const float* x, const float* g_y, const float* 
   if (rows < 0 || n_blocks == 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !g_y || !inv_norm || !std || !g_x || !g_std) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::layernorm_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                     g_y, inv_norm, rows, row_dim, ba, std, g_x, g_std);
+  int64_t lblocks = (rows + 3) / 4;
+  if (lblocks > 512) lblocks = 512;
+  hipLaunchKernelGGL(e3k::layernorm_bwd_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, x, g_y,
+                     inv_norm, rows, row_dim, ba, std, g_x, g_std);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

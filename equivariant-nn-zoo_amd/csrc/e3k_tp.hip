@@ -249,25 +249,62 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
       }
     });
     if constexpr (WITH_SH) {
+      // nine per-lane partials (l2 = 0, 1, 2 components) -> nine wave totals.  A butterfly that halves the value
+      // set at every level (each lane keeps the half its partner discards) needs 5+3+2+1+1+1 = 13 cross-lane
+      // moves instead of 9 x 6, and leaves value `idx` on the lanes whose upper bits spell idx: the nine sums are
+      // added to grad_sh by ONE wave instruction with nine active lanes.
       float* __restrict__ gsr = a.g_sh + (int64_t)e * a.d_sh;
-      const bool lane0 = (threadIdx.x & 63) == 0;
-      if (g.y_off[0] >= 0) {
-        const float v = wave_sum(gy.y0[0]);
-        if (lane0) atomicAdd(gsr + g.y_off[0], v);
-      }
-      if (g.y_off[1] >= 0) {
+      const int lane = threadIdx.x & 63;
+      float v9[9];
+      v9[0] = gy.y0[0];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float v = wave_sum(gy.y1[j]);
-          if (lane0) atomicAdd(gsr + g.y_off[1] + j, v);
-        }
-      }
-      if (g.y_off[2] >= 0) {
+      for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
-          const float v = wave_sum(gy.y2[j]);
-          if (lane0) atomicAdd(gsr + g.y_off[2] + j, v);
-        }
+      for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
+      int idx = 0;
+      const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+      float l5[5], l3[3], l2[2];
+#pragma unroll
+      for (int i = 0; i < 5; ++i) {
+        const float hi = i + 5 < 9 ? v9[i + 5] : 0.0f;
+        const float recv = __shfl_xor(b5 ? v9[i] : hi, 32, 64);
+        l5[i] = (b5 ? hi : v9[i]) + recv;
+      }
+      idx += b5 ? 5 : 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const float hi = i + 3 < 5 ? l5[i + 3] : 0.0f;
+        const float recv = __shfl_xor(b4 ? l5[i] : hi, 16, 64);
+        l3[i] = (b4 ? hi : l5[i]) + recv;
+      }
+      idx += b4 ? 3 : 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const float hi = i + 2 < 3 ? l3[i + 2] : 0.0f;
+        const float recv = __shfl_xor(b3 ? l3[i] : hi, 8, 64);
+        l2[i] = (b3 ? hi : l3[i]) + recv;
+      }
+      idx += b3 ? 2 : 0;
+      float tot = (b2 ? l2[1] : l2[0]) + __shfl_xor(b2 ? l2[0] : l2[1], 4, 64);
+      idx += b2 ? 1 : 0;
+      tot += __shfl_xor(tot, 2, 64);
+      tot += __shfl_xor(tot, 1, 64);
+      // which of the nine values this lane holds: the halving tree over (5|4) -> (3|2) -> (2|1) -> (1|1);
+      // paths that step into padding carry zeros and are skipped
+      // valid index sets: b5=0: counts 5 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
+      //                              b4=1: 2 -> b3=0: 2 -> b2: 1|1 ; b3=1: 0 (padding)
+      //                   b5=1: counts 4 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
+      //                              b4=1: 1 -> b3=0: 1 -> b2=0 only ; b3=1: padding
+      bool valid;
+      if (!b4) valid = !b3 || !b2;
+      else if (!b5) valid = !b3;
+      else valid = !b3 && !b2;
+      if (valid && (lane & 3) == 0) {
+        int off = -1;
+        if (idx == 0) off = g.y_off[0];
+        else if (idx < 4) off = g.y_off[1] >= 0 ? g.y_off[1] + (idx - 1) : -1;
+        else off = g.y_off[2] >= 0 ? g.y_off[2] + (idx - 4) : -1;
+        if (off >= 0) atomicAdd(gsr + off, tot);
       }
     }
   }

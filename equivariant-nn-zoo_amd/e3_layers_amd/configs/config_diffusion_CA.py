@@ -17,10 +17,11 @@ from .layer_configs import featureModel
 
 
 def criteria(data, edge_index):
-    """same chain and |i - j| < 5, or a 2 % random subset (CPU generator, as the reference)."""
+    """same chain and |i - j| < 5, or a 2 % random subset (:58-64; drawn from the generator of the device that holds the
+    batch — the reference draws on the CPU and copies; a 590 k-candidate H2D copy per model call)."""
     mask = (data["chain_id"][edge_index[0]] == data["chain_id"][edge_index[1]]).view(-1)
     mask = torch.logical_and(mask, (edge_index[0] - edge_index[1]).abs() < 5)
-    extra = torch.rand((edge_index.shape[1],)).to(mask.device)
+    extra = torch.rand((edge_index.shape[1],), device=mask.device)
     return torch.logical_or(mask, extra < 0.02)
 
 

@@ -47,18 +47,23 @@ def computeEdgeVector(data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]
 
 
 def _all_pairs(n_nodes: Tensor, device) -> Tensor:
-    """[2, sum n_g^2] candidate edges, graphs concatenated, (i, j) lexicographic inside a graph."""
-    n = n_nodes.reshape(-1).to("cpu", torch.long)
-    if n.numel() == 0 or int(n.sum()) == 0:
-        return torch.zeros(2, 0, dtype=torch.long, device=device)
-    start = torch.cumsum(n, 0) - n
+    """[2, sum n_g^2] candidate edges, graphs concatenated, (i, j) lexicographic inside a graph; built on ``device``
+    (one host sync for the candidate count when the counts live on the GPU)."""
+    dev = torch.device(device)
+    n = n_nodes.reshape(-1).to(dev, torch.long)
+    if n.numel() == 0:
+        return torch.zeros(2, 0, dtype=torch.long, device=dev)
     sq = n * n
-    graph = torch.repeat_interleave(torch.arange(n.numel()), sq)
-    local = torch.arange(int(sq.sum())) - torch.repeat_interleave(torch.cumsum(sq, 0) - sq, sq)
+    total_sq = int(sq.sum())
+    if total_sq == 0:
+        return torch.zeros(2, 0, dtype=torch.long, device=dev)
+    start = torch.cumsum(n, 0) - n
+    graph = torch.repeat_interleave(torch.arange(n.numel(), device=dev), sq, output_size=total_sq)
+    local = torch.arange(total_sq, device=dev) - (torch.cumsum(sq, 0) - sq)[graph]
     ng = n[graph]
     src = torch.div(local, ng, rounding_mode="floor") + start[graph]
     dst = local % ng + start[graph]
-    return torch.stack([src, dst]).to(device)
+    return torch.stack([src, dst])
 
 
 _STALE = ("_edge_segment", "_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
@@ -118,7 +123,7 @@ def computeEdgeIndex(data, attrs, r_max: float = None, key: str = "pos", criteri
     if pos.is_cuda and criteria is None and r_max is not None:
         return _radius_graph_device(data, attrs, pos, r_max)
     n_nodes = data["_n_nodes"]
-    total = int(n_nodes.sum())
+    total = pos.shape[0]
     cand = _all_pairs(n_nodes, pos.device)
     dist = torch.linalg.norm(pos[cand[0]] - pos[cand[1]], dim=-1)
     keep = dist < r_max
