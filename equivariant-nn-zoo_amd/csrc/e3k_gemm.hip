@@ -1008,6 +1008,7 @@ int launch_batch(K kernel, const e3k::GemmBatch& gb, int blocks, hipStream_t st)
 
 int validate(const e3k_gemm_problem& P, bool wgrad) {
   if (P.M1 < 0 || P.M2 <= 0 || P.N <= 0 || P.K <= 0) return E3K_ERR_INVALID;
+  if (P.M1 == 0) return E3K_OK;   // empty problem (a batch without edges): skipped, its pointers may be NULL
   if (!P.A || !P.B || !P.C) return E3K_ERR_INVALID;
   if (P.V < 0 || P.V > e3k::VMAX) return E3K_ERR_UNSUPPORTED;
   if (P.V > 0 && (!P.A2 || P.K % P.V != 0)) return E3K_ERR_INVALID;

@@ -250,7 +250,7 @@ namespace {
 int fill_args(e3k::MlpArgs& a, const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
               const float* const* weights, const float* alphas, int32_t act, float cst) {
   if (E < 0 || k0 <= 0 || k0 > 64 || (h != 32 && h != 64) || n_layers < 1 || n_layers > e3k::MLP_MAXL) return E3K_ERR_UNSUPPORTED;
-  if (act < 0 || act > 5 || !weights || !alphas || !x) return E3K_ERR_INVALID;
+  if (act < 0 || act > 5 || !weights || !alphas || (E > 0 && !x)) return E3K_ERR_INVALID;
   a.x = x;
   a.E = E;
   a.k0 = k0;

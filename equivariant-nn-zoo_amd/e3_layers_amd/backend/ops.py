@@ -614,7 +614,7 @@ def _fctp_composed(x, attrs, weight, spec: FctpSpec):
         ob = ins.alpha * torch.einsum("nku,nv,uvw->nkw", xb, attrs, wb)
         if spec.out_layout != "cf":
             ob = ob.transpose(1, 2)
-        y[:, ins.out_off:ins.out_off + ins.mul_out * ins.dim] += ob.reshape(rows, -1)
+        y[:, ins.out_off:ins.out_off + ins.mul_out * ins.dim] += ob.reshape(rows, ins.mul_out * ins.dim)
     return y
 
 
@@ -651,7 +651,7 @@ def _keyed_weights_composed(a_rep, weight, spec: "FctpSpec"):
     parts = []
     for ins in spec.instr:
         w = weight.reshape(-1)[ins.w_off: ins.w_off + ins.mul_in * spec.v * ins.mul_out]
-        parts.append(torch.einsum("tv,uvw->tuw", a_rep, w.reshape(ins.mul_in, spec.v, ins.mul_out)).reshape(a_rep.shape[0], -1))
+        parts.append(torch.einsum("tv,uvw->tuw", a_rep, w.reshape(ins.mul_in, spec.v, ins.mul_out)).reshape(a_rep.shape[0], ins.mul_in * ins.mul_out))
     return torch.cat(parts, dim=1)
 
 

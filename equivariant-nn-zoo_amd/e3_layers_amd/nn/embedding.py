@@ -72,7 +72,8 @@ class SphericalEncoding(Module):
         vec = data["vectors"]
         rows = vec.shape[0]
         sh = ops.spherical_harmonics(vec.reshape(rows * self.mul, 3), self.ls, self.normalize, self.normalization)
-        return ({"spherical_harmonics": sh.view(rows, -1)},
+        width = self.mul * sum(2 * l + 1 for l in self.ls)      # explicit: rows may be 0 (a batch without edges)
+        return ({"spherical_harmonics": sh.view(rows, width)},
                 {"spherical_harmonics": ("edge", self.irreps_out["spherical_harmonics"])})
 
 
@@ -90,7 +91,8 @@ class RadialBasisEncoding(Module):
         x = data["input"]
         b, c = self.basis, self.cutoff
         out = ops.radial_basis(x.reshape(-1), b.bessel_weights, b.r_max, b.r_min, c.p, b.one_over_r, c.cutoff.kind)
-        return ({"radial_embedding": out.view(x.shape[0], -1)},
+        per_row = x.numel() // x.shape[0] if x.shape[0] else (x.shape[1] if x.dim() > 1 else 1)
+        return ({"radial_embedding": out.view(x.shape[0], per_row * out.shape[-1])},
                 {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])})
 
 

@@ -441,7 +441,7 @@ class TensorProduct(nn.Module):
             outs[io] = r if outs[io] is None else outs[io] + r
         cols = []
         for io, (mo, lo, _) in enumerate(self.out):
-            cols.append(x1.new_zeros(z, mo * (2 * lo + 1)) if outs[io] is None else outs[io].reshape(z, -1))
+            cols.append(x1.new_zeros(z, mo * (2 * lo + 1)) if outs[io] is None else outs[io].reshape(z, mo * (2 * lo + 1)))
         return torch.cat(cols, dim=1)
 
 
@@ -514,7 +514,7 @@ class Gate(nn.Module):
         gpos = 0
         for m, l, _ in self.gd:
             blk = x[:, pos : pos + m * (2 * l + 1)].reshape(z, m, 2 * l + 1)
-            cols.append((blk * gates[:, gpos : gpos + m].unsqueeze(-1)).reshape(z, -1))
+            cols.append((blk * gates[:, gpos : gpos + m].unsqueeze(-1)).reshape(z, m * (2 * l + 1)))
             pos += m * (2 * l + 1)
             gpos += m
         assert pos == x.shape[1]
@@ -701,7 +701,8 @@ class SphericalEncoding(OModule):
     def forward(self, data, attrs):
         v = data["vectors"]
         n = v.shape[0]
-        sh = spherical_harmonics(self.ls, v.view(n, self.mul, 3), self.normalize, self.normalization).reshape(n, -1)
+        width = self.mul * sum(2 * l + 1 for l in self.ls)
+        sh = spherical_harmonics(self.ls, v.view(n, self.mul, 3), self.normalize, self.normalization).reshape(n, width)
         return {"spherical_harmonics": sh}, {"spherical_harmonics": ("edge", self.irreps_out["spherical_harmonics"])}
 
 
@@ -758,7 +759,8 @@ class RadialBasisEncoding(OModule):
 
     def forward(self, data, attrs):
         x = data["input"]
-        emb = (self.basis(x) * self.cutoff(x, self.factor, self.p)[:, None]).view(x.shape[0], -1)
+        emb = self.basis(x) * self.cutoff(x, self.factor, self.p)[:, None]
+        emb = emb.reshape(x.shape[0], emb.shape[-1])
         return {"radial_embedding": emb}, {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])}
 
 

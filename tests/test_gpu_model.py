@@ -325,3 +325,30 @@ def test_pc_sampler_rebuilds_edges_on_device(dev):
     ei = out["edge_index"]
     d = (out["pos"][ei[0]] - out["pos"][ei[1]]).norm(dim=1)
     assert float(d.max()) < 2.5
+
+
+def test_edgeless_and_mixed_batches(dev):
+    """Edge cases of the graph structure: a batch without a single edge (isolated atoms) and a batch mixing an isolated
+    atom with ordinary molecules run through every kernel with zero-sized launches and agree with the oracle."""
+    from e3_layers_amd.data import Batch, computeEdgeIndex
+    from e3_layers_amd.data.synthetic import synth_qm9_list
+
+    tree = _energy_tree(2, 16, 3)
+    prod, orc = _build_pair(tree, dev)
+    lst, attrs = synth_qm9_list(5, 3, None, r_max=4.0)
+    lone = {"pos": torch.zeros(1, 3), "species": torch.tensor([[6]]), "total_energy": torch.zeros(1, 1),
+            "_n_nodes": torch.tensor([[1]])}
+    new, _ = computeEdgeIndex(lone, dict(attrs), r_max=4.0)
+    lone["edge_index"] = new["edge_index"]
+    for items in ([dict(lone), dict(lone)], [lst[0], dict(lone), lst[1]]):
+        batch = Batch.from_data_list([dict(d) for d in items], dict(attrs))
+        data, oattrs = batch_to_oracle(batch)
+        out_ref, _ = orc(data, oattrs)
+        xb = batch.clone().to(dev)
+        out = prod(xb)
+        assert out["total_energy"].shape == out_ref["total_energy"].shape
+        assert rel_err(out["total_energy"], out_ref["total_energy"]) < TOL
+        loss = out["total_energy"].square().sum()
+        loss.backward()
+        assert all(torch.isfinite(p.grad).all() for p in prod.parameters() if p.grad is not None)
+        prod.zero_grad()
