@@ -335,6 +335,90 @@ __global__ __launch_bounds__(256) void keyed_weights_bwd_a_reduce_kernel(const f
 }
 
 // ---------------------------------------------------------------------------------------
+// NormActivation (e3nn.nn.NormActivation, e3_layers/nn/message_passing.py:212-219): per irrep channel
+//   n2 = max(sum_m x_m^2, eps^2), n = sqrt(n2), y_m = x_m * act(n) / n        (normalize = 1; else y_m = x_m act(n2'))
+// input channel-fastest [2l+1][mul], output e3nn layout [mul][2l+1] at the same block offsets (as the Gate kernel)
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ void normact_scale(int act, float eps2, int normalize, float n2, float& s, float& ds_over_n) {
+  // s = scaling; ds_over_n = (d s / d n) / n  (0 where the clamp is active), so that d s / d x_m = ds_over_n * x_m
+  if (eps2 > 0.f) {
+    const bool clamped = n2 < eps2;
+    const float n = sqrtf(clamped ? eps2 : n2);
+    const float a = act_f(act, n), da = act_df(act, n);
+    if (normalize) {
+      s = a / n;
+      ds_over_n = clamped ? 0.f : (da * n - a) / (n * n * n);
+    } else {
+      s = a;
+      ds_over_n = clamped ? 0.f : da / n;
+    }
+  } else {   // no epsilon: the argument of the nonlinearity is the SQUARED norm (o3.Norm(squared=True)), no division
+    s = act_f(act, n2);
+    ds_over_n = 2.0f * act_df(act, n2);   // d s / d x_m = act'(n2) * 2 x_m
+  }
+}
+
+__global__ __launch_bounds__(256) void normact_fwd_kernel(const float* __restrict__ x, int64_t rows, int row_dim,
+                                                           BlockArgs ba, int act, float eps2, int normalize,
+                                                           float* __restrict__ y) {
+  const int64_t total = rows * row_dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / row_dim;
+    const int c = (int)(i - r * row_dim);
+    const float* xr = x + r * row_dim;
+    float v = 0.f;
+    for (int k = 0; k < ba.n; ++k) {
+      const e3k_block& b = ba.b[k];
+      const int rel = c - b.off;
+      if (rel >= 0 && rel < b.mul * b.dim) {
+        const int u = rel / b.dim, m = rel - u * b.dim;   // output element (u, m)
+        float n2 = 0.f;
+        for (int q = 0; q < b.dim; ++q) {
+          const float t = xr[b.off + q * b.mul + u];
+          n2 = fmaf(t, t, n2);
+        }
+        float s, d;
+        normact_scale(act, eps2, normalize, n2, s, d);
+        v = s * xr[b.off + m * b.mul + u];
+        break;
+      }
+    }
+    y[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void normact_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                           int64_t rows, int row_dim, BlockArgs ba, int act, float eps2,
+                                                           int normalize, float* __restrict__ gx) {
+  const int64_t total = rows * row_dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / row_dim;
+    const int c = (int)(i - r * row_dim);
+    const float* xr = x + r * row_dim;
+    const float* gr = gy + r * row_dim;
+    float v = 0.f;
+    for (int k = 0; k < ba.n; ++k) {
+      const e3k_block& b = ba.b[k];
+      const int rel = c - b.off;
+      if (rel >= 0 && rel < b.mul * b.dim) {
+        const int m = rel / b.mul, u = rel - m * b.mul;   // input element (m, u), channel-fastest
+        float n2 = 0.f, dot = 0.f;
+        for (int q = 0; q < b.dim; ++q) {
+          const float t = xr[b.off + q * b.mul + u];
+          n2 = fmaf(t, t, n2);
+          dot = fmaf(gr[b.off + u * b.dim + q], t, dot);
+        }
+        float s, d;
+        normact_scale(act, eps2, normalize, n2, s, d);
+        v = fmaf(s, gr[b.off + u * b.dim + m], d * dot * xr[c]);
+        break;
+      }
+    }
+    gx[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // per-block RMS normalisation: one wave per row
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, int64_t rows, int row_dim,
@@ -628,6 +712,35 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
                        (hipStream_t)stream, workspace, (int)blocks, n, g_a);
     E3K_CHECK_LAUNCH();
   }
+  return E3K_OK;
+}
+
+extern "C" int e3k_norm_act_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,
+                                int32_t act, float epsilon, int32_t normalize, float* y, void* stream) {
+  e3k::BlockArgs ba{};
+  const int rc = make_blocks(blocks, n_blocks, row_dim, ba);
+  if (rc != E3K_OK) return rc;
+  if (rows < 0 || n_blocks == 0 || act < 0 || act > 5 || epsilon < 0.f) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!x || !y) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::normact_fwd_kernel, dim3(e3k::grid_for(rows * row_dim)), dim3(256), 0, (hipStream_t)stream, x,
+                     rows, row_dim, ba, act, epsilon * epsilon, normalize, y);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_norm_act_bwd(const float* x, const float* g_y, int64_t rows, int32_t row_dim, const e3k_block* blocks,
+                                int32_t n_blocks, int32_t act, float epsilon, int32_t normalize, float* g_x,
+                                void* stream) {
+  e3k::BlockArgs ba{};
+  const int rc = make_blocks(blocks, n_blocks, row_dim, ba);
+  if (rc != E3K_OK) return rc;
+  if (rows < 0 || n_blocks == 0 || act < 0 || act > 5 || epsilon < 0.f) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::normact_bwd_kernel, dim3(e3k::grid_for(rows * row_dim)), dim3(256), 0, (hipStream_t)stream, x,
+                     g_y, rows, row_dim, ba, act, epsilon * epsilon, normalize, g_x);
+  E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
 

@@ -1174,6 +1174,61 @@ def gate(x, spec: GateSpec):
     return GateFn.apply(_c(x), spec)
 
 
+class NormActFn(torch.autograd.Function):
+    """e3nn.nn.NormActivation: x (channel-fastest) -> x * act(|x|) / |x| per irrep channel, e3nn layout out."""
+
+    @staticmethod
+    def forward(ctx, x, blocks, act_id: int, eps: float, normalize: bool):
+        L.require_cuda(x)
+        x = L.f32c(x)
+        y = torch.empty_like(x)
+        L.check(L.load().e3k_norm_act_fwd(L.ptr(x), x.shape[0], x.shape[1], _blocks(blocks), len(blocks), act_id, eps,
+                                          int(normalize), L.ptr(y), L.stream_ptr()), "e3k_norm_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.cfg = (blocks, act_id, eps, normalize)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        blocks, act_id, eps, normalize = ctx.cfg
+        if torch.is_grad_enabled():   # double backward: torch restatement on the device
+            with torch.enable_grad():
+                (gx,) = torch.autograd.grad(_norm_act_composed(x, blocks, act_id, eps, normalize), x, gy, create_graph=True)
+            return gx, None, None, None, None
+        gy = L.f32c(gy)
+        gx = torch.empty_like(x)
+        L.check(L.load().e3k_norm_act_bwd(L.ptr(x), L.ptr(gy), x.shape[0], x.shape[1], _blocks(blocks), len(blocks), act_id,
+                                          eps, int(normalize), L.ptr(gx), L.stream_ptr()), "e3k_norm_act_bwd")
+        return gx, None, None, None, None
+
+
+_TORCH_ACTS = {1: lambda t: torch.nn.functional.softplus(t) - math.log(2.0), 2: torch.nn.functional.silu,
+               3: lambda t: torch.tanh(t) * t.abs(), 4: torch.tanh, 5: torch.abs, 0: lambda t: t}
+
+
+def _norm_act_composed(x, blocks, act_id, eps, normalize):
+    rows, cols, pos = x.shape[0], [], 0
+    for off, mul, dim in blocks:
+        assert off == pos, "NormActivation blocks must tile the row"
+        blk = x[:, off:off + mul * dim].reshape(rows, dim, mul)
+        n2 = blk.pow(2).sum(1)
+        if eps > 0:
+            n = torch.where(n2 < eps * eps, torch.full_like(n2, eps * eps), n2).sqrt()
+        else:
+            n = n2
+        sc = _TORCH_ACTS[act_id](n)
+        if normalize:
+            sc = sc / n
+        cols.append((blk * sc.unsqueeze(1)).transpose(1, 2).reshape(rows, mul * dim))
+        pos += mul * dim
+    return torch.cat(cols, 1)
+
+
+def norm_activation(x, blocks, act: str, eps: float, normalize: bool):
+    return NormActFn.apply(_c(x), tuple(blocks), ACT_IDS[act], float(eps), bool(normalize))
+
+
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, std, blocks):

@@ -291,6 +291,32 @@ class Gate(nn.Module):
         return ops.gate(x_cf, self._spec)
 
 
+class NormActivation(nn.Module):
+    """``e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False)`` — the
+    ``nonlinearity_type="norm"`` branch of MessagePassing (``e3_layers/nn/message_passing.py:212-219``).  Like ``Gate``
+    it consumes the convolution output in cf layout and emits the e3nn layout."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity, normalize: bool = True, epsilon: Optional[float] = None,
+                 bias: bool = False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("NormActivation(bias=True) is not built (the reference passes bias=False)")
+        self.irreps_in = Irreps(irreps_in)
+        self.irreps_out = Irreps(irreps_in)
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        elif not normalize:
+            epsilon = 0.0
+        self.epsilon, self.normalize = float(epsilon), bool(normalize)
+        self.act = activation_name(scalar_nonlinearity)
+        self._blocks = tuple((off, mi.mul, mi.ir.dim) for off, mi in zip(self.irreps_in.offsets(), self.irreps_in))
+
+    def forward(self, x_cf):
+        return ops.norm_activation(x_cf, self._blocks, self.act, self.epsilon, self.normalize)
+
+
 def tp_slots(l1: int) -> List[Tuple[int, int]]:
     """Valid (l2, l3) pairs for an input of degree l1, in the slot order of e3k_cg_gen.h."""
     return [(l2, l3) for l2 in range(TP_L2MAX + 1) for l3 in range(abs(l1 - l2), min(l1 + l2, TP_L3MAX) + 1)]

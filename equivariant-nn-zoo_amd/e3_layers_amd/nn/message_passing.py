@@ -26,7 +26,7 @@ from ..backend import ops
 from ..backend.graph import get_topology
 from ..o3 import Irrep, Irreps
 from ..utils.utils import _is_mapping, activations, build, tp_path_exists
-from .core import FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, irreps_blocks
+from .core import FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, NormActivation, irreps_blocks
 from .pointwise import LayerNormalization, TensorProductExpansion
 from .sequential import Module
 
@@ -96,8 +96,6 @@ class MessagePassing(Module):
         self.init_irreps(input_features=input_features, output_features=output_features, node_attrs=node_attrs,
                          edge_radial=edge_radial, edge_spherical=edge_spherical, output_keys=["output_features"])
         assert nonlinearity_type in ("gate", "norm")
-        if nonlinearity_type != "gate":
-            raise NotImplementedError("nonlinearity_type='norm' (NormActivation) is not built; every shipped config uses 'gate'")
         acts_s = {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]}
         acts_g = {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}
         sh = Irreps(self.irreps_in["edge_spherical"])
@@ -109,11 +107,16 @@ class MessagePassing(Module):
         irreps_gated = Irreps([mi for mi in reachable if mi.ir.l > 0])
         irreps_layer_out = (irreps_scalars + irreps_gated).simplify()
         irreps_gates = Irreps([(mi.mul, "0e") for mi in irreps_gated])
-        self.equivariant_nonlin = Gate(
-            irreps_scalars=irreps_scalars, act_scalars=[acts_s[mi.ir.p] for mi in irreps_scalars],
-            irreps_gates=irreps_gates, act_gates=[acts_g[mi.ir.p] for mi in irreps_gates],
-            irreps_gated=irreps_gated)
-        conv_irreps_out = self.equivariant_nonlin.irreps_in.simplify()
+        if nonlinearity_type == "gate":
+            self.equivariant_nonlin = Gate(
+                irreps_scalars=irreps_scalars, act_scalars=[acts_s[mi.ir.p] for mi in irreps_scalars],
+                irreps_gates=irreps_gates, act_gates=[acts_g[mi.ir.p] for mi in irreps_gates],
+                irreps_gated=irreps_gated)
+            conv_irreps_out = self.equivariant_nonlin.irreps_in.simplify()
+        else:   # :207-219: the norm is an even scalar, so the 'e' scalar nonlinearity acts on it
+            conv_irreps_out = irreps_layer_out.simplify()
+            self.equivariant_nonlin = NormActivation(conv_irreps_out, nonlinearity_scalars["e"], normalize=True,
+                                                     epsilon=1e-8, bias=False)
         self.resnet = bool(resnet) and irreps_layer_out == prev
         self.conv = build(convolution, input_features=input_features, output_features=conv_irreps_out,
                           node_attrs=node_attrs, edge_radial=edge_radial, edge_spherical=edge_spherical)

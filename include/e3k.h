@@ -222,6 +222,16 @@ int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int32_t in_dim,
 int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t rows, int32_t in_dim, int32_t out_dim,
                   const e3k_gate_seg* segs, int32_t n_segs, float* g_gy, float* g_x, void* stream);
 
+/* NormActivation (e3nn.nn.NormActivation as built at e3_layers/nn/message_passing.py:212-219; the 'norm'
+ * nonlinearity_type of MessagePassing): per irrep channel n2 = max(sum_m x_m^2, epsilon^2), n = sqrt(n2),
+ * y_m = x_m * act(n) / n (normalize = 1).  blocks cover the row (uncovered columns come out zero); input
+ * channel-fastest [2l+1][mul], output e3nn layout [mul][2l+1] at the same offsets; act ids as e3k_act_fwd, raw
+ * (no second-moment constant). */
+int e3k_norm_act_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks, int32_t act,
+                     float epsilon, int32_t normalize, float* y, void* stream);
+int e3k_norm_act_bwd(const float* x, const float* g_y, int64_t rows, int32_t row_dim, const e3k_block* blocks,
+                     int32_t n_blocks, int32_t act, float epsilon, int32_t normalize, float* g_x, void* stream);
+
 /* per-irreps-block RMS normalisation (LayerNormalization, nn/pointwise.py:32-51), e3nn layout */
 int e3k_layernorm_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,
                       const float* std, float* y, float* inv_norm, void* stream);

@@ -866,8 +866,50 @@ class FactorizedConvolution(OModule):
         return {"output_features": x}, {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])}
 
 
+class NormActivation(nn.Module):
+    """``e3nn.nn.NormActivation(irreps_in, scalar_nonlinearity, normalize=True, epsilon=1e-8, bias=False)`` as built
+    at nn/message_passing.py:212-219 (e3nn 0.4.4 ``nn/_normact.py``): per irrep channel the squared norm
+    ``n2 = sum_m x_m^2`` (``o3.Norm(squared=True)``) is clamped from below at epsilon^2, ``n = sqrt(n2)``,
+    ``scaling = act(n) / n`` (normalize) and the channel is multiplied by it.  The activation is the raw function of
+    ``utils.activations`` (no second-moment normalisation: that is ``e3nn.nn.Activation``'s job, not this module's)."""
+
+    def __init__(self, irreps_in, scalar_nonlinearity, normalize=True, epsilon=None, bias=False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("bias=True is not used by the reference")
+        self.irreps_in = parse_irreps(irreps_in) if not isinstance(irreps_in, list) else irreps_in
+        self.irreps_out = self.irreps_in
+        if epsilon is None and normalize:
+            epsilon = 1e-8
+        elif epsilon is not None and not normalize:
+            raise ValueError("epsilon and normalize = False don't make sense together")
+        elif not normalize:
+            epsilon = 0.0
+        self.eps2 = float(epsilon) ** 2
+        self.normalize = normalize
+        self.act = ACTIVATIONS[scalar_nonlinearity] if isinstance(scalar_nonlinearity, str) else scalar_nonlinearity
+
+    def forward(self, x):
+        z, pos, cols = x.shape[0], 0, []
+        for m, l, _ in self.irreps_in:
+            d = 2 * l + 1
+            blk = x[:, pos:pos + m * d].reshape(z, m, d)
+            n2 = blk.pow(2).sum(-1)
+            if self.eps2 > 0:
+                n2 = torch.where(n2 < self.eps2, torch.full_like(n2, self.eps2), n2)
+                n = n2.sqrt()
+            else:
+                n = n2
+            s = self.act(n)
+            if self.normalize:
+                s = s / n
+            cols.append((blk * s.unsqueeze(-1)).reshape(z, m * d))
+            pos += m * d
+        return torch.cat(cols, dim=1)
+
+
 class MessagePassing(OModule):
-    """nn/message_passing.py:127-262 (gate nonlinearity branch)."""
+    """nn/message_passing.py:127-262 (gate and norm nonlinearity branches)."""
 
     def __init__(self, input_features, output_features, node_attrs, edge_radial, edge_spherical, convolution,
                  resnet=False, nonlinearity_type="gate", nonlinearity_scalars=None, nonlinearity_gates=None,
@@ -877,8 +919,7 @@ class MessagePassing(OModule):
         nonlinearity_gates = nonlinearity_gates or {"e": "ssp", "o": "abs"}
         self.init_irreps(input_features=input_features, output_features=output_features, node_attrs=node_attrs,
                          edge_radial=edge_radial, edge_spherical=edge_spherical, output_keys=["output_features"])
-        if nonlinearity_type != "gate":
-            raise NotImplementedError("oracle restates the 'gate' branch only (all shipped configs)")
+        assert nonlinearity_type in ("gate", "norm")
         a_sc = {1: nonlinearity_scalars["e"], -1: nonlinearity_scalars["o"]}
         a_gt = {1: nonlinearity_gates["e"], -1: nonlinearity_gates["o"]}
         prev = parse_irreps(self.irreps_in["input_features"])
@@ -888,8 +929,12 @@ class MessagePassing(OModule):
         gated = [(m, l, p) for m, l, p in hidden if l > 0 and tp_path_exists(prev, sh, (l, p))]
         layer_out = irreps_simplify(scalars + gated)
         gates = [(m, 0, 1) for m, _, _ in gated]
-        self.gate = Gate(scalars, [a_sc[p] for _, _, p in scalars], gates, [a_gt[p] for _, _, p in gates], gated)
-        conv_out = irreps_simplify(self.gate.irreps_in)
+        if nonlinearity_type == "gate":
+            self.gate = Gate(scalars, [a_sc[p] for _, _, p in scalars], gates, [a_gt[p] for _, _, p in gates], gated)
+            conv_out = irreps_simplify(self.gate.irreps_in)
+        else:   # :207-219: the norm is an even scalar, so the 'e' scalar nonlinearity is used
+            conv_out = layer_out
+            self.gate = NormActivation(conv_out, nonlinearity_scalars["e"], normalize=True, epsilon=1e-8, bias=False)
         self.resnet = bool(resnet) and layer_out == prev
         conv_cfg = dict(convolution)
         self.conv = build(conv_cfg, input_features=input_features, output_features=irreps_str(conv_out),

@@ -577,3 +577,32 @@ def test_fused_radial_mlp_falls_back_for_other_widths(dev):
     assert not FullyConnectedNet([8, 16, 16, 30], activations["ssp"]).fused_hidden      # width 16: per-layer path
     assert not FullyConnectedNet([8, 64, 32, 30], activations["ssp"]).fused_hidden      # mixed widths
     assert not FullyConnectedNet([8, 30], None).fused_hidden
+
+
+@pytest.mark.parametrize("act", ["ssp", "silu"])
+def test_norm_activation(dev, act):
+    """NormActivation (the 'norm' nonlinearity_type, message_passing.py:212-219): values, gradient and double
+    backward against the oracle; includes exactly-zero channels (the epsilon clamp) and scalar irreps."""
+    from e3_layers_amd.nn import NormActivation
+
+    torch.manual_seed(14)
+    ir = "8x0e+8x0o+4x1o+6x2e+3x3o"
+    mod = NormActivation(ir, act, normalize=True, epsilon=1e-8)
+    ref = e3ref.NormActivation(ir, act, normalize=True, epsilon=1e-8)
+    x = torch.randn(150, mod.irreps_in.dim, dtype=torch.float64)
+    x[3, 16:28] = 0.0                                   # the 4x1o block of one row: |x| = 0 -> clamped, output 0
+    xin, xr = x.float().to(dev).requires_grad_(True), x.clone().requires_grad_(True)
+    y, yr = mod(to_cf(xin, ir)), ref(xr)
+    assert rel_err(y, yr) < TOL
+    assert float(y.detach()[3, 16:28].abs().max()) == 0.0
+    seed = torch.randn_like(yr)
+    # on the clamped channels the slope is act(eps)/eps: for ssp that is (softplus(1e-8) - ln 2) / 1e-8, which no fp32
+    # evaluation (this kernel's or torch's) resolves -- the float64 oracle says 0.5; leave those 12 entries out
+    seed[3, 16:28] = 0.0
+    (g,) = torch.autograd.grad(y, xin, seed.float().to(dev), create_graph=True)
+    (r,) = torch.autograd.grad(yr, xr, seed, create_graph=True)
+    assert rel_err(g, r) < GTOL
+    c = torch.randn_like(r)
+    (gg,) = torch.autograd.grad((g * c.float().to(dev)).sum(), xin)
+    (rr,) = torch.autograd.grad((r * c).sum(), xr)
+    assert rel_err(gg, rr) < 1e-4
