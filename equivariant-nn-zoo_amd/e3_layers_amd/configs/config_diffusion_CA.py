@@ -3,7 +3,8 @@
 "config_diffusion_protein", which the reference does not register).
 n_dim 64, l_max 2, 8 layers, 32 radial / 32 node-attr channels, avg_num_neighbors 100,
 LayerNormalization on, relative-position encoding of same-chain residue pairs, time encoding.
-Dataset preprocessing (mask/crop, HDF5) is out of scope; ``criteria`` is the edge rule of :58-64.
+``masked2indexed`` (:11-24), ``crop`` (:26-56) and ``criteria`` (:58-64) are the dataset-side preprocess functions of
+that file (host plumbing on CPU tensors, as in the reference); the HDF5 reader itself is out of scope.
 """
 from functools import partial
 
@@ -14,6 +15,52 @@ from ..nn import Broadcast, Concat, PointwiseLinear, RadialBasisEncoding, Relati
 from ..utils import getScaler, insertAfter, replace
 from .config_dict import ConfigDict
 from .layer_configs import featureModel
+
+
+def masked2indexed(batch):
+    """Keep the residues whose ``mask`` is set; ``id`` records their position in the original chain (:11-24)."""
+    from ..data import Batch
+
+    n = int(batch["_n_nodes"].reshape(-1)[0])
+    mask = batch["mask"].view(-1).bool()
+    data = {"id": torch.arange(n)[mask].view(-1, 1), "_n_nodes": mask.sum().view(-1, 1),
+            "species": batch["species"][mask], "chain_id": batch["chain_id"][mask]}
+    attrs = {"id": ("node", "1x0e")}
+    for atom in ("N", "CA", "C", "O"):
+        data[atom] = batch[atom][mask]
+    attrs.update(batch.attrs)
+    return Batch(attrs, **data)
+
+
+def crop(data, attrs, max_nodes, generator=None):
+    """Drop the backbone atoms other than CA; if the protein has more than ``max_nodes`` residues keep those inside a
+    ball around a random residue whose radius a bisection over [20, 70] A (0.5 A resolution) picks so that at most
+    ``max_nodes`` remain (:26-56).  ``generator``: a torch CPU generator for the centre (the reference uses the global
+    numpy stream)."""
+    for key in ("N", "C", "O"):
+        data.pop(key)
+        attrs.pop(key)
+    n = int(data["_n_nodes"].reshape(-1)[0])
+    if n <= max_nodes:
+        return data, attrs
+    x = int(torch.randint(n, (1,), generator=generator))
+    distance = torch.linalg.norm(data["CA"] - data["CA"][x], dim=-1)
+    lo, hi = 20.0, 70.0
+    while hi - lo >= 0.5:                       # the reference's recursion, iteratively
+        mid = 0.5 * (lo + hi)
+        count = int((distance < mid).sum())
+        if count > max_nodes:
+            hi = mid
+        elif count < max_nodes:
+            lo = mid
+        else:
+            lo = mid
+            break
+    mask = (distance < lo).view(-1)
+    data["_n_nodes"] = mask.sum().view(-1, 1)
+    for key in ("id", "species", "chain_id", "CA"):
+        data[key] = data[key][mask]
+    return data, attrs
 
 
 def criteria(data, edge_index):
@@ -38,6 +85,8 @@ def get_config(spec="", l_max=2, num_layers=8, n_dim=64):
     data.std = 25.83
     data.scaler = getScaler([("CA", ("shift", "mean")), ("CA", ("scale", 1 / data.std))])
     data.inverse_scaler = getScaler([("CA", ("scale", data.std))])
+    data.preprocess = [masked2indexed, partial(crop, max_nodes=384)]
+    data.key_map = {}
 
     features = "+".join(f"{model.n_dim}x{l}e+{model.n_dim}x{l}o" for l in range(model.l_max + 1))
     lc = featureModel(n_dim=model.n_dim, l_max=model.l_max, edge_spherical="1x0e+1x1o+1x2e",

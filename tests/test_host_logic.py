@@ -274,3 +274,44 @@ def test_partition_by_edges_balances_and_covers():
     parts = partition_by_edges(counts, 2)
     loads = [sum(counts[i] for i in p) for p in parts]
     assert abs(loads[0] - loads[1]) <= 100
+
+
+def test_protein_preprocess_masked2indexed_and_crop():
+    """config_diffusion_CA's dataset-side preprocess functions (e3_layers/configs/config_diffusion_CA.py:11-56)."""
+    from e3_layers_amd.configs import config_diffusion_CA as cfg
+    from e3_layers_amd.data import Batch
+
+    g = torch.Generator().manual_seed(0)
+    n = 600
+    steps = torch.randn(n, 3, generator=g)
+    ca = torch.cumsum(3.8 * steps / steps.norm(dim=1, keepdim=True), 0)
+    attrs = {k: ("node", "1x1o") for k in ("N", "CA", "C", "O")}
+    attrs.update({"species": ("node", "1x0e"), "chain_id": ("node", "1x0e"), "mask": ("node", "1x0e")})
+    mask = torch.ones(n, 1, dtype=torch.long)
+    mask[::7] = 0
+    raw = Batch(dict(attrs), N=ca + 0.1, CA=ca.clone(), C=ca - 0.1, O=ca + 0.2, species=torch.randint(0, 21, (n, 1), generator=g),
+                chain_id=(torch.arange(n) // 300).view(-1, 1), mask=mask, _n_nodes=torch.tensor([[n]]))
+    b = cfg.masked2indexed(raw)
+    kept = int(mask.sum())
+    assert int(b["_n_nodes"]) == kept and b["CA"].shape == (kept, 3)
+    assert torch.equal(b["id"].view(-1), torch.arange(n)[mask.view(-1).bool()])
+    data, a2 = cfg.crop(dict(b.data), dict(b.attrs), max_nodes=384, generator=torch.Generator().manual_seed(1))
+    m = int(data["_n_nodes"])
+    assert 0 < m <= 384 and "N" not in data and "O" not in a2
+    assert data["CA"].shape == (m, 3) and data["id"].shape[0] == m and data["species"].shape[0] == m
+    # the kept residues form a ball: every kept CA is closer to the (unknown) centre than every dropped one for SOME kept centre
+    kept_ids = set(data["id"].view(-1).tolist())
+    ca_all, ids_all = b["CA"], b["id"].view(-1).tolist()
+    ok = False
+    for c in range(m):
+        d = (ca_all - data["CA"][c]).norm(dim=1)
+        inside = d[[i in kept_ids for i in ids_all]]
+        outside = d[[i not in kept_ids for i in ids_all]]
+        if float(inside.max()) < float(outside.min()):
+            ok = True
+            break
+    assert ok
+    small, _ = cfg.crop(dict(b.data), dict(b.attrs), max_nodes=10_000)
+    assert int(small["_n_nodes"]) == kept          # nothing to crop
+    tree = cfg.get_config()
+    assert [getattr(f, "__name__", getattr(getattr(f, "func", None), "__name__", "")) for f in tree.data_config.preprocess] == ["masked2indexed", "crop"]
