@@ -8,20 +8,21 @@ import torch
 from e3_layers_amd.backend.graph import build_topology
 from e3_layers_amd.configs import config_energy
 from e3_layers_amd.data.synthetic import synth_qm9
-from e3_layers_amd.run.parallel import FlatGradients
+from e3_layers_amd.run.optim import FusedAdamEMA
 from e3_layers_amd.utils import build
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 dev = torch.device("cuda:0")
 cfg = config_energy.get_config(l_max=2)
 torch.manual_seed(0)
 model = build(cfg.model_config).to(dev)
-flat = FlatGradients(model.parameters())
-opt = torch.optim.Adam(flat.params, lr=1e-2)
+opt = FusedAdamEMA(model.parameters(), lr=1e-2)
+flat = opt.grads
+flat.enable_direct_accumulation()
 batch = synth_qm9(1000, B, config_energy.QM9_SHIFTS).to(dev)
 batch.update(build_topology(batch["edge_index"], batch["pos"].shape[0]).as_dict())
 target = batch["total_energy"]
 def step():
-    out = model(batch.clone())
+    out = model(batch.view())
     loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
     flat.zero(); loss.backward(); opt.step()
 for _ in range(3): step()
