@@ -567,6 +567,11 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
     __syncthreads();
     STAMP(3);
     if (tile + 1 < tile_end) gload_b((tile + 1) * BN);
+    // The MFMA is issued with the operands EXCHANGED (weights as the row operand, activations as the column operand):
+    // the accumulator then holds C^T — lane = output row (edge), four consecutive registers = four consecutive
+    // output columns — so every lane stores 16 contiguous bytes straight from its registers.  (The natural
+    // orientation gives a lane one column and 16 scattered rows: 4-byte stores, or a trip through LDS, which
+    // measured as long as the MFMAs of the tile.)
     f32x16 acc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -583,46 +588,40 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
       }
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
-        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b0[s], acc[0], 0, 0, 0);
-        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b1[s], acc[1], 0, 0, 0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(b0[s], a[s], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(b1[s], a[s], acc[1], 0, 0, 0);
       }
     }
     for (; kk < kpad; kk += 2) {
       const float a = ap[kk];
-      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB], acc[0], 0, 0, 0);
-      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB + 32], acc[1], 0, 0, 0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[kk * LDB], a, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(bp[kk * LDB + 32], a, acc[1], 0, 0, 0);
     }
     STAMP(4);
-    // ---- epilogue through LDS: the MFMA layout gives a lane one column (4-byte stores, 2 x 128 B per
-    // wave-instruction: store-issue bound, measured 13k cycles per tile vs 8k for the MFMAs); staged
-    // through the (now idle) B tile each lane stores 16 B and a wave-instruction covers 8 rows x 128 B.
-    __syncthreads();  // every wave is done reading Bs
     {
-      float* cs = Bs + w * 1024;  // per-wave 32 x 32 staging
-      const int rsub = lane >> 3, c4 = (lane & 7) * 4;
+      const long long off = rowC[w * 32 + (lane & 31)];
+      if (off >= 0) {
+        float* crow = P.C + off;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < 2; ++j) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) cs[((i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[j][i];
-        // same wave wrote and reads: LDS ops of one wave complete in order, the compiler waits on lgkmcnt
-        const int n = tile * BN + 32 * j + c4;
-        float4 bias4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (P.bias && n < P.N) bias4 = *reinterpret_cast<const float4*>(P.bias + n);
-#pragma unroll
-        for (int rb = 0; rb < 4; ++rb) {
-          const int r = rb * 8 + rsub;
-          const float4 v = *reinterpret_cast<const float4*>(cs + r * 32 + c4);
-          const long long off = rowC[w * 32 + r];
-          if (off >= 0 && n < P.N) {
-            float4* dst = reinterpret_cast<float4*>(P.C + off + n);
-            float4 o = make_float4(fmaf(P.alpha, v.x, bias4.x), fmaf(P.alpha, v.y, bias4.y), fmaf(P.alpha, v.z, bias4.z),
-                                   fmaf(P.alpha, v.w, bias4.w));
-            if (P.accumulate) {
-              const float4 old = *dst;
-              o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+          for (int q = 0; q < 4; ++q) {
+            const int n = tile * BN + 32 * j + 8 * q + 4 * (lane >> 5);
+            if (n < P.N) {
+              float4 o = make_float4(P.alpha * acc[j][4 * q], P.alpha * acc[j][4 * q + 1], P.alpha * acc[j][4 * q + 2],
+                                     P.alpha * acc[j][4 * q + 3]);
+              if (P.bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(P.bias + n);
+                o.x += b4.x; o.y += b4.y; o.z += b4.z; o.w += b4.w;
+              }
+              float4* dst = reinterpret_cast<float4*>(crow + n);
+              if (P.accumulate) {
+                const float4 old = *dst;
+                o.x += old.x; o.y += old.y; o.z += old.z; o.w += old.w;
+              }
+              o.x = epilogue_act(P, o.x); o.y = epilogue_act(P, o.y); o.z = epilogue_act(P, o.z); o.w = epilogue_act(P, o.w);
+              *dst = o;
             }
-            o.x = epilogue_act(P, o.x); o.y = epilogue_act(P, o.y); o.z = epilogue_act(P, o.z); o.w = epilogue_act(P, o.w);
-            *dst = o;
           }
         }
       }
