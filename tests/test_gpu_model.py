@@ -382,3 +382,82 @@ def test_norm_nonlinearity_model(dev):
         if r.grad is None or float(r.grad.norm()) == 0.0:
             continue
         assert rel_err(p.grad, r.grad) < GTOL, name
+
+
+@pytest.mark.parametrize("use_sc,avg,reduce", [(True, 12.0, True), (False, None, True), (True, None, False), (False, 7.0, False)])
+def test_factorized_convolution_options(dev, use_sc, avg, reduce):
+    """FactorizedConvolution's constructor switches (nn/message_passing.py:25-38): self-connection on/off,
+    avg_num_neighbors scaling or none, reduce=False (per-edge messages, the reference's unfused module API)."""
+    from e3_layers_amd.nn import FactorizedConvolution
+    from oracle import e3ref
+
+    torch.manual_seed(31)
+    f_in, f_out, sh_ir = "16x0e+16x1o+16x2e", "16x0e+16x0o+16x1o+16x1e+16x2e", "1x0e+1x1o+1x2e"
+    kw = dict(input_features=f_in, output_features=f_out, node_attrs="10x0e", edge_radial="8x0e", edge_spherical=sh_ir,
+              invariant_layers=2, invariant_neurons=32, avg_num_neighbors=avg, use_sc=use_sc, reduce=reduce)
+    prod = FactorizedConvolution(**kw).to(dev)
+    orc = e3ref.FactorizedConvolution(**kw)
+    orc.load_state_dict({k: v.cpu() for k, v in prod.state_dict().items()})
+    orc = orc.double()
+    n, deg = 23, 5
+    gen = torch.Generator().manual_seed(2)
+    src = torch.randint(n, (n * deg,), generator=gen)
+    dst = (src + 1 + torch.randint(n - 1, (n * deg,), generator=gen)) % n
+    ei = torch.stack([src, dst])
+    e = ei.shape[1]
+    data = {"input_features": torch.randn(n, 16 * 9, dtype=torch.float64, generator=gen),
+            "node_attrs": torch.randn(n, 10, dtype=torch.float64, generator=gen),
+            "edge_radial": torch.randn(e, 8, dtype=torch.float64, generator=gen),
+            "edge_spherical": e3ref.spherical_harmonics([0, 1, 2], torch.randn(e, 3, dtype=torch.float64, generator=gen)),
+            "edge_index": ei}
+    attrs = {"input_features": ("node", f_in), "node_attrs": ("node", "10x0e"), "edge_radial": ("edge", "8x0e"),
+             "edge_spherical": ("edge", sh_ir)}
+    ddev = {k: (v.float().to(dev).requires_grad_(k != "edge_index") if v.is_floating_point() else v.to(dev)) for k, v in data.items()}
+    dref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() else v) for k, v in data.items()}
+    y = prod(ddev, dict(attrs))[0]["output_features"]
+    yr = orc(dref, dict(attrs))[0]["output_features"]
+    assert y.shape == yr.shape and y.shape[0] == (n if reduce else e)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    keys = ["input_features", "edge_radial", "edge_spherical"] + (["node_attrs"] if use_sc else [])
+    g = torch.autograd.grad(y, [ddev[k] for k in keys] + list(prod.parameters()), seed.float().to(dev), allow_unused=True)
+    r = torch.autograd.grad(yr, [dref[k] for k in keys] + list(orc.parameters()), seed, allow_unused=True)
+    for a, b in zip(g, r):
+        if b is None or float(b.abs().max()) == 0.0:
+            continue
+        assert rel_err(a, b) < GTOL
+
+
+def test_message_passing_resnet(dev):
+    """MessagePassing(resnet=True) adds the input when the layer maps an irreps set onto itself (:252-255)."""
+    from e3_layers_amd.nn import FactorizedConvolution, MessagePassing
+    from oracle import e3ref
+
+    torch.manual_seed(32)
+    f = "8x0e+8x1o+8x2e"
+    conv = {"module": FactorizedConvolution, "invariant_layers": 1, "invariant_neurons": 16, "avg_num_neighbors": 4.0}
+    kw = dict(input_features=f, output_features=f, node_attrs="6x0e", edge_radial="8x0e", edge_spherical="1x0e+1x1o+1x2e",
+              convolution=conv, resnet=True, nonlinearity_scalars={"e": "silu", "o": "tanhlu"},
+              nonlinearity_gates={"e": "silu", "o": "tanhlu"})
+    prod = MessagePassing(**kw).to(dev)
+    okw = dict(kw)
+    okw["convolution"] = {"module": e3ref.FactorizedConvolution, "invariant_layers": 1, "invariant_neurons": 16, "avg_num_neighbors": 4.0}
+    orc = e3ref.MessagePassing(**okw)
+    assert prod.resnet and orc.resnet
+    orc.load_state_dict({k: v.cpu() for k, v in prod.state_dict().items()})
+    orc = orc.double()
+    n = 12
+    gen = torch.Generator().manual_seed(3)
+    ei = torch.stack([torch.arange(n).repeat_interleave(3), (torch.arange(n).repeat_interleave(3) + torch.tensor([1, 2, 5]).repeat(n)) % n])
+    e = ei.shape[1]
+    data = {"input_features": torch.randn(n, 8 * 9, dtype=torch.float64, generator=gen),
+            "node_attrs": torch.randn(n, 6, dtype=torch.float64, generator=gen),
+            "edge_radial": torch.randn(e, 8, dtype=torch.float64, generator=gen),
+            "edge_spherical": e3ref.spherical_harmonics([0, 1, 2], torch.randn(e, 3, dtype=torch.float64, generator=gen)),
+            "edge_index": ei}
+    attrs = {"input_features": ("node", f), "node_attrs": ("node", "6x0e"), "edge_radial": ("edge", "8x0e"),
+             "edge_spherical": ("edge", "1x0e+1x1o+1x2e")}
+    ddev = {k: (v.float().to(dev) if v.is_floating_point() else v.to(dev)) for k, v in data.items()}
+    y = prod(ddev, dict(attrs))[0]["output_features"]
+    yr = orc(dict(data), dict(attrs))[0]["output_features"]
+    assert rel_err(y, yr) < TOL
