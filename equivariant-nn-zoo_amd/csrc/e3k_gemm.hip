@@ -29,8 +29,8 @@
 //                       operands conflict-free), fp32 atomics on the small output.
 //
 // Descriptors: up to 8 problems per launch, passed by value (1.2 KB of kernel arguments); every
-// workgroup copies the batch into LDS with one coalesced read and moves its own problem into
-// scalar registers, instead of re-reading kernel-argument fields all over the kernel.
+// workgroup finds its problem and pulls it into scalar registers with s_load (the batch is wave-uniform).
+#include <algorithm>
 #include <cstdlib>
 
 #include "e3k_common.h"
@@ -47,7 +47,6 @@ struct GemmBatch {
   int aux[GEMM_MAXP];    // wgrad: row splits; smallk: column tiles per block
   e3k_gemm_problem p[GEMM_MAXP];
 };
-constexpr int GB_WORDS = sizeof(GemmBatch) / 4;
 static_assert(sizeof(GemmBatch) % 4 == 0 && sizeof(e3k_gemm_problem) % 4 == 0, "word-copyable descriptors");
 
 constexpr int BN = 64, BK = 32;
@@ -89,27 +88,20 @@ struct BlockProblem {
   int flags, aux, local;
 };
 
-__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int* lds /* GB_WORDS */) {
-  const int* src = reinterpret_cast<const int*>(&gb);
-  for (int i = threadIdx.x; i < GB_WORDS; i += 256) lds[i] = src[i];
-  __syncthreads();
-  const GemmBatch* b = reinterpret_cast<const GemmBatch*>(lds);
-  const int n = uniform(b->n);
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
+  // The batch lives in the kernel-argument segment: everything here is wave-uniform, so the compiler reads it with
+  // scalar loads (s_load_dwordxN at a uniform dynamic offset) straight into SGPRs — no LDS copy, no barrier.
+  const int n = gb.n;
   int pi = 0;
-  for (int i = 1; i < GEMM_MAXP; ++i)
-    if (i < n && (int)blockIdx.x >= uniform(b->tile_start[i])) pi = i;
-  BlockProblem out;
-  out.local = blockIdx.x - uniform(b->tile_start[pi]);
-  out.flags = uniform(b->flags[pi]);
-  out.aux = uniform(b->aux[pi]);
-  union {
-    e3k_gemm_problem p;
-    int w[sizeof(e3k_gemm_problem) / 4];
-  } u;
-  const int* pw = reinterpret_cast<const int*>(&b->p[pi]);
 #pragma unroll
-  for (int i = 0; i < (int)(sizeof(e3k_gemm_problem) / 4); ++i) u.w[i] = uniform(pw[i]);
-  out.P = u.p;
+  for (int i = 1; i < GEMM_MAXP; ++i)
+    if (i < n && (int)blockIdx.x >= gb.tile_start[i]) pi = i;
+  pi = uniform(pi);
+  BlockProblem out;
+  out.local = blockIdx.x - gb.tile_start[pi];
+  out.flags = gb.flags[pi];
+  out.aux = gb.aux[pi];
+  out.P = gb.p[pi];
   if (out.P.row_index && out.P.group_dev) {  // device-side {start, count} of this key group
     const int start = uniform(out.P.group_dev[0]), count = uniform(out.P.group_dev[1]);
     out.P.row_index += start;
@@ -251,8 +243,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  __shared__ int gbs[GB_WORDS];
-  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const BlockProblem bp_ = fetch_problem(gb);
   const e3k_gemm_problem& P = bp_.P;
   const int flags = bp_.flags, local = bp_.local;
   const int M = P.M1 * P.M2;
@@ -414,8 +405,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) __bf16 Bp[3][BN * X3_LDK];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  __shared__ int gbs[GB_WORDS];
-  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const BlockProblem bp_ = fetch_problem(gb);
   const e3k_gemm_problem& P = bp_.P;
   const int flags = bp_.flags, local = bp_.local;
   const int M = P.M1 * P.M2;
@@ -510,9 +500,8 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float Bs[SK_KMAX * LDB];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  __shared__ int gbs[GB_WORDS];
   STAMP_DECL
-  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const BlockProblem bp_ = fetch_problem(gb);
   STAMP(0);
   const e3k_gemm_problem& P = bp_.P;
   const int local = bp_.local, ct = bp_.aux;
@@ -643,8 +632,7 @@ __global__ __launch_bounds__(256) void gemm_outer_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  __shared__ int gbs[GB_WORDS];
-  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const BlockProblem bp_ = fetch_problem(gb);
   const e3k_gemm_problem& P = bp_.P;
   const int flags = bp_.flags, local = bp_.local;
   const int bmode = (flags >> 1) & 3;
@@ -767,8 +755,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
   __shared__ __attribute__((aligned(16))) float Gs[WR * LDWG];
   __shared__ float Vs[OUTER ? WR * LDV : 1];
-  __shared__ int gbs[GB_WORDS];
-  const BlockProblem bp_ = fetch_problem(gb, gbs);
+  const BlockProblem bp_ = fetch_problem(gb);
   const e3k_gemm_problem& P = bp_.P;
   const int flags = bp_.flags, local = bp_.local;
   const int M = P.M1 * P.M2, M2 = P.M2;
@@ -1085,7 +1072,13 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
       b.reset();
       return rc;
     };
-    for (int i = 0; i < n_problems; ++i) {
+    // longest-processing-time-first: workgroups are dispatched in blockIdx order, so the problems with the longest
+    // K loops go first and the short ones fill the tail of the launch
+    int order[64];
+    for (int i = 0; i < n_problems; ++i) order[i] = i;
+    std::stable_sort(order, order + n_problems, [&](int a, int b) { return problems[a].K > problems[b].K; });
+    for (int oi = 0; oi < n_problems; ++oi) {
+      const int i = order[oi];
       if (kind[i] != k) continue;
       const e3k_gemm_problem& P = problems[i];
       const int64_t M = (int64_t)P.M1 * P.M2;
