@@ -37,6 +37,28 @@ OVERLAP_STREAMS = int(_os.environ.get("E3K_OVERLAP", "0"))  # 0 off (default), 1
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 
 
+def side_stream(device) -> "torch.cuda.Stream":
+    """The per-device side stream used for independent branches (forward fork of a convolution, opt-in backward
+    overlap).  Work enqueued there is joined by ``join_side_streams()`` before anything outside autograd (optimizer,
+    all-reduce) reads its results."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    st = _side_streams.get(idx)
+    if st is None:
+        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_streams() -> None:
+    """Make the current stream wait for every side stream of its device (cheap when they are idle).  The gradient
+    sink writes weight gradients without an AccumulateGrad node, so autograd's end-of-backward stream sync does not
+    know about them: the optimizer / all-reduce call this first."""
+    if not _side_streams or not torch.cuda.is_available():
+        return
+    st = _side_streams.get(torch.cuda.current_device())
+    if st is not None and not torch.cuda.is_current_stream_capturing():
+        torch.cuda.current_stream().wait_stream(st)
+
+
 class _Fork:
     """with _Fork(dev) as f: f.side(lambda: ...); ...main work...   -> joins on exit."""
 
@@ -46,11 +68,7 @@ class _Fork:
 
     def __enter__(self):
         self.cur = torch.cuda.current_stream(self.device)
-        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
-        st = _side_streams.get(idx)
-        if st is None:
-            st = _side_streams[idx] = torch.cuda.Stream(device=self.device)
-        self.st = st
+        self.st = side_stream(self.device)
         return self
 
     def side(self, fn):

@@ -17,6 +17,8 @@ re-planned for MI355X:
 """
 from __future__ import annotations
 
+import os
+
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -29,6 +31,11 @@ from ..utils.utils import _is_mapping, activations, build, tp_path_exists
 from .core import FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, NormActivation, irreps_blocks
 from .pointwise import LayerNormalization, TensorProductExpansion
 from .sequential import Module
+
+
+# 1 (default): the edge-side branch of a convolution (radial MLP) runs on a side stream next to the node-side branch
+# (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
+FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
 
 
 class FactorizedConvolution(Module):
@@ -63,11 +70,25 @@ class FactorizedConvolution(Module):
     def forward_cf(self, data: Dict[str, Tensor]) -> Tensor:
         """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
         x = data["input_features"]
-        weight = self.fc(data["edge_radial"])
         topo = get_topology(data, x.shape[0])
-        x_cf = ops.relayout(x, self._in_blocks, True)
-        sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
-        x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
+        if FWD_FORK and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
+            # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
+            main = torch.cuda.current_stream(x.device)
+            side = ops.side_stream(x.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                weight = self.fc(data["edge_radial"])
+            x_cf = ops.relayout(x, self._in_blocks, True)
+            sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
+            x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
+            main.wait_stream(side)
+            weight.record_stream(main)
+        else:
+            weight = self.fc(data["edge_radial"])
+            x_cf = ops.relayout(x, self._in_blocks, True)
+            sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
+            x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
         mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
         scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
         return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)

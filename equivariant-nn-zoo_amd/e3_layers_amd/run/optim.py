@@ -57,6 +57,9 @@ class FusedAdamEMA:
     @torch.no_grad()
     def step(self) -> None:
         """(all-reduce of the flat gradient is the caller's: ``self.grads.all_reduce_mean()``)"""
+        from ..backend import ops
+
+        ops.join_side_streams()      # weight gradients written by side-stream kernels (gradient sink) are complete
         L.check(L.load().e3k_adam_ema_step(
             L.ptr(self.flat), L.ptr(self.grads.buffer), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
             self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.ema_decay,

@@ -97,6 +97,10 @@ class FlatGradients:
         self.buffer.zero_()
 
     def all_reduce_mean(self) -> None:
+        if self.buffer.is_cuda:
+            from ..backend import ops
+
+            ops.join_side_streams()   # side-stream weight-gradient kernels (gradient sink) must land first
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)
             self.buffer.div_(dist.get_world_size())
