@@ -36,6 +36,7 @@ from .sequential import Module
 # 1 (default): the edge-side branch of a convolution (radial MLP) runs on a side stream next to the node-side branch
 # (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
 FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
+FORK_MIN_EDGES = 49152   # below this the step is host-bound and the extra stream switches cost more than they hide
 
 
 class FactorizedConvolution(Module):
@@ -71,7 +72,8 @@ class FactorizedConvolution(Module):
         """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
-        if FWD_FORK and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+        if (FWD_FORK and x.is_cuda and data["edge_radial"].shape[0] >= FORK_MIN_EDGES
+                and not torch.cuda.is_current_stream_capturing()):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
             main = torch.cuda.current_stream(x.device)

@@ -8,7 +8,7 @@ DST = os.path.join(ROOT, "profiles")
 
 
 def counters(d, name):
-    f = glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv"))[0]
+    f = max(glob.glob(os.path.join(SRC, d, "*", "*_counter_collection.csv")), key=os.path.getmtime)
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
@@ -18,7 +18,7 @@ def counters(d, name):
     return agg
 
 
-stats = glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv"))[0]
+stats = max(glob.glob(os.path.join(SRC, "stats", "*", "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run
 shutil.copy(stats, os.path.join(DST, f"{TAG}_bench_kernel_stats.csv"))
 for name in ("bench_under_rocprof.json", "bench_default.json"):
     if os.path.exists(os.path.join(SRC, name)):
