@@ -35,6 +35,9 @@ PROFILE_TP = None
 import os as _os
 OVERLAP_STREAMS = int(_os.environ.get("E3K_OVERLAP", "0"))  # 0 off (default), 1 TP backward only, 2 also GEMM dgrad/wgrad
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
+# E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture; bench --graph: 30.2k vs 29.7k
+# eager at 256 molecules).  Default 1 keeps captures single-stream.
+FORK_IN_CAPTURE = _os.environ.get("E3K_FWD_FORK") == "2"
 
 
 def side_stream(device) -> "torch.cuda.Stream":
@@ -55,7 +58,7 @@ def join_side_streams() -> None:
     if not _side_streams or not torch.cuda.is_available():
         return
     st = _side_streams.get(torch.cuda.current_device())
-    if st is not None and not torch.cuda.is_current_stream_capturing():
+    if st is not None and (FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
         torch.cuda.current_stream().wait_stream(st)
 
 

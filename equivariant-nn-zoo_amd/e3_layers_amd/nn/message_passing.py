@@ -73,7 +73,7 @@ class FactorizedConvolution(Module):
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
         if (FWD_FORK and x.is_cuda and data["edge_radial"].shape[0] >= FORK_MIN_EDGES
-                and not torch.cuda.is_current_stream_capturing()):
+                and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
             main = torch.cuda.current_stream(x.device)
