@@ -40,14 +40,15 @@ _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 FORK_IN_CAPTURE = _os.environ.get("E3K_FWD_FORK") == "2"
 
 
-def side_stream(device) -> "torch.cuda.Stream":
-    """The per-device side stream used for independent branches (forward fork of a convolution, opt-in backward
-    overlap).  Work enqueued there is joined by ``join_side_streams()`` before anything outside autograd (optimizer,
-    all-reduce) reads its results."""
+def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
+    """A per-device side stream for an independent branch (``which`` = 0: radial MLP of a convolution and the opt-in
+    backward overlap; 1: the self-connection).  Work enqueued there is joined by ``join_side_streams()`` before
+    anything outside autograd (optimizer, all-reduce) reads its results."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
-    st = _side_streams.get(idx)
+    key = idx if which == 0 else (idx, which)
+    st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[idx] = torch.cuda.Stream(device=device)
+        st = _side_streams[key] = torch.cuda.Stream(device=device)
     return st
 
 
@@ -57,9 +58,12 @@ def join_side_streams() -> None:
     know about them: the optimizer / all-reduce call this first."""
     if not _side_streams or not torch.cuda.is_available():
         return
-    st = _side_streams.get(torch.cuda.current_device())
-    if st is not None and (FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
-        torch.cuda.current_stream().wait_stream(st)
+    if not (FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()):
+        return
+    cur_dev = torch.cuda.current_device()
+    for key, st in _side_streams.items():
+        if (key if isinstance(key, int) else key[0]) == cur_dev:
+            torch.cuda.current_stream().wait_stream(st)
 
 
 class _Fork:

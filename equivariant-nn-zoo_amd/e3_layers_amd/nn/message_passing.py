@@ -36,6 +36,7 @@ from .sequential import Module
 # 1 (default): the edge-side branch of a convolution (radial MLP) runs on a side stream next to the node-side branch
 # (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
 FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
+FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connection runs on a third stream (+7 % on the bench)
 FORK_MIN_EDGES = 49152   # below this the step is host-bound and the extra stream switches cost more than they hide
 
 
@@ -82,10 +83,24 @@ class FactorizedConvolution(Module):
             with torch.cuda.stream(side):
                 weight = self.fc(data["edge_radial"])
             x_cf = ops.relayout(x, self._in_blocks, True)
-            sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
+            sc = None
+            if self.sc is not None and FWD_FORK_SC:
+                # third branch: the self-connection only meets the others at the trailing Linear
+                side2 = ops.side_stream(x.device, 1)
+                side2.wait_stream(main)
+                with torch.cuda.stream(side2):
+                    sc = self.sc(x_cf, data["node_attrs"])
+            elif self.sc is not None:
+                sc = self.sc(x_cf, data["node_attrs"])
             x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
             main.wait_stream(side)
             weight.record_stream(main)
+            if sc is not None and FWD_FORK_SC:
+                mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
+                main.wait_stream(side2)
+                sc.record_stream(main)
+                scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
+                return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
         else:
             weight = self.fc(data["edge_radial"])
             x_cf = ops.relayout(x, self._in_blocks, True)
