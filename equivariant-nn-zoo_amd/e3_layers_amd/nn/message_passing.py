@@ -37,7 +37,7 @@ from .sequential import Module
 # (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
 FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
 FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connection runs on a third stream (+7 % on the bench)
-FORK_MIN_EDGES = 49152   # below this the step is host-bound and the extra stream switches cost more than they hide
+FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "49152"))   # below this the step is host-bound and the extra stream switches cost more than they hide
 
 
 class FactorizedConvolution(Module):
