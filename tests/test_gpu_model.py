@@ -461,3 +461,40 @@ def test_message_passing_resnet(dev):
     y = prod(ddev, dict(attrs))[0]["output_features"]
     yr = orc(dict(data), dict(attrs))[0]["output_features"]
     assert rel_err(y, yr) < TOL
+
+
+@pytest.mark.parametrize("forces", [False, True])
+def test_three_stream_convolution_equals_single_stream(dev, monkeypatch, forces):
+    """The forked convolution (radial MLP / self-connection / linear_1 on three HIP streams, replayed by autograd in
+    the backward — and in the double backward of force training) gives the single-stream results."""
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.utils import build
+
+    cfg = featureModel(n_dim=32, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+                       num_types=10, num_layers=3, r_max=4.0)
+    cfg = addEnergyOutput(cfg, None, output_key="energy_total")
+    if forces:
+        cfg = addForceOutput(cfg, y="energy_total")
+    torch.manual_seed(0)
+    model = build(cfg).to(dev).train()
+    batch = synth_qm9(9, 24).to(dev)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+
+    def run(fork):
+        monkeypatch.setattr(mp, "FWD_FORK", fork)
+        model.zero_grad(set_to_none=True)
+        out = model(batch.clone())
+        loss = out["energy_total"].square().mean()
+        if forces:
+            loss = loss + 10 * out["forces"].square().mean()
+        loss.backward()
+        torch.cuda.synchronize()
+        return float(loss.detach()), torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None])
+
+    l0, g0 = run(0)
+    for _ in range(2):
+        l1, g1 = run(1)
+        assert abs(l1 - l0) <= 1e-6 * abs(l0)
+        assert rel_err(g1, g0) < 1e-5
