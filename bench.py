@@ -102,6 +102,10 @@ def main():
     # one process per GPU; E3K_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
     backend = os.environ.get("E3K_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
+    if world > torch.cuda.device_count():
+        # ranks share a GPU (smoke-testing the N>1 path on one device): several processes x several HIP streams on one
+        # device time-slice pathologically (measured 18x), so keep each process on one stream there
+        os.environ.setdefault("E3K_FWD_FORK", "0")
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     if world > 1:
