@@ -98,6 +98,8 @@ class _Fork:
 # gradient straight into the (pre-zeroed) flat buffer and returns None for it: no zero-fill of a
 # temporary and no autograd "+=" per parameter.
 GRAD_SINK: Dict[Tuple[int, int], torch.Tensor] = {}
+WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
+WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
 
 
 def _sink_for(t: torch.Tensor):
@@ -345,6 +347,17 @@ class StridedLinearFn(torch.autograd.Function):
                     gw = torch.zeros_like(weight)
                 if OVERLAP_STREAMS >= 2 and ctx.needs_input_grad[0] and rows * spec.d_out >= (1 << 22):
                     fork.side(lambda: _lin_wgrad_raw(x, gy, gw, spec, scale))   # big enough to pay for the stream join
+                elif (sunk and WGRAD_SIDE and ctx.needs_input_grad[0] and rows >= WGRAD_SIDE_MIN_ROWS
+                      and not torch.cuda.is_current_stream_capturing()):
+                    # a weight gradient that lands in the gradient sink is off the critical path: nothing in the
+                    # backward consumes it, so it goes to a side stream that only the optimizer / all-reduce joins
+                    cur = torch.cuda.current_stream(x.device)
+                    st = side_stream(x.device, 2)
+                    st.wait_stream(cur)
+                    with torch.cuda.stream(st):
+                        _lin_wgrad_raw(x, gy, gw, spec, scale)
+                    x.record_stream(st)
+                    gy.record_stream(st)
                 else:
                     _lin_wgrad_raw(x, gy, gw, spec, scale)
             if ctx.needs_input_grad[0]:

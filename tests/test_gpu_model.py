@@ -498,3 +498,34 @@ def test_three_stream_convolution_equals_single_stream(dev, monkeypatch, forces)
         l1, g1 = run(1)
         assert abs(l1 - l0) <= 1e-6 * abs(l0)
         assert rel_err(g1, g0) < 1e-5
+
+
+def test_sunk_weight_gradients_on_side_stream(dev, monkeypatch):
+    """With the gradient sink active the Linear weight gradients are enqueued on a side stream that only the
+    optimizer / all-reduce joins: the flat gradient equals the single-stream one."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    model = build(_energy_tree(2, 32, 3)).to(dev).train()
+    batch = synth_qm9(9, 24).to(dev)
+    flat = FlatGradients(model.parameters())
+    flat.enable_direct_accumulation()
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
+    try:
+        res = []
+        for side in (0, 1, 1):
+            monkeypatch.setattr(ops, "WGRAD_SIDE", side)
+            flat.zero()
+            model(batch.clone())["total_energy"].square().mean().backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            res.append(flat.gather().clone())
+    finally:
+        flat.disable_direct_accumulation()
+    assert float(res[0].norm()) > 0
+    assert rel_err(res[1], res[0]) < 1e-5 and rel_err(res[2], res[0]) < 1e-5
