@@ -100,6 +100,9 @@ class _Fork:
 GRAD_SINK: Dict[Tuple[int, int], torch.Tensor] = {}
 WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
 WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
+# True while a convolution runs its forked (multi-stream) forward: only ops recorded then move their sunk weight
+# gradients to the side stream — small, host-bound batches keep everything on one stream
+IN_FORK = False
 
 
 def _sink_for(t: torch.Tensor):
@@ -310,6 +313,7 @@ class StridedLinearFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight)
         ctx.act, ctx.act_cst = act, act_cst
         ctx.spec, ctx.scale, ctx.has_bias, ctx.has_base = spec, scale, bias is not None, base is not None
+        ctx.in_fork = IN_FORK
         return y
 
     @staticmethod
@@ -347,7 +351,7 @@ class StridedLinearFn(torch.autograd.Function):
                     gw = torch.zeros_like(weight)
                 if OVERLAP_STREAMS >= 2 and ctx.needs_input_grad[0] and rows * spec.d_out >= (1 << 22):
                     fork.side(lambda: _lin_wgrad_raw(x, gy, gw, spec, scale))   # big enough to pay for the stream join
-                elif (sunk and WGRAD_SIDE and ctx.needs_input_grad[0] and rows >= WGRAD_SIDE_MIN_ROWS
+                elif (sunk and WGRAD_SIDE and ctx.in_fork and ctx.needs_input_grad[0] and rows >= WGRAD_SIDE_MIN_ROWS
                       and not torch.cuda.is_current_stream_capturing()):
                     # a weight gradient that lands in the gradient sink is off the critical path: nothing in the
                     # backward consumes it, so it goes to a side stream that only the optimizer / all-reduce joins
@@ -566,6 +570,7 @@ class FctpFn(torch.autograd.Function):
             _run_gemm(probs)
         ctx.save_for_backward(x, attrs, weight)
         ctx.spec = spec
+        ctx.in_fork = IN_FORK
         return y
 
     @staticmethod
@@ -631,7 +636,17 @@ class FctpFn(torch.autograd.Function):
                 p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
                 p.alpha = ins.alpha
                 probs.append(p)
-            _run_gemm(probs, wgrad=True)
+            if (sunk and WGRAD_SIDE and ctx.in_fork and rows >= WGRAD_SIDE_MIN_ROWS
+                    and not torch.cuda.is_current_stream_capturing()):
+                cur = torch.cuda.current_stream(x.device)   # off the critical path: see StridedLinearFn.backward
+                st = side_stream(x.device, 2)
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    _run_gemm(probs, wgrad=True)
+                for t_ in (x, attrs, gy):
+                    t_.record_stream(st)
+            else:
+                _run_gemm(probs, wgrad=True)
         if not ctx.needs_input_grad[0]:
             gx = None
         if not ctx.needs_input_grad[1]:

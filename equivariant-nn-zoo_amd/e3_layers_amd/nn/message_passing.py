@@ -77,32 +77,36 @@ class FactorizedConvolution(Module):
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
-            main = torch.cuda.current_stream(x.device)
-            side = ops.side_stream(x.device)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                weight = self.fc(data["edge_radial"])
-            x_cf = ops.relayout(x, self._in_blocks, True)
-            sc = None
-            if self.sc is not None and FWD_FORK_SC:
-                # third branch: the self-connection only meets the others at the trailing Linear
-                side2 = ops.side_stream(x.device, 1)
-                side2.wait_stream(main)
-                with torch.cuda.stream(side2):
+            ops.IN_FORK = True
+            try:
+                main = torch.cuda.current_stream(x.device)
+                side = ops.side_stream(x.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    weight = self.fc(data["edge_radial"])
+                x_cf = ops.relayout(x, self._in_blocks, True)
+                sc = None
+                if self.sc is not None and FWD_FORK_SC:
+                    # third branch: the self-connection only meets the others at the trailing Linear
+                    side2 = ops.side_stream(x.device, 1)
+                    side2.wait_stream(main)
+                    with torch.cuda.stream(side2):
+                        sc = self.sc(x_cf, data["node_attrs"])
+                elif self.sc is not None:
                     sc = self.sc(x_cf, data["node_attrs"])
-            elif self.sc is not None:
-                sc = self.sc(x_cf, data["node_attrs"])
-            x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
-            main.wait_stream(side)
-            weight.record_stream(main)
-            if sc is not None and FWD_FORK_SC:
-                if FWD_FORK_SC >= 2:   # experiment: join the self-connection before the tensor product
+                x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
+                main.wait_stream(side)
+                weight.record_stream(main)
+                if sc is not None and FWD_FORK_SC:
+                    if FWD_FORK_SC >= 2:   # experiment: join the self-connection before the tensor product
+                        main.wait_stream(side2)
+                    mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
                     main.wait_stream(side2)
-                mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
-                main.wait_stream(side2)
-                sc.record_stream(main)
-                scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
-                return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
+                    sc.record_stream(main)
+                    scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
+                    return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
+            finally:
+                ops.IN_FORK = False
         else:
             weight = self.fc(data["edge_radial"])
             x_cf = ops.relayout(x, self._in_blocks, True)
