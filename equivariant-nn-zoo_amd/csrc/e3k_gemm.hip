@@ -42,6 +42,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int GEMM_MAXP = 8;
 struct GemmBatch {
   int n;
+  int reps;               // > 1: every problem stands for `reps` key groups (its tile range is reps equal sub-ranges);
+  long long key_stride;   //      key t uses B + t*key_stride and the device pair group_dev + 2*t
   int tile_start[GEMM_MAXP + 1];
   int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad)
   int aux[GEMM_MAXP];    // wgrad: row splits; smallk: column tiles per block
@@ -102,6 +104,13 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
   out.flags = gb.flags[pi];
   out.aux = gb.aux[pi];
   out.P = gb.p[pi];
+  if (gb.reps > 1) {  // keyed problem: which key group this workgroup belongs to
+    const int per_key = (gb.tile_start[pi + 1] - gb.tile_start[pi]) / gb.reps;
+    const int key = out.local / per_key;
+    out.local -= key * per_key;
+    out.P.B += (int64_t)key * gb.key_stride;
+    out.P.group_dev += 2 * key;
+  }
   if (out.P.row_index && out.P.group_dev) {  // device-side {start, count} of this key group
     const int start = uniform(out.P.group_dev[0]), count = uniform(out.P.group_dev[1]);
     out.P.row_index += start;
@@ -1021,14 +1030,20 @@ enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_X3, FWD_KINDS };
 struct Batcher {
   e3k::GemmBatch gb{};
   int blocks = 0;
+  int reps = 1;
+  long long key_stride = 0;
+  Batcher(int reps_, long long key_stride_) : reps(reps_), key_stride(key_stride_) { reset(); }
   void reset() {
     gb = e3k::GemmBatch{};
+    gb.reps = reps;
+    gb.key_stride = key_stride;
     blocks = 0;
   }
 };
 }  // namespace
 
-extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream) {
+// reps > 1: every problem is a keyed template (row_index = the key-sorted permutation, group_dev = the pair of key 0)
+static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int reps, long long key_stride, void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
   if (n_problems > 64) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -1045,13 +1060,13 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
     else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows && !(use_x3 & 2)) kind[i] = FWD_SMALLK;
     else {
       kind[i] = (use_x3 && a_vec(P) && b_mode(P) != 0) ? FWD_X3 : FWD_PLAIN;
-      plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
+      plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);   // keyed: the groups partition these rows
     }
   }
   // launches that would leave most of the 256 CUs without a third workgroup use 64-row tiles
   const bool small_grid = plain_tiles128 < 3 * 256;
   for (int k = 0; k < FWD_KINDS; ++k) {
-    Batcher b;
+    Batcher b(reps, key_stride);
     auto flush = [&]() -> int {
       if (!b.blocks) {
         b.reset();
@@ -1095,6 +1110,7 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
       } else {
         blocks = ((M + 127) / 128) * tiles_n;
       }
+      blocks *= reps;
       if (b.blocks + blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
@@ -1114,7 +1130,11 @@ extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* 
   return E3K_OK;
 }
 
-extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream) {
+extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream) {
+  return gemm_fwd_impl(problems, n_problems, 1, 0, stream);
+}
+
+static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, int reps, long long key_stride, void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < n_problems; ++i) {
@@ -1124,7 +1144,7 @@ extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, 
   for (int mode = 0; mode < 4; ++mode) {  // (outer?, 128-wide output tile?)
     const bool outer = mode & 1;
     const int tn = (mode & 2) ? 2 : 1;
-    Batcher b;
+    Batcher b(reps, key_stride);
     auto flush = [&]() -> int {
       if (!b.blocks) {
         b.reset();
@@ -1158,7 +1178,7 @@ extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, 
       gb.flags[gb.n] = f;
       gb.aux[gb.n] = (int)splits;
       gb.tile_start[gb.n] = b.blocks;
-      b.blocks += tiles * (int)splits;
+      b.blocks += tiles * (int)splits * reps;
       if (++gb.n == e3k::GEMM_MAXP) {
         const int rc = flush();
         if (rc != E3K_OK) return rc;
@@ -1179,27 +1199,29 @@ extern "C" int e3k_debug_stamps(unsigned long long* out, int n) {
 }
 #endif
 
+extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream) {
+  return gemm_wgrad_impl(problems, n_problems, 1, 0, stream);
+}
+
 extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
                                 const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
                                 void* stream) {
   if (n_templates < 0 || n_keys <= 0 || !perm || !groups_dev || (n_templates && !templates)) return E3K_ERR_INVALID;
+  // the keys are not expanded on the host: a template occupies one slot of a launch and the workgroups work out their
+  // key from their position in the template's tile range (fetch_problem) -- launches per call = templates / 8, not
+  // templates * keys / 8
   e3k_gemm_problem buf[64];
   int n = 0;
   for (int i = 0; i < n_templates; ++i) {
-    for (int t = 0; t < n_keys; ++t) {
-      e3k_gemm_problem p = templates[i];
-      p.B = p.B + (int64_t)t * b_key_stride;
-      p.row_index = perm;
-      p.group_dev = groups_dev + 2 * t;
-      buf[n++] = p;
-      if (n == 64) {
-        const int rc = wgrad ? e3k_gemm_wgrad(buf, n, stream) : e3k_gemm(buf, n, stream);
-        if (rc != E3K_OK) return rc;
-        n = 0;
-      }
+    buf[n] = templates[i];
+    buf[n].row_index = perm;
+    buf[n].group_dev = groups_dev;
+    if (++n == 64 || i + 1 == n_templates) {
+      const int rc = wgrad ? gemm_wgrad_impl(buf, n, n_keys, b_key_stride, stream) : gemm_fwd_impl(buf, n, n_keys, b_key_stride, stream);
+      if (rc != E3K_OK) return rc;
+      n = 0;
     }
   }
-  if (n) return wgrad ? e3k_gemm_wgrad(buf, n, stream) : e3k_gemm(buf, n, stream);
   return E3K_OK;
 }
 

@@ -103,6 +103,42 @@ WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
 # True while a convolution runs its forked (multi-stream) forward: only ops recorded then move their sunk weight
 # gradients to the side stream — small, host-bound batches keep everything on one stream
 IN_FORK = False
+# True while GradientOutput differentiates its function w.r.t. a data tensor (forces = -dE/dpos): that backward pass
+# needs no parameter gradients, yet ``ctx.needs_input_grad`` of a Python autograd.Function is fixed at forward time
+# and says True for every Parameter — the weight-gradient GEMMs of the force pass would all be computed and dropped.
+# (torch's own ops ask the engine per call; custom Functions cannot.)
+INPUTS_ONLY = False
+
+
+class inputs_only_backward:
+    """``with ops.inputs_only_backward(): torch.autograd.grad(y, data_tensor, ...)``: gradients of Parameters (and of
+    tensors computed from Parameters alone) are skipped inside the e3k backward functions."""
+
+    def __enter__(self):
+        global INPUTS_ONLY
+        self.prev, INPUTS_ONLY = INPUTS_ONLY, True
+
+    def __exit__(self, *exc):
+        global INPUTS_ONLY
+        INPUTS_ONLY = self.prev
+        return False
+
+
+def _param_only(t) -> bool:
+    return isinstance(t, torch.nn.Parameter) or getattr(t, "_e3k_param_only", False)
+
+
+def _param_slots(*inputs):
+    return tuple(i for i, t in enumerate(inputs) if isinstance(t, torch.Tensor) and _param_only(t))
+
+
+def _needs(ctx):
+    need = ctx.needs_input_grad
+    if INPUTS_ONLY:
+        slots = getattr(ctx, "param_slots", ())
+        if slots:
+            need = tuple(False if i in slots else v for i, v in enumerate(need))
+    return need
 
 
 def _sink_for(t: torch.Tensor):
@@ -290,6 +326,7 @@ class StridedLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, base, spec: LinearSpec, scale: float, act: int = 0, act_cst: float = 1.0):
+        ctx.param_slots = _param_slots(x, weight, bias, base)
         L.require_cuda(x, weight)
         x = L.f32c(x)
         weight = L.f32c(weight)
@@ -318,6 +355,7 @@ class StridedLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        need = _needs(ctx)
         spec: LinearSpec = ctx.spec
         scale = ctx.scale
         if torch.is_grad_enabled():   # double backward: stay differentiable
@@ -325,10 +363,10 @@ class StridedLinearFn(torch.autograd.Function):
                 raise NotImplementedError("double backward through a fused linear+activation layer is not built; "
                                           "use the unfused layers (default)")
             x, weight = ctx.saved_tensors
-            gx = LinearDgradFn.apply(gy, weight, spec, scale) if ctx.needs_input_grad[0] else None
-            gw = LinearWgradFn.apply(x, gy, spec, scale, weight.numel()).view_as(weight) if ctx.needs_input_grad[1] else None
-            gb = _bias_grad_diff(gy, spec) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
-            gbase = gy if (ctx.has_base and ctx.needs_input_grad[3]) else None
+            gx = LinearDgradFn.apply(gy, weight, spec, scale) if need[0] else None
+            gw = LinearWgradFn.apply(x, gy, spec, scale, weight.numel()).view_as(weight) if need[1] else None
+            gb = _bias_grad_diff(gy, spec) if (ctx.has_bias and need[2]) else None
+            gbase = gy if (ctx.has_base and need[3]) else None
             return gx, gw, gb, gbase, None, None, None, None
         if ctx.act:
             x, weight, y = ctx.saved_tensors
@@ -344,14 +382,14 @@ class StridedLinearFn(torch.autograd.Function):
         gx = gw = gb = None
         with _Fork(x.device) as fork:
             sunk = False
-            if ctx.needs_input_grad[1]:
+            if need[1]:
                 gw = _sink_for(weight)
                 sunk = gw is not None
                 if not sunk:
                     gw = torch.zeros_like(weight)
-                if OVERLAP_STREAMS >= 2 and ctx.needs_input_grad[0] and rows * spec.d_out >= (1 << 22):
+                if OVERLAP_STREAMS >= 2 and need[0] and rows * spec.d_out >= (1 << 22):
                     fork.side(lambda: _lin_wgrad_raw(x, gy, gw, spec, scale))   # big enough to pay for the stream join
-                elif (sunk and WGRAD_SIDE and ctx.in_fork and ctx.needs_input_grad[0] and rows >= WGRAD_SIDE_MIN_ROWS
+                elif (sunk and WGRAD_SIDE and ctx.in_fork and need[0] and rows >= WGRAD_SIDE_MIN_ROWS
                       and not torch.cuda.is_current_stream_capturing()):
                     # a weight gradient that lands in the gradient sink is off the critical path: nothing in the
                     # backward consumes it, so it goes to a side stream that only the optimizer / all-reduce joins
@@ -364,17 +402,17 @@ class StridedLinearFn(torch.autograd.Function):
                     gy.record_stream(st)
                 else:
                     _lin_wgrad_raw(x, gy, gw, spec, scale)
-            if ctx.needs_input_grad[0]:
+            if need[0]:
                 gx = _lin_dgrad_raw(gy, weight, spec, scale)
         if sunk:
             gw = None   # already accumulated into the flat gradient buffer
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if ctx.has_bias and need[2]:
             nb = sum(m for _, m, _ in spec.bias_blocks)
             gb = torch.zeros(nb, device=x.device, dtype=torch.float32)
             lib = L.load()
             for off, mul, boff in spec.bias_blocks:
                 L.check(lib.e3k_colsum(_addr(gy, off), rows, mul, spec.d_out, _addr(gb, boff), L.stream_ptr()), "e3k_colsum")
-        gbase = gy if (ctx.has_base and ctx.needs_input_grad[3]) else None
+        gbase = gy if (ctx.has_base and need[3]) else None
         return gx, gw, gb, gbase, None, None, None, None
 
 
@@ -456,6 +494,7 @@ class MlpHiddenFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, alphas: Tuple[float, ...], act: str, cst: float, *weights):
+        ctx.param_slots = _param_slots(x, None, None, None, *weights)
         L.require_cuda(x, *weights)
         x = L.f32c(x)
         weights = tuple(L.f32c(w) for w in weights)
@@ -473,24 +512,25 @@ class MlpHiddenFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
+        need = _needs(ctx)
         alphas, act, cst, n = ctx.cfg
         saved = ctx.saved_tensors
         x, weights, zs = saved[0], saved[1:1 + n], saved[1 + n:]
         if torch.is_grad_enabled():   # double backward: differentiate the per-layer ops instead
-            wrt = [t for t, need in zip((x,) + tuple(weights), (ctx.needs_input_grad[0],) + tuple(ctx.needs_input_grad[4:])) if need]
+            wrt = [t for t, nd in zip((x,) + tuple(weights), (need[0],) + tuple(need[4:])) if nd]
             with torch.enable_grad():
                 y = _mlp_unfused(x, weights, alphas, act, cst)
                 grads = list(torch.autograd.grad(y, wrt, g, create_graph=True, allow_unused=True))
-            gx = grads.pop(0) if ctx.needs_input_grad[0] else None
-            gws = [grads.pop(0) if need else None for need in ctx.needs_input_grad[4:]]
+            gx = grads.pop(0) if need[0] else None
+            gws = [grads.pop(0) if nd else None for nd in need[4:]]
             return (gx, None, None, None, *gws)
         g = L.f32c(g)
         e, k0 = x.shape
         h = weights[0].shape[1]
-        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gx = torch.empty_like(x) if need[0] else None
         gws, ret = [], []
-        for w, need in zip(weights, ctx.needs_input_grad[4:]):
-            if not need:
+        for w, nd in zip(weights, need[4:]):
+            if not nd:
                 gws.append(None)
                 ret.append(None)
                 continue
@@ -548,6 +588,7 @@ class FctpFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, attrs, weight, spec: FctpSpec):
+        ctx.param_slots = _param_slots(x, attrs, weight)
         L.require_cuda(x, attrs, weight)
         x, attrs, weight = L.f32c(x), L.f32c(attrs), L.f32c(weight)
         rows = x.shape[0]
@@ -575,22 +616,23 @@ class FctpFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        need = _needs(ctx)
         x, attrs, weight = ctx.saved_tensors
         spec: FctpSpec = ctx.spec
         if torch.is_grad_enabled():
             # double backward of the un-keyed self-connection: differentiate a torch restatement of the
             # same trilinear form on the device (rare path — keyed node attributes take GroupedLinearFn)
-            wrt = [t for t, need in zip((x, attrs, weight), ctx.needs_input_grad[:3]) if need]
+            wrt = [t for t, nd in zip((x, attrs, weight), need[:3]) if nd]
             with torch.enable_grad():
                 y = _fctp_composed(x, attrs, weight, spec)
                 grads = list(torch.autograd.grad(y, wrt, gy, create_graph=True, allow_unused=True))
-            out = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:3]]
+            out = [grads.pop(0) if nd else None for nd in need[:3]]
             return out[0], out[1], out[2], None
         gy = L.f32c(gy)
         rows = x.shape[0]
         lib = L.load()
         gx = ga = gw = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+        if need[0] or need[1]:
             if spec.in_layout != "cf":
                 raise NotImplementedError("self-connection backward expects the channel-fastest input layout")
             gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
@@ -618,7 +660,7 @@ class FctpFn(torch.autograd.Function):
                 )
                 seen_in.add(ins.i_in)
         sunk = False
-        if ctx.needs_input_grad[2]:
+        if need[2]:
             gw = _sink_for(weight)
             sunk = gw is not None
             if not sunk:
@@ -647,9 +689,9 @@ class FctpFn(torch.autograd.Function):
                     t_.record_stream(st)
             else:
                 _run_gemm(probs, wgrad=True)
-        if not ctx.needs_input_grad[0]:
+        if not need[0]:
             gx = None
-        if not ctx.needs_input_grad[1]:
+        if not need[1]:
             ga = None
         if sunk:
             gw = None
@@ -714,6 +756,7 @@ class KeyedWeightsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a_rep, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
+        ctx.param_slots = _param_slots(a_rep, weight)
         L.require_cuda(a_rep, weight)
         a_rep, weight = L.f32c(a_rep), L.f32c(weight)
         k = a_rep.shape[0]
@@ -726,11 +769,14 @@ class KeyedWeightsFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gm):
+        need = _needs(ctx)
         a_rep, weight = ctx.saved_tensors
         spec, m_off, ld_m = ctx.cfg
-        need_a, need_w = ctx.needs_input_grad[:2]
+        need_a, need_w = need[:2]
         if torch.is_grad_enabled():
-            wrt = [t for t, need in zip((a_rep, weight), (need_a, need_w)) if need]
+            wrt = [t for t, nd in zip((a_rep, weight), (need_a, need_w)) if nd]
+            if not wrt:
+                return None, None, None, None, None
             with torch.enable_grad():
                 grads = list(torch.autograd.grad(_keyed_weights_composed(a_rep, weight, spec), wrt, gm, create_graph=True))
             return (grads.pop(0) if need_a else None), (grads.pop(0) if need_w else None), None, None, None
@@ -758,7 +804,10 @@ class KeyedWeightsFn(torch.autograd.Function):
 
 
 def keyed_weights(a_rep, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: int):
-    return KeyedWeightsFn.apply(_c(a_rep), _c(weight), spec, tuple(int(v) for v in m_off), int(ld_m))
+    m = KeyedWeightsFn.apply(_c(a_rep), _c(weight), spec, tuple(int(v) for v in m_off), int(ld_m))
+    if not a_rep.requires_grad and _param_only(weight):
+        m._e3k_param_only = True     # a function of Parameters alone: inputs_only_backward() skips its gradient
+    return m
 
 
 def _grouped_templates(x, m_like, y, spec, m_off, ld_m, mode: str):
@@ -841,6 +890,7 @@ class GroupedLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, m, groups: RowGroups, spec: "FctpSpec", m_off: Tuple[int, ...]):
+        ctx.param_slots = _param_slots(x, m)
         L.require_cuda(x, m)
         x, m = L.f32c(x), L.f32c(m)
         ctx.save_for_backward(x, m)
@@ -849,15 +899,16 @@ class GroupedLinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gy):
+        need = _needs(ctx)
         x, m = ctx.saved_tensors
         a = (ctx.groups, ctx.spec, ctx.m_off)
         if torch.is_grad_enabled():
-            gx = GroupedDgradFn.apply(gy, m, *a) if ctx.needs_input_grad[0] else None
-            gm = GroupedWgradFn.apply(x, gy, tuple(m.shape), *a) if ctx.needs_input_grad[1] else None
+            gx = GroupedDgradFn.apply(gy, m, *a) if need[0] else None
+            gm = GroupedWgradFn.apply(x, gy, tuple(m.shape), *a) if need[1] else None
             return gx, gm, None, None, None
         gy = L.f32c(gy)
-        gx = _grp_dgrad_raw(gy, m, *a) if ctx.needs_input_grad[0] else None
-        gm = _grp_wgrad_raw(x, gy, tuple(m.shape), *a) if ctx.needs_input_grad[1] else None
+        gx = _grp_dgrad_raw(gy, m, *a) if need[0] else None
+        gm = _grp_wgrad_raw(x, gy, tuple(m.shape), *a) if need[1] else None
         return gx, gm, None, None, None
 
 
@@ -1309,7 +1360,7 @@ class LayerNormFn(torch.autograd.Function):
                     parts.append(xb * torch.rsqrt(xb.pow(2).sum(1, keepdim=True) / mul + 1e-6) * std[k])
                     pos += mul * dim
                 y = torch.cat(parts, 1)
-                wrt = [t for t, need in zip((x, std), ctx.needs_input_grad[:2]) if need]
+                wrt = [t for t, nd in zip((x, std), ctx.needs_input_grad[:2]) if nd]
                 grads = list(torch.autograd.grad(y, wrt, gy[:, :pos], create_graph=True))
             out = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:2]]
             if out[0] is not None and pos < x.shape[1]:
@@ -1484,6 +1535,7 @@ def spherical_harmonics(vec, ls: Sequence[int], normalize: bool, normalization: 
 class RadialBasisFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, r, bessel_w, r_max, r_min, p, one_over_r, cutoff_kind):
+        ctx.param_slots = _param_slots(r, bessel_w)
         L.require_cuda(r, bessel_w)
         r_shape = r.shape
         assert r.dim() == 1, "radial_basis() flattens r before apply (saved tensors must be the true inputs)"
@@ -1499,8 +1551,9 @@ class RadialBasisFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_out):
+        need = _needs(ctx)
         r, bessel_w = ctx.saved_tensors
-        need_r, need_w = ctx.needs_input_grad[:2]
+        need_r, need_w = need[:2]
         if torch.is_grad_enabled():
             g_r, g_w = RadialBasisBwdFn.apply(r, bessel_w, g_out, ctx.cfg, bool(need_r), bool(need_w))
         else:

@@ -29,7 +29,9 @@ class GradientOutput(Module):
         old = wrt.requires_grad
         wrt.requires_grad_(True)
         output = self.func(data)
-        (grad,) = torch.autograd.grad(self.inputKeyMap(output)["y"].sum(), wrt, create_graph=self.training)
+        # only d y / d x is asked for: the backward functions skip every Parameter gradient of this pass
+        with ops.inputs_only_backward():
+            (grad,) = torch.autograd.grad(self.inputKeyMap(output)["y"].sum(), wrt, create_graph=self.training)
         wrt.requires_grad_(old)
         is_per = self.inputKeyMap(data.attrs)["x"][0]
         output.attrs.update(self.outputKeyMap({"gradients": (is_per, self.irreps_out["gradients"])}))

@@ -3,7 +3,7 @@
   3. config_energy_force, 64 molecules, loss on energies AND forces (the double backward through every kernel)
   4. config_diffusion score net, 128 fully connected molecules, VP-SDE denoising loss
   5. config_diffusion_CA protein score net, 4 x 384 residues (edges rebuilt by the model's own edge_index layer)
-python tools/config_bench.py [steps]"""
+python tools/config_bench.py [steps] [--graph]     (--graph: also replay configs 3 and 4 as one HIP graph per step)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
@@ -17,10 +17,15 @@ from e3_layers_amd.run.sde_utils import VPSDE, sde_loss
 from e3_layers_amd.utils import build, countParameters
 
 dev = torch.device("cuda:0")
-steps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
+GRAPH = "--graph" in sys.argv
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+steps = int(_pos[0]) if _pos else 10
+ONLY = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--only=")]     # e.g. --only=3
 
 
-def run(name, model, step_fn, n_units, unit):
+def run(name, model, step_fn, n_units, unit, graph=False):
+    if ONLY and int(name.split()[0].split("#")[-1]) not in ONLY:
+        return
     opt = FusedAdamEMA(model.parameters(), lr=1e-3, max_grad_norm=1.0)
     def one():
         opt.zero_grad()
@@ -37,6 +42,28 @@ def run(name, model, step_fn, n_units, unit):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"{name:34s} {dt * 1e3:8.2f} ms/step  {n_units / dt:9.0f} {unit}/s  params {countParameters(model)}  loss {float(loss):.4g}", flush=True)
+    if graph and GRAPH:
+        # whole step (forward, loss, backward or double backward, clip + Adam) as one HIP graph
+        del loss
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                one()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            loss = one()
+        for _ in range(3):
+            g.replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            g.replay()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        print(f"{'  ... replayed as one HIP graph':34s} {dt * 1e3:8.2f} ms/step  {n_units / dt:9.0f} {unit}/s  loss {float(loss):.4g}", flush=True)
 
 
 torch.manual_seed(0)
@@ -49,7 +76,7 @@ f_t = torch.randn_like(batch["pos"]); e_t = torch.randn(64, 1, device=dev)
 def ef_step():
     out = model(batch.view())
     return 1e3 * ((out["total_energy"] - e_t) ** 2).mean() + 3e4 * ((out["forces"] - f_t) ** 2).mean()
-run(f"config_energy_force B=64 (N={batch['pos'].shape[0]}, E={batch['edge_index'].shape[1]})", model, ef_step, 64, "molecules")
+run(f"#3 config_energy_force B=64 (N={batch['pos'].shape[0]}, E={batch['edge_index'].shape[1]})", model, ef_step, 64, "molecules", graph=True)
 
 # --- 4. small-molecule diffusion
 cfg = config_diffusion.get_config()
@@ -57,12 +84,12 @@ model = build(cfg.model_config).to(dev).train()
 batch4 = synth_qm9_diffusion(1, 128).to(dev)
 batch4.update(build_topology(batch4["edge_index"], batch4["pos"].shape[0]).as_dict())
 sde = VPSDE({"pos": 3})
-run(f"config_diffusion B=128 (N={batch4['pos'].shape[0]}, E={batch4['edge_index'].shape[1]})", model,
-    lambda: sde_loss(sde, model, batch4)[0], 128, "molecules")
+run(f"#4 config_diffusion B=128 (N={batch4['pos'].shape[0]}, E={batch4['edge_index'].shape[1]})", model,
+    lambda: sde_loss(sde, model, batch4)[0], 128, "molecules", graph=True)
 
 # --- 5. protein C-alpha diffusion
 cfg = config_diffusion_CA.get_config()
 model = build(cfg.model_config).to(dev).train()
 batch5 = synth_protein(1, 4, n_res=384).to(dev)
 sde5 = VPSDE({"CA": 3})
-run(f"config_diffusion_CA 4x384 residues", model, lambda: sde_loss(sde5, model, batch5)[0], 4, "proteins")
+run(f"#5 config_diffusion_CA 4x384 residues", model, lambda: sde_loss(sde5, model, batch5)[0], 4, "proteins")

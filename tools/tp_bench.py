@@ -37,3 +37,7 @@ y = ops.tp_uvu_scatter(x, sh, w, topo, plan)
 g = torch.randn_like(y)
 us_b = timeit(lambda: torch.autograd.grad(y, [x, w], g, retain_graph=True))
 print(f"   bwd (bwd_w + bwd_x) {us_b:7.1f} us")
+sh2 = sh.clone().requires_grad_(True)
+y2 = ops.tp_uvu_scatter(x, sh2, w, topo, plan)
+us_c = timeit(lambda: torch.autograd.grad(y2, [x, sh2, w], g, retain_graph=True))
+print(f"   bwd with grad_sh (bwd_w<sh> + bwd_x) {us_c:7.1f} us")
