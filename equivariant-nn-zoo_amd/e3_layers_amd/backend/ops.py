@@ -430,7 +430,13 @@ class LinearDgradFn(torch.autograd.Function):
     def backward(ctx, h):   # h: cotangent of gx, shaped like x
         gy, weight = ctx.saved_tensors
         g_gy = StridedLinearFn.apply(h, weight, None, None, ctx.spec, ctx.scale) if ctx.needs_input_grad[0] else None
-        g_w = LinearWgradFn.apply(h, gy, ctx.spec, ctx.scale, weight.numel()) if ctx.needs_input_grad[1] else None
+        g_w = None
+        if ctx.needs_input_grad[1]:
+            sink = None if torch.is_grad_enabled() else _sink_for(weight)
+            if sink is not None:    # last backward of a force-training step: straight into the flat gradient buffer
+                _lin_wgrad_raw(L.f32c(h), gy, sink, ctx.spec, ctx.scale)
+            else:
+                g_w = LinearWgradFn.apply(h, gy, ctx.spec, ctx.scale, weight.numel())
         return g_gy, g_w, None, None
 
 

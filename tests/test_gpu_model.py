@@ -529,3 +529,52 @@ def test_sunk_weight_gradients_on_side_stream(dev, monkeypatch):
         flat.disable_direct_accumulation()
     assert float(res[0].norm()) > 0
     assert rel_err(res[1], res[0]) < 1e-5 and rel_err(res[2], res[0]) < 1e-5
+
+
+def test_force_training_gradient_sink_and_inputs_only_pass(dev, monkeypatch):
+    """Force-training step (double backward): (a) the force pass asks only for dE/dpos, so the e3k backward functions
+    skip every Parameter gradient there (``ops.inputs_only_backward``); (b) with the gradient sink the weight gradients
+    of the last backward, including those born in the dgrad nodes of the force pass, are added straight into the flat
+    buffer.  Both must leave the parameter gradients of the plain autograd route unchanged."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.parallel import FlatGradients
+    from e3_layers_amd.utils import build
+
+    cfg = featureModel(n_dim=16, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+                       num_types=10, num_layers=3, r_max=4.0)
+    cfg = addForceOutput(addEnergyOutput(cfg, None, output_key="energy_total"), y="energy_total")
+    torch.manual_seed(0)
+    model = build(cfg).to(dev).train()
+    batch = synth_qm9(11, 6).to(dev)
+    f_t = torch.randn_like(batch["pos"])
+    flat = FlatGradients(model.parameters())
+
+    def step():
+        flat.zero()
+        out = model(batch.clone())
+        (out["energy_total"].square().mean() + (out["forces"] - f_t).square().mean()).backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return flat.gather().clone()
+
+    class _Everything:     # the pre-existing behaviour: every backward computes every gradient it can
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *exc):
+            return False
+
+    ref_skip = step()
+    monkeypatch.setattr(ops, "inputs_only_backward", _Everything)
+    ref_full = step()
+    monkeypatch.undo()
+    flat.enable_direct_accumulation()
+    try:
+        sunk = step()
+    finally:
+        flat.disable_direct_accumulation()
+    assert float(ref_full.norm()) > 0
+    assert rel_err(ref_skip, ref_full) < 1e-5
+    assert rel_err(sunk, ref_full) < 1e-5

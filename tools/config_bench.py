@@ -27,6 +27,7 @@ def run(name, model, step_fn, n_units, unit, graph=False):
     if ONLY and int(name.split()[0].split("#")[-1]) not in ONLY:
         return
     opt = FusedAdamEMA(model.parameters(), lr=1e-3, max_grad_norm=1.0)
+    opt.grads.enable_direct_accumulation()      # weight-gradient kernels add straight into the flat gradient buffer
     def one():
         opt.zero_grad()
         loss = step_fn()
@@ -42,6 +43,8 @@ def run(name, model, step_fn, n_units, unit, graph=False):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     print(f"{name:34s} {dt * 1e3:8.2f} ms/step  {n_units / dt:9.0f} {unit}/s  params {countParameters(model)}  loss {float(loss):.4g}", flush=True)
+    if not (graph and GRAPH):
+        opt.grads.disable_direct_accumulation()
     if graph and GRAPH:
         # whole step (forward, loss, backward or double backward, clip + Adam) as one HIP graph
         del loss
@@ -63,6 +66,7 @@ def run(name, model, step_fn, n_units, unit, graph=False):
             g.replay()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        opt.grads.disable_direct_accumulation()
         print(f"{'  ... replayed as one HIP graph':34s} {dt * 1e3:8.2f} ms/step  {n_units / dt:9.0f} {unit}/s  loss {float(loss):.4g}", flush=True)
 
 
