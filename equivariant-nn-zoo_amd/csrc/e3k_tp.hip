@@ -241,7 +241,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
           gk[k] = go[OFF + k];
           dot = fmaf(gk[k], tt[k], dot);
         }
-        if (active) gwr[g.w_off[Q]] = dot * g.coeff[Q];
+        if (active && a.g_w) gwr[g.w_off[Q]] = dot * g.coeff[Q];
         if constexpr (WITH_SH) {
           const float wv = active ? wr[g.w_off[Q]] * g.coeff[Q] : 0.0f;
           CG<L1, L2, L3>::xg(xc, gk, wv, yref<L2>(gy));
@@ -645,7 +645,7 @@ extern "C" int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float
                             int64_t N, int64_t E, float* g_w, float* g_sh, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0 || E == 0) return E3K_OK;
-  if (!x || !sh || !g_out || !src || !dst_ptr || !dst_perm || !g_w) return E3K_ERR_INVALID;
+  if (!x || !sh || !g_out || !src || !dst_ptr || !dst_perm || (!g_w && !g_sh)) return E3K_ERR_INVALID;
   if (g_sh && !w) return E3K_ERR_INVALID;
   e3k::TpArgs a{};
   a.x = x; a.sh = sh; a.w = w; a.g_out = g_out; a.g_w = g_w; a.g_sh = g_sh;

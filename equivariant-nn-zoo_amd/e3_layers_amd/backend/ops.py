@@ -124,6 +124,35 @@ class inputs_only_backward:
         return False
 
 
+# True while the caller differentiates w.r.t. Parameters only (``with ops.params_only_backward(): loss.backward(inputs=
+# params)``): in a force-training step ``pos`` still requires grad when the loss is differentiated, so every backward
+# would also produce d loss / d pos through the spherical harmonics -- three extra grad_sh edge passes per layer that
+# nothing consumes.  Tensors the geometry layers mark as functions of the input data alone get no gradient then.
+PARAMS_ONLY = False
+
+
+class params_only_backward:
+    def __enter__(self):
+        global PARAMS_ONLY
+        self.prev, PARAMS_ONLY = PARAMS_ONLY, True
+
+    def __exit__(self, *exc):
+        global PARAMS_ONLY
+        PARAMS_ONLY = self.prev
+        return False
+
+
+def is_data_only(t) -> bool:
+    """Set by computeEdgeVector / SphericalEncoding on tensors computed from the input positions alone."""
+    return bool(getattr(t, "_e3k_data_only", False))
+
+
+def mark_data_only(t, flag: bool = True):
+    if flag and t is not None:
+        t._e3k_data_only = True
+    return t
+
+
 def _param_only(t) -> bool:
     return isinstance(t, torch.nn.Parameter) or getattr(t, "_e3k_param_only", False)
 
@@ -1014,9 +1043,10 @@ def _tp_bwd_x_raw(sh, w, g_out, topo: GraphTopo, plan: TpPlan):
     return gx
 
 
-def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool):
+def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool, want_w: bool = True):
     n, e = topo.num_nodes, topo.num_edges
-    gw = torch.empty(e, plan.w_numel, device=x.device, dtype=torch.float32)
+    assert want_w or want_sh
+    gw = torch.empty(e, plan.w_numel, device=x.device, dtype=torch.float32) if want_w else None
     gsh = torch.zeros(e, plan.d_sh, device=x.device, dtype=torch.float32) if want_sh else None
     L.check(L.load().e3k_tp_bwd_w(plan.handle(x.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
                                   L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
@@ -1027,14 +1057,15 @@ def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool)
 class TpFn(torch.autograd.Function):
     """out[n] = sum over edges into n of TP(x[src], sh, w): trilinear in (x, sh, w).  With
     F = <g, TP(x, sh, w)> every derivative of every order is one of three kernels — forward (contract
-    nothing), bwd_x (leave x open), bwd_w (leave w and sh open) — with operands exchanged."""
+    nothing), bwd_x (leave x open), bwd_w (leave w and sh open) — with operands exchanged.
+    ``sh_data``: sh is a function of the input data alone (no gradient under ``params_only_backward``)."""
 
     @staticmethod
-    def forward(ctx, x, sh, w, topo: GraphTopo, plan: TpPlan):
+    def forward(ctx, x, sh, w, topo: GraphTopo, plan: TpPlan, sh_data: bool = False):
         L.require_cuda(x, sh, w)
         x, sh, w = L.f32c(x), L.f32c(sh), L.f32c(w)
         ctx.save_for_backward(x, sh, w)
-        ctx.topo, ctx.plan = topo, plan
+        ctx.topo, ctx.plan, ctx.sh_data = topo, plan, sh_data
         return _tp_fwd_raw(x, sh, w, topo, plan)
 
     @staticmethod
@@ -1042,32 +1073,31 @@ class TpFn(torch.autograd.Function):
         x, sh, w = ctx.saved_tensors
         topo, plan = ctx.topo, ctx.plan
         need_x, need_sh, need_w = ctx.needs_input_grad[:3]
+        need_sh = need_sh and not (PARAMS_ONLY and ctx.sh_data)
         if torch.is_grad_enabled():
-            gx = TpBwdXFn.apply(sh, w, g_out, topo, plan) if need_x else None
+            gx = TpBwdXFn.apply(sh, w, g_out, topo, plan, ctx.sh_data) if need_x else None
             gw = gsh = None
             if need_sh or need_w:
-                gw, gsh = TpBwdWFn.apply(x, sh, w, g_out, topo, plan, bool(need_sh))
-            return gx, (gsh if need_sh else None), (gw if need_w else None), None, None
+                gw, gsh = TpBwdWFn.apply(x, sh, w, g_out, topo, plan, bool(need_sh), bool(need_w), ctx.sh_data)
+            return gx, (gsh if need_sh else None), (gw if need_w else None), None, None, None
         g_out = L.f32c(g_out)
         gx = gsh = gw = None
         with _Fork(x.device) as fork:
             if need_x:
                 gx = fork.side(lambda: _tp_bwd_x_raw(sh, w, g_out, topo, plan))
             if need_sh or need_w:
-                gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, bool(need_sh))
-        if not need_w:
-            gw = None
-        return gx, gsh, gw, None, None
+                gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, bool(need_sh), bool(need_w))
+        return gx, gsh, gw, None, None, None
 
 
 class TpBwdXFn(torch.autograd.Function):
     """gx = dF/dx (sh, w, g)."""
 
     @staticmethod
-    def forward(ctx, sh, w, g_out, topo: GraphTopo, plan: TpPlan):
+    def forward(ctx, sh, w, g_out, topo: GraphTopo, plan: TpPlan, sh_data: bool = False):
         sh, w, g_out = L.f32c(sh), L.f32c(w), L.f32c(g_out)
         ctx.save_for_backward(sh, w, g_out)
-        ctx.topo, ctx.plan = topo, plan
+        ctx.topo, ctx.plan, ctx.sh_data = topo, plan, sh_data
         return _tp_bwd_x_raw(sh, w, g_out, topo, plan)
 
     @staticmethod
@@ -1075,26 +1105,34 @@ class TpBwdXFn(torch.autograd.Function):
         sh, w, g_out = ctx.saved_tensors
         topo, plan = ctx.topo, ctx.plan
         need_sh, need_w, need_g = ctx.needs_input_grad[:3]
-        g_g = TpFn.apply(h, sh, w, topo, plan) if need_g else None
+        need_sh = need_sh and not (PARAMS_ONLY and ctx.sh_data)
+        g_g = TpFn.apply(h, sh, w, topo, plan, ctx.sh_data) if need_g else None
         g_w = g_sh = None
         if need_sh or need_w:
-            g_w, g_sh = TpBwdWFn.apply(h, sh, w, g_out, topo, plan, bool(need_sh))
-        return (g_sh if need_sh else None), (g_w if need_w else None), g_g, None, None
+            g_w, g_sh = TpBwdWFn.apply(h, sh, w, g_out, topo, plan, bool(need_sh), bool(need_w), ctx.sh_data)
+        return (g_sh if need_sh else None), (g_w if need_w else None), g_g, None, None, None
 
 
 class TpBwdWFn(torch.autograd.Function):
     """(gw, gsh) = (dF/dw, dF/dsh) (x, sh, w, g);  gw does not depend on w, gsh does not depend on sh."""
 
     @staticmethod
-    def forward(ctx, x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool):
+    def forward(ctx, x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool, want_w: bool = True,
+                sh_data: bool = False):
         x, sh, w, g_out = L.f32c(x), L.f32c(sh), L.f32c(w), L.f32c(g_out)
         ctx.save_for_backward(x, sh, w, g_out)
-        ctx.topo, ctx.plan, ctx.want_sh = topo, plan, want_sh
+        ctx.topo, ctx.plan, ctx.want_sh, ctx.want_w, ctx.sh_data = topo, plan, want_sh, want_w, sh_data
         ctx.set_materialize_grads(False)
-        gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, want_sh)
+        gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, want_sh, want_w)
+        dead = []
         if gsh is None:
             gsh = torch.zeros(0, device=x.device)
-            ctx.mark_non_differentiable(gsh)
+            dead.append(gsh)
+        if gw is None:
+            gw = torch.zeros(0, device=x.device)
+            dead.append(gw)
+        if dead:
+            ctx.mark_non_differentiable(*dead)
         return gw, gsh
 
     @staticmethod
@@ -1102,8 +1140,11 @@ class TpBwdWFn(torch.autograd.Function):
         x, sh, w, g_out = ctx.saved_tensors
         topo, plan = ctx.topo, ctx.plan
         need_x, need_sh, need_w, need_g = ctx.needs_input_grad[:4]
+        need_sh = need_sh and not (PARAMS_ONLY and ctx.sh_data)
         if not ctx.want_sh:
             hsh = None
+        if not ctx.want_w:
+            hw = None
         t = (topo, plan)
         g_x = g_sh = g_w = g_g = None
 
@@ -1111,11 +1152,11 @@ class TpBwdWFn(torch.autograd.Function):
             return b if a is None else a + b
         if hw is not None:      # term <g, TP(x, sh, hw)>
             if need_x:
-                g_x = acc(g_x, TpBwdXFn.apply(sh, hw, g_out, *t))
+                g_x = acc(g_x, TpBwdXFn.apply(sh, hw, g_out, *t, ctx.sh_data))
             if need_g:
-                g_g = acc(g_g, TpFn.apply(x, sh, hw, *t))
-            if need_sh:
-                g_sh = acc(g_sh, TpBwdWFn.apply(x, sh, hw, g_out, *t, True)[1])
+                g_g = acc(g_g, TpFn.apply(x, sh, hw, *t, ctx.sh_data))
+            if need_sh:     # only the sh half of the kernel: no [E, W] gradient is written
+                g_sh = acc(g_sh, TpBwdWFn.apply(x, sh, hw, g_out, *t, True, False, ctx.sh_data)[1])
         if hsh is not None:     # term <g, TP(x, hsh, w)>
             if need_x:
                 g_x = acc(g_x, TpBwdXFn.apply(hsh, w, g_out, *t))
@@ -1123,11 +1164,11 @@ class TpBwdWFn(torch.autograd.Function):
                 g_g = acc(g_g, TpFn.apply(x, hsh, w, *t))
             if need_w:
                 g_w = acc(g_w, TpBwdWFn.apply(x, hsh, w, g_out, *t, False)[0])
-        return g_x, g_sh, g_w, g_g, None, None, None
+        return g_x, g_sh, g_w, g_g, None, None, None, None, None
 
 
 def tp_uvu_scatter(x, sh, w, topo: GraphTopo, plan: TpPlan):
-    return TpFn.apply(_c(x), _c(sh), _c(w), topo, plan)
+    return TpFn.apply(_c(x), _c(sh), _c(w), topo, plan, is_data_only(sh))
 
 
 # --------------------------------------------------------------------------------------

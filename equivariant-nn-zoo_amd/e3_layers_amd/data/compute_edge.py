@@ -40,6 +40,10 @@ def computeEdgeVector(data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]
     topo = get_topology(data, pos.shape[0])
     data.update(topo.as_dict())
     vec, length = ops.edge_vector(pos, topo)
+    # functions of the input positions alone: no gradient under ops.params_only_backward()
+    from_input = pos.grad_fn is None and not isinstance(pos, torch.nn.Parameter)
+    ops.mark_data_only(vec, from_input)
+    ops.mark_data_only(length, from_input)
     data["edge_vector"] = vec
     if with_lengths:
         data["edge_length"] = length

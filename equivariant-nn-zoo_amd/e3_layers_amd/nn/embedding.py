@@ -73,7 +73,8 @@ class SphericalEncoding(Module):
         rows = vec.shape[0]
         sh = ops.spherical_harmonics(vec.reshape(rows * self.mul, 3), self.ls, self.normalize, self.normalization)
         width = self.mul * sum(2 * l + 1 for l in self.ls)      # explicit: rows may be 0 (a batch without edges)
-        return ({"spherical_harmonics": sh.view(rows, width)},
+        sh = ops.mark_data_only(sh.view(rows, width), ops.is_data_only(vec))
+        return ({"spherical_harmonics": sh},
                 {"spherical_harmonics": ("edge", self.irreps_out["spherical_harmonics"])})
 
 

@@ -62,6 +62,17 @@ def flat_layout(params: Sequence[torch.Tensor], align: int = FLAT_ALIGN):
     return offs, off
 
 
+def backward_parameters(loss: torch.Tensor, params: Iterable[torch.nn.Parameter]) -> None:
+    """``loss.backward()`` of a training step: gradients of the Parameters only.  In a force-training step ``pos``
+    still requires grad when the loss is differentiated; plain ``loss.backward()`` would also compute d loss / d pos
+    (three more grad_sh edge passes per convolution that nothing reads).  ``inputs=`` lets the engine drop the nodes
+    that lead to ``pos`` alone, ``ops.params_only_backward`` tells the e3k backward functions the same."""
+    from ..backend import ops
+
+    with ops.params_only_backward():
+        loss.backward(inputs=[p for p in params if p.requires_grad])
+
+
 class FlatGradients:
     """Points every ``p.grad`` at a slice of one contiguous buffer."""
 

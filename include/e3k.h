@@ -169,7 +169,8 @@ void e3k_tp_plan_destroy(e3k_tp_plan* plan);
  * dst_perm [E] = edge ids grouped by destination, ascending inside a group); out [N,d_mid]. */
 int e3k_tp_fwd(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const int32_t* src,
                const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out, void* stream);
-/* g_w [E,w_numel] written; g_sh [E,d_sh] accumulated with atomics when non-null (needs w). */
+/* g_w [E,w_numel] written (may be NULL when only g_sh is wanted); g_sh [E,d_sh] accumulated with atomics when
+ * non-null (needs w). */
 int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out,
                  const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
                  float* g_w, float* g_sh, void* stream);

@@ -567,6 +567,19 @@ def test_force_training_gradient_sink_and_inputs_only_pass(dev, monkeypatch):
             return False
 
     ref_skip = step()
+
+    def step_params_only():
+        from e3_layers_amd.run.parallel import backward_parameters
+
+        flat.zero()
+        out = model(batch.clone())
+        assert ops.is_data_only(out["edge_spherical"]) if "edge_spherical" in out else True
+        backward_parameters(out["energy_total"].square().mean() + (out["forces"] - f_t).square().mean(), model.parameters())
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return flat.gather().clone()
+
+    params_only = step_params_only()
     monkeypatch.setattr(ops, "inputs_only_backward", _Everything)
     ref_full = step()
     monkeypatch.undo()
@@ -578,3 +591,4 @@ def test_force_training_gradient_sink_and_inputs_only_pass(dev, monkeypatch):
     assert float(ref_full.norm()) > 0
     assert rel_err(ref_skip, ref_full) < 1e-5
     assert rel_err(sunk, ref_full) < 1e-5
+    assert rel_err(params_only, ref_full) < 1e-5      # d loss / d pos skipped (ops.params_only_backward), same d loss / d theta

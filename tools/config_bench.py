@@ -13,6 +13,7 @@ from e3_layers_amd.backend.graph import build_topology
 from e3_layers_amd.configs import config_diffusion, config_diffusion_CA, config_energy_force
 from e3_layers_amd.data.synthetic import synth_protein, synth_qm9, synth_qm9_diffusion
 from e3_layers_amd.run.optim import FusedAdamEMA
+from e3_layers_amd.run.parallel import backward_parameters
 from e3_layers_amd.run.sde_utils import VPSDE, sde_loss
 from e3_layers_amd.utils import build, countParameters
 
@@ -27,11 +28,15 @@ def run(name, model, step_fn, n_units, unit, graph=False):
     if ONLY and int(name.split()[0].split("#")[-1]) not in ONLY:
         return
     opt = FusedAdamEMA(model.parameters(), lr=1e-3, max_grad_norm=1.0)
-    opt.grads.enable_direct_accumulation()      # weight-gradient kernels add straight into the flat gradient buffer
+    if os.environ.get("E3K_CB_SINK", "1") != "0":
+        opt.grads.enable_direct_accumulation()      # weight-gradient kernels add straight into the flat gradient buffer
     def one():
         opt.zero_grad()
         loss = step_fn()
-        loss.backward()
+        if os.environ.get("E3K_CB_PARAMS_ONLY", "1") != "0":
+            backward_parameters(loss, opt.params)
+        else:
+            loss.backward()
         opt.step()
         return loss
     for _ in range(3):
