@@ -33,8 +33,12 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
     const float v = g[(n4 << 2) + threadIdx.x];
     acc = fmaf(v, v, acc);
   }
+  // one atomic per workgroup (same-address atomics serialise: 8 k of them cost 100 us)
+  __shared__ float part[4];
   acc = wave_sum(acc);
-  if ((threadIdx.x & 63) == 0) atomicAdd(state + 5, acc);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(state + 5, (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 __global__ void tick_kernel(float* __restrict__ state, float beta1, float beta2, float max_norm, int have_norm,
@@ -146,7 +150,7 @@ extern "C" int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg
   if (blocks < 1) blocks = 1;
   const int have_norm = (max_grad_norm > 0.f || skip_nonfinite) ? 1 : 0;
   if (have_norm) {
-    hipLaunchKernelGGL(e3k::sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, st, grad, n, state);
+    hipLaunchKernelGGL(e3k::sumsq_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, st, grad, n, state);
     E3K_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(e3k::tick_kernel, dim3(1), dim3(1), 0, st, state, beta1, beta2, max_grad_norm,
