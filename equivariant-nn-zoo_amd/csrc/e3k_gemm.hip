@@ -949,6 +949,56 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G
   if (ph == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// Coalesced variant for V in {4, 8, 16, 32} (V/4 lanes share one u, a lane owns four consecutive v for the whole row):
+// one wave per (r1, r2) row streams the row's U*V floats as 16-byte loads, 1 KB per wave-instruction.  (The generic
+// kernel below lets every lane walk its own 4*V-byte segment: 64 cache lines in flight per instruction, 0.75 TB/s.)
+template <int V>
+__global__ __launch_bounds__(256) void fctp_reduce_vec_kernel(const float* __restrict__ H, const float* __restrict__ X,
+                                                               const float* __restrict__ A2, int M1, int M2, int U,
+                                                               int64_t x_r1, int64_t x_r2, int64_t a2_r1,
+                                                               float* __restrict__ dX, int dx_acc, float* __restrict__ dA2) {
+  constexpr int LPU = V / 4;          // lanes per u
+  constexpr int UPI = 64 / LPU;       // u values per wave-iteration
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)M1 * M2) return;
+  const int lane = threadIdx.x & 63;
+  const int r1 = (int)(row / M2), r2 = (int)(row - (int64_t)r1 * M2);
+  const float4* h4 = reinterpret_cast<const float4*>(H + row * (int64_t)U * V);
+  const float* x = X + (int64_t)r1 * x_r1 + (int64_t)r2 * x_r2;
+  float* dx = dX + (int64_t)r1 * x_r1 + (int64_t)r2 * x_r2;
+  const int v0 = (lane % LPU) * 4, usub = lane / LPU;
+  const float4 av = *reinterpret_cast<const float4*>(A2 + (int64_t)r1 * a2_r1 + v0);
+  float4 da = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int ub = 0; ub < U; ub += UPI) {
+    const int u = ub + usub;
+    const bool ok = u < U;
+    const float4 hv = ok ? h4[(int64_t)(ub / UPI) * 64 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    const float xv = ok ? x[u] : 0.f;
+    float s = fmaf(av.x, hv.x, fmaf(av.y, hv.y, fmaf(av.z, hv.z, av.w * hv.w)));
+#pragma unroll
+    for (int off = 1; off < LPU; off <<= 1) s += __shfl_xor(s, off, 64);
+    da.x = fmaf(xv, hv.x, da.x);
+    da.y = fmaf(xv, hv.y, da.y);
+    da.z = fmaf(xv, hv.z, da.z);
+    da.w = fmaf(xv, hv.w, da.w);
+    if (ok && (lane % LPU) == 0) dx[u] = dx_acc ? dx[u] + s : s;
+  }
+#pragma unroll
+  for (int off = LPU; off < 64; off <<= 1) {
+    da.x += __shfl_xor(da.x, off, 64);
+    da.y += __shfl_xor(da.y, off, 64);
+    da.z += __shfl_xor(da.z, off, 64);
+    da.w += __shfl_xor(da.w, off, 64);
+  }
+  if (lane < LPU) {
+    float* o = dA2 + (int64_t)r1 * a2_r1 + v0;
+    atomicAdd(o + 0, da.x);
+    atomicAdd(o + 1, da.y);
+    atomicAdd(o + 2, da.z);
+    atomicAdd(o + 3, da.w);
+  }
+}
+
 // one wave per (r1, r2) row: lanes over u; H row = [U*V] (u-major, v-minor)
 __global__ __launch_bounds__(256) void fctp_reduce_kernel(const float* __restrict__ H, const float* __restrict__ X,
                                                            const float* __restrict__ A2, int M1, int M2, int U, int V,
@@ -1244,8 +1294,21 @@ extern "C" int e3k_fctp_reduce_bwd(const float* H, const float* X, const float* 
   if (M1 == 0) return E3K_OK;
   if (!H || !X || !A2 || !dX || !dA2) return E3K_ERR_INVALID;
   const int64_t rows = (int64_t)M1 * M2;
-  hipLaunchKernelGGL(e3k::fctp_reduce_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, H, X,
-                     A2, M1, M2, U, V, x_r1, x_r2, a2_r1, dX, dx_accumulate, dA2);
+  const dim3 grid((unsigned)((rows + 3) / 4));
+  hipStream_t st = (hipStream_t)stream;
+  // 16-byte streams need: H rows (U*V floats) and the A2 rows 16-byte aligned
+  const bool vec = aligned16(H) && aligned16(A2) && a2_r1 % 4 == 0 && ((int64_t)U * V) % 4 == 0 && 64 % (V / 4 > 0 ? V / 4 : 1) == 0;
+#define E3K_FCTP_VEC(VV)                                                                                              \
+  hipLaunchKernelGGL(e3k::fctp_reduce_vec_kernel<VV>, grid, dim3(256), 0, st, H, X, A2, M1, M2, U, x_r1, x_r2, a2_r1, dX, \
+                     dx_accumulate, dA2)
+  if (vec && V == 32) E3K_FCTP_VEC(32);
+  else if (vec && V == 16) E3K_FCTP_VEC(16);
+  else if (vec && V == 8) E3K_FCTP_VEC(8);
+  else if (vec && V == 4) E3K_FCTP_VEC(4);
+  else
+    hipLaunchKernelGGL(e3k::fctp_reduce_kernel, grid, dim3(256), 0, st, H, X, A2, M1, M2, U, V, x_r1, x_r2, a2_r1, dX,
+                       dx_accumulate, dA2);
+#undef E3K_FCTP_VEC
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

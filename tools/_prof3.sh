@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof3 -o ef -- python3 $GRAFT_REPO_ROOT/tools/config_bench.py 10 --only=3 > $GRAFT_REPO_ROOT/gpurun_out/prof3.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof$1 -o cfg -- python3 $GRAFT_REPO_ROOT/tools/config_bench.py 10 --only=$1 > $GRAFT_REPO_ROOT/gpurun_out/prof$1.log 2>&1
 cd $GRAFT_REPO_ROOT
-f=$(ls -t gpurun_out/prof3/*/*kernel_stats.csv gpurun_out/prof3/*kernel_stats.csv 2>/dev/null | head -1)
+f=$(ls -t gpurun_out/prof$1/*/*kernel_stats.csv gpurun_out/prof$1/*kernel_stats.csv 2>/dev/null | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
