@@ -157,19 +157,11 @@ def main():
     run = step
     graph = None
     if args.graph:
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                step()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = step()
+        from e3_layers_amd.run.graph_step import CapturedStep
 
-        def run():
-            graph.replay()
-            return static_loss
+        captured = CapturedStep(step, warmup=3)
+        graph = captured.graph
+        run = captured
 
     for _ in range(args.warmup):
         run()

@@ -261,15 +261,6 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
       for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
-#ifdef E3K_EXP_NO_BUTTERFLY
-      {
-        float t9 = 0.f;
-#pragma unroll
-        for (int i = 0; i < 9; ++i) t9 += v9[i];
-        if (t9 == 12345.f) gsr[lane] = t9;
-        continue;
-      }
-#endif
       int idx = 0;
       const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
       float l5[5], l3[3], l2[2];
@@ -313,11 +304,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
         if (idx == 0) off = g.y_off[0];
         else if (idx < 4) off = g.y_off[1] >= 0 ? g.y_off[1] + (idx - 1) : -1;
         else off = g.y_off[2] >= 0 ? g.y_off[2] + (idx - 4) : -1;
-#ifndef E3K_EXP_NO_SH_ATOMIC
         if (off >= 0) atomicAdd(gsr + off, tot);
-#else
-        if (off >= 0 && tot == 12345.f) gsr[off] = tot;
-#endif
       }
     }
   }

@@ -335,6 +335,8 @@ class Linear(nn.Module):
     def forward(self, x: Tensor) -> Tensor:
         z = x.shape[0]
         sl_in, sl_out = irreps_slices(self.irreps_in), irreps_slices(self.irreps_out)
+        # e3nn's generated forward reshapes to (-1, irreps_in.dim): a narrower input is an error, not a silent mis-slice
+        assert x.shape[-1] == (sl_in[-1][1] if sl_in else 0), (tuple(x.shape), sl_in[-1][1] if sl_in else 0)
         outs = [None] * len(self.irreps_out)
         pos = 0
         for i, o in self.instr:

@@ -592,3 +592,56 @@ def test_force_training_gradient_sink_and_inputs_only_pass(dev, monkeypatch):
     assert rel_err(ref_skip, ref_full) < 1e-5
     assert rel_err(sunk, ref_full) < 1e-5
     assert rel_err(params_only, ref_full) < 1e-5      # d loss / d pos skipped (ops.params_only_backward), same d loss / d theta
+
+
+def test_captured_force_training_step_equals_eager(dev):
+    """run.graph_step.CapturedStep: a whole force-training step (forward, force pass, double backward, clip + Adam) replayed
+    as one HIP graph moves the parameters exactly like the same steps launched eagerly."""
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import CapturedStep
+    from e3_layers_amd.run.optim import FusedAdamEMA
+    from e3_layers_amd.run.parallel import backward_parameters
+    from e3_layers_amd.utils import build
+
+    cfg = featureModel(n_dim=16, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+                       num_types=10, num_layers=3, r_max=4.0)    # (3 layers: the declared output irreps need them all reachable)
+    cfg = addForceOutput(addEnergyOutput(cfg, None, output_key="energy_total"), y="energy_total")
+    batch = synth_qm9(5, 6).to(dev)
+    f_t = torch.randn_like(batch["pos"])
+    n_warm, n_steps = 3, 4
+
+    def make():
+        torch.manual_seed(0)
+        model = build(cfg).to(dev).train()
+        opt = FusedAdamEMA(model.parameters(), lr=1e-3, max_grad_norm=1.0)
+        opt.grads.enable_direct_accumulation()
+
+        def one():
+            opt.zero_grad()
+            out = model(batch.view())
+            loss = out["energy_total"].square().mean() + (out["forces"] - f_t).square().mean()
+            backward_parameters(loss, opt.params)
+            opt.step()
+            return loss.detach()
+        return opt, one
+
+    try:
+        opt_e, one_e = make()
+        for _ in range(n_warm + 1 + n_steps):      # CapturedStep: n_warm eager runs, the capture run, then the replays
+            loss_e = one_e()
+        flat_e = opt_e.flat.clone()
+        opt_e.grads.disable_direct_accumulation()
+        opt_g, one_g = make()
+        step = CapturedStep(one_g, warmup=n_warm)
+        # capturing records the step without executing it: n_warm steps taken so far
+        assert opt_g.steps_taken == n_warm
+        for _ in range(1 + n_steps):
+            loss_g = step()
+        torch.cuda.synchronize()
+        assert opt_g.steps_taken == opt_e.steps_taken == n_warm + 1 + n_steps
+        assert rel_err(opt_g.flat, flat_e) < 1e-5
+        assert abs(float(loss_g) - float(loss_e)) <= 1e-4 * abs(float(loss_e))
+    finally:
+        from e3_layers_amd.backend import ops
+        ops.GRAD_SINK.clear()

@@ -53,22 +53,15 @@ def run(name, model, step_fn, n_units, unit, graph=False):
     if graph and GRAPH:
         # whole step (forward, loss, backward or double backward, clip + Adam) as one HIP graph
         del loss
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                one()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            loss = one()
+        from e3_layers_amd.run.graph_step import CapturedStep
+        g = CapturedStep(one, warmup=3)
+        loss = g.out
         for _ in range(3):
-            g.replay()
+            g()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            g.replay()
+            g()
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
         opt.grads.disable_direct_accumulation()
