@@ -1253,6 +1253,28 @@ extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, 
   return gemm_wgrad_impl(problems, n_problems, 1, 0, stream);
 }
 
+extern "C" int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base,
+                                const void* a2_base, const void* b_base, void* c_base, const void* bias_base,
+                                int64_t M1, int32_t wgrad, void* stream) {
+  if (n_templates < 0 || n_templates > 64 || (n_templates && !templates) || M1 < 0 || M1 > 0x7fffffffLL) return E3K_ERR_INVALID;
+  // the host caches one descriptor array per (layer, pass): pointer fields hold byte offsets, only the bases and the
+  // row count change from call to call
+  e3k_gemm_problem buf[64];
+  for (int i = 0; i < n_templates; ++i) {
+    e3k_gemm_problem p = templates[i];
+    const auto off = [](const void* q) { return reinterpret_cast<uintptr_t>(q); };
+    p.A = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(a_base) + off(p.A));
+    p.B = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(b_base) + off(p.B));
+    p.C = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(c_base) + off(p.C));
+    p.A2 = p.A2 ? reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(a2_base) + off(p.A2) - 1) : nullptr;
+    p.bias = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(bias_base) + off(p.bias) - 1) : nullptr;
+    if ((p.A2 && !a2_base) || (p.bias && !bias_base)) return E3K_ERR_INVALID;
+    p.M1 = (int32_t)M1;
+    buf[i] = p;
+  }
+  return wgrad ? gemm_wgrad_impl(buf, n_templates, 1, 0, stream) : gemm_fwd_impl(buf, n_templates, 1, 0, stream);
+}
+
 extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
                                 const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
                                 void* stream) {

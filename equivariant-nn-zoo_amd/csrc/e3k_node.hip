@@ -50,30 +50,41 @@ struct BlockArgs {
   e3k_block b[MAXBLK];
 };
 
+// Column-fixed threads: the output column -> source column map is the same for every row, so a thread resolves its
+// block once and then walks rows (grid.y strides).  The first version recomputed a 64-bit division and the block search
+// per element: 54 us for a [4.6 k, 1152] tensor that moves 43 MB.
 __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__ x, int64_t rows, int row_dim,
                                                         BlockArgs ba, int to_cf, float* __restrict__ y) {
-  const int64_t total = rows * row_dim;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / row_dim;
-    const int c = (int)(i - r * row_dim);
-    // i indexes the OUTPUT element; find its block
-    int src = c;
-    for (int k = 0; k < ba.n; ++k) {
-      const e3k_block& b = ba.b[k];
-      const int rel = c - b.off;
-      if (rel >= 0 && rel < b.mul * b.dim) {
-        if (to_cf) {  // out [dim][mul] <- in [mul][dim]
-          const int m = rel / b.mul, u = rel - m * b.mul;
-          src = b.off + u * b.dim + m;
-        } else {      // out [mul][dim] <- in [dim][mul]
-          const int u = rel / b.dim, m = rel - u * b.dim;
-          src = b.off + m * b.mul + u;
-        }
-        break;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= row_dim) return;
+  int src = c;
+  for (int k = 0; k < ba.n; ++k) {
+    const e3k_block& b = ba.b[k];
+    const int rel = c - b.off;
+    if (rel >= 0 && rel < b.mul * b.dim) {
+      if (to_cf) {  // out [dim][mul] <- in [mul][dim]
+        const int m = rel / b.mul, u = rel - m * b.mul;
+        src = b.off + u * b.dim + m;
+      } else {      // out [mul][dim] <- in [dim][mul]
+        const int u = rel / b.dim, m = rel - u * b.dim;
+        src = b.off + m * b.mul + u;
       }
+      break;
     }
-    y[i] = x[r * row_dim + src];
   }
+  const float* __restrict__ xp = x + src;
+  float* __restrict__ yp = y + c;
+  const int64_t step = gridDim.y;
+  int64_t r = blockIdx.y;
+  for (; r + 3 * step < rows; r += 4 * step) {
+    const float v0 = xp[r * row_dim], v1 = xp[(r + step) * row_dim], v2 = xp[(r + 2 * step) * row_dim],
+                v3 = xp[(r + 3 * step) * row_dim];
+    yp[r * row_dim] = v0;
+    yp[(r + step) * row_dim] = v1;
+    yp[(r + 2 * step) * row_dim] = v2;
+    yp[(r + 3 * step) * row_dim] = v3;
+  }
+  for (; r < rows; r += step) yp[r * row_dim] = xp[r * row_dim];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -84,66 +95,81 @@ struct GateArgs {
   e3k_gate_seg s[MAXBLK];
 };
 
+// (column-fixed threads, as in relayout_kernel: the segment of a column is resolved once, rows are walked after)
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ x, int64_t rows, int in_dim,
                                                         int out_dim, GateArgs ga, float* __restrict__ y) {
-  const int64_t total = rows * out_dim;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / out_dim;
-    const int c = (int)(i - r * out_dim);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= out_dim) return;
+  int mode = -1, xi = 0, gi = 0, act = 0;
+  float cst = 0.f;
+  for (int k = 0; k < ga.n; ++k) {
+    const e3k_gate_seg& s = ga.s[k];
+    const int rel = c - s.out_off;
+    if (rel >= 0 && rel < s.mul * s.dim) {
+      mode = s.kind, act = s.act, cst = s.cst;
+      if (s.kind == 0) {
+        xi = s.in_off + rel;
+      } else {
+        const int u = rel / s.dim, m = rel - u * s.dim;
+        xi = s.in_off + m * s.mul + u;
+        gi = s.gate_off + u;
+      }
+      break;
+    }
+  }
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
     const float* xr = x + r * in_dim;
     float v = 0.f;
-    for (int k = 0; k < ga.n; ++k) {
-      const e3k_gate_seg& s = ga.s[k];
-      const int rel = c - s.out_off;
-      if (rel >= 0 && rel < s.mul * s.dim) {
-        if (s.kind == 0) {
-          v = s.cst * act_f(s.act, xr[s.in_off + rel]);
-        } else {
-          const int u = rel / s.dim, m = rel - u * s.dim;
-          v = xr[s.in_off + m * s.mul + u] * (s.cst * act_f(s.act, xr[s.gate_off + u]));
-        }
-        break;
-      }
-    }
-    y[i] = v;
+    if (mode == 0) v = cst * act_f(act, xr[xi]);
+    else if (mode > 0) v = xr[xi] * (cst * act_f(act, xr[gi]));
+    y[r * out_dim + c] = v;
   }
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                         int64_t rows, int in_dim, int out_dim, GateArgs ga,
                                                         float* __restrict__ gx) {
-  const int64_t total = rows * in_dim;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / in_dim;
-    const int c = (int)(i - r * in_dim);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= in_dim) return;
+  // 0: activated scalar, 1: gate scalar (dot over the gated block), 2: gated element, -1: feeds nothing
+  int mode = -1, go = 0, xi = 0, dim = 0, mul = 0, act = 0;
+  float cst = 0.f;
+  for (int k = 0; k < ga.n; ++k) {
+    const e3k_gate_seg& s = ga.s[k];
+    if (s.kind == 0) {
+      const int rel = c - s.in_off;
+      if (rel >= 0 && rel < s.mul) {
+        mode = 0, go = s.out_off + rel, act = s.act, cst = s.cst;
+        break;
+      }
+    } else {
+      const int relg = c - s.gate_off;
+      if (relg >= 0 && relg < s.mul) {
+        mode = 1, go = s.out_off + relg * s.dim, xi = s.in_off + relg, dim = s.dim, mul = s.mul, act = s.act, cst = s.cst;
+        break;
+      }
+      const int rel = c - s.in_off;
+      if (rel >= 0 && rel < s.mul * s.dim) {
+        const int m = rel / s.mul, u = rel - m * s.mul;
+        mode = 2, go = s.out_off + u * s.dim + m, xi = s.gate_off + u, act = s.act, cst = s.cst;
+        break;
+      }
+    }
+  }
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
     const float* xr = x + r * in_dim;
     const float* gr = gy + r * out_dim;
     float v = 0.f;
-    for (int k = 0; k < ga.n; ++k) {
-      const e3k_gate_seg& s = ga.s[k];
-      if (s.kind == 0) {
-        const int rel = c - s.in_off;
-        if (rel >= 0 && rel < s.mul) {
-          v = gr[s.out_off + rel] * s.cst * act_df(s.act, xr[c]);
-          break;
-        }
-      } else {
-        const int relg = c - s.gate_off;
-        if (relg >= 0 && relg < s.mul) {
-          float dot = 0.f;
-          for (int m = 0; m < s.dim; ++m) dot = fmaf(gr[s.out_off + relg * s.dim + m], xr[s.in_off + m * s.mul + relg], dot);
-          v = dot * s.cst * act_df(s.act, xr[c]);
-          break;
-        }
-        const int rel = c - s.in_off;
-        if (rel >= 0 && rel < s.mul * s.dim) {
-          const int m = rel / s.mul, u = rel - m * s.mul;
-          v = gr[s.out_off + u * s.dim + m] * (s.cst * act_f(s.act, xr[s.gate_off + u]));
-          break;
-        }
-      }
+    if (mode == 0) {
+      v = gr[go] * cst * act_df(act, xr[c]);
+    } else if (mode == 1) {
+      float dot = 0.f;
+      for (int m = 0; m < dim; ++m) dot = fmaf(gr[go + m], xr[xi + m * mul], dot);
+      v = dot * cst * act_df(act, xr[c]);
+    } else if (mode == 2) {
+      v = gr[go] * (cst * act_f(act, xr[xi]));
     }
-    gx[i] = v;
+    gx[r * in_dim + c] = v;
   }
 }
 
@@ -151,10 +177,10 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void gate_bwd2_gy_kernel(const float* __restrict__ x, const float* __restrict__ gh,
                                                             int64_t rows, int in_dim, int out_dim, GateArgs ga,
                                                             float* __restrict__ g_gy) {
-  const int64_t total = rows * out_dim;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / out_dim;
-    const int c = (int)(i - r * out_dim);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= out_dim) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t i = r * out_dim + c;
     const float* xr = x + r * in_dim;
     const float* hr = gh + r * in_dim;
     float v = 0.f;
@@ -181,10 +207,10 @@ __global__ __launch_bounds__(256) void gate_bwd2_gy_kernel(const float* __restri
 __global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            const float* __restrict__ gh, int64_t rows, int in_dim,
                                                            int out_dim, GateArgs ga, float* __restrict__ g_x) {
-  const int64_t total = rows * in_dim;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t r = i / in_dim;
-    const int c = (int)(i - r * in_dim);
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= in_dim) return;
+  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+    const int64_t i = r * in_dim + c;
     const float* xr = x + r * in_dim;
     const float* hr = gh + r * in_dim;
     const float* gr = gy + r * out_dim;
@@ -498,6 +524,15 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   }
 }
 
+// column-fixed kernels: grid.x covers the columns, grid.y strides the rows (about 8 k workgroups in all)
+inline dim3 grid_cols(int cols, int64_t rows) {
+  const int gx = (cols + 255) / 256;
+  int64_t gy = 8192 / (gx > 0 ? gx : 1);
+  if (gy > rows) gy = rows;
+  if (gy < 1) gy = 1;
+  return dim3((unsigned)gx, (unsigned)gy);
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   if (g > 8192) g = 8192;
@@ -593,7 +628,7 @@ extern "C" int e3k_relayout(const float* x, int64_t rows, int32_t row_dim, const
   if (rows < 0 || row_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !y) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::relayout_kernel, dim3(e3k::grid_for(rows * row_dim)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(e3k::relayout_kernel, e3k::grid_cols(row_dim, rows), dim3(256), 0, (hipStream_t)stream, x,
                      rows, row_dim, ba, to_cf, y);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -607,7 +642,7 @@ extern "C" int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !y) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::gate_fwd_kernel, dim3(e3k::grid_for(rows * out_dim)), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(e3k::gate_fwd_kernel, e3k::grid_cols(out_dim, rows), dim3(256), 0, (hipStream_t)stream, x,
                      rows, in_dim, out_dim, ga, y);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -621,7 +656,7 @@ extern "C" int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int3
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::gate_bwd_kernel, dim3(e3k::grid_for(rows * in_dim)), dim3(256), 0, (hipStream_t)stream, x, g_y,
+  hipLaunchKernelGGL(e3k::gate_bwd_kernel, e3k::grid_cols(in_dim, rows), dim3(256), 0, (hipStream_t)stream, x, g_y,
                      rows, in_dim, out_dim, ga, g_x);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -637,12 +672,12 @@ extern "C" int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_ha
   if (rows == 0) return E3K_OK;
   if (!x || !g_hat || (!g_gy && !g_x) || (g_x && !g_y)) return E3K_ERR_INVALID;
   if (g_gy) {
-    hipLaunchKernelGGL(e3k::gate_bwd2_gy_kernel, dim3(e3k::grid_for(rows * out_dim)), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(e3k::gate_bwd2_gy_kernel, e3k::grid_cols(out_dim, rows), dim3(256), 0, (hipStream_t)stream,
                        x, g_hat, rows, in_dim, out_dim, ga, g_gy);
     E3K_CHECK_LAUNCH();
   }
   if (g_x) {
-    hipLaunchKernelGGL(e3k::gate_bwd2_x_kernel, dim3(e3k::grid_for(rows * in_dim)), dim3(256), 0, (hipStream_t)stream, x,
+    hipLaunchKernelGGL(e3k::gate_bwd2_x_kernel, e3k::grid_cols(in_dim, rows), dim3(256), 0, (hipStream_t)stream, x,
                        g_y, g_hat, rows, in_dim, out_dim, ga, g_x);
     E3K_CHECK_LAUNCH();
   }

@@ -260,29 +260,58 @@ class LinearSpec:
         return out
 
 
-def _lin_fwd_raw(x, weight, bias, y, spec: LinearSpec, scale: float, accumulate: bool, act: int = 0, act_cst: float = 1.0):
-    """y (+)= sum over instructions alpha*scale * x_block @ W_block (+ bias); raw launch, no autograd."""
-    rows = x.shape[0]
-    bias_at = {}
-    if bias is not None:
-        for off, mul, boff in spec.bias_blocks:
-            bias_at[off] = _addr(bias, boff)
+class _GemmTemplates:
+    """Descriptor arrays of one (layer, pass), built once: pointer fields hold byte offsets (``e3k_gemm_rebased``)."""
+
+    __slots__ = ("rounds", "shapes", "loose_bias")
+
+    def __init__(self, rounds: List[List[L.GemmProblem]], loose_bias=()):
+        self.rounds = [((L.GemmProblem * len(g))(*g), len(g)) for g in rounds if g]
+        self.shapes = [[(p.M2, p.N, p.K, p.V) for p in g] for g in rounds if g]
+        self.loose_bias = tuple(loose_bias)
+
+    def run(self, a, a2, b, c, bias, rows: int, wgrad: bool = False) -> None:
+        lib, st = L.load(), L.stream_ptr()
+        prof = PROFILE_GEMM
+        for (arr, n), shapes in zip(self.rounds, self.shapes):
+            if prof is not None:
+                ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                ev0.record()
+            L.check(lib.e3k_gemm_rebased(arr, n, a, a2, b, c, bias, rows, int(wgrad), st), "e3k_gemm_rebased")
+            if prof is not None:
+                ev1.record()
+                prof.append((ev0, ev1, wgrad, [(rows,) + sh for sh in shapes]))
+
+
+def _templates(spec, key, build) -> _GemmTemplates:
+    cache = spec.__dict__.get("_gemm_templates")
+    if cache is None:
+        cache = spec.__dict__["_gemm_templates"] = {}
+    t = cache.get(key)
+    if t is None:
+        t = cache[key] = build()
+    return t
+
+
+def _lin_fwd_templates(spec: "LinearSpec", scale: float, accumulate: bool, act: int, act_cst: float, has_bias: bool):
+    bias_at = {off: 4 * boff + 1 for off, mul, boff in spec.bias_blocks} if has_bias else {}
     done_bias = set()
     rounds = spec.rounds("i_out")
     if act and len(rounds) != 1:
         raise NotImplementedError("fused activation needs single-round linears")
+    out = []
     for r, group in enumerate(rounds):
         probs = []
         for ins in group:
             a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
             c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
             p = L.GemmProblem()
-            p.A, p.A2, p.B, p.C = _addr(x, ins.in_off), None, _addr(weight, ins.w_off), _addr(y, ins.out_off)
+            p.A, p.A2, p.B, p.C = 4 * ins.in_off, None, 4 * ins.w_off, 4 * ins.out_off
             p.bias = None
             if r == 0 and ins.out_off in bias_at:
                 p.bias = bias_at[ins.out_off]
                 done_bias.add(ins.out_off)
-            p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
+            p.M1, p.M2, p.N, p.K, p.V = 0, ins.dim, ins.mul_out, ins.mul_in, 0
             p.accumulate = 1 if (r > 0 or accumulate) else 0
             p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
             p.b_k, p.b_n = ins.mul_out, 1
@@ -291,51 +320,72 @@ def _lin_fwd_raw(x, weight, bias, y, spec: LinearSpec, scale: float, accumulate:
             if act:
                 p.act, p.act_cst = act, act_cst
             probs.append(p)
-        _run_gemm(probs)
-    for off, mul, boff in spec.bias_blocks:  # biased block without any incoming path
-        if bias is not None and off not in done_bias:
-            y[:, off:off + mul] += bias[boff:boff + mul]
+        out.append(probs)
+    # biased blocks without any incoming path
+    loose = [(off, mul, boff) for off, mul, boff in spec.bias_blocks if has_bias and off not in done_bias]
+    return _GemmTemplates(out, loose)
 
 
-def _lin_dgrad_raw(gy, weight, spec: LinearSpec, scale: float):
-    """gx = sum over instructions alpha*scale * gy_block @ W_block^T."""
-    rows = gy.shape[0]
-    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
+def _lin_fwd_raw(x, weight, bias, y, spec: LinearSpec, scale: float, accumulate: bool, act: int = 0, act_cst: float = 1.0):
+    """y (+)= sum over instructions alpha*scale * x_block @ W_block (+ bias); raw launch, no autograd."""
+    has_bias = bias is not None
+    t = _templates(spec, ("fwd", scale, bool(accumulate), act, act_cst, has_bias),
+                   lambda: _lin_fwd_templates(spec, scale, bool(accumulate), act, act_cst, has_bias))
+    t.run(x.data_ptr(), None, weight.data_ptr(), y.data_ptr(), bias.data_ptr() if has_bias else None, x.shape[0])
+    for off, mul, boff in t.loose_bias:
+        y[:, off:off + mul] += bias[boff:boff + mul]
+
+
+def _lin_dgrad_templates(spec: "LinearSpec", scale: float):
+    out = []
     for r, group in enumerate(spec.rounds("i_in")):
         probs = []
         for ins in group:
             a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
             c_r2, c_n = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
             p = L.GemmProblem()
-            p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(gx, ins.in_off), None
-            p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_in, ins.mul_out, 0
+            p.A, p.A2, p.B, p.C, p.bias = 4 * ins.out_off, None, 4 * ins.w_off, 4 * ins.in_off, None
+            p.M1, p.M2, p.N, p.K, p.V = 0, ins.dim, ins.mul_in, ins.mul_out, 0
             p.accumulate = 1 if r > 0 else 0
             p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
             p.b_k, p.b_n = 1, ins.mul_out  # W^T
             p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
             p.alpha = ins.alpha * scale
             probs.append(p)
-        _run_gemm(probs)
+        out.append(probs)
+    return _GemmTemplates(out)
+
+
+def _lin_dgrad_raw(gy, weight, spec: LinearSpec, scale: float):
+    """gx = sum over instructions alpha*scale * gy_block @ W_block^T."""
+    rows = gy.shape[0]
+    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
+    t = _templates(spec, ("dgrad", scale), lambda: _lin_dgrad_templates(spec, scale))
+    t.run(gy.data_ptr(), None, weight.data_ptr(), gx.data_ptr(), None, rows)
     return gx
 
 
-def _lin_wgrad_raw(x, gy, gw, spec: LinearSpec, scale: float) -> None:
-    """gw += alpha*scale * x_block^T @ gy_block per instruction (gw pre-zeroed or a gradient sink)."""
-    rows = x.shape[0]
+def _lin_wgrad_templates(spec: "LinearSpec", scale: float):
     probs = []
     for ins in spec.instr:
         a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
         c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
         p = L.GemmProblem()
-        p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), None, _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
-        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in, 0
+        p.A, p.A2, p.B, p.C, p.bias = 4 * ins.in_off, None, 4 * ins.w_off, 4 * ins.out_off, None
+        p.M1, p.M2, p.N, p.K, p.V = 0, ins.dim, ins.mul_out, ins.mul_in, 0
         p.accumulate = 1
         p.a_r1, p.a_r2, p.a_k = spec.d_in, a_r2, a_k
         p.b_k, p.b_n = ins.mul_out, 1
         p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
         p.alpha = ins.alpha * scale
         probs.append(p)
-    _run_gemm(probs, wgrad=True)
+    return _GemmTemplates([probs])
+
+
+def _lin_wgrad_raw(x, gy, gw, spec: LinearSpec, scale: float) -> None:
+    """gw += alpha*scale * x_block^T @ gy_block per instruction (gw pre-zeroed or a gradient sink)."""
+    t = _templates(spec, ("wgrad", scale), lambda: _lin_wgrad_templates(spec, scale))
+    t.run(x.data_ptr(), None, gw.data_ptr(), gy.data_ptr(), None, x.shape[0], wgrad=True)
 
 
 def _bias_grad_diff(gy, spec: LinearSpec):
@@ -514,12 +564,17 @@ def _ptr_array(tensors):
     return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
 
 
+_DENSE_SPECS: Dict[Tuple[int, int, float], "LinearSpec"] = {}   # specs own the cached descriptor templates
+
+
 def _mlp_unfused(x, weights, alphas, act: str, cst: float):
     """The same chain through the per-layer ops (used to build a double-backward graph)."""
     cur = x
     for w, al in zip(weights, alphas):
         k, n = w.shape
-        spec = LinearSpec(k, n, [LinInstr(0, 0, k, n, 1, 0, al)], "e3nn", "e3nn", [], True, True, k * n)
+        spec = _DENSE_SPECS.get((k, n, al))
+        if spec is None:
+            spec = _DENSE_SPECS[(k, n, al)] = LinearSpec(k, n, [LinInstr(0, 0, k, n, 1, 0, al)], "e3nn", "e3nn", [], True, True, k * n)
         cur = activation(strided_linear(cur, w.reshape(-1), None, spec), act, cst)
     return cur
 

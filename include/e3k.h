@@ -81,6 +81,14 @@ int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream);
  * (C is read as the incoming gradient, B is accumulated with fp32 atomics; the caller zeroes B). */
 int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream);
 
+/* Cached-descriptor launch: `templates` is an array the host built once per (layer, pass); its pointer fields hold
+ * BYTE OFFSETS instead of addresses -- A, B, C relative to a_base, b_base, c_base; A2 and bias hold offset + 1
+ * (0 = absent) relative to a2_base, bias_base -- and M1 is overwritten by the argument.  wgrad != 0 runs
+ * e3k_gemm_wgrad semantics.  Same kernels, same results as e3k_gemm / e3k_gemm_wgrad on the resolved problems. */
+int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base, const void* a2_base,
+                     const void* b_base, void* c_base, const void* bias_base, int64_t M1, int32_t wgrad,
+                     void* stream);
+
 /* Grouped launch over key groups: every template problem is expanded into n_keys problems, one per
  * key t, with  B += t * b_key_stride,  row_index = perm,  group_dev = groups_dev + 2*t  and M1 kept as the
  * (host-known) upper bound of the group size.  wgrad != 0 runs e3k_gemm_wgrad semantics (B accumulated).
