@@ -1275,9 +1275,9 @@ extern "C" int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templat
   return wgrad ? gemm_wgrad_impl(buf, n_templates, 1, 0, stream) : gemm_fwd_impl(buf, n_templates, 1, 0, stream);
 }
 
-extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
-                                const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
-                                void* stream) {
+static int gemm_grouped_impl(const e3k_gemm_problem* templates, int n_templates, uintptr_t a_base, uintptr_t b_base,
+                             uintptr_t c_base, int64_t M1, const int32_t* perm, const int32_t* groups_dev, int32_t n_keys,
+                             int64_t b_key_stride, int32_t wgrad, void* stream) {
   if (n_templates < 0 || n_keys <= 0 || !perm || !groups_dev || (n_templates && !templates)) return E3K_ERR_INVALID;
   // the keys are not expanded on the host: a template occupies one slot of a launch and the workgroups work out their
   // key from their position in the template's tile range (fetch_problem) -- launches per call = templates / 8, not
@@ -1285,9 +1285,14 @@ extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templat
   e3k_gemm_problem buf[64];
   int n = 0;
   for (int i = 0; i < n_templates; ++i) {
-    buf[n] = templates[i];
-    buf[n].row_index = perm;
-    buf[n].group_dev = groups_dev;
+    e3k_gemm_problem& p = buf[n];
+    p = templates[i];
+    p.A = reinterpret_cast<const float*>(a_base + reinterpret_cast<uintptr_t>(p.A));
+    p.B = reinterpret_cast<const float*>(b_base + reinterpret_cast<uintptr_t>(p.B));
+    p.C = reinterpret_cast<float*>(c_base + reinterpret_cast<uintptr_t>(p.C));
+    if (M1 >= 0) p.M1 = (int32_t)M1;
+    p.row_index = perm;
+    p.group_dev = groups_dev;
     if (++n == 64 || i + 1 == n_templates) {
       const int rc = wgrad ? gemm_wgrad_impl(buf, n, n_keys, b_key_stride, stream) : gemm_fwd_impl(buf, n, n_keys, b_key_stride, stream);
       if (rc != E3K_OK) return rc;
@@ -1295,6 +1300,21 @@ extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templat
     }
   }
   return E3K_OK;
+}
+
+extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
+                                const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
+                                void* stream) {
+  return gemm_grouped_impl(templates, n_templates, 0, 0, 0, -1, perm, groups_dev, n_keys, b_key_stride, wgrad, stream);
+}
+
+extern "C" int e3k_gemm_grouped_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base,
+                                        const void* b_base, void* c_base, int64_t M1, const int32_t* perm,
+                                        const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
+                                        void* stream) {
+  if (M1 < 0 || M1 > 0x7fffffffLL) return E3K_ERR_INVALID;
+  return gemm_grouped_impl(templates, n_templates, reinterpret_cast<uintptr_t>(a_base), reinterpret_cast<uintptr_t>(b_base),
+                           reinterpret_cast<uintptr_t>(c_base), M1, perm, groups_dev, n_keys, b_key_stride, wgrad, stream);
 }
 
 extern "C" int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream) {

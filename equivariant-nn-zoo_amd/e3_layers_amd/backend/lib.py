@@ -67,6 +67,7 @@ SIGNATURES = {
     "e3k_gemm": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
     "e3k_gemm_wgrad": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P]),
     "e3k_gemm_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _P, _P, _I64, _I32, _P]),
+    "e3k_gemm_grouped_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _I64, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_gemm_grouped": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),

@@ -825,10 +825,12 @@ class RowGroups:
 
 
 def _kw_array(spec: "FctpSpec", m_off):
-    arr = (L.KwInstr * len(spec.instr))()
-    for i, (ins, mo) in enumerate(zip(spec.instr, m_off)):
-        arr[i].w_off, arr[i].m_off, arr[i].u, arr[i].w_out = ins.w_off, int(mo), ins.mul_in, ins.mul_out
-    return arr
+    def build():
+        arr = (L.KwInstr * len(spec.instr))()
+        for i, (ins, mo) in enumerate(zip(spec.instr, m_off)):
+            arr[i].w_off, arr[i].m_off, arr[i].u, arr[i].w_out = ins.w_off, int(mo), ins.mul_in, ins.mul_out
+        return arr
+    return _templates(spec, ("kw", tuple(m_off)), build)
 
 
 def _keyed_weights_composed(a_rep, weight, spec: "FctpSpec"):
@@ -900,76 +902,80 @@ def keyed_weights(a_rep, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: i
     return m
 
 
-def _grouped_templates(x, m_like, y, spec, m_off, ld_m, mode: str):
-    """One template problem per instruction; e3k_gemm_grouped expands them over the keys."""
-    rows = x.shape[0]
-    out = []
-    for j, ins in enumerate(spec.instr):
-        in_r2, in_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-        out_r2, out_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-        p = L.GemmProblem()
-        p.bias, p.A2, p.V = None, None, 0
-        p.M1, p.M2 = rows, ins.dim
-        p.alpha = ins.alpha
-        if mode == "fwd":      # y = x . M
-            p.A, p.B, p.C = _addr(x, ins.in_off), _addr(m_like, m_off[j]), _addr(y, ins.out_off)
-            p.N, p.K = ins.mul_out, ins.mul_in
-            p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
-            p.b_k, p.b_n = ins.mul_out, 1
-            p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
-        elif mode == "dgrad":  # gx = gy . M^T      (x := gy, y := gx)
-            p.A, p.B, p.C = _addr(x, ins.out_off), _addr(m_like, m_off[j]), _addr(y, ins.in_off)
-            p.N, p.K = ins.mul_in, ins.mul_out
-            p.a_r1, p.a_r2, p.a_k = spec.d_out, out_r2, out_n
-            p.b_k, p.b_n = 1, ins.mul_out
-            p.c_r1, p.c_r2, p.c_n = spec.d_in, in_r2, in_k
-        else:                  # wgrad: gm += x^T . gy   (y := gy)
-            p.A, p.B, p.C = _addr(x, ins.in_off), _addr(m_like, m_off[j]), _addr(y, ins.out_off)
-            p.N, p.K = ins.mul_out, ins.mul_in
-            p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
-            p.b_k, p.b_n = ins.mul_out, 1
-            p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
-        out.append((ins, p))
-    return out
+def _grouped_templates(spec, m_off, mode: str):
+    """One template problem per instruction with byte offsets in the pointer fields (``e3k_gemm_grouped_rebased``
+    expands them over the keys inside the kernel), split into rounds so that no two problems of one launch write the
+    same block; cached on the spec."""
+    def build():
+        tmpl = []
+        for j, ins in enumerate(spec.instr):
+            in_r2, in_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+            out_r2, out_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+            p = L.GemmProblem()
+            p.bias, p.A2, p.V = None, None, 0
+            p.M1, p.M2 = 0, ins.dim
+            p.alpha = ins.alpha
+            if mode == "fwd":      # y = x . M
+                p.A, p.B, p.C = 4 * ins.in_off, 4 * m_off[j], 4 * ins.out_off
+                p.N, p.K = ins.mul_out, ins.mul_in
+                p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
+                p.b_k, p.b_n = ins.mul_out, 1
+                p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
+            elif mode == "dgrad":  # gx = gy . M^T      (A := gy, C := gx)
+                p.A, p.B, p.C = 4 * ins.out_off, 4 * m_off[j], 4 * ins.in_off
+                p.N, p.K = ins.mul_in, ins.mul_out
+                p.a_r1, p.a_r2, p.a_k = spec.d_out, out_r2, out_n
+                p.b_k, p.b_n = 1, ins.mul_out
+                p.c_r1, p.c_r2, p.c_n = spec.d_in, in_r2, in_k
+            else:                  # wgrad: gm += x^T . gy   (C := gy)
+                p.A, p.B, p.C = 4 * ins.in_off, 4 * m_off[j], 4 * ins.out_off
+                p.N, p.K = ins.mul_out, ins.mul_in
+                p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
+                p.b_k, p.b_n = ins.mul_out, 1
+                p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
+            tmpl.append((ins, p))
+        key = {"fwd": "i_out", "dgrad": "i_in", "wgrad": ""}[mode]
+        seen: Dict[int, int] = {}
+        rounds: List[List] = []
+        for ins, p in tmpl:
+            k = getattr(ins, key) if key else id(p)
+            r = seen.get(k, 0)
+            seen[k] = r + 1
+            while len(rounds) <= r:
+                rounds.append([])
+            p.accumulate = 1 if (r > 0 or mode == "wgrad") else 0
+            rounds[r].append(p)
+        return [((L.GemmProblem * len(g))(*g), len(g)) for g in rounds]
+
+    return _templates(spec, ("grouped", mode, tuple(m_off)), build)
 
 
-def _run_grouped(templates, groups: RowGroups, ld_m: int, wgrad: bool, key: str):
-    """Launch rounds so that no two problems of one launch write the same block."""
-    seen: Dict[int, int] = {}
-    rounds: List[List] = []
-    for ins, p in templates:
-        k = getattr(ins, key) if key else id(p)
-        r = seen.get(k, 0)
-        seen[k] = r + 1
-        while len(rounds) <= r:
-            rounds.append([])
-        p.accumulate = 1 if (r > 0 or wgrad) else 0
-        rounds[r].append(p)
-    lib = L.load()
-    for grp in rounds:
-        arr = (L.GemmProblem * len(grp))(*grp)
-        L.check(lib.e3k_gemm_grouped(arr, len(grp), L.ptr(groups.perm), L.ptr(groups.bounds), groups.n_keys, ld_m,
-                                     int(wgrad), L.stream_ptr()), "e3k_gemm_grouped")
+def _run_grouped(rounds, a, b, c, rows: int, groups: RowGroups, ld_m: int, wgrad: bool):
+    lib, st = L.load(), L.stream_ptr()
+    perm, bounds = groups.perm.data_ptr(), groups.bounds.data_ptr()
+    for arr, n in rounds:
+        L.check(lib.e3k_gemm_grouped_rebased(arr, n, a.data_ptr(), b.data_ptr(), c.data_ptr(), rows, perm, bounds,
+                                             groups.n_keys, ld_m, int(wgrad), st), "e3k_gemm_grouped_rebased")
 
 
 def _grp_fwd_raw(x, m, groups, spec, m_off):
     rows, ld_m = x.shape[0], m.shape[1]
     # rows of absent keys do not exist, every node belongs to exactly one key: full coverage
     y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
-    _run_grouped(_grouped_templates(x, m, y, spec, m_off, ld_m, "fwd"), groups, ld_m, False, "i_out")
+    _run_grouped(_grouped_templates(spec, m_off, "fwd"), x, m, y, rows, groups, ld_m, False)
     return y
 
 
 def _grp_dgrad_raw(gy, m, groups, spec, m_off):
     rows, ld_m = gy.shape[0], m.shape[1]
     gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
-    _run_grouped(_grouped_templates(gy, m, gx, spec, m_off, ld_m, "dgrad"), groups, ld_m, False, "i_in")
+    _run_grouped(_grouped_templates(spec, m_off, "dgrad"), gy, m, gx, rows, groups, ld_m, False)
     return gx
 
 
 def _grp_wgrad_raw(x, gy, m_shape, groups, spec, m_off):
     gm = torch.zeros(m_shape, device=x.device, dtype=torch.float32)
-    _run_grouped(_grouped_templates(x, gm, gy, spec, m_off, m_shape[1], "wgrad"), groups, m_shape[1], True, "")
+    _run_grouped(_grouped_templates(spec, m_off, "wgrad"), x, gm, gy, x.shape[0], groups, m_shape[1], True)
     return gm
 
 
@@ -1281,10 +1287,17 @@ def activation(x, name: str, cst: float):
     return ActFn.apply(_c(x), ACT_IDS[name], float(cst))
 
 
+_BLOCK_ARRAYS: Dict[Tuple, object] = {}
+
+
 def _blocks(blocks: Sequence[Tuple[int, int, int]]):
-    arr = (L.Block * max(len(blocks), 1))()
-    for i, (off, mul, dim) in enumerate(blocks):
-        arr[i].off, arr[i].mul, arr[i].dim = off, mul, dim
+    key = tuple(blocks)
+    arr = _BLOCK_ARRAYS.get(key)
+    if arr is None:
+        arr = (L.Block * max(len(blocks), 1))()
+        for i, (off, mul, dim) in enumerate(blocks):
+            arr[i].off, arr[i].mul, arr[i].dim = off, mul, dim
+        _BLOCK_ARRAYS[key] = arr
     return arr
 
 
@@ -1319,9 +1332,12 @@ class GateSpec:
     segs: List[Tuple[int, int, int, int, int, int, int, float]]  # kind,in_off,gate_off,out_off,mul,dim,act,cst
 
     def c_array(self):
-        arr = (L.GateSeg * len(self.segs))()
-        for i, s in enumerate(self.segs):
-            (arr[i].kind, arr[i].in_off, arr[i].gate_off, arr[i].out_off, arr[i].mul, arr[i].dim, arr[i].act, arr[i].cst) = s
+        arr = self.__dict__.get("_arr")
+        if arr is None:
+            arr = (L.GateSeg * len(self.segs))()
+            for i, s in enumerate(self.segs):
+                (arr[i].kind, arr[i].in_off, arr[i].gate_off, arr[i].out_off, arr[i].mul, arr[i].dim, arr[i].act, arr[i].cst) = s
+            self.__dict__["_arr"] = arr
         return arr
 
 

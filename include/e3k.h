@@ -96,6 +96,13 @@ int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const v
 int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
                      const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad, void* stream);
 
+/* e3k_gemm_grouped over cached descriptors: A, B, C of the templates hold byte offsets relative to the bases (as in
+ * e3k_gemm_rebased; no A2 / bias in keyed problems), M1 is overwritten. */
+int e3k_gemm_grouped_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base,
+                             const void* b_base, void* c_base, int64_t M1, const int32_t* perm,
+                             const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
+                             void* stream);
+
 /* Column sums: out[n] += sum_r G[r*ld + n]   (bias gradients) */
 int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream);
 
