@@ -29,11 +29,7 @@ from .graph import GraphTopo
 # fused TP+reduce forward kernel (HIP events on the launching stream); None = no profiling.
 PROFILE_TP = None
 
-# Independent backward kernels of one op (e.g. grad-wrt-weights streams grad_w to HBM while
-# grad-wrt-x gathers from L2/MALL; dgrad and wgrad of a GEMM read the same gradient) are issued on
-# two HIP streams so that they overlap; the side stream is joined before the op returns.
 import os as _os
-OVERLAP_STREAMS = int(_os.environ.get("E3K_OVERLAP", "0"))  # 0 off (default), 1 TP backward only, 2 also GEMM dgrad/wgrad
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 # E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture; bench --graph: 30.2k vs 29.7k
 # eager at 256 molecules).  Default 1 keeps captures single-stream.
@@ -41,8 +37,8 @@ FORK_IN_CAPTURE = _os.environ.get("E3K_FWD_FORK") == "2"
 
 
 def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
-    """A per-device side stream for an independent branch (``which`` = 0: radial MLP of a convolution and the opt-in
-    backward overlap; 1: the self-connection).  Work enqueued there is joined by ``join_side_streams()`` before
+    """A per-device side stream for an independent branch (``which`` = 0: radial MLP of a convolution; 1: the self-connection; 2: sunk
+    weight gradients).  Work enqueued there is joined by ``join_side_streams()`` before
     anything outside autograd (optimizer, all-reduce) reads its results."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = idx if which == 0 else (idx, which)
@@ -64,33 +60,6 @@ def join_side_streams() -> None:
     for key, st in _side_streams.items():
         if (key if isinstance(key, int) else key[0]) == cur_dev:
             torch.cuda.current_stream().wait_stream(st)
-
-
-class _Fork:
-    """with _Fork(dev) as f: f.side(lambda: ...); ...main work...   -> joins on exit."""
-
-    def __init__(self, device):
-        self.device = device
-        self.used = False
-
-    def __enter__(self):
-        self.cur = torch.cuda.current_stream(self.device)
-        self.st = side_stream(self.device)
-        return self
-
-    def side(self, fn):
-        if not OVERLAP_STREAMS or torch.cuda.is_current_stream_capturing():
-            return fn()
-        self.st.wait_stream(self.cur)
-        with torch.cuda.stream(self.st):
-            out = fn()
-        self.used = True
-        return out
-
-    def __exit__(self, *exc):
-        if self.used:
-            self.cur.wait_stream(self.st)
-        return False
 
 
 # Gradient sink: run/parallel.FlatGradients registers (data_ptr, numel) -> view of its flat gradient
@@ -459,30 +428,27 @@ class StridedLinearFn(torch.autograd.Function):
         gy = L.f32c(gy)
         rows = x.shape[0]
         gx = gw = gb = None
-        with _Fork(x.device) as fork:
-            sunk = False
-            if need[1]:
-                gw = _sink_for(weight)
-                sunk = gw is not None
-                if not sunk:
-                    gw = torch.zeros_like(weight)
-                if OVERLAP_STREAMS >= 2 and need[0] and rows * spec.d_out >= (1 << 22):
-                    fork.side(lambda: _lin_wgrad_raw(x, gy, gw, spec, scale))   # big enough to pay for the stream join
-                elif (sunk and WGRAD_SIDE and ctx.in_fork and need[0] and rows >= WGRAD_SIDE_MIN_ROWS
-                      and not torch.cuda.is_current_stream_capturing()):
-                    # a weight gradient that lands in the gradient sink is off the critical path: nothing in the
-                    # backward consumes it, so it goes to a side stream that only the optimizer / all-reduce joins
-                    cur = torch.cuda.current_stream(x.device)
-                    st = side_stream(x.device, 2)
-                    st.wait_stream(cur)
-                    with torch.cuda.stream(st):
-                        _lin_wgrad_raw(x, gy, gw, spec, scale)
-                    x.record_stream(st)
-                    gy.record_stream(st)
-                else:
+        sunk = False
+        if need[1]:
+            gw = _sink_for(weight)
+            sunk = gw is not None
+            if not sunk:
+                gw = torch.zeros_like(weight)
+            if (sunk and WGRAD_SIDE and ctx.in_fork and need[0] and rows >= WGRAD_SIDE_MIN_ROWS
+                    and not torch.cuda.is_current_stream_capturing()):
+                # a weight gradient that lands in the gradient sink is off the critical path: nothing in the
+                # backward consumes it, so it goes to a side stream that only the optimizer / all-reduce joins
+                cur = torch.cuda.current_stream(x.device)
+                st = side_stream(x.device, 2)
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
                     _lin_wgrad_raw(x, gy, gw, spec, scale)
-            if need[0]:
-                gx = _lin_dgrad_raw(gy, weight, spec, scale)
+                x.record_stream(st)
+                gy.record_stream(st)
+            else:
+                _lin_wgrad_raw(x, gy, gw, spec, scale)
+        if need[0]:
+            gx = _lin_dgrad_raw(gy, weight, spec, scale)
         if sunk:
             gw = None   # already accumulated into the flat gradient buffer
         if ctx.has_bias and need[2]:
@@ -1143,11 +1109,10 @@ class TpFn(torch.autograd.Function):
             return gx, (gsh if need_sh else None), (gw if need_w else None), None, None, None
         g_out = L.f32c(g_out)
         gx = gsh = gw = None
-        with _Fork(x.device) as fork:
-            if need_x:
-                gx = fork.side(lambda: _tp_bwd_x_raw(sh, w, g_out, topo, plan))
-            if need_sh or need_w:
-                gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, bool(need_sh), bool(need_w))
+        if need_x:
+            gx = _tp_bwd_x_raw(sh, w, g_out, topo, plan)
+        if need_sh or need_w:
+            gw, gsh = _tp_bwd_w_raw(x, sh, w, g_out, topo, plan, bool(need_sh), bool(need_w))
         return gx, gsh, gw, None, None, None
 
 
