@@ -37,7 +37,12 @@ from .sequential import Module
 # (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
 FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
 FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connection runs on a third stream (+7 % on the bench)
-FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "49152"))   # below this the step is host-bound and the extra stream switches cost more than they hide
+# The fork pays when the branches are long enough to hide the extra stream switches (≈ 0.3 ms of host time per
+# step): the yardstick is the size of the per-edge weight tensor, edges x weight_numel, counted in edges of a
+# 1920-weight layer (n_dim 64, l_max 2).  Measured: config_energy 256 molecules (69 k x 1920) +12 %, protein
+# (29 k x 1920) +10 %, config_diffusion (42 k x 960) -15 %, config_energy_force 64 molecules (20 k x 1920) -10 %.
+FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
+_FORK_REF_WIDTH = 1920
 
 
 class FactorizedConvolution(Module):
@@ -61,6 +66,7 @@ class FactorizedConvolution(Module):
         self.tp = TensorProductExpansion(f_in, (sh, "edge_spherical"), (f_out, "edge_features"), "uvu",
                                          internal_weight=False)
         n_radial = Irreps(self.irreps_in["edge_radial"]).num_irreps
+        self._weight_numel = int(self.tp.tp.weight_numel)
         self.fc = FullyConnectedNet([n_radial] + invariant_layers * [invariant_neurons] + [self.tp.tp.weight_numel],
                                     activations["ssp"])
         self.sc = None
@@ -69,11 +75,15 @@ class FactorizedConvolution(Module):
         self._in_blocks = tuple(irreps_blocks(f_in))
         self._out_blocks = tuple(irreps_blocks(f_out))
 
+    def _fork_pays(self, n_edges: int) -> bool:
+        # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
+        return (n_edges * self._weight_numel >= FORK_MIN_EDGES * _FORK_REF_WIDTH) or n_edges >= 2 * FORK_MIN_EDGES
+
     def forward_cf(self, data: Dict[str, Tensor]) -> Tensor:
         """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
-        if (FWD_FORK and x.is_cuda and data["edge_radial"].shape[0] >= FORK_MIN_EDGES
+        if (FWD_FORK and x.is_cuda and self._fork_pays(data["edge_radial"].shape[0])
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
