@@ -163,27 +163,47 @@ def main():
         graph = captured.graph
         run = captured
 
-    for _ in range(args.warmup):
+    def max_over_ranks(seconds: float) -> float:
+        t = torch.tensor([seconds], device=dev, dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    # W untimed warm-up steps; the last few are clocked only as a reference rate, to recognise a timed region that an
+    # external stall (another tenant of the box, a clock dip) stretched several-fold
+    n_ref = min(args.warmup, 3)
+    for _ in range(args.warmup - n_ref):
         run()
     fence()
-    ops.PROFILE_TP = [] if graph is None else None
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = run()
+    for _ in range(n_ref):
+        run()
     fence()
-    elapsed = time.perf_counter() - t0
-    records, ops.PROFILE_TP = ops.PROFILE_TP, None
+    ref_step = max_over_ranks(time.perf_counter() - t0) / n_ref if n_ref else None
+
+    def timed_region():
+        ops.PROFILE_TP = [] if graph is None else None
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = run()
+        fence()
+        seconds = time.perf_counter() - t0
+        recs, ops.PROFILE_TP = ops.PROFILE_TP, None
+        return max_over_ranks(seconds), recs, out
+
+    elapsed, records, loss = timed_region()
+    first_elapsed = None
+    if ref_step is not None and elapsed / args.steps > 3.0 * ref_step:
+        # exactly K steps are timed again, once; the line reports the repeat and says so (config.retimed_after_stall)
+        first_elapsed = elapsed
+        elapsed, records, loss = timed_region()
     if graph is not None:  # per-kernel events cannot be read back from a replayed graph: eager pass for the roofline block
         ops.PROFILE_TP = []
         for _ in range(min(args.steps, 5)):
             step()
         torch.cuda.synchronize()
         records, ops.PROFILE_TP = ops.PROFILE_TP, None
-
-    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
 
     # roofline of the fused TP+reduce forward kernel (rank 0's launches in the timed region)
     tot_bytes, tot_ms = 0.0, 0.0
@@ -226,6 +246,9 @@ def main():
             },
             "roofline": roofline,
         }
+        if first_elapsed is not None:
+            result["config"]["retimed_after_stall"] = {"first_ms_per_step": round(1e3 * first_elapsed / args.steps, 3),
+                                                       "warmup_ms_per_step": round(1e3 * ref_step, 3)}
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(tree, config_energy.QM9_SHIFTS, args.cpu_sample)
         print(json.dumps(result), flush=True)
