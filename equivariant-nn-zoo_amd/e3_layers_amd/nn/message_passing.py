@@ -43,6 +43,10 @@ FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connec
 # (29 k x 1920) +10 %, config_diffusion (42 k x 960) -15 %, config_energy_force 64 molecules (20 k x 1920) -10 %.
 FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
 _FORK_REF_WIDTH = 1920
+# 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
+# as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next
+RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "1"))
+AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 
 
 class FactorizedConvolution(Module):
@@ -75,6 +79,9 @@ class FactorizedConvolution(Module):
         self._in_blocks = tuple(irreps_blocks(f_in))
         self._out_blocks = tuple(irreps_blocks(f_out))
 
+    _next_conv = None      # set by SequentialGraphNetwork
+    _prefetched = None     # (edge embedding, weights, ready event, grad mode) issued by the previous convolution
+
     def _fork_pays(self, n_edges: int) -> bool:
         # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
         return (n_edges * self._weight_numel >= FORK_MIN_EDGES * _FORK_REF_WIDTH) or n_edges >= 2 * FORK_MIN_EDGES
@@ -91,9 +98,24 @@ class FactorizedConvolution(Module):
             try:
                 main = torch.cuda.current_stream(x.device)
                 side = ops.side_stream(x.device)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    weight = self.fc(data["edge_radial"])
+                radial = data["edge_radial"]
+                pref, self._prefetched = self._prefetched, None
+                if pref is not None and pref[0] is radial and pref[3] == torch.is_grad_enabled():
+                    weight, ready = pref[1], pref[2]      # issued one layer ago
+                    AHEAD_STATS[0] += 1
+                else:
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        weight = self.fc(radial)
+                        ready = torch.cuda.Event()
+                        ready.record(side)
+                nxt = self._next_conv if RADIAL_AHEAD else None
+                if nxt is not None and nxt._fork_pays(radial.shape[0]):
+                    with torch.cuda.stream(side):
+                        w_next = nxt.fc(radial)
+                        ev_next = torch.cuda.Event()
+                        ev_next.record(side)
+                    nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
                 x_cf = ops.relayout(x, self._in_blocks, True)
                 sc = None
                 if self.sc is not None and FWD_FORK_SC:
@@ -105,7 +127,7 @@ class FactorizedConvolution(Module):
                 elif self.sc is not None:
                     sc = self.sc(x_cf, data["node_attrs"])
                 x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
-                main.wait_stream(side)
+                main.wait_event(ready)
                 weight.record_stream(main)
                 if sc is not None and FWD_FORK_SC:
                     if FWD_FORK_SC >= 2:   # experiment: join the self-connection before the tensor product

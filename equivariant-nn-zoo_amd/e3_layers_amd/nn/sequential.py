@@ -64,6 +64,17 @@ class SequentialGraphNetwork(torch.nn.Sequential):
             else:
                 raise TypeError(f"invalid config node for layer {key!r}")
         super().__init__(modules)
+        # radial look-ahead (nn/message_passing.py): every convolution knows the next one whose radial MLP reads the
+        # same edge embedding, so that MLP can be issued one layer early on the side stream
+        prev = None
+        for _, layer in self.layers:
+            conv = getattr(layer, "conv", None)
+            if conv is None or not hasattr(conv, "fc") or not getattr(conv, "reduce", False):
+                continue
+            src = next((g for g, loc in getattr(layer, "input_key_mapping", {}).items() if loc == "edge_radial"), None)
+            if prev is not None and prev[1] == src and src is not None:
+                object.__setattr__(prev[0], "_next_conv", conv)     # a plain reference, not a registered submodule
+            prev = (conv, src)
 
     def forward(self, batch):
         data, attrs = batch.data, batch.attrs

@@ -645,3 +645,36 @@ def test_captured_force_training_step_equals_eager(dev):
     finally:
         from e3_layers_amd.backend import ops
         ops.GRAD_SINK.clear()
+
+
+def test_radial_look_ahead_equals_in_order(dev, monkeypatch):
+    """The radial MLP of the next convolution is issued one layer early on the side stream (E3K_RADIAL_AHEAD): same
+    energies and parameter gradients as the in-order schedule, and the look-ahead weights are the ones consumed."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    model = build(_energy_tree(2, 16, 3)).to(dev).train()
+    batch = synth_qm9(4, 12).to(dev)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+
+    def run(ahead):
+        monkeypatch.setattr(mp, "RADIAL_AHEAD", ahead)
+        mp.AHEAD_STATS[0] = 0
+        model.zero_grad(set_to_none=True)
+        out = model(batch.clone())["total_energy"]
+        out.square().mean().backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return out.detach().clone(), torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]), mp.AHEAD_STATS[0]
+
+    e0, g0, hits0 = run(0)
+    e1, g1, hits1 = run(1)
+    with torch.no_grad():      # a look-ahead issued under another grad mode must not be consumed
+        model(batch.clone())
+    e2, g2, _ = run(1)
+    assert hits0 == 0 and hits1 == 2       # three convolutions: the second and third find their weights waiting
+    assert rel_err(e1, e0) < 1e-6 and rel_err(g1, g0) < 1e-5
+    assert rel_err(e2, e0) < 1e-6 and rel_err(g2, g0) < 1e-5
