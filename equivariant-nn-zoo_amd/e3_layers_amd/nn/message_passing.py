@@ -49,6 +49,27 @@ RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "1"))
 AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 
 
+def _stream_alias(t: Tensor, stream) -> Tensor:
+    """A view of ``t`` whose autograd node lives on ``stream`` (call it with that stream current).  Every convolution
+    reads the edge embedding on the radial side stream and the node attributes on the self-connection stream; without
+    the alias their gradient contributions are summed at the producer's node, on the MAIN stream, which then waits
+    for each layer's side branch in turn (≈ 250 us per layer in the backward).  Summed at the alias they stay on the
+    side stream and reach the main stream once."""
+    if not (t.requires_grad and torch.is_grad_enabled()):
+        return t
+    cache = getattr(t, "_e3k_alias", None)
+    if cache is None:
+        cache = t._e3k_alias = {}
+    key = stream.cuda_stream
+    alias = cache.get(key)
+    if alias is None:
+        alias = cache[key] = t.view_as(t)
+        for attr in ("_e3k_key", "_e3k_data_only", "_e3k_param_only"):      # row keys / provenance marks ride along
+            if hasattr(t, attr):
+                setattr(alias, attr, getattr(t, attr))
+    return alias
+
+
 class FactorizedConvolution(Module):
     avg_num_neighbors: Optional[float]
     use_sc: bool
@@ -106,13 +127,13 @@ class FactorizedConvolution(Module):
                 else:
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        weight = self.fc(radial)
+                        weight = self.fc(_stream_alias(radial, side))
                         ready = torch.cuda.Event()
                         ready.record(side)
                 nxt = self._next_conv if RADIAL_AHEAD else None
                 if nxt is not None and nxt._fork_pays(radial.shape[0]):
                     with torch.cuda.stream(side):
-                        w_next = nxt.fc(radial)
+                        w_next = nxt.fc(_stream_alias(radial, side))
                         ev_next = torch.cuda.Event()
                         ev_next.record(side)
                     nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
@@ -123,7 +144,7 @@ class FactorizedConvolution(Module):
                     side2 = ops.side_stream(x.device, 1)
                     side2.wait_stream(main)
                     with torch.cuda.stream(side2):
-                        sc = self.sc(x_cf, data["node_attrs"])
+                        sc = self.sc(x_cf, _stream_alias(data["node_attrs"], side2))
                 elif self.sc is not None:
                     sc = self.sc(x_cf, data["node_attrs"])
                 x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
