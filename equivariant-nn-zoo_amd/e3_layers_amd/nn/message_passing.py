@@ -44,8 +44,11 @@ FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connec
 FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
 _FORK_REF_WIDTH = 1920
 # 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
-# as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next
-RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "1"))
+# as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next.
+# Measured at 256 molecules: step 7.06 -> 6.91 ms (-2 %), but the HBM-bound tensor product then shares the memory
+# system with an MFMA GEMM that writes 0.5 GB: 134 -> 182 us per launch (roofline 0.64 -> 0.47).  Opt-in; issuing it
+# only after the tensor product (under the node-side launches) changed nothing.
+RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "0"))
 AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 
 
@@ -103,6 +106,14 @@ class FactorizedConvolution(Module):
     _next_conv = None      # set by SequentialGraphNetwork
     _prefetched = None     # (edge embedding, weights, ready event, grad mode) issued by the previous convolution
 
+    @staticmethod
+    def _issue_ahead(nxt, radial, side):
+        with torch.cuda.stream(side):
+            w_next = nxt.fc(_stream_alias(radial, side))
+            ev_next = torch.cuda.Event()
+            ev_next.record(side)
+        nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
+
     def _fork_pays(self, n_edges: int) -> bool:
         # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
         return (n_edges * self._weight_numel >= FORK_MIN_EDGES * _FORK_REF_WIDTH) or n_edges >= 2 * FORK_MIN_EDGES
@@ -131,12 +142,10 @@ class FactorizedConvolution(Module):
                         ready = torch.cuda.Event()
                         ready.record(side)
                 nxt = self._next_conv if RADIAL_AHEAD else None
-                if nxt is not None and nxt._fork_pays(radial.shape[0]):
-                    with torch.cuda.stream(side):
-                        w_next = nxt.fc(_stream_alias(radial, side))
-                        ev_next = torch.cuda.Event()
-                        ev_next.record(side)
-                    nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
+                if nxt is not None and not nxt._fork_pays(radial.shape[0]):
+                    nxt = None
+                if nxt is not None:
+                    self._issue_ahead(nxt, radial, side)
                 x_cf = ops.relayout(x, self._in_blocks, True)
                 sc = None
                 if self.sc is not None and FWD_FORK_SC:
