@@ -251,7 +251,7 @@ __global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restric
 // keyed self-connection weights:  M[t, (j,u,w)] = sum_v a[t,v] W_j[u,v,w]
 // (W_j stored [U][V][Wout] as e3nn's 'uvw' weights; one thread per column (j,u,w), coalesced along w)
 // ---------------------------------------------------------------------------------------
-constexpr int KW_MAXI = 16, KW_MAXV = 32, KW_MAXK = 64;
+constexpr int KW_MAXI = 16, KW_MAXV = 32, KW_MAXK = 1 << 22;
 struct KwArgs {
   int n, K, V;
   int64_t ld_m, total;
@@ -269,12 +269,17 @@ __device__ __forceinline__ const float* kw_locate(const KwArgs& ka, int64_t c, c
   return W + in.w_off + (int64_t)u * ka.V * in.w_out + w;
 }
 
+// grid.y tiles the keys (KW_KT per workgroup): a handful of species keys is one tile; the un-keyed self-connection
+// uses the same kernels with one key per node (thousands of keys)
+constexpr int KW_KT = 64;
 template <int MODE>   // 0: M = a . W    1: gW (+)= a^T . gM    (MODE 1: `M` is gM, `Wout_` is gW)
 __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restrict__ a, const float* __restrict__ W,
                                                              KwArgs ka, float* __restrict__ M, float* __restrict__ Wout_,
                                                              int accumulate) {
-  __shared__ float as[KW_MAXK * KW_MAXV];
-  for (int i = threadIdx.x; i < ka.K * ka.V; i += 256) as[i] = a[i];
+  __shared__ float as[KW_KT * KW_MAXV];
+  const int t0 = blockIdx.y * KW_KT;
+  const int kt = (ka.K - t0 < KW_KT) ? ka.K - t0 : KW_KT;
+  for (int i = threadIdx.x; i < kt * ka.V; i += 256) as[i] = a[(int64_t)t0 * ka.V + i];
   __syncthreads();
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= ka.total) return;
@@ -284,27 +289,54 @@ __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restr
     float wv[KW_MAXV];
 #pragma unroll
     for (int v = 0; v < KW_MAXV; ++v) wv[v] = v < ka.V ? base[(int64_t)v * wout] : 0.f;
-    for (int t = 0; t < ka.K; ++t) {
+    for (int t = 0; t < kt; ++t) {
       float acc = 0.f;
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
         if (v < ka.V) acc = fmaf(as[t * ka.V + v], wv[v], acc);
-      M[(int64_t)t * ka.ld_m + c] = acc;
+      M[(int64_t)(t0 + t) * ka.ld_m + c] = acc;
     }
   } else {
     float gv[KW_MAXV];
 #pragma unroll
     for (int v = 0; v < KW_MAXV; ++v) gv[v] = 0.f;
-    for (int t = 0; t < ka.K; ++t) {
-      const float g = M[(int64_t)t * ka.ld_m + c];
+    for (int t = 0; t < kt; ++t) {
+      const float g = M[(int64_t)(t0 + t) * ka.ld_m + c];
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
         if (v < ka.V) gv[v] = fmaf(as[t * ka.V + v], g, gv[v]);
     }
     float* dst = Wout_ + (base - W);
+    if (gridDim.y == 1) {
 #pragma unroll
-    for (int v = 0; v < KW_MAXV; ++v)
-      if (v < ka.V) dst[(int64_t)v * wout] = accumulate ? dst[(int64_t)v * wout] + gv[v] : gv[v];
+      for (int v = 0; v < KW_MAXV; ++v)
+        if (v < ka.V) dst[(int64_t)v * wout] = accumulate ? dst[(int64_t)v * wout] + gv[v] : gv[v];
+    } else {   // several key tiles add into the same element (the launcher zero-fills when not accumulating)
+#pragma unroll
+      for (int v = 0; v < KW_MAXV; ++v)
+        if (v < ka.V) atomicAdd(dst + (int64_t)v * wout, gv[v]);
+    }
+  }
+}
+
+// W_j[u][v][w] (e3nn 'uvw' order)  <->  Wv[v][c], c = packed (j,u,w): the dense [V x C] operand of the per-node weight
+// GEMMs (M = attrs . Wv and its two gradients).  One thread per column c, coalesced along w both ways.
+template <int TO_VC>
+__global__ __launch_bounds__(256) void kw_permute_kernel(const float* __restrict__ src, KwArgs ka, float* __restrict__ dst,
+                                                          int accumulate) {
+  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (c >= ka.total) return;
+  int wout;
+  const float* base = kw_locate(ka, c, (const float*)nullptr, wout);   // offset of W[u][0][w] as a pointer from 0
+  const int64_t off = base - (const float*)nullptr;
+  for (int v = 0; v < ka.V; ++v) {
+    if (TO_VC) {
+      dst[(int64_t)v * ka.ld_m + c] = src[off + (int64_t)v * wout];
+    } else {
+      const float g = src[(int64_t)v * ka.ld_m + c];
+      float* d = dst + off + (int64_t)v * wout;
+      *d = accumulate ? *d + g : g;
+    }
   }
 }
 
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restr
 // Stage 1: a block stages 256 columns of gM ([K][256]) and of W ([V][256]) in LDS with coalesced loads; thread
 // (t, v) then owns one output and walks the 256 columns with 16-byte LDS reads; the block's K*V partials go to a
 // workspace row.  Stage 2: one block sums the workspace rows into ga (no same-address atomics: they serialised).
-constexpr int KWA_COLS = 256, KWA_KT = 16;
+constexpr int KWA_COLS = 256, KWA_KT = 16, KWA_RANGE = 128;
 __global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* __restrict__ gM, const float* __restrict__ W,
                                                                    KwArgs ka, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
@@ -326,8 +358,11 @@ __global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* _
     for (int v = 0; v < ka.V; ++v) wsm[v][t_id] = ok ? base[(int64_t)v * wout] : 0.f;
   }
   float* out = ws + (int64_t)blockIdx.x * ka.K * ka.V;
-  for (int t0 = 0; t0 < ka.K; t0 += KWA_KT) {
-    const int kt = (ka.K - t0 < KWA_KT) ? ka.K - t0 : KWA_KT;
+  // grid.y splits the keys into ranges of KWA_RANGE (outputs of different keys are distinct: no conflicts)
+  const int t_begin = blockIdx.y * KWA_RANGE;
+  const int t_end = (t_begin + KWA_RANGE < ka.K) ? t_begin + KWA_RANGE : ka.K;
+  for (int t0 = t_begin; t0 < t_end; t0 += KWA_KT) {
+    const int kt = (t_end - t0 < KWA_KT) ? t_end - t0 : KWA_KT;
     __syncthreads();   // previous chunk's readers are done (and wsm is complete on the first trip)
     for (int t = 0; t < kt; ++t) gs[t][t_id] = ok ? gM[(int64_t)(t0 + t) * ka.ld_m + c] : 0.f;
     __syncthreads();
@@ -711,8 +746,22 @@ extern "C" int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_k
   const int rc = make_kw(instr, n_instr, n_keys, V, ld_m, ka);
   if (rc != E3K_OK) return rc;
   if (!a || !W || !M) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::keyed_weights_kernel<0>, dim3((unsigned)((ka.total + 255) / 256)), dim3(256), 0,
+  hipLaunchKernelGGL(e3k::keyed_weights_kernel<0>,
+                     dim3((unsigned)((ka.total + 255) / 256), (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT)), dim3(256), 0,
                      (hipStream_t)stream, a, W, ka, M, (float*)nullptr, 0);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_fctp_weight_permute(const float* src, const e3k_kw_instr* instr, int32_t n_instr, int32_t V,
+                                       int64_t ld_m, float* dst, int32_t to_vc, int32_t accumulate, void* stream) {
+  e3k::KwArgs ka{};
+  const int rc = make_kw(instr, n_instr, 1, V, ld_m, ka);
+  if (rc != E3K_OK) return rc;
+  if (!src || !dst) return E3K_ERR_INVALID;
+  const dim3 grid((unsigned)((ka.total + 255) / 256));
+  if (to_vc) hipLaunchKernelGGL(e3k::kw_permute_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, ka, dst, 0);
+  else hipLaunchKernelGGL(e3k::kw_permute_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, ka, dst, accumulate);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
@@ -732,15 +781,23 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
   if (rc != E3K_OK) return rc;
   if (!a || !W || !g_M || (!g_a && !g_W)) return E3K_ERR_INVALID;
   if (g_W) {
-    hipLaunchKernelGGL(e3k::keyed_weights_kernel<1>, dim3((unsigned)((ka.total + 255) / 256)), dim3(256), 0,
+    const unsigned tiles = (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT);
+    if (tiles > 1 && !accumulate_w) {   // the key tiles add with atomics: start from zero
+      for (int i = 0; i < n_instr; ++i)
+        if (hipMemsetAsync(g_W + instr[i].w_off, 0, sizeof(float) * (size_t)instr[i].u * V * instr[i].w_out,
+                           (hipStream_t)stream) != hipSuccess)
+          return E3K_ERR_LAUNCH;
+    }
+    hipLaunchKernelGGL(e3k::keyed_weights_kernel<1>, dim3((unsigned)((ka.total + 255) / 256), tiles), dim3(256), 0,
                        (hipStream_t)stream, a, W, ka, const_cast<float*>(g_M), g_W, accumulate_w);
     E3K_CHECK_LAUNCH();
   }
   if (g_a) {
     if (!workspace) return E3K_ERR_INVALID;
     const int64_t blocks = (ka.total + e3k::KWA_COLS - 1) / e3k::KWA_COLS;
-    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, g_M, W,
-                       ka, workspace);
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_kernel,
+                       dim3((unsigned)blocks, (unsigned)((n_keys + e3k::KWA_RANGE - 1) / e3k::KWA_RANGE)), dim3(256), 0,
+                       (hipStream_t)stream, g_M, W, ka, workspace);
     E3K_CHECK_LAUNCH();
     const int n = n_keys * V;
     hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,

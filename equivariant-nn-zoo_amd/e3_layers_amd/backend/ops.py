@@ -774,6 +774,203 @@ def fctp(x, attrs, weight, spec: FctpSpec):
 
 
 # --------------------------------------------------------------------------------------
+# Un-keyed self-connection through per-node contracted weights (csrc/e3k_fctp.hip): M[n] = sum_v attrs[n,v] W[:,v,:]
+# (KeyedWeightsFn with one key per node), then  out[n,k,:] = alpha * x[n,k,:] . M[n]  (RowMatFn below).
+# --------------------------------------------------------------------------------------
+def rowmat_supported(spec: "FctpSpec") -> bool:
+    """The second stage needs cf blocks, output blocks owned by one instruction each, <= 64 input channels per block
+    (backward), and must save work: with A = sum dim*U*W and B = sum U*W the direct form costs V*A multiply-adds, the
+    two-stage form V*B + A (plus six passes over the N x B matrix M): taken from a 1.5-fold saving on."""
+    ins = spec.instr
+    if spec.in_layout != "cf" or spec.out_layout != "cf" or not ins or len(ins) > 16 or spec.v > 32:
+        return False
+    if len({i.i_out for i in ins}) != len(ins):
+        return False
+    if any(i.mul_in > 64 or i.dim > 7 for i in ins):
+        return False
+    a = sum(i.dim * i.mul_in * i.mul_out for i in ins)
+    b = sum(i.mul_in * i.mul_out for i in ins)
+    return spec.v * a >= 1.5 * (spec.v * b + a)
+
+
+def _dense_problem(a, b, c, m1, n, k, a_r1, b_k, b_n, c_r1, accumulate=0):
+    p = L.GemmProblem()
+    p.A, p.A2, p.B, p.C, p.bias = a, None, b, c, None
+    p.M1, p.M2, p.N, p.K, p.V = m1, 1, n, k, 0
+    p.accumulate = accumulate
+    p.a_r1, p.a_r2, p.a_k = a_r1, 0, 1
+    p.b_k, p.b_n = b_k, b_n
+    p.c_r1, p.c_r2, p.c_n = c_r1, 0, 1
+    p.alpha = 1.0
+    return p
+
+
+class RowWeightsFn(torch.autograd.Function):
+    """M[n, c] = sum_v attrs[n, v] Wv[v, c]: one contracted weight matrix per node as a dense MFMA GEMM over the
+    [V, C] view of the 'uvw' weight (``e3k_fctp_weight_permute``); both gradients are dense GEMMs too — the one w.r.t.
+    attrs has a 32-wide output and a 40 k-deep reduction, so it runs as 16 K-slices with separate partial outputs."""
+
+    K_SLICES = 16
+
+    @staticmethod
+    def forward(ctx, attrs, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
+        ctx.param_slots = _param_slots(attrs, weight)
+        L.require_cuda(attrs, weight)
+        attrs, weight = L.f32c(attrs), L.f32c(weight)
+        rows, v = attrs.shape
+        lib = L.load()
+        wv = torch.empty(v, ld_m, device=attrs.device, dtype=torch.float32)
+        L.check(lib.e3k_fctp_weight_permute(L.ptr(weight), _kw_array(spec, m_off), len(spec.instr), v, ld_m, L.ptr(wv), 1, 0,
+                                            L.stream_ptr()), "e3k_fctp_weight_permute")
+        m = torch.empty(rows, ld_m, device=attrs.device, dtype=torch.float32)
+        _run_gemm([_dense_problem(_addr(attrs), _addr(wv), _addr(m), rows, ld_m, v, v, ld_m, 1, ld_m)])
+        ctx.save_for_backward(attrs, weight, wv)
+        ctx.cfg = (spec, m_off, ld_m)
+        return m
+
+    @staticmethod
+    def backward(ctx, gm):
+        need = _needs(ctx)
+        attrs, weight, wv = ctx.saved_tensors
+        spec, m_off, ld_m = ctx.cfg
+        need_a, need_w = need[:2]
+        if torch.is_grad_enabled():
+            wrt = [t for t, nd in zip((attrs, weight), (need_a, need_w)) if nd]
+            if not wrt:
+                return None, None, None, None, None
+            with torch.enable_grad():
+                grads = list(torch.autograd.grad(_keyed_weights_composed(attrs, weight, spec), wrt, gm, create_graph=True))
+            return (grads.pop(0) if need_a else None), (grads.pop(0) if need_w else None), None, None, None
+        gm = L.f32c(gm)
+        rows, v = attrs.shape
+        lib = L.load()
+        ga = ret_w = None
+        if need_w:
+            gwv = torch.zeros(v, ld_m, device=attrs.device, dtype=torch.float32)
+            _run_gemm([_dense_problem(_addr(attrs), _addr(gwv), _addr(gm), rows, ld_m, v, v, ld_m, 1, ld_m, 1)], wgrad=True)
+            gw = _sink_for(weight)
+            acc = 1
+            if gw is None:
+                covered = sum(i.mul_in * spec.v * i.mul_out for i in spec.instr) == weight.numel()
+                gw = ret_w = (torch.empty_like(weight) if covered else torch.zeros_like(weight))
+                acc = 0
+            L.check(lib.e3k_fctp_weight_permute(L.ptr(gwv), _kw_array(spec, m_off), len(spec.instr), v, ld_m, L.ptr(gw), 0, acc,
+                                                L.stream_ptr()), "e3k_fctp_weight_permute")
+        if need_a:
+            # ga = gm . Wv^T: output [rows, V], reduction over ld_m columns -> K slices with their own partial outputs
+            ks = RowWeightsFn.K_SLICES
+            chunk = -(-ld_m // ks)
+            chunk += (-chunk) % 4
+            ks = -(-ld_m // chunk)
+            part = torch.empty(ks, rows, v, device=attrs.device, dtype=torch.float32)
+            probs = []
+            for i in range(ks):
+                k = min(chunk, ld_m - i * chunk)
+                probs.append(_dense_problem(_addr(gm, i * chunk), _addr(wv, i * chunk), _addr(part, i * rows * v), rows, v, k,
+                                            ld_m, 1, ld_m, v))
+            _run_gemm(probs)
+            ga = part.sum(0)
+        return ga, ret_w, None, None, None
+
+
+def row_weights(attrs, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: int):
+    return RowWeightsFn.apply(_c(attrs), _c(weight), spec, tuple(int(v) for v in m_off), int(ld_m))
+
+
+def _rowmat_fill(arr, k, ins, mo, x_accumulate=0):
+    (arr[k].m_off, arr[k].in_off, arr[k].out_off, arr[k].u, arr[k].w_out, arr[k].dim, arr[k].alpha, arr[k].x_accumulate) = (
+        int(mo), ins.in_off, ins.out_off, ins.mul_in, ins.mul_out, ins.dim, ins.alpha, x_accumulate)
+
+
+def _rowmat_array(spec: "FctpSpec", m_off):
+    def build():
+        arr = (L.RowmatInstr * len(spec.instr))()
+        for k, (ins, mo) in enumerate(zip(spec.instr, m_off)):
+            _rowmat_fill(arr, k, ins, mo)
+        return arr
+    return _templates(spec, ("rowmat", tuple(m_off)), build)
+
+
+def _rowmat_bwd_rounds(spec: "FctpSpec", m_off):
+    """Instructions that read the same input block accumulate its gradient: one launch per round."""
+    def build():
+        seen: Dict[int, int] = {}
+        rounds: List[List] = []
+        for ins, mo in zip(spec.instr, m_off):
+            r = seen.get(ins.i_in, 0)
+            seen[ins.i_in] = r + 1
+            while len(rounds) <= r:
+                rounds.append([])
+            rounds[r].append((ins, mo))
+        out = []
+        for r, group in enumerate(rounds):
+            arr = (L.RowmatInstr * len(group))()
+            for k, (ins, mo) in enumerate(group):
+                _rowmat_fill(arr, k, ins, mo, 1 if r > 0 else 0)
+            out.append((arr, len(group)))
+        return out
+    return _templates(spec, ("rowmat_bwd", tuple(m_off)), build)
+
+
+def _rowmat_composed(x, m, spec: "FctpSpec", m_off):
+    """torch restatement of RowMatFn.forward (double-backward graph only)."""
+    rows = x.shape[0]
+    parts = torch.zeros(rows, spec.d_out, device=x.device, dtype=x.dtype)
+    for ins, mo in zip(spec.instr, m_off):
+        xb = x[:, ins.in_off:ins.in_off + ins.dim * ins.mul_in].reshape(rows, ins.dim, ins.mul_in)
+        mb = m[:, mo:mo + ins.mul_in * ins.mul_out].reshape(rows, ins.mul_in, ins.mul_out)
+        ob = ins.alpha * torch.einsum("nku,nuw->nkw", xb, mb)
+        parts[:, ins.out_off:ins.out_off + ins.dim * ins.mul_out] = ob.reshape(rows, ins.dim * ins.mul_out)
+    return parts
+
+
+class RowMatFn(torch.autograd.Function):
+    """y[n, k, :] = alpha * x[n, k, :] . M[n]  per instruction (cf blocks)."""
+
+    @staticmethod
+    def forward(ctx, x, m, spec: "FctpSpec", m_off: Tuple[int, ...]):
+        L.require_cuda(x, m)
+        x, m = L.f32c(x), L.f32c(m)
+        rows = x.shape[0]
+        assert x.shape[1] == spec.d_in and m.shape[0] == rows
+        y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
+        arr = _rowmat_array(spec, m_off)
+        L.check(L.load().e3k_rowmat_fwd(L.ptr(x), L.ptr(m), arr, len(spec.instr), rows, spec.d_in, spec.d_out, m.shape[1],
+                                        L.ptr(y), L.stream_ptr()), "e3k_rowmat_fwd")
+        ctx.save_for_backward(x, m)
+        ctx.spec, ctx.m_off = spec, m_off
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, m = ctx.saved_tensors
+        spec, m_off = ctx.spec, ctx.m_off
+        need_x, need_m = ctx.needs_input_grad[:2]
+        if torch.is_grad_enabled():   # double backward: differentiate the torch restatement of the same bilinear form
+            wrt = [t for t, nd in zip((x, m), (need_x, need_m)) if nd]
+            if not wrt:
+                return None, None, None, None
+            with torch.enable_grad():
+                grads = list(torch.autograd.grad(_rowmat_composed(x, m, spec, m_off), wrt, gy, create_graph=True))
+            return (grads.pop(0) if need_x else None), (grads.pop(0) if need_m else None), None, None
+        gy = L.f32c(gy)
+        rows = x.shape[0]
+        gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32) if need_x else None
+        covered = sum(i.mul_in * i.mul_out for i in spec.instr) == m.shape[1]
+        gm = (torch.empty_like(m) if covered else torch.zeros_like(m)) if need_m else None
+        if gx is not None or gm is not None:
+            lib, st = L.load(), L.stream_ptr()
+            for arr, n in _rowmat_bwd_rounds(spec, m_off):
+                L.check(lib.e3k_rowmat_bwd(L.ptr(x), L.ptr(m), L.ptr(gy), arr, n, rows, spec.d_in, spec.d_out, m.shape[1],
+                                           L.ptr(gx), L.ptr(gm), st), "e3k_rowmat_bwd")
+        return gx, gm, None, None
+
+
+def row_matmul(x, m, spec: "FctpSpec", m_off: Sequence[int]):
+    return RowMatFn.apply(_c(x), _c(m), spec, tuple(int(v) for v in m_off))
+
+
+# --------------------------------------------------------------------------------------
 # Self-connection over *keyed* node attributes: rows of node_attrs that carry the same integer key
 # (structurally identical rows, e.g. attrs = Linear(one_hot(species))) share the contracted weight
 # M[t] = sum_v attrs_t[v] W[:, v, :], so the self-connection becomes one small GEMM per key group
