@@ -26,6 +26,7 @@ from torch import Tensor
 from ..backend import lib as L
 from ..backend import ops
 from ..backend.graph import get_topology
+from .data import segment_ids
 
 
 def computeEdgeVector(data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]], key: str = "pos",
@@ -62,7 +63,7 @@ def _all_pairs(n_nodes: Tensor, device) -> Tensor:
     if total_sq == 0:
         return torch.zeros(2, 0, dtype=torch.long, device=dev)
     start = torch.cumsum(n, 0) - n
-    graph = torch.repeat_interleave(torch.arange(n.numel(), device=dev), sq, output_size=total_sq)
+    graph = segment_ids(sq, total_sq)
     local = torch.arange(total_sq, device=dev) - (torch.cumsum(sq, 0) - sq)[graph]
     ng = n[graph]
     src = torch.div(local, ng, rounding_mode="floor") + start[graph]
@@ -81,7 +82,7 @@ def _radius_graph_device(data, attrs, pos: Tensor, r_max: float):
     n = data["_n_nodes"].reshape(-1).to(dev)
     total = pos.shape[0]
     n_graphs = n.numel()
-    gid = torch.repeat_interleave(torch.arange(n_graphs, device=dev), n, output_size=total)
+    gid = segment_ids(n, total)
     ends = torch.cumsum(n, 0)
     g_end = ends[gid].to(torch.int32)
     g_start = (ends - n)[gid].to(torch.int32)
@@ -152,7 +153,7 @@ def computeEdgeIndex(data, attrs, r_max: float = None, key: str = "pos", criteri
                 fresh = torch.zeros((edge_index.shape[1],) + tuple(prev.shape[1:]), dtype=prev.dtype, device=pos.device)
                 fresh[where] = prev
                 data[k] = fresh
-    seg = torch.repeat_interleave(torch.arange(n_nodes.numel(), device=pos.device), n_nodes.reshape(-1).to(pos.device))
+    seg = segment_ids(n_nodes.reshape(-1).to(pos.device))
     n_edges = torch.bincount(seg[edge_index[0]], minlength=n_nodes.numel()).view(-1, 1)
     attrs["_n_edges"] = ("graph", "1x0e")
     data["_n_edges"] = n_edges

@@ -678,3 +678,23 @@ def test_radial_look_ahead_equals_in_order(dev, monkeypatch):
     assert hits0 == 0 and hits1 == 2       # three convolutions: the second and third find their weights waiting
     assert rel_err(e1, e0) < 1e-6 and rel_err(g1, g0) < 1e-5
     assert rel_err(e2, e0) < 1e-6 and rel_err(g2, g0) < 1e-5
+
+
+def test_batch_index_select_on_device(dev):
+    """Sub-batches of a device Batch are gathered on the device (segment arithmetic + one index_select per tensor) and
+    equal the host result; a model evaluated on the sub-batch equals the corresponding rows of the full evaluation."""
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.utils import build
+
+    b = synth_qm9(6, 30)
+    sel = [4, 17, 17, 0, 29]
+    host = b[sel]
+    on_dev = b.clone().to(dev)[sel]
+    for k, v in host.data.items():
+        assert on_dev.data[k].is_cuda and torch.equal(on_dev.data[k].cpu(), v), k
+    torch.manual_seed(0)
+    model = build(_energy_tree(2, 16, 3)).to(dev).eval()
+    with torch.no_grad():
+        full = model(b.clone().to(dev))["total_energy"]
+        part = model(on_dev)["total_energy"]
+    assert rel_err(part, full[torch.tensor(sel, device=dev)]) < 1e-5

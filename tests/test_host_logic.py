@@ -315,3 +315,30 @@ def test_protein_preprocess_masked2indexed_and_crop():
     assert int(small["_n_nodes"]) == kept          # nothing to crop
     tree = cfg.get_config()
     assert [getattr(f, "__name__", getattr(getattr(f, "func", None), "__name__", "")) for f in tree.data_config.preprocess] == ["masked2indexed", "crop"]
+
+
+def test_batch_index_select_is_one_gather_per_tensor():
+    """Batch.index_select / slicing / boolean masks (e3_layers/data/batch.py:133-162, 180-186) through segment arithmetic:
+    identical, tensor for tensor, to rebuilding the sub-batch from per-graph Data objects; order and repeats honoured."""
+    import torch
+    from e3_layers_amd.data import Batch
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    b = synth_qm9(3, 40)
+    attrs = {k: v for k, v in b.attrs.items() if k not in ("_node_segment", "_edge_segment")}
+    mask = torch.zeros(40, dtype=torch.bool)
+    mask[[2, 11, 39]] = True
+    for sel, ids in ([[5, 3, 3, 38, -1], [5, 3, 3, 38, 39]], [slice(4, 20, 3), list(range(4, 20, 3))], [mask, [2, 11, 39]],
+                     [torch.tensor([7, 0]), [7, 0]]):
+        new = b[sel]
+        old = Batch.from_data_list([b.get(i) for i in ids], dict(attrs))
+        assert set(new.data) == set(old.data)
+        for k in old.data:
+            assert new.data[k].dtype == old.data[k].dtype and torch.equal(new.data[k], old.data[k]), k
+    assert len(b[[]]) == 0 and b[[]]["pos"].shape == (0, 3)
+    with pytest.raises(IndexError):
+        b[[40]]
+    # per-graph access after the counts tensor was replaced sees the new offsets (no stale cache)
+    first = b[1]["pos"].clone()
+    sub = b[[1, 2]]
+    assert torch.equal(sub[0]["pos"], first)
