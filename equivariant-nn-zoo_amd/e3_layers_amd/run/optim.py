@@ -26,7 +26,8 @@ from .parallel import FlatGradients, flat_layout
 class FusedAdamEMA:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.0, ema_decay: Optional[float] = None,
-                 ema_use_num_updates: bool = True, max_grad_norm: Optional[float] = None, skip_nonfinite: bool = False):
+                 ema_use_num_updates: bool = True, max_grad_norm: Optional[float] = None, skip_nonfinite: bool = False,
+                 max_steps_ahead: int = 2):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("no trainable parameters")
@@ -49,6 +50,14 @@ class FusedAdamEMA:
         self.ema_use_num_updates = bool(ema_use_num_updates)
         self.max_grad_norm = float(max_grad_norm) if (max_grad_norm is not None and max_grad_norm < float("inf")) else 0.0
         self.skip_nonfinite = bool(skip_nonfinite)
+        # The host enqueues a step in less time than the GPU runs it, so without a bound it drifts many steps ahead.
+        # With several HIP streams that is not harmless: a block that was used on a side stream (record_stream) only
+        # returns to the caching allocator when the GPU has passed that point, so every step the host is ahead needs
+        # its own set of activations -- 156 GB reserved for a 14 GB working set at 1024 molecules, grown by
+        # multi-second hipMalloc storms in the middle of a run.  step() therefore waits for the step issued
+        # ``max_steps_ahead`` steps ago (0 = unbounded).
+        self.max_steps_ahead = int(max_steps_ahead)
+        self._step_events = []
 
     # ------------------------------------------------------------------ step
     def zero_grad(self) -> None:
@@ -65,6 +74,12 @@ class FusedAdamEMA:
             self.flat.numel(), self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.ema_decay,
             int(self.ema_use_num_updates), self.max_grad_norm, int(self.skip_nonfinite), L.ptr(self.state),
             L.stream_ptr()), "e3k_adam_ema_step")
+        if self.max_steps_ahead > 0 and not torch.cuda.is_current_stream_capturing():
+            done = torch.cuda.Event()
+            done.record()
+            self._step_events.append(done)
+            if len(self._step_events) > self.max_steps_ahead:
+                self._step_events.pop(0).synchronize()
 
     # ------------------------------------------------------------------ introspection (each is a device->host sync)
     @property
