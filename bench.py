@@ -140,6 +140,16 @@ def main():
     target = batch["total_energy"]
     n_nodes, n_edges = batch["pos"].shape[0], batch["edge_index"].shape[1]
 
+    # setup, not a step of the workload: libe3k.so is loaded, the TP plans are created and the code objects of every
+    # kernel on the path are paged in by one forward/backward over EIGHT molecules (no optimizer step, gradients zeroed
+    # after) -- otherwise the first timed-or-warm-up step carries 0.2 s of lazy initialisation
+    tiny = synth_qm9(7, 8, config_energy.QM9_SHIFTS).to(dev)
+    (1e3 * torch.nn.functional.mse_loss(model(tiny)["total_energy"], tiny["total_energy"])).backward()
+    ops.join_side_streams()
+    flat.zero()
+    torch.cuda.synchronize()
+    del tiny
+
     def step():
         out = model(batch.view())   # fresh key dict over the resident tensors (the model adds keys, never mutates inputs)
         loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
