@@ -166,8 +166,6 @@ class FactorizedConvolution(Module):
                 main.wait_event(ready)
                 weight.record_stream(main)
                 if sc is not None and FWD_FORK_SC:
-                    if FWD_FORK_SC >= 2:   # experiment: join the self-connection before the tensor product
-                        main.wait_stream(side2)
                     mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
                     main.wait_stream(side2)
                     sc.record_stream(main)
