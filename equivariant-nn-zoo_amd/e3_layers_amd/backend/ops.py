@@ -16,6 +16,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os as _os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -29,16 +30,15 @@ from .graph import GraphTopo
 # fused TP+reduce forward kernel (HIP events on the launching stream); None = no profiling.
 PROFILE_TP = None
 
-import os as _os
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
-# E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture; bench --graph: 30.2k vs 29.7k
-# eager at 256 molecules).  Default 1 keeps captures single-stream.
+# E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture).  ROCm's graph executor did not
+# run the captured branches concurrently (8.45 vs 8.35 ms at 256 molecules), so the default keeps captures single-stream.
 FORK_IN_CAPTURE = _os.environ.get("E3K_FWD_FORK") == "2"
 
 
 def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
-    """A per-device side stream for an independent branch (``which`` = 0: radial MLP of a convolution; 1: the self-connection; 2: sunk
-    weight gradients).  Work enqueued there is joined by ``join_side_streams()`` before
+    """A per-device side stream for an independent branch (``which`` = 0: radial MLP of a convolution; 1: the
+    self-connection; 2: sunk weight gradients).  Work enqueued there is joined by ``join_side_streams()`` before
     anything outside autograd (optimizer, all-reduce) reads its results."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     key = idx if which == 0 else (idx, which)
