@@ -739,3 +739,44 @@ def test_training_steps_do_not_accumulate_device_memory(dev, monkeypatch):
         gc.enable()
         opt.grads.disable_direct_accumulation()
         ops.join_side_streams()
+
+
+def test_forked_convolution_with_unkeyed_attributes(dev, monkeypatch):
+    """config_diffusion's score net (general node attributes: time embedding -> the un-keyed self-connection) through
+    the multi-stream convolution with the gradient sink, the sunk self-connection / Linear weight gradients on their
+    side stream and the radial look-ahead: same score and flat gradient as the single-stream, in-order schedule."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.configs import config_diffusion
+    from e3_layers_amd.data.synthetic import synth_qm9_diffusion
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    model = build(config_diffusion.get_config().model_config).to(dev).train()
+    batch = synth_qm9_diffusion(5, 6).to(dev)
+    batch["t"] = torch.rand(len(batch), 1, device=dev)
+    flat = FlatGradients(model.parameters())
+    flat.enable_direct_accumulation()
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
+
+    def run(fork, ahead):
+        monkeypatch.setattr(mp, "FWD_FORK", fork)
+        monkeypatch.setattr(mp, "RADIAL_AHEAD", ahead)
+        flat.zero()
+        score = model(batch.clone())["score"]
+        score.square().mean().backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return score.detach().clone(), flat.gather().clone()
+
+    try:
+        s0, g0 = run(0, 0)
+        s1, g1 = run(1, 0)
+        s2, g2 = run(1, 1)
+    finally:
+        flat.disable_direct_accumulation()
+    assert float(g0.norm()) > 0
+    assert rel_err(s1, s0) < 1e-6 and rel_err(g1, g0) < 1e-5
+    assert rel_err(s2, s0) < 1e-6 and rel_err(g2, g0) < 1e-5
