@@ -124,7 +124,18 @@ class OneHotEncoding(Module):
         self.init_irreps(input=irreps_in, one_hot=irreps_out, output_keys="one_hot")
 
     def forward(self, data, attrs):
-        idx = data["input"].squeeze(-1)
+        src = data["input"]
+        # the same index VIEW object for the same source tensor (and version): the key groups of the keyed
+        # self-connection are memoised on the identity of this tensor (nn/core.py: row_groups), so a batch that is
+        # stepped repeatedly (batch.view()) sorts its species once, not once per step
+        memo = getattr(src, "_e3k_flat_index", None)
+        if memo is not None and memo[0] == src._version:
+            idx = memo[1]
+        else:
+            # a COPY, not a view: a view keeps a C++ reference to its base, and base -> attribute -> view -> base is a
+            # cycle through the C++ reference counts that nothing ever collects
+            idx = src.squeeze(-1).clone()
+            src._e3k_flat_index = (src._version, idx)
         one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
         set_row_key(one_hot, idx, self.num_types)   # rows are a function of the type index only
         return {"one_hot": one_hot}, {"one_hot": (attrs["input"][0], self.irreps_out["one_hot"])}

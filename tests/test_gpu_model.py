@@ -735,6 +735,30 @@ def test_training_steps_do_not_accumulate_device_memory(dev, monkeypatch):
         torch.cuda.synchronize()
         assert len(opt._step_events) <= opt.max_steps_ahead
         assert torch.cuda.memory_allocated() <= base + (1 << 16), (torch.cuda.memory_allocated() - base)
+
+        # ... and with a NEW batch object every step (a training loop): tensor attributes set by the layers (row keys,
+        # memoised index views, stream aliases) must not tie a batch's tensors into uncollectable cycles
+        def step_fresh():
+            fresh = batch.clone()
+            opt.zero_grad()
+            model(fresh)["total_energy"].square().mean().backward()
+            opt.step()
+
+        from e3_layers_amd.backend import graph as topo_cache
+        from e3_layers_amd.nn import core
+
+        def settled():      # the two bounded memo tables (topology per edge_index, key groups per index) emptied
+            torch.cuda.synchronize()
+            topo_cache._cache.clear()
+            core._groups_cache.clear()
+            return torch.cuda.memory_allocated()
+
+        for _ in range(5):
+            step_fresh()
+        base = settled()
+        for _ in range(25):
+            step_fresh()
+        assert settled() <= base + (1 << 16), (settled() - base)
     finally:
         gc.enable()
         opt.grads.disable_direct_accumulation()
