@@ -456,6 +456,7 @@ struct e3k_tp_plan {
   int32_t max_l1; // largest input degree among the groups (selects the kernel instantiation)
   int32_t max_l3; // largest output degree any group's mask enables
   int32_t split;  // 1: groups with l1 >= 1 are walked by two waves (slot parts 0 / 1)
+  int32_t x_cols; // input columns owned by some group: sum over groups of (2 l1 + 1) * mul
 };
 
 extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
@@ -560,13 +561,20 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     p->n_gc = cnt;
     p->max_l1 = 0;
     p->max_l3 = 0;
+    p->x_cols = 0;
     for (int i = 0; i < n_groups; ++i) {
+      p->x_cols += (2 * groups[i].l1 + 1) * groups[i].mul;
       p->max_l1 = groups[i].l1 > p->max_l1 ? groups[i].l1 : p->max_l1;
       p->max_l3 = plan_max_l3(groups[i]) > p->max_l3 ? plan_max_l3(groups[i]) : p->max_l3;
     }
   }
   *out = p;
   return E3K_OK;
+}
+
+extern "C" int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* p) {
+  // every element of g_x is stored exactly once: one group per input block, all of [0, d_in) covered, single-wave groups
+  return (p && !p->split && p->x_cols == p->d_in) ? 1 : 0;
 }
 
 extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {

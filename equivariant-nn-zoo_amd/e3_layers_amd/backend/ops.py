@@ -1217,6 +1217,7 @@ class TpPlan:
         self.groups = list(groups)
         self.d_in, self.d_sh, self.w_numel, self.d_mid = d_in, d_sh, w_numel, d_mid
         self._handles: Dict[int, int] = {}  # device index -> plan pointer
+        self._bwd_x_overwrites: Optional[bool] = None
 
     def handle(self, device: torch.device) -> int:
         idx = device.index if device.index is not None else torch.cuda.current_device()
@@ -1231,6 +1232,12 @@ class TpPlan:
             h = out.value
             self._handles[idx] = h
         return h
+
+    def bwd_x_overwrites(self, device: torch.device) -> bool:
+        """g_x needs no zero-fill: the backward w.r.t. x stores every element (see e3k_tp_bwd_x_overwrites)."""
+        if self._bwd_x_overwrites is None:
+            self._bwd_x_overwrites = bool(L.load().e3k_tp_bwd_x_overwrites(self.handle(device)))
+        return self._bwd_x_overwrites
 
     def __del__(self):
         try:
@@ -1261,7 +1268,7 @@ def _tp_fwd_raw(x, sh, w, topo: GraphTopo, plan: TpPlan):
 
 def _tp_bwd_x_raw(sh, w, g_out, topo: GraphTopo, plan: TpPlan):
     n, e = topo.num_nodes, topo.num_edges
-    gx = torch.zeros(n, plan.d_in, device=sh.device, dtype=torch.float32)
+    gx = (torch.empty if plan.bwd_x_overwrites(sh.device) else torch.zeros)(n, plan.d_in, device=sh.device, dtype=torch.float32)
     L.check(L.load().e3k_tp_bwd_x(plan.handle(sh.device), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
                                   L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x")
     return gx

@@ -192,6 +192,8 @@ int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const
 /* g_x [N,d_in]: the CALLER ZERO-FILLS it; plans whose groups are walked by two waves (l_max = 3: more than 24
  * accumulators per group) add their two partial sums with atomics (order independent), the others store.
  * CSR by source (src_ptr, src_perm), dst [E]. */
+/* 1 when e3k_tp_bwd_x stores every element of g_x (no zero-fill needed): single-wave groups that tile [0, d_in). */
+int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* plan);
 int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
