@@ -113,8 +113,8 @@ class FactorizedConvolution(Module):
     _prefetched = None     # (edge embedding, weights, ready event, grad mode) issued by the previous convolution
 
     @staticmethod
-    def _issue_ahead(nxt, radial, side):
-        with torch.cuda.stream(side):
+    def _issue_ahead(nxt, radial, side, main):
+        with ops.on_stream(side, main):
             w_next = nxt.fc(_stream_alias(radial, side))
             ev_next = torch.cuda.Event()
             ev_next.record(side)
@@ -143,7 +143,7 @@ class FactorizedConvolution(Module):
                     AHEAD_STATS[0] += 1
                 else:
                     side.wait_stream(main)
-                    with torch.cuda.stream(side):
+                    with ops.on_stream(side, main):
                         weight = self.fc(_stream_alias(radial, side))
                         ready = torch.cuda.Event()
                         ready.record(side)
@@ -151,14 +151,14 @@ class FactorizedConvolution(Module):
                 if nxt is not None and not nxt._fork_pays(radial.shape[0]):
                     nxt = None
                 if nxt is not None:
-                    self._issue_ahead(nxt, radial, side)
+                    self._issue_ahead(nxt, radial, side, main)
                 x_cf = ops.relayout(x, self._in_blocks, True)
                 sc = None
                 if self.sc is not None and FWD_FORK_SC:
                     # third branch: the self-connection only meets the others at the trailing Linear
                     side2 = ops.side_stream(x.device, 1)
                     side2.wait_stream(main)
-                    with torch.cuda.stream(side2):
+                    with ops.on_stream(side2, main):
                         sc = self.sc(x_cf, _stream_alias(data["node_attrs"], side2))
                 elif self.sc is not None:
                     sc = self.sc(x_cf, data["node_attrs"])
