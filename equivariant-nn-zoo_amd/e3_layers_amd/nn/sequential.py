@@ -78,13 +78,23 @@ class SequentialGraphNetwork(torch.nn.Sequential):
 
     def forward(self, batch):
         data, attrs = batch.data, batch.attrs
+        # layer names appear in a torch profile when one is running; otherwise the 2 x 14 record_function ops per forward
+        # are 0.3 ms of pure host time
+        profiling = torch.autograd._profiler_enabled()
         for key, layer in self.layers:
-            with record_function(key):
-                mapped = isinstance(layer, Module)
-                d, a = (layer.inputKeyMap(data), layer.inputKeyMap(attrs)) if mapped else (data, attrs)
-                d, a = layer(d, a)
-                if mapped:
-                    d, a = layer.outputKeyMap(d), layer.outputKeyMap(a)
-                data.update(d)
-                attrs.update(a)
+            if profiling:
+                with record_function(key):
+                    self._run_layer(layer, data, attrs)
+            else:
+                self._run_layer(layer, data, attrs)
         return Batch(attrs, **data)
+
+    @staticmethod
+    def _run_layer(layer, data, attrs):
+        mapped = isinstance(layer, Module)
+        d, a = (layer.inputKeyMap(data), layer.inputKeyMap(attrs)) if mapped else (data, attrs)
+        d, a = layer(d, a)
+        if mapped:
+            d, a = layer.outputKeyMap(d), layer.outputKeyMap(a)
+        data.update(d)
+        attrs.update(a)
