@@ -32,14 +32,15 @@ def masked2indexed(batch):
     return Batch(attrs, **data)
 
 
-def crop(data, attrs, max_nodes, generator=None):
-    """Drop the backbone atoms other than CA; if the protein has more than ``max_nodes`` residues keep those inside a
-    ball around a random residue whose radius a bisection over [20, 70] A (0.5 A resolution) picks so that at most
-    ``max_nodes`` remain (:26-56).  ``generator``: a torch CPU generator for the centre (the reference uses the global
-    numpy stream)."""
+def crop(data, attrs, max_nodes, generator=None, atoms=("CA",)):
+    """Drop the backbone atoms other than ``atoms`` (CA only here; ``config_diffusion_backbone`` keeps all four); if
+    the protein has more than ``max_nodes`` residues keep those inside a ball around a random residue whose radius a
+    bisection over [20, 70] A (0.5 A resolution) picks so that at most ``max_nodes`` remain (:26-56).  ``generator``:
+    a torch CPU generator for the centre (the reference uses the global numpy stream)."""
     for key in ("N", "C", "O"):
-        data.pop(key)
-        attrs.pop(key)
+        if key not in atoms:
+            data.pop(key)
+            attrs.pop(key)
     n = int(data["_n_nodes"].reshape(-1)[0])
     if n <= max_nodes:
         return data, attrs
@@ -58,7 +59,7 @@ def crop(data, attrs, max_nodes, generator=None):
             break
     mask = (distance < lo).view(-1)
     data["_n_nodes"] = mask.sum().view(-1, 1)
-    for key in ("id", "species", "chain_id", "CA"):
+    for key in ("id", "species", "chain_id") + tuple(atoms):
         data[key] = data[key][mask]
     return data, attrs
 
@@ -73,19 +74,27 @@ def criteria(data, edge_index):
 
 
 def get_config(spec="", l_max=2, num_layers=8, n_dim=64):
+    data = ConfigDict()
+    data.std = 25.83
+    data.scaler = getScaler([("CA", ("shift", "mean")), ("CA", ("scale", 1 / data.std))])
+    data.inverse_scaler = getScaler([("CA", ("scale", data.std))])
+    data.preprocess = [masked2indexed, partial(crop, max_nodes=384)]
+    return score_config({"CA": 3}, data, l_max, num_layers, n_dim)
+
+
+def score_config(diffusion_keys, data, l_max, num_layers, n_dim, side_atoms=()):
+    """The tree both protein configs share (``config_diffusion_CA.py:66-194``, ``config_diffusion_backbone.py:64-194``):
+    one ``score_{key}`` head per diffusion key; ``side_atoms`` (backbone: C, N, O relative positions) are mixed into the
+    node features after ``layer3`` by a ``Concat`` (``config_diffusion_backbone.py:169-176``)."""
     config = ConfigDict()
-    data, model = ConfigDict(), ConfigDict()
+    model = ConfigDict()
     config.data_config, config.model_config = data, model
-    config.diffusion_keys = {"CA": 3}
+    config.diffusion_keys = dict(diffusion_keys)
     config.update(dict(learning_rate=2e-3, batch_size=4, grad_acc=4, grad_clid_norm=1.0))
 
     model.n_dim, model.l_max, model.r_max, model.num_layers = n_dim, l_max, 5.0, num_layers
     model.edge_radial, model.node_attrs, model.jit = "32x0e", "32x0e", True
     num_types = 21
-    data.std = 25.83
-    data.scaler = getScaler([("CA", ("shift", "mean")), ("CA", ("scale", 1 / data.std))])
-    data.inverse_scaler = getScaler([("CA", ("scale", data.std))])
-    data.preprocess = [masked2indexed, partial(crop, max_nodes=384)]
     data.key_map = {}
 
     features = "+".join(f"{model.n_dim}x{l}e+{model.n_dim}x{l}o" for l in range(model.l_max + 1))
@@ -114,6 +123,11 @@ def get_config(spec="", l_max=2, num_layers=8, n_dim=64):
                            "time_encoding": (f"{model.n_dim}x0e", "time_encoding"),
                            "irreps_out": (model.node_attrs, "node_attrs")})
     lc.layers = insertAfter(lc.layers, "graph2node", concat2)
+    if side_atoms:
+        concat3 = {"module": Concat, "node_features": (lc.node_features, "node_features")}
+        concat3.update({atom: ("1x1o", atom) for atom in side_atoms})
+        concat3["irreps_out"] = (lc.node_features, "node_features")
+        lc.layers = insertAfter(lc.layers, "layer3", ("concat3", concat3))
     for key in config.diffusion_keys:
         lc.layers = list(lc.layers) + [(f"score_{key}", {"module": PointwiseLinear,
                                                          "irreps_in": (features, "node_features"),

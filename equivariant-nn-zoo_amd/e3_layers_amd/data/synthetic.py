@@ -88,14 +88,19 @@ def synth_qm9_diffusion(seed: int, n_mol: int, std: float = 1.4) -> Batch:
     return Batch.from_data_list(lst, attrs)
 
 
-def synth_protein(seed: int, n_prot: int, n_res: int = 384, std: float = 25.83, n_chains: int = 2) -> Batch:
+def synth_protein(seed: int, n_prot: int, n_res: int = 384, std: float = 25.83, n_chains: int = 2,
+                  backbone: bool = False) -> Batch:
     """Inputs of the residue-level score network (``config_diffusion_CA``): per protein a C-alpha
     random walk with 3.8 A steps split into ``n_chains`` chains, residue types in [0, 21), residue
     index ``id``, ``chain_id``, a diffusion time per graph; CA centred and scaled by 1/std as the
-    config's scaler does.  No edges: the model's first layer (computeEdgeIndex) builds them."""
+    config's scaler does.  No edges: the model's first layer (computeEdgeIndex) builds them.
+    ``backbone``: also N, C, O as ``config_diffusion_backbone``'s scaler leaves them — C and N relative to CA, O relative
+    to C (bond lengths 1.52 / 1.46 / 1.23 A in random directions), scaled by 1/std."""
     gen = torch.Generator(device="cpu").manual_seed(seed)
     attrs = {"CA": ("node", "1x1o"), "species": ("node", "1x0e"), "chain_id": ("node", "1x0e"), "id": ("node", "1x0e"),
              "t": ("graph", "1x0e")}
+    if backbone:
+        attrs.update({"N": ("node", "1x1o"), "C": ("node", "1x1o"), "O": ("node", "1x1o")})
     lst = []
     for _ in range(n_prot):
         steps = torch.randn(n_res, 3, generator=gen)
@@ -106,6 +111,10 @@ def synth_protein(seed: int, n_prot: int, n_res: int = 384, std: float = 25.83, 
         lst.append({"CA": ca.float(), "species": torch.randint(0, 21, (n_res, 1), generator=gen),
                     "chain_id": chain.long(), "id": torch.arange(n_res).view(-1, 1),
                     "t": torch.rand(1, 1, generator=gen) * (1.0 - 1e-5) + 1e-5, "_n_nodes": torch.tensor([[n_res]])})
+        if backbone:
+            for atom, bond in (("C", 1.52), ("N", 1.46), ("O", 1.23)):
+                d = torch.randn(n_res, 3, generator=gen)
+                lst[-1][atom] = (bond * d / d.norm(dim=1, keepdim=True) / std).float()
     b = Batch.from_data_list(lst, attrs)
     b.attrs.pop("_n_edges", None)
     return b

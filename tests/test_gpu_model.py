@@ -212,6 +212,67 @@ def test_config_diffusion_CA_protein_network(dev):
     assert res["score_CA"].shape == (80, 3) and int(res["_n_edges"].sum()) == res["edge_index"].shape[1]
 
 
+def _protein_parity(dev, module, n_layers, l_max, n_res, backbone, heads, tol, gtol):
+    """Product vs float64 oracle on the protein score net with a CPU-built, seeded edge set fed to both sides."""
+    from e3_layers_amd.data.synthetic import synth_protein
+
+    tree = module.get_config(num_layers=n_layers, l_max=l_max).model_config
+    batch = synth_protein(21, 2, n_res=n_res, backbone=backbone)
+    torch.manual_seed(5)
+    edge_layer = dict(tree.layers)["edge_index"]
+    new, _ = edge_layer(batch.data, batch.attrs)
+    batch["edge_index"] = new["edge_index"]
+    tree.layers = [l for l in tree.layers if l[0] != "edge_index"]
+    prod, orc = _build_pair(tree, dev)
+    with torch.no_grad():
+        for m in prod.modules():
+            if hasattr(m, "std") and isinstance(getattr(m, "std"), torch.nn.Parameter):
+                m.std.uniform_(0.7, 1.3)
+    orc = oracle_like(prod, tree)
+    data, attrs = batch_to_oracle(batch)
+    out_ref, _ = orc(data, attrs)
+    out = prod(batch.clone().to(dev))
+    for key in ("node_features",) + tuple(heads):
+        assert rel_err(out[key], out_ref[key]) < tol, key
+    loss = sum(out[h].square().mean() for h in heads)
+    loss_ref = sum(out_ref[h].square().mean() for h in heads)
+    loss.backward()
+    loss_ref.backward()
+    ref_params = dict(orc.named_parameters())
+    checked = 0
+    for name, p in prod.named_parameters():
+        r = ref_params["mods." + name]
+        if r.grad is None or float(r.grad.norm()) == 0.0:
+            continue
+        assert rel_err(p.grad, r.grad) < gtol, name
+        checked += 1
+    assert checked > 10 * n_layers
+
+
+def test_config_diffusion_CA_protein_network_as_shipped_depth(dev):
+    """BASELINE configs[4] at the shipped depth: all 8 normalised layers (n_dim 64, l_max 2), 2 x 96 residues,
+    forward and parameter gradients against the float64 oracle."""
+    from e3_layers_amd.configs import config_diffusion_CA
+
+    _protein_parity(dev, config_diffusion_CA, 8, 2, 96, False, ("score_CA",), 4e-5, 2e-4)
+
+
+def test_config_diffusion_CA_protein_network_lmax3(dev):
+    """The l_max = 3 variant BASELINE configs[4] names (features up to 3e/3o, spherical harmonics to l = 2 as the
+    config fixes them): two-wave TP groups, 3 layers deep so that every l = 3 path exists."""
+    from e3_layers_amd.configs import config_diffusion_CA
+
+    _protein_parity(dev, config_diffusion_CA, 4, 3, 40, False, ("score_CA",), 2e-5, 1e-4)
+
+
+def test_config_diffusion_backbone_network(dev):
+    """config_diffusion_backbone (e3_layers/configs/config_diffusion_backbone.py:64-194): C/N/O enter through concat3
+    after layer3; four score heads.  5 layers (one convolution after the concat), 2 x 40 residues."""
+    from e3_layers_amd.configs import config_diffusion_backbone
+
+    _protein_parity(dev, config_diffusion_backbone, 5, 2, 40, True, ("score_CA", "score_C", "score_O", "score_N"), 2e-5, 1e-4)
+
+
 def _noise_bank(shapes_gen, n, seed):
     gen = torch.Generator().manual_seed(seed)
     return [torch.randn(shapes_gen, dtype=torch.float64, generator=gen) for _ in range(n)]

@@ -62,7 +62,8 @@ def test_config_energy_tables_match_survey_appendix_b():
     assert [getattr(m2, f"layer{i}").conv.tp.tp.d_mid for i in range(5)] == [576, 3264, 5952, 6528, 6528]
 
 
-@pytest.mark.parametrize("name", ["config_energy", "config_energy_force", "config_diffusion"])
+@pytest.mark.parametrize("name", ["config_energy", "config_energy_force", "config_diffusion", "config_diffusion_CA",
+                                  "config_diffusion_backbone"])
 def test_config_trees_build_and_share_state_dict_names_with_oracle(name):
     import importlib
 
@@ -315,6 +316,49 @@ def test_protein_preprocess_masked2indexed_and_crop():
     assert int(small["_n_nodes"]) == kept          # nothing to crop
     tree = cfg.get_config()
     assert [getattr(f, "__name__", getattr(getattr(f, "func", None), "__name__", "")) for f in tree.data_config.preprocess] == ["masked2indexed", "crop"]
+
+
+def test_backbone_config_keeps_four_atoms_and_scaler_round_trips():
+    """config_diffusion_backbone (e3_layers/configs/config_diffusion_backbone.py): crop keeps N/CA/C/O (:53-54), the
+    scaler expresses C, N relative to CA and O relative to C, centres CA per protein and divides by std (:100-102);
+    the inverse scaler undoes everything but the centring; the tree has the concat3 layer after layer3 (:169-176) and
+    one score head per diffused atom (:179-189)."""
+    from e3_layers_amd.configs import config_diffusion_backbone as cfg
+    from e3_layers_amd.data import Batch
+
+    g = torch.Generator().manual_seed(3)
+    n = 500
+    steps = torch.randn(n, 3, generator=g)
+    ca = torch.cumsum(3.8 * steps / steps.norm(dim=1, keepdim=True), 0)
+    attrs = {k: ("node", "1x1o") for k in ("N", "CA", "C", "O")}
+    attrs.update({"species": ("node", "1x0e"), "chain_id": ("node", "1x0e"), "mask": ("node", "1x0e")})
+    off = {k: torch.randn(n, 3, generator=g) for k in ("N", "C", "O")}
+    raw = Batch(dict(attrs), N=ca + off["N"], CA=ca.clone(), C=ca + off["C"], O=ca + off["C"] + off["O"],
+                species=torch.randint(0, 21, (n, 1), generator=g), chain_id=(torch.arange(n) // 250).view(-1, 1),
+                mask=torch.ones(n, 1, dtype=torch.long), _n_nodes=torch.tensor([[n]]))
+    conf = cfg.get_config()
+    b = conf.data_config.preprocess[0](raw)
+    data, a2 = conf.data_config.preprocess[1](dict(b.data), dict(b.attrs), generator=torch.Generator().manual_seed(0))
+    m = int(data["_n_nodes"])
+    assert 0 < m <= 384
+    for atom in ("N", "CA", "C", "O"):
+        assert data[atom].shape == (m, 3) and atom in a2
+    cropped = Batch(a2, **{k: v for k, v in data.items() if k not in ("_node_segment", "_edge_segment")})
+    scaled = conf.data_config.scaler(cropped)
+    std = conf.data_config.std
+    keep = data["id"].view(-1)
+    assert torch.allclose(scaled["C"], off["C"][keep] / std, atol=1e-5)
+    assert torch.allclose(scaled["N"], off["N"][keep] / std, atol=1e-5)
+    assert torch.allclose(scaled["O"], off["O"][keep] / std, atol=1e-5)
+    assert float(scaled["CA"].mean(0).abs().max()) < 1e-5
+    back = conf.data_config.inverse_scaler(scaled)
+    shift = cropped["CA"].mean(0, keepdim=True)
+    for atom in ("N", "CA", "C", "O"):
+        assert torch.allclose(back[atom], cropped[atom] - shift, atol=2e-4), atom
+    names = [k for k, _ in conf.model_config.layers]
+    assert names.index("concat3") == names.index("layer3") + 1
+    assert names[-4:] == ["score_CA", "score_C", "score_O", "score_N"]
+    assert conf.diffusion_keys == {"CA": 3, "C": 3, "O": 3, "N": 3}
 
 
 def test_batch_index_select_is_one_gather_per_tensor():
