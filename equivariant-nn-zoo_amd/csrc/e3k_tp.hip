@@ -20,98 +20,11 @@
 // Backward: bwd_w has the forward's shape (per destination node; writes grad_w[e] rows,
 // optionally reduces grad_sh[e] over lanes), bwd_x walks the out-edges of a source node
 // (CSR by source) and accumulates grad_x in registers.
-#include <type_traits>
-
 #include <cstdlib>
 
-#include "e3k_common.h"
-#include "e3k_cg_gen.h"
-
-#ifndef E3K_TP_FWD_PIPE
-#define E3K_TP_FWD_PIPE 0    // 1: loads of edge t+1 issued before edge t is consumed; costs a second register set, and
-                             // occupancy buys more here: measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
-#endif
-#ifndef E3K_TP_BWDX_PIPE
-#define E3K_TP_BWDX_PIPE 0   // same trade for the backward wrt x: 495 vs 498 us (l_max 2), 1005 vs 1131 us (l_max 3)
-#endif
-
-static_assert(E3K_MAXQ == E3K_TP_MAXQ, "e3k.h and e3k_cg_gen.h disagree on the slot count");
-static_assert(E3K_L2MAX == 2, "YRegs below is written for sh degrees 0..2");
+#include "e3k_tp_body.h"
 
 namespace e3k {
-
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-  if constexpr (I < N) {
-    f(std::integral_constant<int, I>{});
-    static_for<I + 1, N>(f);
-  }
-}
-
-struct YRegs {
-  float y0[1];
-  float y1[3];
-  float y2[5];
-};
-template <int L2>
-__device__ __forceinline__ auto& yref(YRegs& y) {
-  if constexpr (L2 == 0) return y.y0;
-  else if constexpr (L2 == 1) return y.y1;
-  else return y.y2;
-}
-
-struct TpArgs {
-  const float* x;      // [N, d_in]  cf
-  const float* sh;     // [E, d_sh]
-  const float* w;      // [E, W]
-  const float* g_out;  // [N, d_mid] cf (backward)
-  float* out;          // [N, d_mid] cf (forward)
-  float* g_w;          // [E, W]
-  float* g_sh;         // [E, d_sh]
-  float* g_x;          // [N, d_in]
-  const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
-  const int32_t* ptr;  // CSR row pointers [N+1]
-  const int32_t* perm; // CSR edge ids [E]
-  int32_t d_in, d_sh, W, d_mid;
-  int64_t n_items;
-};
-
-struct GroupRegs {
-  int x_off, mul;
-  unsigned mask;
-  int y_off[3];
-};
-
-__device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, const e3k_tp_group& g) {
-  // wave-uniform addresses: these become scalar loads
-  if (g.y_off[0] >= 0) y.y0[0] = yr[g.y_off[0]];
-  if (g.y_off[1] >= 0) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j) y.y1[j] = yr[g.y_off[1] + j];
-  }
-  if (g.y_off[2] >= 0) {
-#pragma unroll
-    for (int j = 0; j < 5; ++j) y.y2[j] = yr[g.y_off[2] + j];
-  }
-}
-
-// ------------------------------------------------------------------------------------------
-// forward
-// ------------------------------------------------------------------------------------------
-// visits the path slots whose output degree the plan can contain: slots with l3 > L3MAX are compiled out, so an
-// l_max = 2 model carries no accumulators for l3 = 3 outputs (14 of the 36 registers of an l1 = 2 group)
-// PART splits a group's slots between two waves (0: slots below the split point, 1: the rest, 2: all of them): at
-// l_max = 3 a group carries 27-36 accumulators; halving them takes the kernels from 3-4 to 6-7 waves per SIMD at the
-// price of gathering x[src] twice (an L2 hit).  Split points: l1 = 1 -> slot 4, l1 = 2 -> slot 4, l1 = 3 -> slot 3.
-template <int L1> struct SplitAt { static constexpr int Q = L1 == 3 ? 3 : 4; };
-template <class S, int L1, int L3MAX, int PART, class F>
-__device__ __forceinline__ void slot_for_part(F&& f) {
-  static_for<0, S::NQ>([&](auto qc) {
-    constexpr int Q = decltype(qc)::value;
-    constexpr bool in_part = PART == 2 || (PART == 0 ? Q < SplitAt<L1>::Q : Q >= SplitAt<L1>::Q);
-    if constexpr (S::L3[Q] <= L3MAX && in_part) f(qc);
-  });
-}
 
 template <int L1, int L3MAX, int PART>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
@@ -127,7 +40,8 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   if (beg < end) {
-    // software pipeline: the loads of edge t+1 are issued before edge t is consumed
+    // no software pipeline (loads of edge t+1 before edge t is consumed): it costs a second register set and
+    // occupancy buys more here -- measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
     float xn[D1], wn[S::NQ];
     YRegs yn;
     auto issue = [&](int t) {
@@ -143,23 +57,11 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
       });
       load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
     };
-#if !E3K_TP_FWD_PIPE
     for (int t = beg; t < end; ++t) {
       issue(t);
       float (&xc)[D1] = xn;
       float (&wc)[S::NQ] = wn;
       YRegs& yc = yn;
-#else
-    issue(beg);
-    for (int t = beg; t < end; ++t) {
-      float xc[D1], wc[S::NQ];
-      YRegs yc = yn;
-#pragma unroll
-      for (int i = 0; i < D1; ++i) xc[i] = xn[i];
-#pragma unroll
-      for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
-      if (t + 1 < end) issue(t + 1);
-#endif
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
@@ -326,7 +228,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   if (beg < end) {
-    // software pipeline: the gathers of edge t+1 are in flight while edge t is consumed
+    // (a one-deep software pipeline measured the same: 495 vs 498 us at l_max 2)
     float gn[S::TOTAL], wn[S::NQ];
     YRegs yn;
     auto issue = [&](int t) {
@@ -345,23 +247,11 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
         }
       });
     };
-#if !E3K_TP_BWDX_PIPE
     for (int t = beg; t < end; ++t) {
       issue(t);
       float (&gc)[S::TOTAL] = gn;
       float (&wc)[S::NQ] = wn;
       YRegs& yc = yn;
-#else
-    issue(beg);
-    for (int t = beg; t < end; ++t) {
-      float gc[S::TOTAL], wc[S::NQ];
-      YRegs yc = yn;
-#pragma unroll
-      for (int i = 0; i < S::TOTAL; ++i) gc[i] = gn[i];
-#pragma unroll
-      for (int q = 0; q < S::NQ; ++q) wc[q] = wn[q];
-      if (t + 1 < end) issue(t + 1);
-#endif
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
@@ -378,8 +268,9 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
     float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off + u;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
-      if constexpr (PART == 2) gxr[i * mul] = gx[i];
-      else atomicAdd(gxr + i * mul, gx[i]);   // two waves per group, g_x pre-zeroed: a + b is order independent
+      if (PART == 2 && !a.x_shared) gxr[i * mul] = gx[i];
+      else atomicAdd(gxr + i * mul, gx[i]);   // two waves per group (a + b is order independent) or several groups on
+                                              // one input block (repeated sh degree): g_x is pre-zeroed
     }
   }
 }
@@ -448,16 +339,6 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
 // ------------------------------------------------------------------------------------------
 // plan + C ABI
 // ------------------------------------------------------------------------------------------
-struct e3k_tp_plan {
-  int32_t n_groups, d_in, d_sh, w_numel, d_mid;
-  e3k_tp_group* d_groups;
-  int2* d_gc;     // (group, 64-channel chunk) work list, all degrees
-  int32_t n_gc;
-  int32_t max_l1; // largest input degree among the groups (selects the kernel instantiation)
-  int32_t max_l3; // largest output degree any group's mask enables
-  int32_t split;  // 1: groups with l1 >= 1 are walked by two waves (slot parts 0 / 1)
-  int32_t x_cols; // input columns owned by some group: sum over groups of (2 l1 + 1) * mul
-};
 
 extern "C" void e3k_tp_limits(int* l1max, int* l2max, int* l3max) {
   if (l1max) *l1max = E3K_L1MAX;
@@ -518,6 +399,8 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
   p->d_groups = nullptr;
   p->d_gc = nullptr;
   p->n_gc = 0;
+  p->d_chunks = nullptr;
+  p->n_chunks = 0;
   if (hipMalloc(&p->d_groups, sizeof(e3k_tp_group) * n_groups) != hipSuccess) {
     delete p;
     return E3K_ERR_LAUNCH;
@@ -530,19 +413,30 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     // work list: (group, 64-channel chunk | part << 16).  A group whose enabled slots hold more than
     // E3K_TP_SPLIT_ACC accumulators (l_max = 3 models) is walked by two waves, one per slot part.
     static const int split_acc = getenv("E3K_TP_SPLIT_ACC") ? atoi(getenv("E3K_TP_SPLIT_ACC")) : 24;
-    int2* host = new int2[2 * 1024];
+    int64_t cap = 0;
+    for (int i = 0; i < n_groups; ++i) cap += 2 * ((groups[i].mul + 63) / 64);
+    if (cap > (1 << 20)) {   // the work item index packs (chunk | part << 16): far beyond any irreps this path serves
+      e3k_tp_plan_destroy(p);
+      return E3K_ERR_UNSUPPORTED;
+    }
+    int2* host = new int2[cap ? cap : 1];
     int cnt = 0;
     bool any = false;
     for (int i = 0; i < n_groups; ++i) {
       int n_acc = 0, lo = 0, hi = 0;
       plan_slot_counts(groups[i], n_acc, lo, hi);
       if (groups[i].l1 >= 1 && n_acc > split_acc) any = true;
+      if ((groups[i].mul + 63) / 64 > 0xffff) {
+        delete[] host;
+        e3k_tp_plan_destroy(p);
+        return E3K_ERR_UNSUPPORTED;
+      }
     }
     p->split = any ? 1 : 0;
     for (int i = 0; i < n_groups; ++i) {
       int n_acc = 0, lo = 0, hi = 0;
       plan_slot_counts(groups[i], n_acc, lo, hi);
-      for (int c = 0; c < (groups[i].mul + 63) / 64 && cnt + 2 <= 2 * 1024; ++c) {
+      for (int c = 0; c < (groups[i].mul + 63) / 64; ++c) {
         if (any && groups[i].l1 >= 1) {   // in a split plan every l1 >= 1 group goes by parts (empty parts are skipped)
           if (lo > 0) host[cnt++] = make_int2(i, c | (0 << 16));
           if (hi > 0) host[cnt++] = make_int2(i, c | (1 << 16));
@@ -562,10 +456,68 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     p->max_l1 = 0;
     p->max_l3 = 0;
     p->x_cols = 0;
+    p->x_shared = 0;
     for (int i = 0; i < n_groups; ++i) {
+      const int lo_i = groups[i].x_off, hi_i = lo_i + (2 * groups[i].l1 + 1) * groups[i].mul;
+      for (int j = 0; j < i; ++j) {
+        const int lo_j = groups[j].x_off, hi_j = lo_j + (2 * groups[j].l1 + 1) * groups[j].mul;
+        if (lo_i < hi_j && lo_j < hi_i) p->x_shared = 1;
+      }
       p->x_cols += (2 * groups[i].l1 + 1) * groups[i].mul;
       p->max_l1 = groups[i].l1 > p->max_l1 ? groups[i].l1 : p->max_l1;
       p->max_l3 = plan_max_l3(groups[i]) > p->max_l3 ? plan_max_l3(groups[i]) : p->max_l3;
+    }
+  }
+  {
+    // chunk list of the radial-fused kernels: the set slots of a group in pairs, per 64-channel chunk
+    bool ok = true;
+    int64_t n = 0;
+    for (int l = 0; l < 3; ++l) p->y_off[l] = -1;
+    for (int i = 0; i < n_groups; ++i) {
+      for (int l = 0; l < 3; ++l) {
+        if (groups[i].y_off[l] < 0) continue;
+        if (p->y_off[l] >= 0 && p->y_off[l] != groups[i].y_off[l]) ok = false;   // an sh degree that repeats
+        p->y_off[l] = groups[i].y_off[l];
+      }
+      if (groups[i].mul % 64) ok = false;
+      n += (int64_t)((groups[i].mul + 63) / 64) * ((__builtin_popcount(groups[i].mask) + 1) / 2);
+    }
+    if (ok && n > 0 && n < (1 << 16)) {
+      e3k_rtp_chunk* hc = new e3k_rtp_chunk[n];
+      int cnt = 0;
+      for (int i = 0; i < n_groups; ++i) {
+        for (int c = 0; c < groups[i].mul / 64; ++c) {
+          e3k_rtp_chunk blank{};
+          blank.group = i;
+          blank.cchunk = c;
+          blank.l1 = groups[i].l1;
+          blank.x_off = groups[i].x_off;
+          blank.mul = groups[i].mul;
+          for (int t = 0; t < 3; ++t) blank.y_off[t] = groups[i].y_off[t];
+          e3k_rtp_chunk cur = blank;
+          for (int q = 0; q < E3K_TP_MAXQ; ++q) {
+            if (!(groups[i].mask & (1u << q))) continue;
+            cur.mask |= 1u << q;
+            cur.col[cur.np] = groups[i].w_off[q] + 64 * c;
+            cur.out_off[cur.np] = groups[i].out_off[q];
+            cur.out_stride[cur.np] = groups[i].out_stride[q];
+            cur.coeff[cur.np] = groups[i].coeff[q];
+            if (++cur.np == 2) {
+              hc[cnt++] = cur;
+              cur = blank;
+            }
+          }
+          if (cur.np) hc[cnt++] = cur;
+        }
+      }
+      hipError_t e1 = hipMalloc(&p->d_chunks, sizeof(e3k_rtp_chunk) * cnt);
+      hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_chunks, hc, sizeof(e3k_rtp_chunk) * cnt, hipMemcpyHostToDevice) : e1;
+      delete[] hc;
+      if (e2 != hipSuccess) {
+        e3k_tp_plan_destroy(p);
+        return E3K_ERR_LAUNCH;
+      }
+      p->n_chunks = cnt;
     }
   }
   *out = p;
@@ -574,13 +526,14 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
 
 extern "C" int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* p) {
   // every element of g_x is stored exactly once: one group per input block, all of [0, d_in) covered, single-wave groups
-  return (p && !p->split && p->x_cols == p->d_in) ? 1 : 0;
+  return (p && !p->split && !p->x_shared && p->x_cols == p->d_in) ? 1 : 0;
 }
 
 extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
   if (!p) return;
   if (p->d_groups) (void)hipFree(p->d_groups);
   if (p->d_gc) (void)hipFree(p->d_gc);
+  if (p->d_chunks) (void)hipFree(p->d_chunks);
   delete p;
 }
 
@@ -657,6 +610,7 @@ extern "C" int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const floa
   if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !w || !dst || !src_perm))) return E3K_ERR_INVALID;
   e3k::TpArgs a{};
   a.sh = sh; a.w = w; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X, a, plan, N, (hipStream_t)stream);
 }

@@ -1,0 +1,116 @@
+// Pieces shared by the tensor-product kernels (e3k_tp.hip: per-edge weights read from HBM; e3k_rtp.hip: per-edge
+// weights formed in the kernel from the radial hidden activations): compile-time loops over the (l2, l3) slots of an
+// input degree, the spherical-harmonics registers, the plan object.
+#pragma once
+#include <type_traits>
+
+#include "e3k_common.h"
+#include "e3k_cg_gen.h"
+
+static_assert(E3K_MAXQ == E3K_TP_MAXQ, "e3k.h and e3k_cg_gen.h disagree on the slot count");
+static_assert(E3K_L2MAX == 2, "YRegs below is written for sh degrees 0..2");
+
+namespace e3k {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
+
+struct YRegs {
+  float y0[1];
+  float y1[3];
+  float y2[5];
+};
+template <int L2>
+__device__ __forceinline__ auto& yref(YRegs& y) {
+  if constexpr (L2 == 0) return y.y0;
+  else if constexpr (L2 == 1) return y.y1;
+  else return y.y2;
+}
+
+struct TpArgs {
+  const float* x;      // [N, d_in]  cf
+  const float* sh;     // [E, d_sh]
+  const float* w;      // [E, W]
+  const float* g_out;  // [N, d_mid] cf (backward)
+  float* out;          // [N, d_mid] cf (forward)
+  float* g_w;          // [E, W]
+  float* g_sh;         // [E, d_sh]
+  float* g_x;          // [N, d_in]
+  const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
+  const int32_t* ptr;  // CSR row pointers [N+1]
+  const int32_t* perm; // CSR edge ids [E]
+  int32_t d_in, d_sh, W, d_mid;
+  int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
+  int64_t n_items;
+};
+
+struct GroupRegs {
+  int x_off, mul;
+  unsigned mask;
+  int y_off[3];
+};
+
+__device__ __forceinline__ void load_y(YRegs& y, const float* __restrict__ yr, const e3k_tp_group& g) {
+  // wave-uniform addresses: these become scalar loads
+  if (g.y_off[0] >= 0) y.y0[0] = yr[g.y_off[0]];
+  if (g.y_off[1] >= 0) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) y.y1[j] = yr[g.y_off[1] + j];
+  }
+  if (g.y_off[2] >= 0) {
+#pragma unroll
+    for (int j = 0; j < 5; ++j) y.y2[j] = yr[g.y_off[2] + j];
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// visits the path slots whose output degree the plan can contain: slots with l3 > L3MAX are compiled out, so an
+// l_max = 2 model carries no accumulators for l3 = 3 outputs (14 of the 36 registers of an l1 = 2 group)
+// PART splits a group's slots between two waves (0: slots below the split point, 1: the rest, 2: all of them): at
+// l_max = 3 a group carries 27-36 accumulators; halving them takes the kernels from 3-4 to 6-7 waves per SIMD at the
+// price of gathering x[src] twice (an L2 hit).  Split points: l1 = 1 -> slot 4, l1 = 2 -> slot 4, l1 = 3 -> slot 3.
+template <int L1> struct SplitAt { static constexpr int Q = L1 == 3 ? 3 : 4; };
+template <class S, int L1, int L3MAX, int PART, class F>
+__device__ __forceinline__ void slot_for_part(F&& f) {
+  static_for<0, S::NQ>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    constexpr bool in_part = PART == 2 || (PART == 0 ? Q < SplitAt<L1>::Q : Q >= SplitAt<L1>::Q);
+    if constexpr (S::L3[Q] <= L3MAX && in_part) f(qc);
+  });
+}
+
+}  // namespace e3k
+
+// radial-fused kernels (e3k_rtp.hip): at most two paths of one group and one 64-channel chunk per matrix phase
+// (self-contained: the vector phase reads nothing of the group table, the whole descriptor sits in scalar registers)
+struct e3k_rtp_chunk {
+  int32_t group, cchunk, np;
+  uint32_t mask;          // the chunk's slots (a subset of the group's mask)
+  int32_t col[2];         // first weight column of each path: w_off[q] + 64 * cchunk
+  int32_t l1, x_off, mul;
+  int32_t y_off[3];
+  int32_t out_off[2], out_stride[2];
+  float coeff[2];
+};
+
+struct e3k_tp_plan {
+  int32_t n_groups, d_in, d_sh, w_numel, d_mid;
+  e3k_tp_group* d_groups;
+  int2* d_gc;     // (group, 64-channel chunk) work list, all degrees
+  int32_t n_gc;
+  int32_t max_l1; // largest input degree among the groups (selects the kernel instantiation)
+  int32_t max_l3; // largest output degree any group's mask enables
+  int32_t split;  // 1: groups with l1 >= 1 are walked by two waves (slot parts 0 / 1)
+  int32_t x_cols; // input columns owned by some group: sum over groups of (2 l1 + 1) * mul
+  e3k_rtp_chunk* d_chunks; // NULL when the radial-fused kernels do not serve this plan (a mul that is not a multiple of 64)
+  int32_t n_chunks;
+  int32_t y_off[3];        // sh column of each degree when every group agrees on it (the radial-fused kernels stage sh rows once per tile)
+  int32_t x_shared; // 1: two groups read overlapping input columns (an sh degree that repeats opens a second group)
+};

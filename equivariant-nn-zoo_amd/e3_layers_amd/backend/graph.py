@@ -18,7 +18,9 @@ from typing import Dict, Optional
 
 import torch
 
-TOPO_KEYS = ("_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm")
+TOPO_KEYS = ("_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
+             "_e3k_dst_own0", "_e3k_src_own0")
+RTP_TILE = 64      # edges per tile of the radial-fused kernels (csrc/e3k_rtp.hip: RT_TE; checked against the library)
 
 
 @dataclass
@@ -29,6 +31,8 @@ class GraphTopo:
     dst_perm: torch.Tensor  # int32 [E]
     src_ptr: torch.Tensor   # int32 [N+1]
     src_perm: torch.Tensor  # int32 [E]
+    dst_own0: torch.Tensor  # int32 [ceil(E / RTP_TILE) + 1]: nodes whose dst segment starts before each tile border
+    src_own0: torch.Tensor  # the same for the CSR by source
 
     @property
     def num_nodes(self) -> int:
@@ -53,7 +57,11 @@ def _csr(index: torch.Tensor, num_nodes: int):
     counts = torch.bincount(index, minlength=num_nodes)
     ptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=index.device)
     ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    return ptr, perm.to(torch.int32)
+    borders = torch.arange(0, index.numel(), RTP_TILE, device=index.device, dtype=torch.int32)
+    own0 = torch.empty(borders.numel() + 1, dtype=torch.int32, device=index.device)
+    own0[:-1] = torch.searchsorted(ptr[:-1], borders, right=False)
+    own0[-1] = num_nodes
+    return ptr, perm.to(torch.int32), own0
 
 
 def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
@@ -63,9 +71,9 @@ def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
     if edge_index.numel() and int(num_nodes) >= 2 ** 31:
         raise ValueError("node ids must fit in int32")
     src64, dst64 = edge_index[0].contiguous(), edge_index[1].contiguous()
-    dst_ptr, dst_perm = _csr(dst64, num_nodes)
-    src_ptr, src_perm = _csr(src64, num_nodes)
-    return GraphTopo(src64.to(torch.int32), dst64.to(torch.int32), dst_ptr, dst_perm, src_ptr, src_perm)
+    dst_ptr, dst_perm, dst_own0 = _csr(dst64, num_nodes)
+    src_ptr, src_perm, src_own0 = _csr(src64, num_nodes)
+    return GraphTopo(src64.to(torch.int32), dst64.to(torch.int32), dst_ptr, dst_perm, src_ptr, src_perm, dst_own0, src_own0)
 
 
 _cache: "Dict[int, tuple]" = {}

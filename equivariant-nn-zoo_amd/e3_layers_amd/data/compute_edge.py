@@ -25,7 +25,7 @@ from torch import Tensor
 
 from ..backend import lib as L
 from ..backend import ops
-from ..backend.graph import get_topology
+from ..backend.graph import TOPO_KEYS, get_topology
 from .data import segment_ids
 
 
@@ -71,8 +71,7 @@ def _all_pairs(n_nodes: Tensor, device) -> Tensor:
     return torch.stack([src, dst])
 
 
-_STALE = ("_edge_segment", "_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
-          "edge_vector", "edge_length")
+_STALE = ("_edge_segment",) + TOPO_KEYS + ("edge_vector", "edge_length")
 
 
 def _radius_graph_device(data, attrs, pos: Tensor, r_max: float):

@@ -27,6 +27,7 @@ from typing import Callable, Dict, Optional, Sequence
 
 import torch
 
+from ..backend.graph import TOPO_KEYS
 from .sde_utils import VPSDE, _node_t, _randn, get_score_fn, prior_sampling, reverse_step
 
 _PREDICTORS: Dict[str, type] = {}
@@ -119,8 +120,7 @@ class NoneCorrector(Corrector):
         return batch
 
 
-_EDGE_KEYS = ("edge_index", "edge_vector", "edge_length", "_n_edges", "_edge_segment", "_e3k_src", "_e3k_dst",
-              "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm")
+_EDGE_KEYS = ("edge_index", "edge_vector", "edge_length", "_n_edges", "_edge_segment") + TOPO_KEYS
 
 
 def get_pc_sampler(sde: VPSDE, predictor, corrector, inverse_scaler: Callable = None, snr: float = 0.16,

@@ -198,6 +198,26 @@ int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radial-fused tensor product (csrc/e3k_rtp.hip): SURVEY.md 8d "variant B".
+ * Replaces the LAST layer of the radial FullyConnectedNet (nn/message_passing.py:74-79,93: weight = fc(edge_radial))
+ * together with the gather + TensorProduct 'uvu' + scatter above (nn/message_passing.py:104-109), so that
+ * weight[E, weight_numel] never exists in HBM:
+ *     w[e, c] = w_scale * sum_k h[e, k] wl[k, c]           (formed tile by tile on the matrix pipe, kept in LDS)
+ *     out     = e3k_tp_fwd(x, sh, w)
+ * h [E,k]: activations of the last hidden layer (k = 64); wl [k, weight_numel] row-major (e3nn's weight of the last
+ * layer); w_scale = 1/sqrt(k).  Tiles are runs of e3k_rtp_tile_edges() consecutive positions of the CSR order;
+ * own0 [n_tiles+1] (int32): own0[t] = number of nodes whose segment starts before position t * tile
+ * (= lower bound of t * tile in ptr[0..N)), own0[n_tiles] = N.
+ * e3k_rtp_supported(plan): 1 when these kernels serve the plan (every mul a multiple of 64), else the caller forms
+ * w with e3k_gemm and uses e3k_tp_*.
+ * ------------------------------------------------------------------------------------------ */
+int e3k_rtp_supported(const e3k_tp_plan* plan);
+int e3k_rtp_tile_edges(void);
+int e3k_rtp_fwd(const e3k_tp_plan* plan, const float* h, const float* wl, int32_t k, float w_scale, const float* x,
+                const float* sh, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm,
+                const int32_t* dst_own0, int64_t N, int64_t E, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Un-keyed self-connection, second stage (csrc/e3k_fctp.hip).
  * Replaces o3.FullyConnectedTensorProduct(in, node_attrs, out) with general scalar attributes
  * (nn/message_passing.py:81-87,100) together with e3k_keyed_weights_fwd/bwd run with one key per node:

@@ -312,6 +312,40 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
     assert rel_err(y_edges, yr_edges) < TOL
 
 
+def test_tp_repeated_sh_degree_shares_an_input_block(dev):
+    """An edge_spherical with a degree that repeats ('1x1o+1x1e') opens a second group on the same input block: the
+    backward w.r.t. x must ADD the groups' contributions (it stored, so the last group won: ADVICE r1)."""
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(12)
+    left, sh_ir, out = "16x0e+16x1o+16x1e", "1x0e+1x1o+1x1e", "16x0e+16x0o+16x1o+16x1e+16x2e"
+    n = 23
+    ei = _random_graph(n, 5, 9)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    ref = e3ref.TensorProductExpansion(left, (sh_ir, "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).double()
+    assert ref.tp.weight_numel == mod.tp.weight_numel
+    ref.load_state_dict({k: v.cpu() for k, v in mod.state_dict().items()})
+    x = torch.randn(n, mod.tp.irreps_in1.dim, dtype=torch.float64)
+    sh = torch.randn(e, 7, dtype=torch.float64)
+    w = torch.randn(e, mod.tp.weight_numel, dtype=torch.float64)
+    xin = to_cf(x, left).float().to(dev).requires_grad_(True)
+    shin = sh.float().to(dev).requires_grad_(True)
+    win = w.float().to(dev).requires_grad_(True)
+    topo = build_topology(ei.to(dev), n)
+    y = mod.linear(mod.tp.fused(xin, shin, win, topo), in_layout="cf", out_layout="e3nn")
+    xr, shr, wr = x.clone().requires_grad_(True), sh.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = e3ref.scatter(ref(left=xr[ei[0]], right=shr, weight=wr), ei[1], dim_size=n)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    gx, gsh, gw = _grads(y, [xin, shin, win], seed.float().to(dev))
+    rx, rsh, rw = _grads(yr, [xr, shr, wr], seed)
+    assert rel_err(from_cf(gx.cpu(), left), rx) < GTOL
+    assert rel_err(gw, rw) < GTOL
+    assert rel_err(gsh, rsh) < GTOL
+
+
 def test_tp_empty_and_isolated(dev):
     """No edges at all, and nodes without in-edges: outputs are exact zeros."""
     from e3_layers_amd.backend.graph import build_topology
