@@ -1,28 +1,35 @@
 #!/usr/bin/env python3
 """bench.py — molecules/s of the config_energy training step on MI355X (the BASELINE.json metric).
 
-A step = one pass of the hot path over one synthetic QM9-like batch, exactly what the reference's
-``Trainer.batch_step`` does (``e3_layers/run/trainer.py:358-399``): forward of the
-SequentialGraphNetwork, loss ``1e3 * MSE(total_energy)`` (``e3_layers/configs/config_energy.py:27``),
-backward, (gradient all-reduce when N > 1), Adam step.  Inputs are resident in HBM before the
-timed region.  Workload at every N: BASELINE.json configs[1] — config_energy, l_max=2, n_dim 64,
-5 layers, 256 molecules per GPU (weak scaling: graph-parallel data parallelism).
+A step = one pass of the hot path over one synthetic QM9-like batch, what the reference's ``Trainer.batch_step``
+does (``e3_layers/run/trainer.py:358-399``): forward of the SequentialGraphNetwork, loss ``1e3 * MSE(total_energy)``
+(``e3_layers/configs/config_energy.py:27``), backward, (gradient all-reduce when N > 1), Adam step, EMA update
+(``config_energy.py:18-20``: use_ema).  Workload at every N: BASELINE.json configs[1] — config_energy, l_max=2,
+n_dim 64, 5 layers, 256 molecules per GPU (weak scaling: graph-parallel data parallelism).
+
+Every step sees a NEW batch object: four distinct batches are resident in HBM and each step works on a fresh device
+copy of the next one's tensors, so everything the framework derives per batch (CSR topology by destination and by
+source, tile ownership, species key groups, one-hot indices) is rebuilt inside the timed step, as in training, where
+a batch is never seen twice.  ``per_batch_prep_ms`` reports that part on its own.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line carrying the metric plus
-  roofline     — fused TP+reduce forward kernel (e3k::tp_fwd_kernel): algorithmic bytes (SURVEY.md §8d
-                 variant A) / HIP-event time of its launches inside the timed region, vs 8 TB/s;
-  cpu_baseline — the oracle (unfused PyTorch restatement, kind "port") timed on the host cores
-                 on a bounded 32-molecule sample of the same workload (rank 0, N=1 only).
+  roofline     — the fused TP+reduce forward kernel (e3k::tp_fwd_kernel): algorithmic bytes (SURVEY.md §8d variant A)
+                 / HIP-event time of its launches inside the timed region, vs 8 TB/s; ``kernels`` lists the other
+                 edge kernels and the radial GEMM the same way (the step's weakest kernel is in there, not hidden);
+  cpu_baseline — the oracle (unfused PyTorch restatement, kind "port") on the host cores at BASELINE configs[0]
+                 (config_energy as shipped: l_max 3, 32 molecules): warm-up + median, forward and forward+backward
+                 (rank 0, N=1 only).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -34,7 +41,9 @@ for _p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
 import torch
 import torch.distributed as dist
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (the clock an MFMA loop sustains is lower)
+TRAFFIC_FILE = "profiles/r02_tp_traffic.json"   # rocprofv3 --pmc passes over this command (tools/collect_profiles.sh)
 
 
 def parse():
@@ -46,46 +55,66 @@ def parse():
     ap.add_argument("--lmax", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
-                    help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) in one HIP graph and replay it; the "
-                         "roofline block then comes from an eager pass after the timed region")
-    ap.add_argument("--cpu-sample", type=int, default=96, help="molecules in the CPU-baseline sample")
+                    help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) on ONE resident batch in a HIP graph and "
+                         "replay it (no per-batch work in the replayed step: disclosed in config.launch)")
+    ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the baseline leg")
     return ap.parse_args()
 
 
-def cpu_baseline(tree, shifts, n_mol, budget_s=20.0):
-    """Oracle fwd+bwd on the host cores, fp32.  One timed step on a bounded sample: a 4-molecule
-    probe step is timed first and the sample is sized so that the timed step takes about
-    ``budget_s`` seconds (at most ``n_mol`` molecules)."""
-    from e3_layers_amd.data.synthetic import synth_qm9
+def _cpu_model_times(tree, batch, target, reps_fwd, reps_bwd, budget_s):
+    """(median forward seconds, median forward+backward seconds, reps actually timed) of the oracle network."""
     from oracle import e3ref
 
-    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds fork/join overhead on these op sizes
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     net = e3ref.build(tree).float()
 
-    def step(batch):
-        data = {k: v for k, v in batch.data.items()}
+    def fwd():
         t0 = time.perf_counter()
-        out, _ = net(data, dict(batch.attrs))
-        loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], batch["total_energy"])
-        t1 = time.perf_counter()
+        with torch.no_grad():
+            net(dict(batch.data), dict(batch.attrs))
+        return time.perf_counter() - t0
+
+    def fwd_bwd():
+        t0 = time.perf_counter()
+        out, _ = net(dict(batch.data), dict(batch.attrs))
+        loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
         net.zero_grad(set_to_none=True)
         loss.backward()
-        return t1 - t0, time.perf_counter() - t0
+        return time.perf_counter() - t0
 
-    step(synth_qm9(1, 2, shifts))  # lazy-init warm-up, untimed
-    _, probe = step(synth_qm9(2, 4, shifts))
-    n_mol = int(max(4, min(n_mol, 4 * budget_s / max(probe, 1e-3))))
-    fwd, total = step(synth_qm9(0, n_mol, shifts))
+    t_start = time.perf_counter()
+    fwd()                                                    # warm-up (thread pool, allocator)
+    f = [fwd() for _ in range(reps_fwd)]
+    if reps_bwd == 0:
+        return statistics.median(f), None, (len(f), 0)
+    warm = fwd_bwd()                                         # warm-up
+    left = budget_s - (time.perf_counter() - t_start)
+    n = max(1, min(reps_bwd, int(left / max(warm, 1e-3))))   # bounded: the default run must finish within minutes
+    b = [fwd_bwd() for _ in range(n)]
+    return statistics.median(f), statistics.median(b), (len(f), len(b))
+
+
+def cpu_baseline(budget_s):
+    """the oracle in fp32 on the host cores.  Primary figure: BASELINE configs[0] (config_energy as
+    shipped, l_max 3, 32 molecules), forward and forward+backward, warm-up + median.  Second field: forward of the
+    bench's own model (l_max 2) on 32 molecules, the denominator of the ">= 15x CPU forward" north-star clause."""
+    from e3_layers_amd.configs import config_energy
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds fork/join overhead on these op sizes
+    torch.set_num_threads(cores)
+    n_mol = 32
+    batch = synth_qm9(0, n_mol, config_energy.QM9_SHIFTS)
+    target = batch["total_energy"]
+    f3, b3, (nf3, nb3) = _cpu_model_times(config_energy.get_config(l_max=3).model_config, batch, target, 5, 10, 0.75 * budget_s)
+    f2, _, (nf2, _) = _cpu_model_times(config_energy.get_config(l_max=2).model_config, batch, target, 3, 0, 0.25 * budget_s)
     return {
-        "value": round(n_mol / total, 4),
-        "unit": "molecules/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": (f"oracle/e3ref.py fp32 on {cores} threads, 1 fwd+bwd step on synth_qm9(seed 0, {n_mol} molecules), "
-                   f"same model; {total:.1f} s total, forward-only {n_mol / fwd:.3f} molecules/s"),
-        "forward_only_value": round(n_mol / fwd, 4),
+        "value": round(n_mol / b3, 4), "unit": "molecules/s", "cores": cores, "kind": "port",
+        "sample": (f"oracle/e3ref.py fp32 on {cores} threads, BASELINE configs[0]: config_energy l_max 3, synth_qm9(seed 0, "
+                   f"{n_mol} molecules): fwd+bwd 1 warm-up + median of {nb3} ({b3:.2f} s/step), forward 1 warm-up + median of "
+                   f"{nf3} ({f3:.2f} s); second field: forward of the l_max 2 model on the same molecules, median of {nf2}"),
+        "forward_only_value": round(n_mol / f3, 4),
+        "lmax2_forward_only_value": round(n_mol / f2, 4),
     }
 
 
@@ -99,6 +128,9 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: start it as "
+                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     # one process per GPU; E3K_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
     backend = os.environ.get("E3K_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)
@@ -113,8 +145,7 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    if args.gpus != world and rank == 0:
-        print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+        assert dist.get_world_size() == args.gpus
 
     from e3_layers_amd.backend import ops
     from e3_layers_amd.backend.graph import build_topology
@@ -129,16 +160,17 @@ def main():
     torch.manual_seed(0)
     model = build(tree).to(dev)
     broadcast_parameters(model)
-    # parameters, gradients and Adam moments as flat vectors: one all-reduce, one fused optimizer launch
-    opt = FusedAdamEMA(model.parameters(), lr=cfg.learning_rate)
+    # parameters, gradients, Adam moments and the EMA shadow as flat vectors: one all-reduce, one fused optimizer launch
+    opt = FusedAdamEMA(model.parameters(), lr=cfg.learning_rate,
+                       ema_decay=cfg.ema_decay if cfg.use_ema else None, ema_use_num_updates=cfg.ema_use_num_updates)
     flat = opt.grads
     flat.enable_direct_accumulation()
 
-    # every rank owns its own 256 molecules (weak scaling); seeded per rank, resident in HBM
-    batch = synth_qm9(1000 + rank, args.batch, config_energy.QM9_SHIFTS).to(dev)
-    batch.update(build_topology(batch["edge_index"], batch["pos"].shape[0]).as_dict())
-    target = batch["total_energy"]
-    n_nodes, n_edges = batch["pos"].shape[0], batch["edge_index"].shape[1]
+    # every rank owns its own molecules (weak scaling): four distinct seeded batches per rank, resident in HBM
+    n_res = 4
+    resident = [synth_qm9(1000 + 17 * k + rank, args.batch, config_energy.QM9_SHIFTS).to(dev) for k in range(n_res)]
+    n_nodes = [b["pos"].shape[0] for b in resident]
+    n_edges = [b["edge_index"].shape[1] for b in resident]
 
     # setup, not a step of the workload: libe3k.so is loaded, the TP plans are created and the code objects of every
     # kernel on the path are paged in by one forward/backward over EIGHT molecules (no optimizer step, gradients zeroed
@@ -150,8 +182,19 @@ def main():
     torch.cuda.synchronize()
     del tiny
 
-    def step():
-        out = model(batch.view())   # fresh key dict over the resident tensors (the model adds keys, never mutates inputs)
+    counter = [0]
+
+    def next_batch():
+        """A batch the framework has never seen: fresh device copies of the next resident batch's tensors (what a
+        collated batch arriving from the loader is), so no per-batch memo (topology, key groups) can hit."""
+        b = resident[counter[0] % n_res].clone()
+        counter[0] += 1
+        return b
+
+    def step(batch=None):
+        batch = next_batch() if batch is None else batch
+        target = batch["total_energy"]          # the model writes its prediction under the same key of the same Batch
+        out = model(batch)
         loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
         flat.zero()
         loss.backward()
@@ -169,7 +212,9 @@ def main():
     if args.graph:
         from e3_layers_amd.run.graph_step import CapturedStep
 
-        captured = CapturedStep(step, warmup=3)
+        fixed = resident[0]
+        fixed.update(build_topology(fixed["edge_index"], fixed["pos"].shape[0]).as_dict())
+        captured = CapturedStep(lambda: step(fixed.view()), warmup=3)
         graph = captured.graph
         run = captured
 
@@ -192,52 +237,106 @@ def main():
     ref_step = max_over_ranks(time.perf_counter() - t0) / n_ref if n_ref else None
 
     def timed_region():
-        ops.PROFILE_TP = [] if graph is None else None
+        ops.PROFILE = {} if graph is None else None
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = run()
         fence()
         seconds = time.perf_counter() - t0
-        recs, ops.PROFILE_TP = ops.PROFILE_TP, None
+        recs, ops.PROFILE = ops.PROFILE, None
         return max_over_ranks(seconds), recs, out
 
     elapsed, records, loss = timed_region()
-    first_elapsed = None
+    retimed = None
     if ref_step is not None and elapsed / args.steps > 3.0 * ref_step:
-        # exactly K steps are timed again, once; the line reports the repeat and says so (config.retimed_after_stall)
-        first_elapsed = elapsed
+        # exactly K steps are timed again, once; the line reports the repeat and the discarded figure
+        retimed = {"first_ms_per_step": round(1e3 * elapsed / args.steps, 3), "warmup_ms_per_step": round(1e3 * ref_step, 3)}
         elapsed, records, loss = timed_region()
     if graph is not None:  # per-kernel events cannot be read back from a replayed graph: eager pass for the roofline block
-        ops.PROFILE_TP = []
+        ops.PROFILE = {}
         for _ in range(min(args.steps, 5)):
             step()
         torch.cuda.synchronize()
-        records, ops.PROFILE_TP = ops.PROFILE_TP, None
+        records, ops.PROFILE = ops.PROFILE, None
 
-    # roofline of the fused TP+reduce forward kernel (rank 0's launches in the timed region)
-    tot_bytes, tot_ms = 0.0, 0.0
-    for start, end, n, e, plan in records:
-        tot_ms += start.elapsed_time(end)
-        tot_bytes += e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
-    n_launch = max(len(records), 1)
-    achieved = tot_bytes / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-    # HBM bytes per launch from the PMC counters cannot be read in-process; they come from the committed
-    # rocprofv3 --pmc passes over this same command (profiles/, tools/collect_profiles.sh) when the
-    # workload matches, else null
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "r01_tp_fwd_traffic.json")
+    # ---- outside the timed region: the pieces of a step on their own (rank 0 reports them) -------------------------
+    def event_ms(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    def forward_only():
+        with torch.no_grad():
+            model(next_batch())
+
+    forward_only()
+    fwd_ms = event_ms(forward_only, 10)
+
+    def prep_only():
+        b = next_batch()
+        build_topology(b["edge_index"], b["pos"].shape[0])
+
+    prep_only()
+    prep_ms = event_ms(prep_only, 10)
+
+    # ---- roofline blocks (rank 0's launches in the timed region) ---------------------------------------------------
+    def tp_bytes(kind, n, e, plan):
+        """Algorithmic bytes of one launch (SURVEY.md 8d variant A)."""
+        if kind == "tp_fwd":        # x[src] gather + sh + w stream + out rows
+            return e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
+        if kind == "tp_bwd_w":      # x[src] gather + sh + g_w stream + g_mid rows
+            return e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
+        if kind == "tp_bwd_x":      # compulsory: w stream + sh + g_mid once + g_x rows (the g_mid[dst] gather is not counted)
+            return e * (4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * (plan.d_mid + plan.d_in)
+        raise KeyError(kind)
+
+    def summarise(kind):
+        recs = (records or {}).get(kind, [])
+        tot_b = sum(tp_bytes(kind, *meta) for _, _, meta in recs)
+        tot_ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
+        n = max(len(recs), 1)
+        ach = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
+        return {"kernel": f"e3k::{kind}_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4), "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / n, 2),
+                "avg_launch_algorithmic_MB": round(tot_b / n / 1e6, 2)}
+
+    traffic = {}
+    tfile = os.path.join(ROOT, TRAFFIC_FILE)
     if os.path.exists(tfile) and args.batch == 256 and args.lmax == 2:
         try:
-            traffic = round(json.load(open(tfile))["traffic_bytes_per_launch"])
+            traffic = json.load(open(tfile))
         except Exception:
-            traffic = None
-    roofline = {
-        "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "kernel": "e3k::tp_fwd_kernel", "launches": len(records),
-        "avg_launch_us": round(1e3 * tot_ms / n_launch, 2), "avg_launch_algorithmic_MB": round(tot_bytes / n_launch / 1e6, 2),
-    }
+            traffic = {}
+    main_k = summarise("tp_fwd")
+    roofline = {k: main_k[k] for k in ("bound", "achieved", "peak", "unit", "frac")}
+    t_fwd = traffic.get("tp_fwd", {}).get("traffic_bytes_per_launch")
+    roofline["traffic"] = round(t_fwd) if t_fwd else None
+    roofline["traffic_source"] = (f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, "
+                                  "NOT this run)") if t_fwd else None
+    if t_fwd and main_k["avg_launch_us"] > 0:   # DRAM-side rate: counter bytes / this run's launch time / peak
+        roofline["dram_frac"] = round(t_fwd / (main_k["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+    roofline.update({k: main_k[k] for k in ("kernel", "launches", "avg_launch_us", "avg_launch_algorithmic_MB")})
+    kernels = []
+    for kind in ("tp_bwd_x", "tp_bwd_w"):
+        k = summarise(kind)
+        t_k = traffic.get(kind, {}).get("traffic_bytes_per_launch")
+        k["traffic"] = round(t_k) if t_k else None
+        if t_k and k["avg_launch_us"] > 0:
+            k["dram_frac"] = round(t_k / (k["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        kernels.append(k)
+    recs = (records or {}).get("radial_last_fwd", [])
+    if recs:
+        flops = sum(2.0 * e * k * w for _, _, (e, k, w) in recs)
+        ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
+        kernels.append({"kernel": "e3k::gemm_smallk_kernel (radial MLP last layer, forward)", "bound": "mfma",
+                        "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "launches": len(recs),
+                        "avg_launch_us": round(1e3 * ms / len(recs), 2)})
+    roofline["kernels"] = kernels
 
     if rank == 0:
         result = {
@@ -250,17 +349,23 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {
                 "workload": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU "
-                            f"(rank 0: N={n_nodes} nodes, E={n_edges} edges), fwd + 1e3*MSE + bwd + Adam",
-                "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}", "launch": "hip-graph replay" if graph is not None else "eager",
+                            f"(rank 0: {n_res} resident batches, a fresh copy per step, N={min(n_nodes)}-{max(n_nodes)} nodes, "
+                            f"E={min(n_edges)}-{max(n_edges)} edges), fwd + 1e3*MSE + bwd + Adam + EMA",
+                "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
+                "ranks": dist.get_world_size() if world > 1 else 1,
+                "launch": "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager",
                 "parameters": countParameters(model), "final_loss": round(float(loss.detach()), 4),
+                "retimed_after_stall": retimed,
             },
+            "per_batch_prep_ms": round(prep_ms, 3),
+            "gpu_forward_only_ms": round(fwd_ms, 3),
+            "gpu_forward_only_molecules_per_s": round(args.batch / (fwd_ms * 1e-3), 1),
             "roofline": roofline,
         }
-        if first_elapsed is not None:
-            result["config"]["retimed_after_stall"] = {"first_ms_per_step": round(1e3 * first_elapsed / args.steps, 3),
-                                                       "warmup_ms_per_step": round(1e3 * ref_step, 3)}
         if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(tree, config_energy.QM9_SHIFTS, args.cpu_sample)
+            cb = cpu_baseline(args.cpu_budget)
+            result["cpu_baseline"] = cb
+            result["gpu_vs_cpu_forward"] = round(result["gpu_forward_only_molecules_per_s"] / cb["lmax2_forward_only_value"], 1)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

@@ -26,9 +26,31 @@ from torch.autograd.function import once_differentiable
 from . import lib as L
 from .graph import GraphTopo
 
-# bench.py sets this to a list to collect (start_event, end_event, N, E, plan) per launch of the
-# fused TP+reduce forward kernel (HIP events on the launching stream); None = no profiling.
-PROFILE_TP = None
+# bench.py sets this to a dict to collect, per named kernel, (start_event, end_event, meta) of every launch: HIP
+# events recorded on the LAUNCHING stream (the convolution branches run on side streams, which an event pair on
+# torch's current stream taken by the caller would not see); None = no profiling.
+PROFILE: Optional[Dict[str, list]] = None
+
+
+class timed_launch:
+    """``with timed_launch("tp_fwd", meta): <one kernel launch>`` -- a no-op unless ``PROFILE`` is a dict."""
+
+    __slots__ = ("name", "meta", "ev0")
+
+    def __init__(self, name: str, meta):
+        self.name, self.meta, self.ev0 = name, meta, None
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.ev0 = torch.cuda.Event(enable_timing=True)
+            self.ev0.record()
+
+    def __exit__(self, *exc):
+        if self.ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record()
+            PROFILE.setdefault(self.name, []).append((self.ev0, ev1, self.meta))
+        return False
 
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 # E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture).  ROCm's graph executor did not
@@ -1276,23 +1298,19 @@ def _tp_fwd_raw(x, sh, w, topo: GraphTopo, plan: TpPlan):
     assert topo.num_nodes == n and topo.num_edges == e
     out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
     handle = plan.handle(x.device)
-    prof = PROFILE_TP
-    if prof is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    L.check(L.load().e3k_tp_fwd(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
-                                L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd")
-    if prof is not None:
-        ev1.record()
-        prof.append((ev0, ev1, n, e, plan))
+    with timed_launch("tp_fwd", (n, e, plan)):
+        L.check(L.load().e3k_tp_fwd(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(topo.src), L.ptr(topo.dst_ptr),
+                                    L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd")
     return out
 
 
 def _tp_bwd_x_raw(sh, w, g_out, topo: GraphTopo, plan: TpPlan):
     n, e = topo.num_nodes, topo.num_edges
     gx = (torch.empty if plan.bwd_x_overwrites(sh.device) else torch.zeros)(n, plan.d_in, device=sh.device, dtype=torch.float32)
-    L.check(L.load().e3k_tp_bwd_x(plan.handle(sh.device), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
-                                  L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x")
+    handle = plan.handle(sh.device)
+    with timed_launch("tp_bwd_x", (n, e, plan)):
+        L.check(L.load().e3k_tp_bwd_x(handle, L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
+                                      L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x")
     return gx
 
 
@@ -1301,9 +1319,11 @@ def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool,
     assert want_w or want_sh
     gw = torch.empty(e, plan.w_numel, device=x.device, dtype=torch.float32) if want_w else None
     gsh = torch.zeros(e, plan.d_sh, device=x.device, dtype=torch.float32) if want_sh else None
-    L.check(L.load().e3k_tp_bwd_w(plan.handle(x.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
-                                  L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
-                                  L.stream_ptr()), "e3k_tp_bwd_w")
+    handle = plan.handle(x.device)
+    with timed_launch("tp_bwd_w_sh" if want_sh else "tp_bwd_w", (n, e, plan)):
+        L.check(L.load().e3k_tp_bwd_w(handle, L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.src),
+                                      L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
+                                      L.stream_ptr()), "e3k_tp_bwd_w")
     return gw, gsh
 
 
@@ -1313,16 +1333,11 @@ def _rtp_fwd_raw(h, wl, w_scale: float, x, sh, topo: GraphTopo, plan: TpPlan):
     assert x.shape[1] == plan.d_in and sh.shape[1] == plan.d_sh and h.shape[0] == e and wl.shape == (h.shape[1], plan.w_numel)
     assert topo.num_nodes == n and topo.num_edges == e
     out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
-    prof = PROFILE_TP
-    if prof is not None:
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        ev0.record()
-    L.check(L.load().e3k_rtp_fwd(plan.handle(x.device), L.ptr(h), L.ptr(wl), h.shape[1], float(w_scale), L.ptr(x), L.ptr(sh),
-                                 L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), L.ptr(topo.dst_own0), n, e,
-                                 L.ptr(out), L.stream_ptr()), "e3k_rtp_fwd")
-    if prof is not None:
-        ev1.record()
-        prof.append((ev0, ev1, n, e, plan))
+    handle = plan.handle(x.device)
+    with timed_launch("rtp_fwd", (n, e, plan)):
+        L.check(L.load().e3k_rtp_fwd(handle, L.ptr(h), L.ptr(wl), h.shape[1], float(w_scale), L.ptr(x), L.ptr(sh),
+                                     L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), L.ptr(topo.dst_own0), n, e,
+                                     L.ptr(out), L.stream_ptr()), "e3k_rtp_fwd")
     return out
 
 

@@ -184,7 +184,8 @@ class FullyConnectedNet(nn.Sequential):
         hidden, last = layers[:-1], layers[-1]
         h = ops.mlp_hidden(x, [m.weight for m in hidden], [1.0 / math.sqrt(m.h_in) for m in hidden], self.act_name,
                            hidden[0].cst)
-        return last(h)
+        with ops.timed_launch("radial_last_fwd", (h.shape[0], last.h_in, last.h_out)):
+            return last(h)
 
 
 class FullyConnectedTensorProduct(nn.Module):
