@@ -1,0 +1,162 @@
+// Per-batch graph topology on the device for gfx950: int32 endpoints and the two CSR views of the edge list
+// (by destination for the forward reduce and the weight gradients, by source for the feature gradients), with the
+// edge ids ASCENDING inside every segment -- the order of a stable sort by endpoint, i.e. the summation order of the
+// reference's CPU scatter (torch_runstats.scatter -> index_add_: e3_layers/nn/message_passing.py:109) -- plus the
+// tile ownership lists of the radial-fused kernels.  SURVEY.md 8f-1; replaces, per batch, two stable argsorts, two
+// bincounts, two cumsums, two searchsorteds and their dtype conversions (about 25 launches) by five:
+//   count   one thread per edge: int32 endpoints out, atomic histogram of both endpoints
+//   scan    one workgroup per CSR: exclusive scan of the histogram into the row pointers (+ a cursor copy)
+//   fill    one thread per edge: claims a slot in its source row and its destination row (order arbitrary)
+//   sort    one wave per (node, CSR): ranks the row's edge ids -> ascending order (rows are short: a node's degree)
+//   own0    one thread per tile border: lower bound of the border in the row starts
+// The result does not depend on the order in which the atomics of `fill` land.
+#include "e3k_common.h"
+
+namespace e3k {
+
+__global__ __launch_bounds__(256) void csr_count_kernel(const int64_t* __restrict__ edge_index, int64_t E, int32_t N,
+                                                        int32_t* __restrict__ src, int32_t* __restrict__ dst,
+                                                        int32_t* __restrict__ dst_ptr, int32_t* __restrict__ src_ptr,
+                                                        int32_t* __restrict__ bad) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = edge_index[e], d = edge_index[E + e];
+  if (s < 0 || s >= N || d < 0 || d >= N) {   // reported by the host wrapper after the build (no sync here)
+    *bad = 1;
+    src[e] = 0;
+    dst[e] = 0;
+    return;
+  }
+  src[e] = (int32_t)s;
+  dst[e] = (int32_t)d;
+  atomicAdd(src_ptr + s + 1, 1);
+  atomicAdd(dst_ptr + d + 1, 1);
+}
+
+// ptr[0] = 0, ptr[i + 1] = counts of nodes 0..i (counts arrive in ptr[1..N]); cursor[i] = ptr[i].  One workgroup.
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int32_t* __restrict__ dst_ptr, int32_t* __restrict__ src_ptr,
+                                                        int32_t* __restrict__ dst_cur, int32_t* __restrict__ src_cur, int32_t N) {
+  int32_t* ptr = blockIdx.x == 0 ? dst_ptr : src_ptr;
+  int32_t* cur = blockIdx.x == 0 ? dst_cur : src_cur;
+  __shared__ int32_t wave_tot[16];
+  __shared__ int32_t carry_s;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < N; base += 1024) {
+    const int i = base + t;
+    const int32_t v = i < N ? ptr[i + 1] : 0;
+    int32_t x = v;      // inclusive scan inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[w] = x;
+    __syncthreads();
+    int32_t before = carry_s;
+    for (int k = 0; k < w; ++k) before += wave_tot[k];
+    const int32_t incl = before + x;
+    if (i < N) {
+      ptr[i + 1] = incl;
+      cur[i] = incl - v;
+    }
+    __syncthreads();
+    if (t == 1023) carry_s = incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void csr_fill_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ dst, int64_t E,
+                                                       int32_t* __restrict__ dst_cur, int32_t* __restrict__ src_cur,
+                                                       int32_t* __restrict__ dst_tmp, int32_t* __restrict__ src_tmp) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  dst_tmp[atomicAdd(dst_cur + dst[e], 1)] = (int32_t)e;
+  src_tmp[atomicAdd(src_cur + src[e], 1)] = (int32_t)e;
+}
+
+// one wave per (node, CSR): out[beg + rank(v)] = v with rank = number of smaller ids in the row (ids are distinct)
+__global__ __launch_bounds__(256) void csr_sort_kernel(const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
+                                                       const int32_t* __restrict__ dst_tmp, const int32_t* __restrict__ src_tmp,
+                                                       int32_t* __restrict__ dst_perm, int32_t* __restrict__ src_perm, int32_t N) {
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= 2 * (int64_t)N) return;
+  const bool by_src = item >= N;
+  const int node = (int)(by_src ? item - N : item);
+  const int32_t* ptr = by_src ? src_ptr : dst_ptr;
+  const int32_t* in = by_src ? src_tmp : dst_tmp;
+  int32_t* out = by_src ? src_perm : dst_perm;
+  const int beg = uniform(ptr[node]), len = uniform(ptr[node + 1]) - beg;
+  const int lane = threadIdx.x & 63;
+  if (len <= 64) {
+    const int32_t v = lane < len ? in[beg + lane] : 0x7fffffff;
+    int rank = 0;
+    for (int j = 0; j < len; ++j) rank += __shfl(v, j, 64) < v ? 1 : 0;
+    if (lane < len) out[beg + rank] = v;
+  } else {                       // long rows (dense graphs): every lane ranks its elements against the whole row
+    for (int i = lane; i < len; i += 64) {
+      const int32_t v = in[beg + i];
+      int rank = 0;
+      for (int j = 0; j < len; ++j) rank += in[beg + j] < v ? 1 : 0;
+      out[beg + rank] = v;
+    }
+  }
+}
+
+// own0[t] = number of rows that start before position t * tile (lower bound of t * tile in ptr[0..N)); own0[n_tiles] = N
+__global__ __launch_bounds__(256) void csr_own0_kernel(const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
+                                                       int32_t N, int32_t n_tiles, int32_t tile, int32_t* __restrict__ dst_own0,
+                                                       int32_t* __restrict__ src_own0) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= 2 * (n_tiles + 1)) return;
+  const bool by_src = i > n_tiles;
+  const int t = by_src ? i - (n_tiles + 1) : i;
+  const int32_t* ptr = by_src ? src_ptr : dst_ptr;
+  int32_t* own = by_src ? src_own0 : dst_own0;
+  if (t == n_tiles) {
+    own[t] = N;
+    return;
+  }
+  const int32_t key = t * tile;
+  int lo = 0, hi = N;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  own[t] = lo;
+}
+
+}  // namespace e3k
+
+extern "C" int64_t e3k_csr_workspace_ints(int64_t N, int64_t E) { return 2 * N + 2 * E + 2; }
+
+extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile, int32_t* src, int32_t* dst,
+                             int32_t* dst_ptr, int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* dst_own0,
+                             int32_t* src_own0, int32_t* workspace, int32_t* bad_flag, void* stream) {
+  if (N < 0 || E < 0 || tile <= 0) return E3K_ERR_INVALID;
+  if (N >= 0x7fffffffLL || E >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
+  if (!dst_ptr || !src_ptr || !dst_own0 || !src_own0 || !bad_flag) return E3K_ERR_INVALID;
+  if (E > 0 && (!edge_index || !src || !dst || !dst_perm || !src_perm || !workspace)) return E3K_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  if (hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  const int32_t n_tiles = (int32_t)((E + tile - 1) / tile);
+  if (E > 0 && N > 0) {
+    int32_t* dst_cur = workspace;
+    int32_t* src_cur = workspace + N;
+    int32_t* dst_tmp = workspace + 2 * N;
+    int32_t* src_tmp = workspace + 2 * N + E;
+    const unsigned eb = (unsigned)((E + 255) / 256);
+    hipLaunchKernelGGL(e3k::csr_count_kernel, dim3(eb), dim3(256), 0, st, edge_index, E, (int32_t)N, src, dst, dst_ptr, src_ptr, bad_flag);
+    hipLaunchKernelGGL(e3k::csr_scan_kernel, dim3(2), dim3(1024), 0, st, dst_ptr, src_ptr, dst_cur, src_cur, (int32_t)N);
+    hipLaunchKernelGGL(e3k::csr_fill_kernel, dim3(eb), dim3(256), 0, st, src, dst, E, dst_cur, src_cur, dst_tmp, src_tmp);
+    hipLaunchKernelGGL(e3k::csr_sort_kernel, dim3((unsigned)((2 * N + 3) / 4)), dim3(256), 0, st, dst_ptr, src_ptr, dst_tmp, src_tmp,
+                       dst_perm, src_perm, (int32_t)N);
+  }
+  hipLaunchKernelGGL(e3k::csr_own0_kernel, dim3((unsigned)((2 * (n_tiles + 1) + 255) / 256)), dim3(256), 0, st, dst_ptr, src_ptr,
+                     (int32_t)N, n_tiles, tile, dst_own0, src_own0);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}

@@ -8,7 +8,9 @@ in-edges; building that list with a *stable* sort keeps the ascending-edge-id or
 segment, so the sum order (and hence fp32 rounding) follows the reference's CPU path, with no
 atomics.  The by-source CSR serves the backward pass (grad wrt node features, grad wrt pos).
 
-torch is used here as plumbing only (sort / bincount / cumsum on the device, once per batch).
+On the device the lists are built by ``csrc/e3k_graph.hip`` (count -> scan -> fill -> per-row rank sort: five small
+launches, no host sync); the torch construction below (stable argsort / bincount / cumsum) serves CPU tensors (host
+logic tests, gloo runs) and is the reference the device build is tested bit-exact against.
 """
 from __future__ import annotations
 
@@ -64,12 +66,63 @@ def _csr(index: torch.Tensor, num_nodes: int):
     return ptr, perm.to(torch.int32), own0
 
 
+_pending_flags: list = []      # (event, pinned host flag) of device builds whose index check has not been read yet
+
+
+def _check_pending_flags() -> None:
+    """Out-of-range endpoints are detected by the device build without a host sync: the flag travels to pinned memory
+    asynchronously and is looked at by the NEXT build (or by ``check_indices()``) once its copy has landed."""
+    while _pending_flags and _pending_flags[0][0].query():
+        _, host = _pending_flags.pop(0)
+        if int(host[0]) != 0:
+            raise ValueError("an earlier batch's edge_index held node ids outside [0, num_nodes): its topology is invalid")
+
+
+def check_indices() -> None:
+    """Block until every device-built topology so far has been validated (tests; debugging)."""
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    _check_pending_flags()
+
+
+def _build_topology_device(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
+    """csrc/e3k_graph.hip: five small launches, no host sync, bit-identical to the stable-sort construction."""
+    from . import lib as L
+
+    lib = L.load()
+    dev = edge_index.device
+    e = edge_index.shape[1]
+    ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
+    n_tiles = (e + RTP_TILE - 1) // RTP_TILE
+    i32 = dict(dtype=torch.int32, device=dev)
+    # one allocation for every output and the workspace (row pointers first: they are zero-filled by the library)
+    sizes = [num_nodes + 1, num_nodes + 1, e, e, e, e, n_tiles + 1, n_tiles + 1, 1, int(lib.e3k_csr_workspace_ints(num_nodes, e))]
+    buf = torch.empty(sum(sizes), **i32)
+    dst_ptr, src_ptr, src, dst, dst_perm, src_perm, dst_own0, src_own0, flag, work = torch.split(buf, sizes)
+    with torch.cuda.device(dev):
+        L.check(lib.e3k_csr_build(L.ptr(ei), num_nodes, e, RTP_TILE, L.ptr(src), L.ptr(dst), L.ptr(dst_ptr), L.ptr(dst_perm),
+                                  L.ptr(src_ptr), L.ptr(src_perm), L.ptr(dst_own0), L.ptr(src_own0), L.ptr(work), L.ptr(flag),
+                                  L.stream_ptr()), "e3k_csr_build")
+        if not torch.cuda.is_current_stream_capturing():
+            _check_pending_flags()
+            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            host.copy_(flag, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            _pending_flags.append((ev, host))
+            if len(_pending_flags) > 256:
+                check_indices()
+    return GraphTopo(src, dst, dst_ptr, dst_perm, src_ptr, src_perm, dst_own0, src_own0)
+
+
 def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
     """edge_index: int64 [2, E] (row 0 = source, row 1 = destination)."""
     if edge_index.dim() != 2 or edge_index.shape[0] != 2:
         raise ValueError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
-    if edge_index.numel() and int(num_nodes) >= 2 ** 31:
-        raise ValueError("node ids must fit in int32")
+    if int(num_nodes) >= 2 ** 31 - 1 or edge_index.shape[1] >= 2 ** 31 - 1:
+        raise ValueError("node and edge ids must fit in int32")
+    if edge_index.is_cuda:
+        return _build_topology_device(edge_index, int(num_nodes))
     src64, dst64 = edge_index[0].contiguous(), edge_index[1].contiguous()
     dst_ptr, dst_perm, dst_own0 = _csr(dst64, num_nodes)
     src_ptr, src_perm, src_own0 = _csr(src64, num_nodes)

@@ -222,11 +222,17 @@ class Batch(Data):
     # ---- construction ----------------------------------------------------------
     @classmethod
     def from_data_list(cls, lst: Sequence, attrs=None):
+        """Padding-free concatenation of samples (``e3_layers/data/batch.py:39-111``).  Samples may live on the host or on
+        the device: counts are taken from shapes, the per-graph ``edge_index`` offsets are applied to the concatenated
+        tensor by ONE gather-add (not one add per sample), and nothing is read back from the device -- a list of
+        device-resident samples is collated without a host sync."""
         attrs = {} if attrs is None else attrs
         attrs["_n_nodes"] = ("graph", "1x0e")
         attrs["_n_edges"] = ("graph", "1x0e")
         items = [dict(x.items()) if not isinstance(x, dict) else dict(x) for x in lst]
+        dev = next((v.device for v in items[0].values() if isinstance(v, torch.Tensor)), torch.device("cpu"))
         node_key = next((k for k in items[0] if k in attrs and attrs[k][0] == "node"), None)
+        node_tot = []         # nodes per SAMPLE as host ints when shapes tell (a sample may itself hold several graphs)
         for it in items:
             if "_n_nodes" not in it:
                 if node_key is None:
@@ -235,8 +241,17 @@ class Batch(Data):
                 t = torch.as_tensor(it[node_key])
                 n = t.reshape(-1, width).shape[0] if width else t.shape[0]
                 it["_n_nodes"] = torch.full((1, 1), n, dtype=torch.long)
+                node_tot.append(n)
             else:
                 it["_n_nodes"] = torch.as_tensor(it["_n_nodes"], dtype=torch.long).reshape(-1, 1)
+                if node_key is not None and node_key in it:
+                    width = feature_dim(attrs[node_key][1])
+                    t = torch.as_tensor(it[node_key])
+                    node_tot.append(t.reshape(-1, width).shape[0] if width else t.shape[0])
+                elif not it["_n_nodes"].is_cuda:
+                    node_tot.append(int(it["_n_nodes"].sum()))
+                else:
+                    node_tot.append(None)
             if "edge_index" in it:
                 ei = torch.as_tensor(it["edge_index"]).long()
                 it["edge_index"] = ei
@@ -246,18 +261,25 @@ class Batch(Data):
                 it["_n_edges"] = torch.as_tensor(it["_n_edges"], dtype=torch.long).reshape(-1, 1)
 
         merged: Dict[str, torch.Tensor] = {}
-        merged["_n_nodes"] = torch.cat([it["_n_nodes"] for it in items])
+        merged["_n_nodes"] = torch.cat([it["_n_nodes"].to(dev) for it in items])
         if "_n_edges" in items[0]:
-            merged["_n_edges"] = torch.cat([it["_n_edges"] for it in items])
+            merged["_n_edges"] = torch.cat([it["_n_edges"].to(dev) for it in items])
         for key in items[0]:
             if key in merged or key in ("_node_segment", "_edge_segment"):
                 continue
             if key == "edge_index":
-                parts, offset = [], 0
-                for it in items:
-                    parts.append(it[key] + offset)
-                    offset += int(it["_n_nodes"].sum())
-                merged[key] = torch.cat(parts, dim=-1)
+                cat = torch.cat([it[key].to(dev) for it in items], dim=-1)
+                if any(n is None for n in node_tot):          # counts only known on the device: one sync, as a last resort
+                    node_tot = [int(it["_n_nodes"].sum()) for it in items]
+                starts, run = [], 0
+                for n in node_tot:
+                    starts.append(run)
+                    run += n
+                sizes = [it[key].shape[-1] for it in items]
+                offs = torch.repeat_interleave(torch.tensor(starts, dtype=torch.long).to(dev, non_blocking=True),
+                                               torch.tensor(sizes, dtype=torch.long).to(dev, non_blocking=True),
+                                               output_size=sum(sizes))
+                merged[key] = cat + offs
                 continue
             width = feature_dim(attrs[key][1]) if key in attrs else None
             parts = []
@@ -266,6 +288,11 @@ class Batch(Data):
                 parts.append(t.reshape(-1, width) if width is not None else t)
             t = torch.cat(parts, dim=cat_dim(key))
             merged[key] = t.long() if t.dtype in _INT_DTYPES else t.float()
+        if dev.type != "cpu":        # segment ids with their lengths known from shapes: the constructor would sync for them
+            if all(n is not None for n in node_tot):
+                merged["_node_segment"] = segment_ids(merged["_n_nodes"], output_size=sum(node_tot))
+            if "edge_index" in merged and "_n_edges" in merged:
+                merged["_edge_segment"] = segment_ids(merged["_n_edges"], output_size=merged["edge_index"].shape[-1])
         return cls(attrs, **merged)
 
     # ---- list-like access --------------------------------------------------------

@@ -198,6 +198,21 @@ int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-batch graph topology (csrc/e3k_graph.hip).
+ * Replaces what the reference leaves to scatter(ef, edge_dst) (nn/message_passing.py:109) and Batch's segment
+ * bookkeeping (data/batch.py:164-178): from edge_index int64 [2,E] (row 0 sources, row 1 destinations) builds
+ *   src, dst [E] int32; dst_ptr/src_ptr [N+1] row pointers; dst_perm/src_perm [E] edge ids grouped by endpoint,
+ *   ASCENDING inside a row (= a stable sort by endpoint, the reference's CPU summation order);
+ *   dst_own0/src_own0 [ceil(E/tile)+1]: rows that start before each tile border (e3k_rtp_*), last entry N.
+ * workspace: e3k_csr_workspace_ints(N, E) int32.  bad_flag [1]: set to 1 when an endpoint is outside [0, N)
+ * (such edges are attached to node 0; the caller reads the flag when it chooses to).
+ * ------------------------------------------------------------------------------------------ */
+int64_t e3k_csr_workspace_ints(int64_t N, int64_t E);
+int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile, int32_t* src, int32_t* dst,
+                  int32_t* dst_ptr, int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* dst_own0,
+                  int32_t* src_own0, int32_t* workspace, int32_t* bad_flag, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radial-fused tensor product (csrc/e3k_rtp.hip): SURVEY.md 8d "variant B".
  * Replaces the LAST layer of the radial FullyConnectedNet (nn/message_passing.py:74-79,93: weight = fc(edge_radial))
  * together with the gather + TensorProduct 'uvu' + scatter above (nn/message_passing.py:104-109), so that

@@ -264,6 +264,53 @@ def test_topology_matches_stable_sort(dev):
     assert int(ptr[-1]) == ei.shape[1]
 
 
+@pytest.mark.parametrize("n,deg,shuffle", [(37, 7, False), (500, 15, True), (3, 150, True), (64, 1, True), (9, 0, False)])
+def test_device_csr_build_is_the_stable_sort(dev, n, deg, shuffle):
+    """csrc/e3k_graph.hip (count -> scan -> fill -> per-row rank sort) against the torch construction (stable argsort /
+    bincount / cumsum / searchsorted) on the host: every list bit-identical, whatever order the fill atomics landed in.
+    Cases: sparse rows, shuffled edge lists, rows longer than a wave (150 > 64), isolated nodes, no edges at all."""
+    from e3_layers_amd.backend import graph as G
+
+    gen = torch.Generator().manual_seed(n * 131 + deg)
+    if deg == 0:
+        ei = torch.zeros(2, 0, dtype=torch.long)
+    else:
+        e = n * deg
+        ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)])
+        ei[1, : e // 3] = ei[1, 0]                      # a hub: one long destination row
+        if not shuffle:
+            ei = ei[:, torch.argsort(ei[0] * n + ei[1], stable=True)]
+    ref = G.build_topology(ei, n + 2)                   # two trailing isolated nodes
+    got = G.build_topology(ei.to(dev), n + 2)
+    G.check_indices()
+    for key in G.TOPO_KEYS:
+        a, b = getattr(ref, key[len("_e3k_"):]), getattr(got, key[len("_e3k_"):])
+        assert b.dtype == torch.int32 and b.is_cuda
+        assert torch.equal(a, b.cpu()), key
+    # out-of-range endpoints are reported (asynchronously: by the next check)
+    if deg:
+        bad = ei.clone()
+        bad[1, 0] = n + 5
+        G.build_topology(bad.to(dev), n + 2)
+        with pytest.raises(ValueError):
+            G.check_indices()
+
+
+def test_batch_from_device_resident_samples(dev):
+    """Batch.from_data_list on samples that already live in HBM: same Batch as collating on the host and copying."""
+    from e3_layers_amd.data import Batch
+    from e3_layers_amd.data.synthetic import synth_qm9_list
+
+    lst, attrs = synth_qm9_list(5, 9, None, 4.0)
+    host = Batch.from_data_list([dict(s) for s in lst], dict(attrs))
+    on_dev = Batch.from_data_list([{k: (v.to(dev) if isinstance(v, torch.Tensor) else v) for k, v in s.items()} for s in lst],
+                                  dict(attrs))
+    assert set(host.keys()) == set(on_dev.keys())
+    for key in host.keys():
+        assert on_dev[key].is_cuda and torch.equal(host[key], on_dev[key].cpu()), key
+    assert torch.equal(on_dev[3]["pos"].cpu(), host[3]["pos"])
+
+
 @pytest.mark.parametrize("mul,left,out", [
     (16, "16x0e+16x1o+16x2e", "16x0e+16x1o+16x2e+16x1e+16x3o"),
     (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
