@@ -168,12 +168,21 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def require_cuda(*tensors: torch.Tensor) -> None:
+    """Operands must live on the CURRENT device: launches go to ``stream_ptr()``, the current stream of the current
+    device, and the C ABI never calls hipSetDevice (one process per GPU; use ``torch.cuda.set_device`` / ``device()``)."""
+    cur = _cur_device() if _cur_device is not None else torch.cuda.current_device()
     for t in tensors:
-        if t is not None and not t.is_cuda:
+        if t is None:
+            continue
+        if not t.is_cuda:
             raise RuntimeError(
                 "e3_layers_amd kernels run on the GPU only (got a CPU tensor); there is no CPU "
                 "fallback in the product path — the float64 CPU restatement lives in oracle/ for tests."
             )
+        if t.device.index != cur:
+            raise RuntimeError(
+                f"tensor on cuda:{t.device.index} but the current device is cuda:{cur}: the kernels launch on the current "
+                "device's stream — wrap the call in `with torch.cuda.device(tensor.device):`")
 
 
 def f32c(t: torch.Tensor) -> torch.Tensor:

@@ -23,6 +23,8 @@ from typing import Dict, List, Optional, Sequence, Tuple
 import torch
 from torch.autograd.function import once_differentiable
 
+import weakref
+
 from . import lib as L
 from .graph import GraphTopo
 
@@ -106,7 +108,10 @@ def join_side_streams() -> None:
 # buffer for every parameter.  A backward that finds its weight there accumulates the weight
 # gradient straight into the (pre-zeroed) flat buffer and returns None for it: no zero-fill of a
 # temporary and no autograd "+=" per parameter.
-GRAD_SINK: Dict[Tuple[int, int], torch.Tensor] = {}
+# Entries are (buffer slice, weak reference to the Parameter): an address is only trusted while the Parameter that
+# registered it is alive and still lives there (``model.to()``, ``load_state_dict(assign=True)`` move parameters, and
+# the allocator may hand the old address to an unrelated tensor).
+GRAD_SINK: Dict[Tuple[int, int], Tuple[torch.Tensor, "weakref.ref"]] = {}
 WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
 WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
 # True while a convolution runs its forked (multi-stream) forward: only ops recorded then move their sunk weight
@@ -180,7 +185,18 @@ def _needs(ctx):
 
 
 def _sink_for(t: torch.Tensor):
-    return GRAD_SINK.get((t.data_ptr(), t.numel())) if GRAD_SINK else None
+    if not GRAD_SINK:
+        return None
+    key = (t.data_ptr(), t.numel())
+    hit = GRAD_SINK.get(key)
+    if hit is None:
+        return None
+    buf, ref = hit
+    p = ref()
+    if p is None or p.data_ptr() != key[0] or p.numel() != key[1]:
+        del GRAD_SINK[key]       # stale: the parameter was freed or re-allocated after enable_direct_accumulation()
+        return None
+    return buf
 
 
 ACT_IDS = {None: 0, "identity": 0, "ssp": 1, "silu": 2, "tanhlu": 3, "tanh": 4, "abs": 5}

@@ -11,6 +11,7 @@ flatten/unflatten copies.
 """
 from __future__ import annotations
 
+import weakref
 from typing import Iterable, List, Sequence
 
 import torch
@@ -84,7 +85,7 @@ class FlatGradients:
         self._sink = {}
         for p, off in zip(self.params, self.offsets):
             p.grad = self.buffer[off:off + p.numel()].view_as(p)
-            self._sink[(p.data_ptr(), p.numel())] = self.buffer[off:off + p.numel()]
+            self._sink[(p.data_ptr(), p.numel())] = (self.buffer[off:off + p.numel()], weakref.ref(p))
 
     def gather(self) -> torch.Tensor:
         """The gradients without the alignment padding, concatenated in parameter order."""
@@ -92,7 +93,12 @@ class FlatGradients:
 
     def enable_direct_accumulation(self) -> None:
         """Let the HIP weight-gradient kernels add straight into this buffer (it must be zeroed with
-        ``zero()`` before every backward; each parameter must feed exactly the op that owns it)."""
+        ``zero()`` before every backward; each parameter must feed exactly the op that owns it).
+
+        Sunk gradients are written by side-stream kernels that autograd does not know about (there is no AccumulateGrad
+        node for them): ``p.grad`` is only complete after ``ops.join_side_streams()``, which ``all_reduce_mean()`` and
+        ``FusedAdamEMA.step()`` call.  A training loop that reads ``p.grad`` itself after ``backward()`` (a stock torch
+        optimizer, ``clip_grad_norm_``) must call ``ops.join_side_streams()`` first -- or not enable this mode."""
         if self.buffer.is_cuda:
             from ..backend import ops
 
