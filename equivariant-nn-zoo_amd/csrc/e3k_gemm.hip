@@ -342,163 +342,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
 }
 
-// ---------------------------------------------------------------------------------------
-// fp32 GEMM on the bf16 matrix pipe ("bf16x3 split, 6 products")
-// The f32-input MFMA runs at 1/16 of the bf16 rate (MI355X_MICROARCH "Matrix cores").  Every fp32 value is an
-// exact sum of three bf16 numbers (8 + 8 + 8 significand bits):  a = a_h + a_m + a_l.  Of the nine cross products
-// of a*b the three smallest (a_m b_l, a_l b_m, a_l b_l <= 2^-25 |ab|) are below fp32 resolution; the other six are
-// bf16 x bf16 products (exact in fp32) accumulated in fp32 by v_mfma_f32_32x32x16_bf16:
-//     a*b ~= a_l b_h + a_h b_l + a_m b_m + a_m b_h + a_h b_m + a_h b_h          (error <= 2^-24 |ab|)
-// Six bf16 MFMAs (6 x 32 cycles per 32x32x16 block) replace eight f32 MFMAs (8 x 64 cycles): 2.7x the matrix
-// rate at fp32 accuracy.  The split happens once per element when a tile is staged into LDS (three bf16 planes,
-// rows padded to 80 B so that the 16-byte fragment reads of 16 consecutive rows hit distinct bank groups).
-// ---------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-constexpr int X3_LDK = 40;   // bf16 elements per LDS row (32 + 8 pad = 80 B)
-
-__device__ __forceinline__ void split3(float a, __bf16& h, __bf16& m, __bf16& l) {
-  h = (__bf16)a;
-  const float r1 = a - (float)h;
-  m = (__bf16)r1;
-  l = (__bf16)(r1 - (float)m);
-}
-
-__device__ __forceinline__ void split3_store4(const float4& v, __bf16* ph, __bf16* pm, __bf16* pl) {
-  bf16x4 h, m, l;
-  const float in[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    __bf16 a, b, c;
-    split3(in[j], a, b, c);
-    h[j] = a; m[j] = b; l[j] = c;
-  }
-  *reinterpret_cast<bf16x4*>(ph) = h;
-  *reinterpret_cast<bf16x4*>(pm) = m;
-  *reinterpret_cast<bf16x4*>(pl) = l;
-}
-
-__device__ __forceinline__ void split3_store8(const float (&v)[8], __bf16* ph, __bf16* pm, __bf16* pl) {
-  bf16x8 h, m, l;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    __bf16 a, b, c;
-    split3(v[j], a, b, c);
-    h[j] = a; m[j] = b; l[j] = c;
-  }
-  *reinterpret_cast<bf16x8*>(ph) = h;
-  *reinterpret_cast<bf16x8*>(pm) = m;
-  *reinterpret_cast<bf16x8*>(pl) = l;
-}
-
-// six-product update of one 32x32 accumulator from the three planes of A and B (smallest terms first)
-__device__ __forceinline__ f32x16 mfma_x3(const bf16x8 (&a)[3], const bf16x8 (&b)[3], f32x16 c) {
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], c, 0, 0, 0);
-  c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], c, 0, 0, 0);
-  return c;
-}
-
-// forward / dgrad on the split path: A k-contiguous (16-byte loads), B in vector mode 1 (n-contiguous) or 2
-// (k-contiguous); tile (32*WM) x 64 x 32 as gemm_kernel
-template <int WM>
-__global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmBatch gb) {
-  constexpr int BM_ = 32 * WM;
-  constexpr int WN = 4 / WM;
-  constexpr int NT = (BN / WN) / 32;
-  constexpr int PASSES = BM_ / 32;
-  __shared__ __attribute__((aligned(16))) __bf16 Ap[3][BM_ * X3_LDK];
-  __shared__ __attribute__((aligned(16))) __bf16 Bp[3][BN * X3_LDK];
-  __shared__ long long rowA[BM_];
-  __shared__ long long rowC[BM_];
-  const BlockProblem bp_ = fetch_problem(gb);
-  const e3k_gemm_problem& P = bp_.P;
-  const int flags = bp_.flags, local = bp_.local;
-  const int M = P.M1 * P.M2;
-  const int tiles_n = (P.N + BN - 1) / BN;
-  const int row0 = (local / tiles_n) * BM_, n0 = (local % tiles_n) * BN;
-  if (row0 >= M) return;
-  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-  const int wm = w % WM, wn = w / WM;
-  const int bmode = (flags >> 1) & 3;
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-
-  fill_row_tables<BM_>(P, row0, M, rowA, rowC);
-  __syncthreads();
-
-  const float* arow[PASSES];
-#pragma unroll
-  for (int pass = 0; pass < PASSES; ++pass) {
-    const long long off = rowA[(t >> 3) + 32 * pass];
-    arow[pass] = off >= 0 ? P.A + off : nullptr;
-  }
-  const int kq = (t & 7) * 4;
-  // B staging role: column n = t & 63, eight consecutive k starting at 8 * (t >> 6)
-  const int bn = t & 63, bk = (t >> 6) * 8;
-  float4 ra[PASSES];
-  float rb[8];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-      ra[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (arow[pass] && k0 + kq < P.K) ra[pass] = *reinterpret_cast<const float4*>(arow[pass] + k0 + kq);
-    }
-    const bool nok = n0 + bn < P.N;
-    if (bmode == 1) {
-      const float* src = P.B + (int64_t)(k0 + bk) * P.b_k + (n0 + bn);
-#pragma unroll
-      for (int j = 0; j < 8; ++j) rb[j] = (nok && k0 + bk + j < P.K) ? src[(int64_t)j * P.b_k] : 0.f;
-    } else {
-      const float* src = P.B + (int64_t)(n0 + bn) * P.b_n + (k0 + bk);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (nok && k0 + bk + 4 * h < P.K) v = *reinterpret_cast<const float4*>(src + 4 * h);
-        rb[4 * h] = v.x; rb[4 * h + 1] = v.y; rb[4 * h + 2] = v.z; rb[4 * h + 3] = v.w;
-      }
-    }
-  };
-  const int a_frag = (wm * 32 + (lane & 31)) * X3_LDK + 8 * (lane >> 5);
-  const int b_frag = (wn * (BN / WN) + (lane & 31)) * X3_LDK + 8 * (lane >> 5);
-
-  gload(0);
-  for (int k0 = 0; k0 < P.K; k0 += BK) {
-#pragma unroll
-    for (int pass = 0; pass < PASSES; ++pass) {
-      const int o = ((t >> 3) + 32 * pass) * X3_LDK + kq;
-      split3_store4(ra[pass], Ap[0] + o, Ap[1] + o, Ap[2] + o);
-    }
-    {
-      const int o = bn * X3_LDK + bk;
-      split3_store8(rb, Bp[0] + o, Bp[1] + o, Bp[2] + o);
-    }
-    __syncthreads();
-    if (k0 + BK < P.K) gload(k0 + BK);
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-      bf16x8 a[3];
-#pragma unroll
-      for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(Ap[p] + a_frag + 16 * s);
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        bf16x8 b[3];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) b[p] = *reinterpret_cast<const bf16x8*>(Bp[p] + b_frag + 32 * j * X3_LDK + 16 * s);
-        acc[j] = mfma_x3(a, b, acc[j]);
-      }
-    }
-    __syncthreads();
-  }
-  store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
-}
+// (An fp32 GEMM on the bf16 matrix pipe -- every operand split into three bf16 planes, six 32x32x16 bf16 MFMAs per k-block
+// instead of eight 32x32x2 f32 ones -- was built and measured in round 1: 2.7x cheaper on the matrix pipe and as accurate,
+// but +12 % at best (K = N = 1024) and -12 % on the radial shapes: the split costs VALU per staged element and these GEMMs
+// are not matrix-pipe-bound.  Removed in round 2)
 
 // ---------------------------------------------------------------------------------------
 // small-K forward (K <= 64, A k-contiguous, B n-contiguous): A tile resident, walk column tiles
@@ -1075,7 +922,7 @@ int b_mode(const e3k_gemm_problem& P) {
   return 0;
 }
 
-enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_X3, FWD_KINDS };
+enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_KINDS };
 
 struct Batcher {
   e3k::GemmBatch gb{};
@@ -1099,7 +946,6 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
   hipStream_t st = (hipStream_t)stream;
   int kind[64];
   int64_t plain_tiles128 = 0;
-  static const int use_x3 = getenv("E3K_GEMM_X3") ? atoi(getenv("E3K_GEMM_X3")) : 0;
   static const int64_t sk_min_rows = getenv("E3K_SK_MIN_ROWS") ? atoll(getenv("E3K_SK_MIN_ROWS")) : 1024;
   for (int i = 0; i < n_problems; ++i) {
     const e3k_gemm_problem& P = problems[i];
@@ -1107,9 +953,9 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
     if (rc != E3K_OK) return rc;
     const int64_t M = (int64_t)P.M1 * P.M2;
     if (P.V > 0) kind[i] = FWD_OUTER;
-    else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows && !(use_x3 & 2)) kind[i] = FWD_SMALLK;
+    else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows) kind[i] = FWD_SMALLK;
     else {
-      kind[i] = (use_x3 && a_vec(P) && b_mode(P) != 0) ? FWD_X3 : FWD_PLAIN;
+      kind[i] = FWD_PLAIN;
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);   // keyed: the groups partition these rows
     }
   }
@@ -1129,9 +975,6 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
           rc = small_grid ? launch_batch(e3k::gemm_kernel<2>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4>, b.gb, b.blocks, st);
           break;
         case FWD_SMALLK: rc = launch_batch(e3k::gemm_smallk_kernel, b.gb, b.blocks, st); break;
-        case FWD_X3:
-          rc = small_grid ? launch_batch(e3k::gemm_x3_kernel<2>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_x3_kernel<4>, b.gb, b.blocks, st);
-          break;
         default: rc = launch_batch(e3k::gemm_outer_kernel, b.gb, b.blocks, st); break;
       }
       b.reset();
@@ -1155,7 +998,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
         static const int sk_ct = getenv("E3K_SK_CT") ? atoi(getenv("E3K_SK_CT")) : e3k::SK_CT;
         aux = tiles_n < sk_ct ? tiles_n : sk_ct;
         blocks = ((M + 127) / 128) * ((tiles_n + aux - 1) / aux);
-      } else if ((k == FWD_PLAIN || k == FWD_X3) && small_grid) {
+      } else if (k == FWD_PLAIN && small_grid) {
         blocks = ((M + 63) / 64) * tiles_n;
       } else {
         blocks = ((M + 127) / 128) * tiles_n;

@@ -319,27 +319,6 @@ __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restr
   }
 }
 
-// W_j[u][v][w] (e3nn 'uvw' order)  <->  Wv[v][c], c = packed (j,u,w): the dense [V x C] operand of the per-node weight
-// GEMMs (M = attrs . Wv and its two gradients).  One thread per column c, coalesced along w both ways.
-template <int TO_VC>
-__global__ __launch_bounds__(256) void kw_permute_kernel(const float* __restrict__ src, KwArgs ka, float* __restrict__ dst,
-                                                          int accumulate) {
-  const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (c >= ka.total) return;
-  int wout;
-  const float* base = kw_locate(ka, c, (const float*)nullptr, wout);   // offset of W[u][0][w] as a pointer from 0
-  const int64_t off = base - (const float*)nullptr;
-  for (int v = 0; v < ka.V; ++v) {
-    if (TO_VC) {
-      dst[(int64_t)v * ka.ld_m + c] = src[off + (int64_t)v * wout];
-    } else {
-      const float g = src[(int64_t)v * ka.ld_m + c];
-      float* d = dst + off + (int64_t)v * wout;
-      *d = accumulate ? *d + g : g;
-    }
-  }
-}
-
 // ga[t,v] += sum_c gM[t,c] W[c,v]  (c over all ~1e5 columns): a [K x C] x [C x V] product with a tiny output.
 // Stage 1: a block stages 256 columns of gM ([K][256]) and of W ([V][256]) in LDS with coalesced loads; thread
 // (t, v) then owns one output and walks the 256 columns with 16-byte LDS reads; the block's K*V partials go to a
@@ -749,19 +728,6 @@ extern "C" int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_k
   hipLaunchKernelGGL(e3k::keyed_weights_kernel<0>,
                      dim3((unsigned)((ka.total + 255) / 256), (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT)), dim3(256), 0,
                      (hipStream_t)stream, a, W, ka, M, (float*)nullptr, 0);
-  E3K_CHECK_LAUNCH();
-  return E3K_OK;
-}
-
-extern "C" int e3k_fctp_weight_permute(const float* src, const e3k_kw_instr* instr, int32_t n_instr, int32_t V,
-                                       int64_t ld_m, float* dst, int32_t to_vc, int32_t accumulate, void* stream) {
-  e3k::KwArgs ka{};
-  const int rc = make_kw(instr, n_instr, 1, V, ld_m, ka);
-  if (rc != E3K_OK) return rc;
-  if (!src || !dst) return E3K_ERR_INVALID;
-  const dim3 grid((unsigned)((ka.total + 255) / 256));
-  if (to_vc) hipLaunchKernelGGL(e3k::kw_permute_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, src, ka, dst, 0);
-  else hipLaunchKernelGGL(e3k::kw_permute_kernel<0>, grid, dim3(256), 0, (hipStream_t)stream, src, ka, dst, accumulate);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

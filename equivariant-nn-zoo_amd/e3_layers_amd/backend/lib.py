@@ -47,12 +47,6 @@ class KwInstr(C.Structure):
     _fields_ = [("w_off", C.c_int64), ("m_off", C.c_int64), ("u", C.c_int32), ("w_out", C.c_int32)]
 
 
-class RowmatInstr(C.Structure):
-    _fields_ = [("m_off", C.c_int64), ("in_off", C.c_int32), ("out_off", C.c_int32), ("u", C.c_int32),
-                ("w_out", C.c_int32), ("dim", C.c_int32), ("alpha", C.c_float), ("x_accumulate", C.c_int32),
-                ("_pad", C.c_int32)]
-
-
 class Block(C.Structure):
     _fields_ = [("off", C.c_int32), ("mul", C.c_int32), ("dim", C.c_int32), ("_pad", C.c_int32)]
 
@@ -75,9 +69,6 @@ SIGNATURES = {
     "e3k_gemm_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "e3k_gemm_grouped_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _I64, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_gemm_grouped": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _I32, _I64, _I32, _P]),
-    "e3k_fctp_weight_permute": (C.c_int, [_P, C.POINTER(KwInstr), _I32, _I32, _I64, _P, _I32, _I32, _P]),
-    "e3k_rowmat_fwd": (C.c_int, [_P, _P, C.POINTER(RowmatInstr), _I32, _I64, _I64, _I64, _I64, _P, _P]),
-    "e3k_rowmat_bwd": (C.c_int, [_P, _P, _P, C.POINTER(RowmatInstr), _I32, _I64, _I64, _I64, _I64, _P, _P, _P]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),

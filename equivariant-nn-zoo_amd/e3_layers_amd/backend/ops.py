@@ -114,46 +114,67 @@ def join_side_streams() -> None:
 GRAD_SINK: Dict[Tuple[int, int], Tuple[torch.Tensor, "weakref.ref"]] = {}
 WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
 WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
-# True while a convolution runs its forked (multi-stream) forward: only ops recorded then move their sunk weight
-# gradients to the side stream — small, host-bound batches keep everything on one stream
-IN_FORK = False
-# True while GradientOutput differentiates its function w.r.t. a data tensor (forces = -dE/dpos): that backward pass
-# needs no parameter gradients, yet ``ctx.needs_input_grad`` of a Python autograd.Function is fixed at forward time
-# and says True for every Parameter — the weight-gradient GEMMs of the force pass would all be computed and dropped.
-# (torch's own ops ask the engine per call; custom Functions cannot.)
-INPUTS_ONLY = False
+class _Mode:
+    """A process-wide mode flag with an owner.  These flags steer the e3k autograd functions from OUTSIDE a forward or
+    backward call (a fork scope around a convolution, a gradient-selection scope around ``autograd.grad`` /
+    ``backward``).  They cannot be thread-local -- the autograd engine runs backward functions on its own threads, not on
+    the caller's -- so they are process-wide, and therefore guarded: a second thread entering a scope that another
+    thread holds raises instead of silently inheriting (or clobbering) the other's mode.  Truthiness = inside a scope."""
+
+    __slots__ = ("name", "depth", "owner", "_lock")
+
+    def __init__(self, name: str):
+        import threading
+
+        self.name, self.depth, self.owner, self._lock = name, 0, None, threading.Lock()
+
+    def __bool__(self) -> bool:
+        return self.depth > 0
+
+    def __enter__(self):
+        import threading
+
+        me = threading.get_ident()
+        with self._lock:
+            if self.depth and self.owner != me:
+                raise RuntimeError(f"ops.{self.name} is held by another thread: the e3k backward modes are process-wide "
+                                   "(one model step at a time per process; use one process per GPU)")
+            self.owner = me
+            self.depth += 1
+        return self
+
+    def __exit__(self, *exc):
+        with self._lock:
+            self.depth -= 1
+            if self.depth == 0:
+                self.owner = None
+        return False
 
 
-class inputs_only_backward:
+# Inside ``with ops.IN_FORK:`` a convolution runs its forked (multi-stream) forward: only ops recorded then move their
+# sunk weight gradients to the side stream -- small, host-bound batches keep everything on one stream.  (Each autograd
+# function copies the flag into its ``ctx`` at forward time; the backward reads the copy, never the flag.)
+IN_FORK = _Mode("IN_FORK")
+# Inside ``with ops.inputs_only_backward():`` GradientOutput differentiates its function w.r.t. a data tensor (forces =
+# -dE/dpos): that backward pass needs no parameter gradients, yet ``ctx.needs_input_grad`` of a Python autograd.Function
+# is fixed at forward time and says True for every Parameter -- the weight-gradient GEMMs of the force pass would all
+# be computed and dropped.  (torch's own ops ask the engine per call; custom Functions cannot.)
+INPUTS_ONLY = _Mode("INPUTS_ONLY")
+# Inside ``with ops.params_only_backward(): loss.backward(inputs=params)`` the caller differentiates w.r.t. Parameters
+# only: in a force-training step ``pos`` still requires grad when the loss is differentiated, so every backward would
+# also produce d loss / d pos through the spherical harmonics -- three extra grad_sh edge passes per layer that nothing
+# consumes.  Tensors the geometry layers mark as functions of the input data alone get no gradient then.
+PARAMS_ONLY = _Mode("PARAMS_ONLY")
+
+
+def inputs_only_backward() -> _Mode:
     """``with ops.inputs_only_backward(): torch.autograd.grad(y, data_tensor, ...)``: gradients of Parameters (and of
     tensors computed from Parameters alone) are skipped inside the e3k backward functions."""
-
-    def __enter__(self):
-        global INPUTS_ONLY
-        self.prev, INPUTS_ONLY = INPUTS_ONLY, True
-
-    def __exit__(self, *exc):
-        global INPUTS_ONLY
-        INPUTS_ONLY = self.prev
-        return False
+    return INPUTS_ONLY
 
 
-# True while the caller differentiates w.r.t. Parameters only (``with ops.params_only_backward(): loss.backward(inputs=
-# params)``): in a force-training step ``pos`` still requires grad when the loss is differentiated, so every backward
-# would also produce d loss / d pos through the spherical harmonics -- three extra grad_sh edge passes per layer that
-# nothing consumes.  Tensors the geometry layers mark as functions of the input data alone get no gradient then.
-PARAMS_ONLY = False
-
-
-class params_only_backward:
-    def __enter__(self):
-        global PARAMS_ONLY
-        self.prev, PARAMS_ONLY = PARAMS_ONLY, True
-
-    def __exit__(self, *exc):
-        global PARAMS_ONLY
-        PARAMS_ONLY = self.prev
-        return False
+def params_only_backward() -> _Mode:
+    return PARAMS_ONLY
 
 
 def is_data_only(t) -> bool:
@@ -454,7 +475,7 @@ class StridedLinearFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight)
         ctx.act, ctx.act_cst = act, act_cst
         ctx.spec, ctx.scale, ctx.has_bias, ctx.has_base = spec, scale, bias is not None, base is not None
-        ctx.in_fork = IN_FORK
+        ctx.in_fork = bool(IN_FORK)
         return y
 
     @staticmethod
@@ -723,7 +744,7 @@ class FctpFn(torch.autograd.Function):
             _run_gemm(probs)
         ctx.save_for_backward(x, attrs, weight)
         ctx.spec = spec
-        ctx.in_fork = IN_FORK
+        ctx.in_fork = bool(IN_FORK)
         return y
 
     @staticmethod
@@ -830,203 +851,6 @@ def fctp(x, attrs, weight, spec: FctpSpec):
 
 
 # --------------------------------------------------------------------------------------
-# Un-keyed self-connection through per-node contracted weights (csrc/e3k_fctp.hip): M[n] = sum_v attrs[n,v] W[:,v,:]
-# (KeyedWeightsFn with one key per node), then  out[n,k,:] = alpha * x[n,k,:] . M[n]  (RowMatFn below).
-# --------------------------------------------------------------------------------------
-def rowmat_supported(spec: "FctpSpec") -> bool:
-    """The second stage needs cf blocks, output blocks owned by one instruction each, <= 64 input channels per block
-    (backward), and must save work: with A = sum dim*U*W and B = sum U*W the direct form costs V*A multiply-adds, the
-    two-stage form V*B + A (plus six passes over the N x B matrix M): taken from a 1.5-fold saving on."""
-    ins = spec.instr
-    if spec.in_layout != "cf" or spec.out_layout != "cf" or not ins or len(ins) > 16 or spec.v > 32:
-        return False
-    if len({i.i_out for i in ins}) != len(ins):
-        return False
-    if any(i.mul_in > 64 or i.dim > 7 for i in ins):
-        return False
-    a = sum(i.dim * i.mul_in * i.mul_out for i in ins)
-    b = sum(i.mul_in * i.mul_out for i in ins)
-    return spec.v * a >= 1.5 * (spec.v * b + a)
-
-
-def _dense_problem(a, b, c, m1, n, k, a_r1, b_k, b_n, c_r1, accumulate=0):
-    p = L.GemmProblem()
-    p.A, p.A2, p.B, p.C, p.bias = a, None, b, c, None
-    p.M1, p.M2, p.N, p.K, p.V = m1, 1, n, k, 0
-    p.accumulate = accumulate
-    p.a_r1, p.a_r2, p.a_k = a_r1, 0, 1
-    p.b_k, p.b_n = b_k, b_n
-    p.c_r1, p.c_r2, p.c_n = c_r1, 0, 1
-    p.alpha = 1.0
-    return p
-
-
-class RowWeightsFn(torch.autograd.Function):
-    """M[n, c] = sum_v attrs[n, v] Wv[v, c]: one contracted weight matrix per node as a dense MFMA GEMM over the
-    [V, C] view of the 'uvw' weight (``e3k_fctp_weight_permute``); both gradients are dense GEMMs too — the one w.r.t.
-    attrs has a 32-wide output and a 40 k-deep reduction, so it runs as 16 K-slices with separate partial outputs."""
-
-    K_SLICES = 16
-
-    @staticmethod
-    def forward(ctx, attrs, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
-        ctx.param_slots = _param_slots(attrs, weight)
-        L.require_cuda(attrs, weight)
-        attrs, weight = L.f32c(attrs), L.f32c(weight)
-        rows, v = attrs.shape
-        lib = L.load()
-        wv = torch.empty(v, ld_m, device=attrs.device, dtype=torch.float32)
-        L.check(lib.e3k_fctp_weight_permute(L.ptr(weight), _kw_array(spec, m_off), len(spec.instr), v, ld_m, L.ptr(wv), 1, 0,
-                                            L.stream_ptr()), "e3k_fctp_weight_permute")
-        m = torch.empty(rows, ld_m, device=attrs.device, dtype=torch.float32)
-        _run_gemm([_dense_problem(_addr(attrs), _addr(wv), _addr(m), rows, ld_m, v, v, ld_m, 1, ld_m)])
-        ctx.save_for_backward(attrs, weight, wv)
-        ctx.cfg = (spec, m_off, ld_m)
-        return m
-
-    @staticmethod
-    def backward(ctx, gm):
-        need = _needs(ctx)
-        attrs, weight, wv = ctx.saved_tensors
-        spec, m_off, ld_m = ctx.cfg
-        need_a, need_w = need[:2]
-        if torch.is_grad_enabled():
-            wrt = [t for t, nd in zip((attrs, weight), (need_a, need_w)) if nd]
-            if not wrt:
-                return None, None, None, None, None
-            with torch.enable_grad():
-                grads = list(torch.autograd.grad(_keyed_weights_composed(attrs, weight, spec), wrt, gm, create_graph=True))
-            return (grads.pop(0) if need_a else None), (grads.pop(0) if need_w else None), None, None, None
-        gm = L.f32c(gm)
-        rows, v = attrs.shape
-        lib = L.load()
-        ga = ret_w = None
-        if need_w:
-            gwv = torch.zeros(v, ld_m, device=attrs.device, dtype=torch.float32)
-            _run_gemm([_dense_problem(_addr(attrs), _addr(gwv), _addr(gm), rows, ld_m, v, v, ld_m, 1, ld_m, 1)], wgrad=True)
-            gw = _sink_for(weight)
-            acc = 1
-            if gw is None:
-                covered = sum(i.mul_in * spec.v * i.mul_out for i in spec.instr) == weight.numel()
-                gw = ret_w = (torch.empty_like(weight) if covered else torch.zeros_like(weight))
-                acc = 0
-            L.check(lib.e3k_fctp_weight_permute(L.ptr(gwv), _kw_array(spec, m_off), len(spec.instr), v, ld_m, L.ptr(gw), 0, acc,
-                                                L.stream_ptr()), "e3k_fctp_weight_permute")
-        if need_a:
-            # ga = gm . Wv^T: output [rows, V], reduction over ld_m columns -> K slices with their own partial outputs
-            ks = RowWeightsFn.K_SLICES
-            chunk = -(-ld_m // ks)
-            chunk += (-chunk) % 4
-            ks = -(-ld_m // chunk)
-            part = torch.empty(ks, rows, v, device=attrs.device, dtype=torch.float32)
-            probs = []
-            for i in range(ks):
-                k = min(chunk, ld_m - i * chunk)
-                probs.append(_dense_problem(_addr(gm, i * chunk), _addr(wv, i * chunk), _addr(part, i * rows * v), rows, v, k,
-                                            ld_m, 1, ld_m, v))
-            _run_gemm(probs)
-            ga = part.sum(0)
-        return ga, ret_w, None, None, None
-
-
-def row_weights(attrs, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: int):
-    return RowWeightsFn.apply(_c(attrs), _c(weight), spec, tuple(int(v) for v in m_off), int(ld_m))
-
-
-def _rowmat_fill(arr, k, ins, mo, x_accumulate=0):
-    (arr[k].m_off, arr[k].in_off, arr[k].out_off, arr[k].u, arr[k].w_out, arr[k].dim, arr[k].alpha, arr[k].x_accumulate) = (
-        int(mo), ins.in_off, ins.out_off, ins.mul_in, ins.mul_out, ins.dim, ins.alpha, x_accumulate)
-
-
-def _rowmat_array(spec: "FctpSpec", m_off):
-    def build():
-        arr = (L.RowmatInstr * len(spec.instr))()
-        for k, (ins, mo) in enumerate(zip(spec.instr, m_off)):
-            _rowmat_fill(arr, k, ins, mo)
-        return arr
-    return _templates(spec, ("rowmat", tuple(m_off)), build)
-
-
-def _rowmat_bwd_rounds(spec: "FctpSpec", m_off):
-    """Instructions that read the same input block accumulate its gradient: one launch per round."""
-    def build():
-        seen: Dict[int, int] = {}
-        rounds: List[List] = []
-        for ins, mo in zip(spec.instr, m_off):
-            r = seen.get(ins.i_in, 0)
-            seen[ins.i_in] = r + 1
-            while len(rounds) <= r:
-                rounds.append([])
-            rounds[r].append((ins, mo))
-        out = []
-        for r, group in enumerate(rounds):
-            arr = (L.RowmatInstr * len(group))()
-            for k, (ins, mo) in enumerate(group):
-                _rowmat_fill(arr, k, ins, mo, 1 if r > 0 else 0)
-            out.append((arr, len(group)))
-        return out
-    return _templates(spec, ("rowmat_bwd", tuple(m_off)), build)
-
-
-def _rowmat_composed(x, m, spec: "FctpSpec", m_off):
-    """torch restatement of RowMatFn.forward (double-backward graph only)."""
-    rows = x.shape[0]
-    parts = torch.zeros(rows, spec.d_out, device=x.device, dtype=x.dtype)
-    for ins, mo in zip(spec.instr, m_off):
-        xb = x[:, ins.in_off:ins.in_off + ins.dim * ins.mul_in].reshape(rows, ins.dim, ins.mul_in)
-        mb = m[:, mo:mo + ins.mul_in * ins.mul_out].reshape(rows, ins.mul_in, ins.mul_out)
-        ob = ins.alpha * torch.einsum("nku,nuw->nkw", xb, mb)
-        parts[:, ins.out_off:ins.out_off + ins.dim * ins.mul_out] = ob.reshape(rows, ins.dim * ins.mul_out)
-    return parts
-
-
-class RowMatFn(torch.autograd.Function):
-    """y[n, k, :] = alpha * x[n, k, :] . M[n]  per instruction (cf blocks)."""
-
-    @staticmethod
-    def forward(ctx, x, m, spec: "FctpSpec", m_off: Tuple[int, ...]):
-        L.require_cuda(x, m)
-        x, m = L.f32c(x), L.f32c(m)
-        rows = x.shape[0]
-        assert x.shape[1] == spec.d_in and m.shape[0] == rows
-        y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
-        arr = _rowmat_array(spec, m_off)
-        L.check(L.load().e3k_rowmat_fwd(L.ptr(x), L.ptr(m), arr, len(spec.instr), rows, spec.d_in, spec.d_out, m.shape[1],
-                                        L.ptr(y), L.stream_ptr()), "e3k_rowmat_fwd")
-        ctx.save_for_backward(x, m)
-        ctx.spec, ctx.m_off = spec, m_off
-        return y
-
-    @staticmethod
-    def backward(ctx, gy):
-        x, m = ctx.saved_tensors
-        spec, m_off = ctx.spec, ctx.m_off
-        need_x, need_m = ctx.needs_input_grad[:2]
-        if torch.is_grad_enabled():   # double backward: differentiate the torch restatement of the same bilinear form
-            wrt = [t for t, nd in zip((x, m), (need_x, need_m)) if nd]
-            if not wrt:
-                return None, None, None, None
-            with torch.enable_grad():
-                grads = list(torch.autograd.grad(_rowmat_composed(x, m, spec, m_off), wrt, gy, create_graph=True))
-            return (grads.pop(0) if need_x else None), (grads.pop(0) if need_m else None), None, None
-        gy = L.f32c(gy)
-        rows = x.shape[0]
-        gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32) if need_x else None
-        covered = sum(i.mul_in * i.mul_out for i in spec.instr) == m.shape[1]
-        gm = (torch.empty_like(m) if covered else torch.zeros_like(m)) if need_m else None
-        if gx is not None or gm is not None:
-            lib, st = L.load(), L.stream_ptr()
-            for arr, n in _rowmat_bwd_rounds(spec, m_off):
-                L.check(lib.e3k_rowmat_bwd(L.ptr(x), L.ptr(m), L.ptr(gy), arr, n, rows, spec.d_in, spec.d_out, m.shape[1],
-                                           L.ptr(gx), L.ptr(gm), st), "e3k_rowmat_bwd")
-        return gx, gm, None, None
-
-
-def row_matmul(x, m, spec: "FctpSpec", m_off: Sequence[int]):
-    return RowMatFn.apply(_c(x), _c(m), spec, tuple(int(v) for v in m_off))
-
-
-# --------------------------------------------------------------------------------------
 # Self-connection over *keyed* node attributes: rows of node_attrs that carry the same integer key
 # (structurally identical rows, e.g. attrs = Linear(one_hot(species))) share the contracted weight
 # M[t] = sum_v attrs_t[v] W[:, v, :], so the self-connection becomes one small GEMM per key group
@@ -1052,31 +876,48 @@ def _kw_array(spec: "FctpSpec", m_off):
     return _templates(spec, ("kw", tuple(m_off)), build)
 
 
-def _keyed_weights_composed(a_rep, weight, spec: "FctpSpec"):
-    """torch restatement of KeyedWeightsFn.forward (double-backward graph only)."""
-    parts = []
-    for ins in spec.instr:
-        w = weight.reshape(-1)[ins.w_off: ins.w_off + ins.mul_in * spec.v * ins.mul_out]
-        parts.append(torch.einsum("tv,uvw->tuw", a_rep, w.reshape(ins.mul_in, spec.v, ins.mul_out)).reshape(a_rep.shape[0], ins.mul_in * ins.mul_out))
-    return torch.cat(parts, dim=1)
+def _kw_fwd_raw(a_rep, weight, spec: "FctpSpec", m_off, ld_m: int):
+    k = a_rep.shape[0]
+    m = torch.empty(k, ld_m, device=a_rep.device, dtype=torch.float32)
+    L.check(L.load().e3k_keyed_weights_fwd(L.ptr(a_rep), L.ptr(weight), _kw_array(spec, m_off), len(spec.instr), k, spec.v,
+                                           ld_m, L.ptr(m), L.stream_ptr()), "e3k_keyed_weights_fwd")
+    return m
+
+
+def _kw_bwd_raw(a_rep, weight, gm, spec: "FctpSpec", m_off, ld_m: int, want_a: bool, gw, acc: int):
+    """ga [K,V] = sum_c gM[t,c] W[c,v] (needs weight, gm) and / or gw (+)= sum_t a[t,v] gM[t,c] (needs a_rep, gm); the
+    operand a pass does not read may be any tensor of the right dtype."""
+    lib, arr = L.load(), _kw_array(spec, m_off)
+    k = gm.shape[0]
+    ga = work = None
+    if want_a:
+        ga = torch.zeros(k, spec.v, device=gm.device, dtype=torch.float32)
+        work = torch.empty(lib.e3k_keyed_weights_bwd_workspace(arr, len(spec.instr), k, spec.v), device=gm.device, dtype=torch.float32)
+    L.check(lib.e3k_keyed_weights_bwd(L.ptr(a_rep), L.ptr(weight), L.ptr(gm), arr, len(spec.instr), k, spec.v, ld_m, L.ptr(ga),
+                                      L.ptr(gw), acc, L.ptr(work), L.stream_ptr()), "e3k_keyed_weights_bwd")
+    return ga
+
+
+def _kw_weight_buffer(weight, spec: "FctpSpec"):
+    covered = sum(i.mul_in * spec.v * i.mul_out for i in spec.instr) == weight.numel()
+    return torch.empty_like(weight) if covered else torch.zeros_like(weight)
 
 
 class KeyedWeightsFn(torch.autograd.Function):
     """M[t, (j,u,w)] = sum_v a_rep[t,v] W_j[u,v,w]: the per-key contracted self-connection weights, read straight from
-    the e3nn-ordered flat weight (no permuted copies), one launch; backward two launches."""
+    the e3nn-ordered flat weight (no permuted copies), one launch; backward two launches.  M is bilinear in (a, W): with
+    F = <gM, M(a, W)> every derivative of every order is one of three kernels -- forward (leave M open), bwd_a (leave a
+    open), bwd_w (leave W open) -- with operands exchanged, so the double backward of force training
+    (GradientOutput, create_graph=True) runs the same HIP kernels (KwBwdAFn / KwBwdWFn below)."""
 
     @staticmethod
     def forward(ctx, a_rep, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
         ctx.param_slots = _param_slots(a_rep, weight)
         L.require_cuda(a_rep, weight)
         a_rep, weight = L.f32c(a_rep), L.f32c(weight)
-        k = a_rep.shape[0]
-        m = torch.empty(k, ld_m, device=a_rep.device, dtype=torch.float32)
-        L.check(L.load().e3k_keyed_weights_fwd(L.ptr(a_rep), L.ptr(weight), _kw_array(spec, m_off), len(spec.instr), k, spec.v,
-                                               ld_m, L.ptr(m), L.stream_ptr()), "e3k_keyed_weights_fwd")
         ctx.save_for_backward(a_rep, weight)
         ctx.cfg = (spec, m_off, ld_m)
-        return m
+        return _kw_fwd_raw(a_rep, weight, spec, m_off, ld_m)
 
     @staticmethod
     def backward(ctx, gm):
@@ -1085,14 +926,10 @@ class KeyedWeightsFn(torch.autograd.Function):
         spec, m_off, ld_m = ctx.cfg
         need_a, need_w = need[:2]
         if torch.is_grad_enabled():
-            wrt = [t for t, nd in zip((a_rep, weight), (need_a, need_w)) if nd]
-            if not wrt:
-                return None, None, None, None, None
-            with torch.enable_grad():
-                grads = list(torch.autograd.grad(_keyed_weights_composed(a_rep, weight, spec), wrt, gm, create_graph=True))
-            return (grads.pop(0) if need_a else None), (grads.pop(0) if need_w else None), None, None, None
+            ga = KwBwdAFn.apply(gm, weight, spec, m_off, ld_m) if need_a else None
+            gw = KwBwdWFn.apply(a_rep, gm, weight, spec, m_off, ld_m) if need_w else None
+            return ga, gw, None, None, None
         gm = L.f32c(gm)
-        ga = torch.zeros_like(a_rep) if need_a else None
         gw = ret_w = None
         acc = 0
         if need_w:
@@ -1100,18 +937,53 @@ class KeyedWeightsFn(torch.autograd.Function):
             if gw is not None:
                 acc = 1
             else:
-                covered = sum(i.mul_in * spec.v * i.mul_out for i in spec.instr) == weight.numel()
-                gw = ret_w = (torch.empty_like(weight) if covered else torch.zeros_like(weight))
-        if ga is not None or gw is not None:
-            lib, arr = L.load(), _kw_array(spec, m_off)
-            work = None
-            if ga is not None:
-                n_work = lib.e3k_keyed_weights_bwd_workspace(arr, len(spec.instr), a_rep.shape[0], spec.v)
-                work = torch.empty(n_work, device=a_rep.device, dtype=torch.float32)
-            L.check(lib.e3k_keyed_weights_bwd(L.ptr(a_rep), L.ptr(weight), L.ptr(gm), arr, len(spec.instr), a_rep.shape[0], spec.v,
-                                              ld_m, L.ptr(ga), L.ptr(gw), acc, L.ptr(work), L.stream_ptr()),
-                    "e3k_keyed_weights_bwd")
+                gw = ret_w = _kw_weight_buffer(weight, spec)
+        ga = None
+        if need_a or gw is not None:
+            ga = _kw_bwd_raw(a_rep, weight, gm, spec, m_off, ld_m, bool(need_a), gw, acc)
         return ga, ret_w, None, None, None
+
+
+class KwBwdAFn(torch.autograd.Function):
+    """ga = dF/da (gM, W): bilinear in (gM, W)."""
+
+    @staticmethod
+    def forward(ctx, gm, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
+        gm, weight = L.f32c(gm), L.f32c(weight)
+        ctx.save_for_backward(gm, weight)
+        ctx.cfg = (spec, m_off, ld_m)
+        return _kw_bwd_raw(gm, weight, gm, spec, m_off, ld_m, True, None, 0)
+
+    @staticmethod
+    def backward(ctx, ha):      # ha ~ a
+        gm, weight = ctx.saved_tensors
+        spec, m_off, ld_m = ctx.cfg
+        need_g, need_w = ctx.needs_input_grad[:2]
+        g_g = KeyedWeightsFn.apply(ha, weight, spec, m_off, ld_m) if need_g else None
+        g_w = KwBwdWFn.apply(ha, gm, weight, spec, m_off, ld_m) if need_w else None
+        return g_g, g_w, None, None, None
+
+
+class KwBwdWFn(torch.autograd.Function):
+    """gw = dF/dW (a, gM): bilinear in (a, gM); ``weight`` only lends its shape."""
+
+    @staticmethod
+    def forward(ctx, a_rep, gm, weight, spec: "FctpSpec", m_off: Tuple[int, ...], ld_m: int):
+        a_rep, gm = L.f32c(a_rep), L.f32c(gm)
+        ctx.save_for_backward(a_rep, gm)
+        ctx.cfg = (spec, m_off, ld_m)
+        gw = _kw_weight_buffer(weight, spec)
+        _kw_bwd_raw(a_rep, gw, gm, spec, m_off, ld_m, False, gw, 0)
+        return gw
+
+    @staticmethod
+    def backward(ctx, hw):      # hw ~ W
+        a_rep, gm = ctx.saved_tensors
+        spec, m_off, ld_m = ctx.cfg
+        need_a, need_g = ctx.needs_input_grad[:2]
+        g_a = KwBwdAFn.apply(gm, hw, spec, m_off, ld_m) if need_a else None
+        g_g = KeyedWeightsFn.apply(a_rep, hw, spec, m_off, ld_m) if need_g else None
+        return g_a, g_g, None, None, None, None
 
 
 def keyed_weights(a_rep, weight, spec: "FctpSpec", m_off: Sequence[int], ld_m: int):

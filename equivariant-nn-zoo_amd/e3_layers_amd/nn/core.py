@@ -227,25 +227,11 @@ class FullyConnectedTensorProduct(nn.Module):
         key = get_row_key(attrs)
         if key is not None and key[1] <= self.KEY_MAX and x_cf.shape[0] >= self.KEY_MIN_ROWS:
             return self._forward_keyed(x_cf, attrs, key)
-        if self.ROW_WEIGHTS and x_cf.shape[0] >= self.KEY_MIN_ROWS and ops.rowmat_supported(self._spec):
-            # general attributes (e.g. a time embedding): contract them into one weight matrix per node first
-            m_off, ld_m = self._m_offsets()
-            m = ops.row_weights(attrs, self.weight, self._spec, m_off, ld_m)
-            return ops.row_matmul(x_cf, m, self._spec, m_off)
         return ops.fctp(x_cf, attrs, self.weight, self._spec)
 
-    # Opt-in (E3K_ROW_WEIGHTS=1): halves the multiply-adds of the protein configuration's self-connection but moves a
-    # 250 MB per-node weight matrix through HBM six times per layer; measured 18.0 vs 13.4 ms per step there (the
-    # (2l+1) x 64 x 64 per-node products of the backward run at 2 waves / SIMD behind an LDS transpose), so the direct
-    # outer-product GEMMs stay the default.  Kept because the trade flips with more attributes or higher degrees.
-    ROW_WEIGHTS = os.environ.get("E3K_ROW_WEIGHTS", "0") == "1"
-
-    def _m_offsets(self):
-        m_off, pos = [], 0
-        for ins in self._spec.instr:
-            m_off.append(pos)
-            pos += ins.mul_in * ins.mul_out
-        return m_off, pos
+    # (Contracting general attributes into one weight matrix per node first -- M[n] = sum_v a[n,v] W[:,v,:], then a
+    # (2l+1) x U x W product per node -- halves the multiply-adds of the protein configuration but moves a 250 MB matrix
+    # through HBM six times per layer: measured 18.0 vs 13.4 ms per step, removed in round 2.)
 
     def _forward_keyed(self, x_cf, attrs, key):
         groups = row_groups(key[0], key[1])

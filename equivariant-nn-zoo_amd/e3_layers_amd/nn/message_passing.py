@@ -132,8 +132,7 @@ class FactorizedConvolution(Module):
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
-            ops.IN_FORK = True
-            try:
+            with ops.IN_FORK:
                 main = torch.cuda.current_stream(x.device)
                 side = ops.side_stream(x.device)
                 radial = data["edge_radial"]
@@ -171,8 +170,6 @@ class FactorizedConvolution(Module):
                     sc.record_stream(main)
                     scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
                     return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
-            finally:
-                ops.IN_FORK = False
         else:
             weight = self.fc(data["edge_radial"])
             x_cf = ops.relayout(x, self._in_blocks, True)

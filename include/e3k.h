@@ -233,29 +233,6 @@ int e3k_rtp_fwd(const e3k_tp_plan* plan, const float* h, const float* wl, int32_
                 const int32_t* dst_own0, int64_t N, int64_t E, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
- * Un-keyed self-connection, second stage (csrc/e3k_fctp.hip).
- * Replaces o3.FullyConnectedTensorProduct(in, node_attrs, out) with general scalar attributes
- * (nn/message_passing.py:81-87,100) together with e3k_keyed_weights_fwd/bwd run with one key per node:
- *     M[n, m_off + u*w_out + w] = sum_v a[n,v] W[u,v,w]                   (first stage)
- *     y[n, out_off + k*w_out + w] = alpha * sum_u x[n, in_off + k*u_ + u] * M[n, m_off + u*w_out + w]
- * x, y channel-fastest blocks ([2l+1][mul]); every output block belongs to one instruction; instructions that share
- * an input block go to separate e3k_rowmat_bwd launches, the later ones with x_accumulate = 1.
- * ------------------------------------------------------------------------------------------ */
-typedef struct {
-  int64_t m_off;
-  int32_t in_off, out_off;
-  int32_t u, w_out, dim;     /* dim = 2l+1 <= 7 */
-  float alpha;
-  int32_t x_accumulate;      /* backward: g_x block += (an earlier launch already wrote this input block) */
-  int32_t _pad;
-} e3k_rowmat_instr;
-int e3k_rowmat_fwd(const float* x, const float* M, const e3k_rowmat_instr* instr, int32_t n_instr, int64_t rows,
-                   int64_t d_in, int64_t d_out, int64_t ld_m, float* y, void* stream);
-/* g_x [rows, d_in] (u <= 64) and/or g_M [rows, ld_m]; either may be NULL. */
-int e3k_rowmat_bwd(const float* x, const float* M, const float* g_y, const e3k_rowmat_instr* instr, int32_t n_instr,
-                   int64_t rows, int64_t d_in, int64_t d_out, int64_t ld_m, float* g_x, float* g_M, void* stream);
-
-/* ------------------------------------------------------------------------------------------
  * Node-side elementwise kernels.
  * ------------------------------------------------------------------------------------------ */
 /* activation ids: 0 identity, 1 ssp, 2 silu, 3 tanhlu, 4 tanh, 5 abs */
@@ -333,11 +310,6 @@ typedef struct {
   int64_t w_off, m_off;
   int32_t u, w_out;
 } e3k_kw_instr;
-/* W_j[u][v][w] <-> Wv[v][c] (c = m_off_j + u*w_out + w, row length ld_m): to_vc != 0 gathers the dense [V, ld_m]
- * operand of the first-stage GEMMs from the 'uvw' flat weight; to_vc == 0 scatters a [V, ld_m] gradient back
- * (accumulate: += into dst). */
-int e3k_fctp_weight_permute(const float* src, const e3k_kw_instr* instr, int32_t n_instr, int32_t V, int64_t ld_m,
-                            float* dst, int32_t to_vc, int32_t accumulate, void* stream);
 int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys,
                           int32_t V, int64_t ld_m, float* M, void* stream);
 int64_t e3k_keyed_weights_bwd_workspace(const e3k_kw_instr* instr, int32_t n_instr, int32_t n_keys, int32_t V);

@@ -45,7 +45,6 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
         'printf("%zu %zu %zu %zu\\n", sizeof(e3k_gemm_problem), sizeof(e3k_tp_group), sizeof(e3k_block), sizeof(e3k_gate_seg));\n'
         'printf("%zu %zu %zu %zu\\n", offsetof(e3k_gemm_problem, M1), offsetof(e3k_gemm_problem, a_r1), offsetof(e3k_gemm_problem, alpha), offsetof(e3k_tp_group, coeff));\n'
         'printf("%zu %zu\\n", sizeof(e3k_kw_instr), offsetof(e3k_kw_instr, u));\n'
-        'printf("%zu %zu %zu\\n", sizeof(e3k_rowmat_instr), offsetof(e3k_rowmat_instr, alpha), offsetof(e3k_rowmat_instr, x_accumulate));\n'
         "return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -54,7 +53,6 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
     assert sizes[:4] == [C.sizeof(L.GemmProblem), C.sizeof(L.TpGroup), C.sizeof(L.Block), C.sizeof(L.GateSeg)]
     assert sizes[4:8] == [L.GemmProblem.M1.offset, L.GemmProblem.a_r1.offset, L.GemmProblem.alpha.offset, L.TpGroup.coeff.offset]
     assert sizes[8:10] == [C.sizeof(L.KwInstr), L.KwInstr.u.offset]
-    assert sizes[10:] == [C.sizeof(L.RowmatInstr), L.RowmatInstr.alpha.offset, L.RowmatInstr.x_accumulate.offset]
 
 
 def test_limits_agree_with_generated_header():
