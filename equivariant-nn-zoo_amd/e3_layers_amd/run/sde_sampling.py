@@ -30,36 +30,28 @@ import torch
 from ..backend.graph import TOPO_KEYS
 from .sde_utils import VPSDE, _node_t, _randn, get_score_fn, prior_sampling, reverse_step
 
-_PREDICTORS: Dict[str, type] = {}
-_CORRECTORS: Dict[str, type] = {}
+class _Registry(dict):
+    """name -> class table with a decorator: ``@table.register(name="langevin")`` (bare ``@table.register`` uses the
+    class name); a name is registered once."""
+
+    def __init__(self, kind: str):
+        super().__init__()
+        self.kind = kind
+
+    def register(self, cls=None, *, name=None):
+        def add(c):
+            key = name or c.__name__
+            if key in self:
+                raise ValueError(f"{self.kind} {key!r} is already registered")
+            self[key] = c
+            return c
+        return add if cls is None else add(cls)
 
 
-def register_predictor(cls=None, *, name=None):
-    def _register(c):
-        key = name or c.__name__
-        if key in _PREDICTORS:
-            raise ValueError(f"Already registered model with name: {key}")
-        _PREDICTORS[key] = c
-        return c
-    return _register if cls is None else _register(cls)
-
-
-def register_corrector(cls=None, *, name=None):
-    def _register(c):
-        key = name or c.__name__
-        if key in _CORRECTORS:
-            raise ValueError(f"Already registered model with name: {key}")
-        _CORRECTORS[key] = c
-        return c
-    return _register if cls is None else _register(cls)
-
-
-def get_predictor(name):
-    return _PREDICTORS[name]
-
-
-def get_corrector(name):
-    return _CORRECTORS[name]
+_PREDICTORS, _CORRECTORS = _Registry("predictor"), _Registry("corrector")
+# the reference's public names (e3_layers/run/sde_sampling.py:14-60)
+register_predictor, register_corrector = _PREDICTORS.register, _CORRECTORS.register
+get_predictor, get_corrector = _PREDICTORS.__getitem__, _CORRECTORS.__getitem__
 
 
 class Predictor:
