@@ -92,8 +92,18 @@ __global__ __launch_bounds__(256) void relayout_kernel(const float* __restrict__
 // ---------------------------------------------------------------------------------------
 struct GateArgs {
   int n;
+  int out_cf;   // layout of the gate OUTPUT row (y, g_y): 0 = e3nn ([mul][2l+1] blocks), 1 = channel-fastest ([2l+1][mul]):
+                // consecutive MessagePassing layers hand their features over in cf, no relayout in between
   e3k_gate_seg s[MAXBLK];
 };
+// position of gated element (channel u, component m) of segment s in an output row, and its inverse
+__device__ __forceinline__ int gate_out_idx(const e3k_gate_seg& s, int u, int m, int cf) {
+  return s.out_off + (cf ? m * s.mul + u : u * s.dim + m);
+}
+__device__ __forceinline__ void gate_out_um(const e3k_gate_seg& s, int rel, int cf, int& u, int& m) {
+  if (cf) { m = rel / s.mul; u = rel - m * s.mul; }
+  else { u = rel / s.dim; m = rel - u * s.dim; }
+}
 
 // (column-fixed threads, as in relayout_kernel: the segment of a column is resolved once, rows are walked after)
 __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ x, int64_t rows, int in_dim,
@@ -110,7 +120,8 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
       if (s.kind == 0) {
         xi = s.in_off + rel;
       } else {
-        const int u = rel / s.dim, m = rel - u * s.dim;
+        int u, m;
+        gate_out_um(s, rel, ga.out_cf, u, m);
         xi = s.in_off + m * s.mul + u;
         gi = s.gate_off + u;
       }
@@ -127,12 +138,12 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
-                                                        int64_t rows, int in_dim, int out_dim, GateArgs ga,
-                                                        float* __restrict__ gx) {
+                                                        const float* __restrict__ gy2, int64_t rows, int in_dim, int out_dim,
+                                                        GateArgs ga, float* __restrict__ gx) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c >= in_dim) return;
   // 0: activated scalar, 1: gate scalar (dot over the gated block), 2: gated element, -1: feeds nothing
-  int mode = -1, go = 0, xi = 0, dim = 0, mul = 0, act = 0;
+  int mode = -1, go = 0, gstep = 1, xi = 0, dim = 0, mul = 0, act = 0;
   float cst = 0.f;
   for (int k = 0; k < ga.n; ++k) {
     const e3k_gate_seg& s = ga.s[k];
@@ -145,13 +156,14 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
     } else {
       const int relg = c - s.gate_off;
       if (relg >= 0 && relg < s.mul) {
-        mode = 1, go = s.out_off + relg * s.dim, xi = s.in_off + relg, dim = s.dim, mul = s.mul, act = s.act, cst = s.cst;
+        mode = 1, go = gate_out_idx(s, relg, 0, ga.out_cf), gstep = ga.out_cf ? s.mul : 1, xi = s.in_off + relg, dim = s.dim,
+        mul = s.mul, act = s.act, cst = s.cst;
         break;
       }
       const int rel = c - s.in_off;
       if (rel >= 0 && rel < s.mul * s.dim) {
         const int m = rel / s.mul, u = rel - m * s.mul;
-        mode = 2, go = s.out_off + u * s.dim + m, xi = s.gate_off + u, act = s.act, cst = s.cst;
+        mode = 2, go = gate_out_idx(s, u, m, ga.out_cf), xi = s.gate_off + u, act = s.act, cst = s.cst;
         break;
       }
     }
@@ -159,16 +171,19 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
   for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
     const float* xr = x + r * in_dim;
     const float* gr = gy + r * out_dim;
+    const float* gr2 = gy2 ? gy2 + r * out_dim : nullptr;      // second addend of the incoming gradient (same layout)
+#define G(i) (gr2 ? gr[i] + gr2[i] : gr[i])
     float v = 0.f;
     if (mode == 0) {
-      v = gr[go] * cst * act_df(act, xr[c]);
+      v = G(go) * cst * act_df(act, xr[c]);
     } else if (mode == 1) {
       float dot = 0.f;
-      for (int m = 0; m < dim; ++m) dot = fmaf(gr[go + m], xr[xi + m * mul], dot);
+      for (int m = 0; m < dim; ++m) dot = fmaf(G(go + m * gstep), xr[xi + m * mul], dot);
       v = dot * cst * act_df(act, xr[c]);
     } else if (mode == 2) {
-      v = gr[go] * (cst * act_f(act, xr[xi]));
+      v = G(go) * (cst * act_f(act, xr[xi]));
     }
+#undef G
     gx[r * in_dim + c] = v;
   }
 }
@@ -191,7 +206,8 @@ __global__ __launch_bounds__(256) void gate_bwd2_gy_kernel(const float* __restri
         if (s.kind == 0) {
           v = hr[s.in_off + rel] * s.cst * act_df(s.act, xr[s.in_off + rel]);
         } else {
-          const int u = rel / s.dim, m = rel - u * s.dim;
+          int u, m;
+          gate_out_um(s, rel, ga.out_cf, u, m);
           const float gt = xr[s.gate_off + u];
           const int xi = s.in_off + m * s.mul + u;
           v = hr[xi] * (s.cst * act_f(s.act, gt)) + hr[s.gate_off + u] * xr[xi] * (s.cst * act_df(s.act, gt));
@@ -228,7 +244,7 @@ __global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restric
         if (relg >= 0 && relg < s.mul) {
           float dgh = 0.f, dgx = 0.f;   // sum_m gy*gh_gated, sum_m gy*x_gated
           for (int m = 0; m < s.dim; ++m) {
-            const float g = gr[s.out_off + relg * s.dim + m];
+            const float g = gr[gate_out_idx(s, relg, m, ga.out_cf)];
             dgh = fmaf(g, hr[s.in_off + m * s.mul + relg], dgh);
             dgx = fmaf(g, xr[s.in_off + m * s.mul + relg], dgx);
           }
@@ -238,7 +254,7 @@ __global__ __launch_bounds__(256) void gate_bwd2_x_kernel(const float* __restric
         const int rel = c - s.in_off;
         if (rel >= 0 && rel < s.mul * s.dim) {
           const int m = rel / s.mul, u = rel - m * s.mul;
-          v = hr[s.gate_off + u] * gr[s.out_off + u * s.dim + m] * (s.cst * act_df(s.act, xr[s.gate_off + u]));
+          v = hr[s.gate_off + u] * gr[gate_out_idx(s, u, m, ga.out_cf)] * (s.cst * act_df(s.act, xr[s.gate_off + u]));
           break;
         }
       }
@@ -649,10 +665,11 @@ extern "C" int e3k_relayout(const float* x, int64_t rows, int32_t row_dim, const
 }
 
 extern "C" int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_t out_dim, const e3k_gate_seg* segs,
-                            int32_t n_segs, float* y, void* stream) {
+                            int32_t n_segs, int32_t out_cf, float* y, void* stream) {
   e3k::GateArgs ga{};
   const int rc = make_gate(segs, n_segs, ga);
   if (rc != E3K_OK) return rc;
+  ga.out_cf = out_cf ? 1 : 0;
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !y) return E3K_ERR_INVALID;
@@ -662,26 +679,29 @@ extern "C" int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_
   return E3K_OK;
 }
 
-extern "C" int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int32_t in_dim, int32_t out_dim,
-                            const e3k_gate_seg* segs, int32_t n_segs, float* g_x, void* stream) {
+extern "C" int e3k_gate_bwd(const float* x, const float* g_y, const float* g_y2, int64_t rows, int32_t in_dim,
+                            int32_t out_dim, const e3k_gate_seg* segs, int32_t n_segs, int32_t out_cf, float* g_x,
+                            void* stream) {
   e3k::GateArgs ga{};
   const int rc = make_gate(segs, n_segs, ga);
   if (rc != E3K_OK) return rc;
+  ga.out_cf = out_cf ? 1 : 0;
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::gate_bwd_kernel, e3k::grid_cols(in_dim, rows), dim3(256), 0, (hipStream_t)stream, x, g_y,
-                     rows, in_dim, out_dim, ga, g_x);
+                     g_y2, rows, in_dim, out_dim, ga, g_x);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
 
 extern "C" int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t rows, int32_t in_dim,
-                             int32_t out_dim, const e3k_gate_seg* segs, int32_t n_segs, float* g_gy, float* g_x,
-                             void* stream) {
+                             int32_t out_dim, const e3k_gate_seg* segs, int32_t n_segs, int32_t out_cf, float* g_gy,
+                             float* g_x, void* stream) {
   e3k::GateArgs ga{};
   const int rc = make_gate(segs, n_segs, ga);
   if (rc != E3K_OK) return rc;
+  ga.out_cf = out_cf ? 1 : 0;
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !g_hat || (!g_gy && !g_x) || (g_x && !g_y)) return E3K_ERR_INVALID;

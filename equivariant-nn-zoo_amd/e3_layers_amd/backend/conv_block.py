@@ -1,0 +1,266 @@
+"""One MessagePassing layer (FactorizedConvolution + Gate) as ONE autograd node.
+
+The arithmetic is the kernels' (``csrc/``); between them sits the host.  Composed from one ``autograd.Function`` per
+kernel, a convolution layer costs ~12 Function applies forward and ~12 graph nodes backward, each with its own
+argument checks, context bookkeeping, stream switches and engine hand-offs: 0.45 + 0.5 ms of Python per layer and
+step -- at 256 molecules the host enqueue time (6.0 ms per step) had caught up with the GPU time (7.1 ms), so faster
+kernels stopped paying.  Here the launches of a layer are issued back to back from one forward and one backward
+function, on the same three streams (radial MLP | self-connection | node features -> tensor product) plus the
+weight-gradient stream, with explicit events instead of autograd's per-node stream hand-offs.
+
+What it replaces (reference, per layer): ``FactorizedConvolution.forward`` + ``Gate``
+(``e3_layers/nn/message_passing.py:91-124, 249``).  The composed path stays -- it is the definition, it serves
+double backward (force training), un-keyed node attributes, the 'norm' nonlinearity -- and ``E3K_CONV_BLOCK=0``
+forces it; ``tests/test_gpu_model.py::test_conv_block_equals_composed_layers`` pins the two against each other.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as L
+from . import ops
+from .graph import GraphTopo
+
+ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
+BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed)
+
+
+class ConvBlockPlan:
+    """Static description of one layer (specs own their cached launch descriptors)."""
+
+    def __init__(self, *, in_blocks, lin1_spec, mlp_alphas, mlp_act, mlp_cst, last_spec, tp_plan, post_spec, scale,
+                 sc_spec, sc_m_off, sc_ld_m, gate_spec):
+        self.in_blocks, self.lin1_spec = in_blocks, lin1_spec
+        self.mlp_alphas, self.mlp_act, self.mlp_cst, self.last_spec = tuple(mlp_alphas), mlp_act, float(mlp_cst), last_spec
+        self.tp_plan, self.post_spec, self.scale = tp_plan, post_spec, float(scale)
+        self.sc_spec, self.sc_m_off, self.sc_ld_m = sc_spec, tuple(sc_m_off) if sc_m_off is not None else None, sc_ld_m
+        self.gate_spec = gate_spec
+
+
+class _on:
+    """``with _on(stream, main)``: launches go to ``stream`` (no-op when it is ``main``)."""
+
+    __slots__ = ("st", "main")
+
+    def __init__(self, st, main):
+        self.st, self.main = st, main
+
+    def __enter__(self):
+        if self.st is not self.main:
+            torch.cuda.set_stream(self.st)
+
+    def __exit__(self, *exc):
+        if self.st is not self.main:
+            torch.cuda.set_stream(self.main)
+        return False
+
+
+def _wait(consumer, producer):
+    if consumer is not producer:
+        consumer.wait_stream(producer)
+
+
+def _rec(t, st, main):
+    if t is not None and st is not main:
+        t.record_stream(st)
+
+
+def _grad_buffer(weight, need: bool):
+    """(buffer to accumulate into, tensor to return to autograd) for one parameter."""
+    if not need:
+        return None, None
+    sink = ops._sink_for(weight)
+    if sink is not None:
+        return sink, None
+    buf = torch.zeros_like(weight)
+    return buf.view(-1), buf
+
+
+class ConvBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo: GraphTopo, groups, in_cf: bool, out_cf: bool,
+                fork: bool, w_lin1, w_post, w_sc, w_last, *w_hidden):
+        L.require_cuda(x, edge_radial, sh)
+        x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        fork = bool(fork) and not torch.cuda.is_current_stream_capturing()
+        side = ops.side_stream(dev, 0) if fork else main      # radial MLP
+        side2 = ops.side_stream(dev, 1) if fork else main     # self-connection
+        keep = any(ctx.needs_input_grad)
+        has_sc = plan.sc_spec is not None
+        n = x.shape[0]
+
+        # --- radial branch: hidden chain + last layer -> per-edge path weights [E, W]
+        _wait(side, main)
+        with _on(side, main):
+            h, zs = ops._mlp_fwd_raw(edge_radial, w_hidden, plan.mlp_alphas, plan.mlp_act, plan.mlp_cst, keep)
+            w = torch.empty(h.shape[0], plan.last_spec.d_out, device=dev, dtype=torch.float32)
+            with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
+                ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
+        _rec(edge_radial, side, main)
+        # --- node side
+        x_cf = x if in_cf else ops._relayout_raw(x, plan.in_blocks, True)
+        a_rep = m = None
+        if has_sc:
+            node_attrs = L.f32c(node_attrs)
+            _wait(side2, main)
+            with _on(side2, main):
+                a_rep = node_attrs.index_select(0, groups.reps)
+                m = ops._kw_fwd_raw(a_rep, w_sc, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m)
+                conv = ops._grp_fwd_raw(x_cf, m, groups, plan.sc_spec, plan.sc_m_off)       # [N, conv_out] cf
+            _rec(x_cf, side2, main)
+            _rec(node_attrs, side2, main)
+        x1 = torch.empty(n, plan.lin1_spec.d_out, device=dev, dtype=torch.float32)
+        ops._lin_fwd_raw(x_cf, w_lin1, None, x1, plan.lin1_spec, 1.0, False)
+        _wait(main, side)
+        _rec(w, main, side)
+        mid = ops._tp_fwd_raw(x1, sh, w, topo, plan.tp_plan)
+        if has_sc:
+            _wait(main, side2)
+            _rec(conv, main, side2)
+            ops._lin_fwd_raw(mid, w_post, None, conv, plan.post_spec, plan.scale, True)     # conv += scale * Linear(mid)
+        else:
+            conv = (torch.empty if plan.post_spec.out_covered else torch.zeros)(n, plan.post_spec.d_out, device=dev, dtype=torch.float32)
+            ops._lin_fwd_raw(mid, w_post, None, conv, plan.post_spec, plan.scale, False)
+        y = ops._gate_fwd_raw(conv, plan.gate_spec, out_cf)
+        if keep:
+            ctx.save_for_backward(x_cf, edge_radial, sh, h, w, x1, mid, conv, a_rep, m, w_lin1, w_post, w_sc, w_last,
+                                  *w_hidden, *zs)
+            ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden))
+            ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        plan, topo, groups, in_cf, out_cf, fork, n_hidden = ctx.cfg
+        saved = ctx.saved_tensors
+        x_cf, edge_radial, sh, h, w, x1, mid, conv, a_rep, m, w_lin1, w_post, w_sc, w_last = saved[:14]
+        w_hidden, zs = saved[14:14 + n_hidden], saved[14 + n_hidden:]
+        need = ctx.needs_input_grad
+        need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
+        p0 = 10
+        need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
+        need_hidden = need[p0 + 4:]
+        if torch.is_grad_enabled() or need_sh:
+            raise RuntimeError(
+                "the fused convolution block serves first-order training only (no gradient w.r.t. the spherical harmonics, "
+                "no create_graph=True): MessagePassing takes the composed path for those by itself; set E3K_CONV_BLOCK=0 "
+                "if this was reached another way")
+        has_sc = plan.sc_spec is not None
+        dev = gy.device
+        main = torch.cuda.current_stream(dev)
+        fork = fork and not torch.cuda.is_current_stream_capturing()
+        side = ops.side_stream(dev, 0) if fork else main
+        side2 = ops.side_stream(dev, 1) if fork else main
+        side3 = ops.side_stream(dev, 2) if (fork and ops.WGRAD_SIDE) else main
+        gy = L.f32c(gy)
+
+        # gate -> gradient of the convolution output (cf); the self-connection and the trailing Linear both see it
+        g_conv = ops._gate_bwd_raw(conv, gy, plan.gate_spec, out_cf)
+        ev_conv = None
+        if fork:
+            ev_conv = torch.cuda.Event()
+            ev_conv.record(main)
+        g_mid = ops._lin_dgrad_raw(g_conv, w_post, plan.post_spec, plan.scale)
+        ev_mid = None
+        if fork:
+            ev_mid = torch.cuda.Event()
+            ev_mid.record(main)
+        # weight gradient of the trailing Linear: off the critical path
+        ret_post = None
+        if need_post:
+            if side3 is not main:
+                side3.wait_event(ev_conv)
+            with _on(side3, main):           # (a fresh buffer is zero-filled on the stream that accumulates into it)
+                gb_post, ret_post = _grad_buffer(w_post, True)
+                ops._lin_wgrad_raw(mid, g_conv, gb_post, plan.post_spec, plan.scale)
+            _rec(g_conv, side3, main)
+            _rec(mid, side3, main)
+        # self-connection branch: per-key weight gradients and the attribute gradient
+        g_attrs = ret_sc = None
+        if has_sc and (need_sc or need_attrs):
+            if side2 is not main:
+                side2.wait_event(ev_conv)
+            with _on(side2, main):
+                gm = ops._grp_wgrad_raw(x_cf, g_conv, tuple(m.shape), groups, plan.sc_spec, plan.sc_m_off)
+                gb_sc, ret_sc = _grad_buffer(w_sc, need_sc)
+                acc = 1 if (gb_sc is not None and ret_sc is None) else 0      # a sink accumulates, a fresh buffer is written
+                ga = ops._kw_bwd_raw(a_rep, w_sc, gm, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m, bool(need_attrs), gb_sc, acc)
+                if need_attrs:
+                    g_attrs = torch.zeros(ctx.attrs_shape, device=dev, dtype=torch.float32)
+                    g_attrs.index_add_(0, groups.reps, ga)
+            _rec(g_conv, side2, main)
+            _rec(x_cf, side2, main)
+        # tensor product: features on this stream, per-edge weights on the radial stream
+        g_x1 = ops._tp_bwd_x_raw(sh, w, g_mid, topo, plan.tp_plan) if need_x else None
+        g_radial = ret_last = None
+        ret_hidden: List[Optional[torch.Tensor]] = [None] * n_hidden
+        if need_last or need_radial or any(need_hidden):
+            if BWD_W_ON_MAIN:
+                g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
+                _wait(side, main)
+                _rec(g_w, side, main)
+            else:
+                if side is not main:
+                    side.wait_event(ev_mid)
+                with _on(side, main):
+                    g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
+            if need_last:      # the [64, W] weight gradient (K = E: the longest reduction of the layer) joins the other
+                if side3 is not side:          # weight gradients on their stream; the radial chain continues beside it
+                    side3.wait_stream(side)
+                with _on(side3, main):
+                    gb_last, ret_last = _grad_buffer(w_last, True)
+                    ops._lin_wgrad_raw(h, g_w, gb_last, plan.last_spec, 1.0)
+                if side3 is not side:
+                    g_w.record_stream(side3)
+                    h.record_stream(side3)
+            with _on(side, main):
+                if need_radial or any(need_hidden):
+                    g_h = ops._lin_dgrad_raw(g_w, w_last, plan.last_spec, 1.0)
+                    gws = []
+                    for i, wh in enumerate(w_hidden):
+                        buf, ret = _grad_buffer(wh, need_hidden[i])
+                        gws.append(buf)
+                        ret_hidden[i] = ret
+                    g_radial = torch.empty_like(edge_radial) if need_radial else None
+                    ops._mlp_bwd_raw(edge_radial, w_hidden, zs, plan.mlp_alphas, plan.mlp_act, plan.mlp_cst, g_h, gws, g_radial)
+            for t in (g_mid, x1, sh, edge_radial):      # allocated elsewhere, read on the radial stream until it gets there
+                _rec(t, side, main)
+        # node features: linear_1, then the self-connection's contribution accumulated in place (no separate add)
+        g_x = None
+        if need_x:
+            g_xcf = ops._lin_dgrad_raw(g_x1, w_lin1, plan.lin1_spec, 1.0)
+            if has_sc:
+                ops._grp_dgrad_raw(g_conv, m, groups, plan.sc_spec, plan.sc_m_off, out=g_xcf)
+                _rec(m, main, side2)
+            g_x = g_xcf if in_cf else ops._relayout_raw(g_xcf, plan.in_blocks, False)
+        ret_lin1 = None
+        if need_lin1:
+            if g_x1 is None:
+                g_x1 = ops._tp_bwd_x_raw(sh, w, g_mid, topo, plan.tp_plan)
+            if side3 is not main:
+                side3.wait_stream(main)
+            with _on(side3, main):
+                gb_lin1, ret_lin1 = _grad_buffer(w_lin1, True)
+                ops._lin_wgrad_raw(x_cf, g_x1, gb_lin1, plan.lin1_spec, 1.0)
+            _rec(g_x1, side3, main)
+            _rec(x_cf, side3, main)
+        # parameter gradients handed back to autograd (no gradient sink) are consumed on THIS stream
+        if ret_post is not None or ret_lin1 is not None or ret_last is not None:
+            _wait(main, side3)
+        if ret_sc is not None:
+            _wait(main, side2)
+        if any(r is not None for r in ret_hidden):
+            _wait(main, side)
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None,
+                ret_lin1, ret_post, ret_sc, ret_last, *ret_hidden)
+
+
+def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups, in_cf: bool, out_cf: bool, fork: bool,
+               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor]):
+    return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork,
+                             w_lin1, w_post, w_sc, w_last, *w_hidden)

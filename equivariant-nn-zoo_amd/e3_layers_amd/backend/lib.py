@@ -103,9 +103,9 @@ SIGNATURES = {
     "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _F, _P, _P, _P]),
     "e3k_relayout": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _P, _P]),
-    "e3k_gate_fwd": (C.c_int, [_P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
-    "e3k_gate_bwd": (C.c_int, [_P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P]),
-    "e3k_gate_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _P, _P, _P]),
+    "e3k_gate_fwd": (C.c_int, [_P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _I32, _P, _P]),
+    "e3k_gate_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _I32, _P, _P]),
+    "e3k_gate_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _I32, _P, _P, _P]),
     "e3k_norm_act_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _F, _I32, _P, _P]),
     "e3k_norm_act_bwd": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(Block), _I32, _I32, _F, _I32, _P, _P]),
     "e3k_layernorm_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),

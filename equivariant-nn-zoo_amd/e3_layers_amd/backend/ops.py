@@ -382,7 +382,7 @@ def _lin_fwd_raw(x, weight, bias, y, spec: LinearSpec, scale: float, accumulate:
         y[:, off:off + mul] += bias[boff:boff + mul]
 
 
-def _lin_dgrad_templates(spec: "LinearSpec", scale: float):
+def _lin_dgrad_templates(spec: "LinearSpec", scale: float, accumulate: bool = False):
     out = []
     for r, group in enumerate(spec.rounds("i_in")):
         probs = []
@@ -392,7 +392,7 @@ def _lin_dgrad_templates(spec: "LinearSpec", scale: float):
             p = L.GemmProblem()
             p.A, p.A2, p.B, p.C, p.bias = 4 * ins.out_off, None, 4 * ins.w_off, 4 * ins.in_off, None
             p.M1, p.M2, p.N, p.K, p.V = 0, ins.dim, ins.mul_in, ins.mul_out, 0
-            p.accumulate = 1 if r > 0 else 0
+            p.accumulate = 1 if (r > 0 or accumulate) else 0
             p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
             p.b_k, p.b_n = 1, ins.mul_out  # W^T
             p.c_r1, p.c_r2, p.c_n = spec.d_in, c_r2, c_n
@@ -402,11 +402,12 @@ def _lin_dgrad_templates(spec: "LinearSpec", scale: float):
     return _GemmTemplates(out)
 
 
-def _lin_dgrad_raw(gy, weight, spec: LinearSpec, scale: float):
-    """gx = sum over instructions alpha*scale * gy_block @ W_block^T."""
+def _lin_dgrad_raw(gy, weight, spec: LinearSpec, scale: float, out=None, accumulate: bool = False):
+    """gx (+)= sum over instructions alpha*scale * gy_block @ W_block^T  (``out``: write / accumulate into this buffer)."""
     rows = gy.shape[0]
-    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
-    t = _templates(spec, ("dgrad", scale), lambda: _lin_dgrad_templates(spec, scale))
+    gx = out if out is not None else (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
+    accumulate = bool(accumulate and out is not None)
+    t = _templates(spec, ("dgrad", scale, accumulate), lambda: _lin_dgrad_templates(spec, scale, accumulate))
     t.run(gy.data_ptr(), None, weight.data_ptr(), gx.data_ptr(), None, rows)
     return gx
 
@@ -620,6 +621,27 @@ def _mlp_unfused(x, weights, alphas, act: str, cst: float):
             spec = _DENSE_SPECS[(k, n, al)] = LinearSpec(k, n, [LinInstr(0, 0, k, n, 1, 0, al)], "e3nn", "e3nn", [], True, True, k * n)
         cur = activation(strided_linear(cur, w.reshape(-1), None, spec), act, cst)
     return cur
+
+
+def _mlp_fwd_raw(x, weights, alphas, act: str, cst: float, keep: bool):
+    """h = (act o linear)^L (x); ``keep``: also return the pre-activations the backward needs."""
+    e, k0 = x.shape
+    h, n = weights[0].shape[1], len(weights)
+    out = torch.empty(e, h, device=x.device, dtype=torch.float32)
+    zs = [torch.empty(e, h, device=x.device, dtype=torch.float32) for _ in range(n)] if keep else []
+    L.check(L.load().e3k_mlp_hidden_fwd(L.ptr(x), e, k0, h, n, _ptr_array(weights), (C.c_float * n)(*alphas), ACT_IDS[act],
+                                        cst, _ptr_array(zs) if zs else None, L.ptr(out), L.stream_ptr()),
+            "e3k_mlp_hidden_fwd")
+    return out, zs
+
+
+def _mlp_bwd_raw(x, weights, zs, alphas, act: str, cst: float, g, gws, gx):
+    """gws[l] (accumulated; None = skipped), gx ([E,k0] or None) from g = gradient wrt the chain's output."""
+    e, k0 = x.shape
+    h, n = weights[0].shape[1], len(weights)
+    L.check(L.load().e3k_mlp_hidden_bwd(L.ptr(x), e, k0, h, n, _ptr_array(weights), (C.c_float * n)(*alphas), ACT_IDS[act],
+                                        cst, _ptr_array(zs), L.ptr(g), _ptr_array(gws), L.ptr(gx), L.stream_ptr()),
+            "e3k_mlp_hidden_bwd")
 
 
 class MlpHiddenFn(torch.autograd.Function):
@@ -1012,7 +1034,7 @@ def _grouped_templates(spec, m_off, mode: str):
                 p.a_r1, p.a_r2, p.a_k = spec.d_in, in_r2, in_k
                 p.b_k, p.b_n = ins.mul_out, 1
                 p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
-            elif mode == "dgrad":  # gx = gy . M^T      (A := gy, C := gx)
+            elif mode in ("dgrad", "dgrad_acc"):  # gx (+)= gy . M^T      (A := gy, C := gx)
                 p.A, p.B, p.C = 4 * ins.out_off, 4 * m_off[j], 4 * ins.in_off
                 p.N, p.K = ins.mul_in, ins.mul_out
                 p.a_r1, p.a_r2, p.a_k = spec.d_out, out_r2, out_n
@@ -1025,7 +1047,7 @@ def _grouped_templates(spec, m_off, mode: str):
                 p.b_k, p.b_n = ins.mul_out, 1
                 p.c_r1, p.c_r2, p.c_n = spec.d_out, out_r2, out_n
             tmpl.append((ins, p))
-        key = {"fwd": "i_out", "dgrad": "i_in", "wgrad": ""}[mode]
+        key = {"fwd": "i_out", "dgrad": "i_in", "dgrad_acc": "i_in", "wgrad": ""}[mode]
         seen: Dict[int, int] = {}
         rounds: List[List] = []
         for ins, p in tmpl:
@@ -1034,7 +1056,7 @@ def _grouped_templates(spec, m_off, mode: str):
             seen[k] = r + 1
             while len(rounds) <= r:
                 rounds.append([])
-            p.accumulate = 1 if (r > 0 or mode == "wgrad") else 0
+            p.accumulate = 1 if (r > 0 or mode in ("wgrad", "dgrad_acc")) else 0
             rounds[r].append(p)
         return [((L.GemmProblem * len(g))(*g), len(g)) for g in rounds]
 
@@ -1057,8 +1079,12 @@ def _grp_fwd_raw(x, m, groups, spec, m_off):
     return y
 
 
-def _grp_dgrad_raw(gy, m, groups, spec, m_off):
+def _grp_dgrad_raw(gy, m, groups, spec, m_off, out=None):
+    """gx = gy . M[key]^T per instruction; ``out``: accumulate into this buffer instead."""
     rows, ld_m = gy.shape[0], m.shape[1]
+    if out is not None:
+        _run_grouped(_grouped_templates(spec, m_off, "dgrad_acc"), gy, m, out, rows, groups, ld_m, False)
+        return out
     gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=gy.device, dtype=torch.float32)
     _run_grouped(_grouped_templates(spec, m_off, "dgrad"), gy, m, gx, rows, groups, ld_m, False)
     return gx
@@ -1414,6 +1440,16 @@ def _blocks(blocks: Sequence[Tuple[int, int, int]]):
     return arr
 
 
+def _relayout_raw(x, blocks, to_cf: bool):
+    blocks = tuple(b for b in blocks if b[1] > 1 and b[2] > 1)
+    if not blocks:
+        return x
+    y = torch.empty_like(x)
+    L.check(L.load().e3k_relayout(L.ptr(x), x.shape[0], x.shape[1], _blocks(blocks), len(blocks), int(to_cf), L.ptr(y),
+                                  L.stream_ptr()), "e3k_relayout")
+    return y
+
+
 class RelayoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, blocks, to_cf: bool):
@@ -1455,40 +1491,50 @@ class GateSpec:
 
 
 class GateFn(torch.autograd.Function):
+    """x (channel-fastest) -> gated output in the e3nn layout, or (``out_cf``) in the channel-fastest layout: consecutive
+    MessagePassing layers hand their features over in cf, so neither direction pays a relayout between them."""
+
     @staticmethod
-    def forward(ctx, x, spec: GateSpec):
+    def forward(ctx, x, spec: GateSpec, out_cf: bool = False):
         L.require_cuda(x)
         x = L.f32c(x)
         assert x.shape[1] == spec.in_dim
         y = torch.empty(x.shape[0], spec.out_dim, device=x.device, dtype=torch.float32)
         L.check(L.load().e3k_gate_fwd(L.ptr(x), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(), len(spec.segs),
-                                      L.ptr(y), L.stream_ptr()), "e3k_gate_fwd")
+                                      int(out_cf), L.ptr(y), L.stream_ptr()), "e3k_gate_fwd")
         ctx.save_for_backward(x)
-        ctx.spec = spec
+        ctx.spec, ctx.out_cf = spec, bool(out_cf)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         if torch.is_grad_enabled():
-            return GateBwdFn.apply(x, gy, ctx.spec), None
-        return _gate_bwd_raw(x, L.f32c(gy), ctx.spec), None
+            return GateBwdFn.apply(x, gy, ctx.spec, ctx.out_cf), None, None
+        return _gate_bwd_raw(x, L.f32c(gy), ctx.spec, ctx.out_cf), None, None
 
 
-def _gate_bwd_raw(x, gy, spec: GateSpec):
+def _gate_fwd_raw(x, spec: GateSpec, out_cf: bool = False):
+    y = torch.empty(x.shape[0], spec.out_dim, device=x.device, dtype=torch.float32)
+    L.check(L.load().e3k_gate_fwd(L.ptr(x), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(), len(spec.segs),
+                                  int(out_cf), L.ptr(y), L.stream_ptr()), "e3k_gate_fwd")
+    return y
+
+
+def _gate_bwd_raw(x, gy, spec: GateSpec, out_cf: bool = False, gy2=None):
     gx = torch.empty_like(x)
-    L.check(L.load().e3k_gate_bwd(L.ptr(x), L.ptr(gy), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(),
-                                  len(spec.segs), L.ptr(gx), L.stream_ptr()), "e3k_gate_bwd")
+    L.check(L.load().e3k_gate_bwd(L.ptr(x), L.ptr(gy), L.ptr(gy2), x.shape[0], spec.in_dim, spec.out_dim, spec.c_array(),
+                                  len(spec.segs), int(out_cf), L.ptr(gx), L.stream_ptr()), "e3k_gate_bwd")
     return gx
 
 
 class GateBwdFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gy, spec: GateSpec):
+    def forward(ctx, x, gy, spec: GateSpec, out_cf: bool = False):
         x, gy = L.f32c(x), L.f32c(gy)
         ctx.save_for_backward(x, gy)
-        ctx.spec = spec
-        return _gate_bwd_raw(x, gy, spec)
+        ctx.spec, ctx.out_cf = spec, bool(out_cf)
+        return _gate_bwd_raw(x, gy, spec, out_cf)
 
     @staticmethod
     @once_differentiable
@@ -1500,13 +1546,13 @@ class GateBwdFn(torch.autograd.Function):
         g_gy = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
         if g_x is not None or g_gy is not None:
             L.check(L.load().e3k_gate_bwd2(L.ptr(x), L.ptr(gy), L.ptr(h), x.shape[0], spec.in_dim, spec.out_dim,
-                                           spec.c_array(), len(spec.segs), L.ptr(g_gy), L.ptr(g_x), L.stream_ptr()),
-                    "e3k_gate_bwd2")
-        return g_x, g_gy, None
+                                           spec.c_array(), len(spec.segs), int(ctx.out_cf), L.ptr(g_gy), L.ptr(g_x),
+                                           L.stream_ptr()), "e3k_gate_bwd2")
+        return g_x, g_gy, None, None
 
 
-def gate(x, spec: GateSpec):
-    return GateFn.apply(_c(x), spec)
+def gate(x, spec: GateSpec, out_cf: bool = False):
+    return GateFn.apply(_c(x), spec, bool(out_cf))
 
 
 class NormActFn(torch.autograd.Function):

@@ -292,8 +292,8 @@ class Gate(nn.Module):
         self._spec = ops.GateSpec(self.irreps_in.dim, self.irreps_out.dim, segs)
         assert pos == self.irreps_in.dim and out_pos == self.irreps_out.dim
 
-    def forward(self, x_cf):
-        return ops.gate(x_cf, self._spec)
+    def forward(self, x_cf, out_cf: bool = False):
+        return ops.gate(x_cf, self._spec, out_cf)
 
 
 class NormActivation(nn.Module):

@@ -17,6 +17,7 @@ re-planned for MI355X:
 """
 from __future__ import annotations
 
+import math
 import os
 import weakref
 
@@ -25,11 +26,12 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from ..backend import ops
+from ..backend import conv_block, ops
 from ..backend.graph import get_topology
 from ..o3 import Irrep, Irreps
 from ..utils.utils import _is_mapping, activations, build, tp_path_exists
-from .core import FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, NormActivation, irreps_blocks
+from .core import (FullyConnectedNet, FullyConnectedTensorProduct, Gate, Linear, NormActivation, get_row_key, irreps_blocks,
+                   row_groups)
 from .pointwise import LayerNormalization, TensorProductExpansion
 from .sequential import Module
 
@@ -50,6 +52,8 @@ _FORK_REF_WIDTH = 1920
 # system with an MFMA GEMM that writes 0.5 GB: 134 -> 182 us per launch (roofline 0.64 -> 0.47).  Opt-in; issuing it
 # only after the tensor product (under the node-side launches) changed nothing.
 RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "0"))
+# 1: consecutive MessagePassing layers pass their node features in the channel-fastest layout (MessagePassing._emit_cf)
+CF_CHAIN = int(os.environ.get("E3K_CF_CHAIN", "1"))
 AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 
 
@@ -128,6 +132,7 @@ class FactorizedConvolution(Module):
         """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
+        in_cf = bool(getattr(x, "_e3k_cf", False))     # the previous MessagePassing handed its features over in cf
         if (FWD_FORK and x.is_cuda and self._fork_pays(data["edge_radial"].shape[0])
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
@@ -151,7 +156,7 @@ class FactorizedConvolution(Module):
                     nxt = None
                 if nxt is not None:
                     self._issue_ahead(nxt, radial, side, main)
-                x_cf = ops.relayout(x, self._in_blocks, True)
+                x_cf = x if in_cf else ops.relayout(x, self._in_blocks, True)
                 sc = None
                 if self.sc is not None and FWD_FORK_SC:
                     # third branch: the self-connection only meets the others at the trailing Linear
@@ -172,7 +177,7 @@ class FactorizedConvolution(Module):
                     return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
         else:
             weight = self.fc(data["edge_radial"])
-            x_cf = ops.relayout(x, self._in_blocks, True)
+            x_cf = x if in_cf else ops.relayout(x, self._in_blocks, True)
             sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
             x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
         mid = self.tp.tp.fused(x1, data["edge_spherical"], weight, topo)
@@ -231,13 +236,112 @@ class MessagePassing(Module):
         if self.normalize:
             self.norm = LayerNormalization(self.irreps_out["output_features"], self.irreps_out["output_features"])
 
+    # Set by SequentialGraphNetwork when the NEXT layer is a MessagePassing that reads (and overwrites) this layer's
+    # output key and nothing else can see it: the features are then handed over in the channel-fastest layout the
+    # convolution kernels work in -- no cf -> e3nn relayout here, no e3nn -> cf relayout there (nor their backward passes).
+    _emit_cf = False
+
+    def cf_chain_ok(self, nxt) -> bool:
+        """This layer may hand ``nxt`` its output in cf layout (see ``_emit_cf``)."""
+        return (CF_CHAIN and isinstance(nxt, MessagePassing) and isinstance(self.equivariant_nonlin, Gate)
+                and not self.resnet and not self.normalize and not nxt.resnet
+                and isinstance(nxt.conv, FactorizedConvolution) and nxt.conv.reduce
+                and tuple(irreps_blocks(self.equivariant_nonlin.irreps_out)) == nxt.conv._in_blocks)
+
+    # ---- the layer as one autograd node (backend/conv_block.py) --------------------------------------------------
+    def _block_plan(self):
+        """Static part of the fused block, or None when this layer's structure is not served by it."""
+        plan = self.__dict__.get("_cb_plan", False)
+        if plan is not False:
+            return plan
+        plan = None
+        conv = self.conv
+        ok = (isinstance(conv, FactorizedConvolution) and conv.reduce and isinstance(self.equivariant_nonlin, Gate)
+              and conv.fc.fused_hidden and conv.tp.tp.plan is not None and conv.linear_1.bias is None
+              and conv.tp.linear.bias is None)
+        if ok:
+            fc = list(conv.fc.children())
+            hidden, last = fc[:-1], fc[-1]
+            sc_spec = sc_m_off = sc_ld = None
+            if conv.sc is not None:
+                sc_spec = conv.sc._spec
+                sc_m_off, pos = [], 0
+                for ins in sc_spec.instr:
+                    sc_m_off.append(pos)
+                    pos += ins.mul_in * ins.mul_out
+                sc_ld = pos
+            plan = conv_block.ConvBlockPlan(
+                in_blocks=conv._in_blocks, lin1_spec=conv.linear_1.spec("cf", "cf"),
+                mlp_alphas=[1.0 / math.sqrt(m.h_in) for m in hidden], mlp_act=conv.fc.act_name, mlp_cst=hidden[0].cst,
+                last_spec=last._spec, tp_plan=conv.tp.tp.plan, post_spec=conv.tp.linear.spec("cf", "cf"),
+                scale=1.0 if conv.avg_num_neighbors is None else float(conv.avg_num_neighbors) ** -0.5,
+                sc_spec=sc_spec, sc_m_off=sc_m_off, sc_ld_m=sc_ld, gate_spec=self.equivariant_nonlin._spec)
+        self.__dict__["_cb_plan"] = plan
+        return plan
+
+    def _forward_block(self, data, out_cf: bool):
+        """The layer through ``conv_block`` when it applies to this call, else None (composed path)."""
+        if not conv_block.ENABLED:
+            return None
+        x, sh, radial = data["input_features"], data["edge_spherical"], data["edge_radial"]
+        if not x.is_cuda or sh.requires_grad:          # forces / double backward: the composed ops are differentiable twice
+            return None
+        plan = self._block_plan()
+        if plan is None:
+            return None
+        conv = self.conv
+        groups = attrs = None
+        if conv.sc is not None:
+            attrs = data["node_attrs"]
+            key = get_row_key(attrs)
+            if key is None or key[1] > conv.sc.KEY_MAX or x.shape[0] < conv.sc.KEY_MIN_ROWS:
+                return None                            # general (un-keyed) attributes: outer-product GEMMs, composed path
+            groups = row_groups(key[0], key[1])
+        topo = get_topology(data, x.shape[0])
+        fork = bool(FWD_FORK and conv._fork_pays(radial.shape[0])
+                    and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
+        if fork:      # gradient contributions of the shared inputs are summed on the streams that produce them
+            main = torch.cuda.current_stream(x.device)
+            side = ops.side_stream(x.device)
+            with ops.on_stream(side, main):          # (the alias's autograd node lives on the stream current NOW)
+                radial = _stream_alias(radial, side)
+            if attrs is not None:
+                side2 = ops.side_stream(x.device, 1)
+                with ops.on_stream(side2, main):
+                    attrs = _stream_alias(attrs, side2)
+        fc = list(conv.fc.children())
+        y = conv_block.conv_block(x, attrs, radial, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
+                                  conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,
+                                  fc[-1].weight, [m.weight for m in fc[:-1]])
+        return y
+
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
         old_x = data["input_features"]
+        blk = self._forward_block(data, bool(self._emit_cf))
+        if blk is not None:
+            if self._emit_cf:
+                blk._e3k_cf = True
+                return ({"output_features": blk},
+                        {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
+            output = blk
+            if self.resnet:
+                output = old_x + output
+            if self.normalize:
+                output = self.norm({"input": output}, attrs)[0]["output"]
+            return ({"output_features": output},
+                    {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
         if isinstance(self.conv, FactorizedConvolution) and self.conv.reduce:
             conv_cf = self.conv.forward_cf(data)
         else:
+            if getattr(old_x, "_e3k_cf", False):
+                raise RuntimeError("cf hand-over reached a convolution that cannot take it (container bug)")
             out, _ = self.conv(data, attrs)
             conv_cf = ops.relayout(out["output_features"], tuple(irreps_blocks(self.equivariant_nonlin.irreps_in)), True)
+        if self._emit_cf:
+            output = self.equivariant_nonlin(conv_cf, out_cf=True)
+            output._e3k_cf = True
+            return ({"output_features": output},
+                    {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
         output = self.equivariant_nonlin(conv_cf)
         if self.resnet:
             output = old_x + output

@@ -76,6 +76,18 @@ class SequentialGraphNetwork(torch.nn.Sequential):
                 object.__setattr__(prev[0], "_next_conv", conv)     # a plain reference, not a registered submodule
             prev = (conv, src)
 
+        # cf hand-over between directly consecutive MessagePassing layers on one feature key (nn/message_passing.py):
+        # layer i may emit the channel-fastest layout when layer i+1 is the only reader of that key and overwrites it
+        for (_, a), (_, b) in zip(self.layers[:-1], self.layers[1:]):
+            ok = getattr(a, "cf_chain_ok", None)
+            if ok is None or not isinstance(b, Module) or not ok(b):
+                continue
+            key = a.output_key_mapping.get("output_features")
+            reads = [g for g, loc in b.input_key_mapping.items() if loc == "input_features"]
+            other_reads = [g for g, loc in b.input_key_mapping.items() if loc != "input_features"]
+            if key is not None and reads == [key] and key not in other_reads and b.output_key_mapping.get("output_features") == key:
+                a._emit_cf = True
+
     def forward(self, batch):
         data, attrs = batch.data, batch.attrs
         # layer names appear in a torch profile when one is running; otherwise the 2 x 14 record_function ops per forward

@@ -266,14 +266,17 @@ typedef struct {
   int32_t act;     /* activation of the scalars (kind 0) or of the gates (kind 1) */
   float cst;       /* its second-moment normalisation constant */
 } e3k_gate_seg;
+/* out_cf: layout of the OUTPUT row (y, g_y, g_y2, g_gy): 0 = e3nn blocks [mul][2l+1], 1 = channel-fastest [2l+1][mul]
+ * (consecutive MessagePassing layers hand their features over in cf: no relayout between them).  The input row x is
+ * always channel-fastest.  g_y2 (may be NULL): a second addend of the incoming gradient, summed inside the kernel. */
 int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_t out_dim, const e3k_gate_seg* segs,
-                 int32_t n_segs, float* y, void* stream);
-int e3k_gate_bwd(const float* x, const float* g_y, int64_t rows, int32_t in_dim, int32_t out_dim,
-                 const e3k_gate_seg* segs, int32_t n_segs, float* g_x, void* stream);
+                 int32_t n_segs, int32_t out_cf, float* y, void* stream);
+int e3k_gate_bwd(const float* x, const float* g_y, const float* g_y2, int64_t rows, int32_t in_dim, int32_t out_dim,
+                 const e3k_gate_seg* segs, int32_t n_segs, int32_t out_cf, float* g_x, void* stream);
 /* double backward of the gate: g_hat [rows,in_dim] is the cotangent of e3k_gate_bwd's g_x;
  * g_gy [rows,out_dim] = (dy/dx) g_hat,  g_x [rows,in_dim] = d/dx <g_hat, gate_bwd(x, g_y)>  (either may be NULL). */
 int e3k_gate_bwd2(const float* x, const float* g_y, const float* g_hat, int64_t rows, int32_t in_dim, int32_t out_dim,
-                  const e3k_gate_seg* segs, int32_t n_segs, float* g_gy, float* g_x, void* stream);
+                  const e3k_gate_seg* segs, int32_t n_segs, int32_t out_cf, float* g_gy, float* g_x, void* stream);
 
 /* NormActivation (e3nn.nn.NormActivation as built at e3_layers/nn/message_passing.py:212-219; the 'norm'
  * nonlinearity_type of MessagePassing): per irrep channel n2 = max(sum_m x_m^2, epsilon^2), n = sqrt(n2),

@@ -273,6 +273,62 @@ def test_config_diffusion_backbone_network(dev):
     _protein_parity(dev, config_diffusion_backbone, 5, 2, 40, True, ("score_CA", "score_C", "score_O", "score_N"), 2e-5, 1e-4)
 
 
+@pytest.mark.parametrize("fork", [True, False])
+def test_conv_block_equals_composed_layers(dev, monkeypatch, fork):
+    """A MessagePassing layer as one autograd node (backend/conv_block.py: the launches of a layer issued from one
+    forward and one backward function, three streams + explicit events) against the layer composed from one autograd
+    Function per kernel: same energies, same gradient of every parameter, with the gradient sink and without, with
+    the three-stream fork and on one stream; and against the float64 oracle."""
+    from e3_layers_amd.backend import conv_block, ops
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients
+
+    tree = _energy_tree(2, 64, 4)
+    prod, orc = _build_pair(tree, dev)
+    batch = synth_qm9(31, 24)                      # > 256 nodes: the keyed self-connection path
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0 if fork else 10 ** 9)
+    target = batch["total_energy"].to(dev)
+
+    def run(enabled, sink):
+        monkeypatch.setattr(conv_block, "ENABLED", enabled)
+        for p in prod.parameters():
+            p.grad = None
+        flat = None
+        if sink:
+            flat = FlatGradients(prod.parameters())
+            flat.enable_direct_accumulation()
+            flat.zero()
+        try:
+            out = prod(batch.clone().to(dev))
+            e = out["total_energy"]
+            loss = 1e3 * torch.nn.functional.mse_loss(e, target)
+            loss.backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in prod.named_parameters() if p.grad is not None}
+        finally:
+            if flat is not None:
+                flat.disable_direct_accumulation()
+                for p in prod.parameters():
+                    p.grad = None
+        return e.detach().clone(), grads
+
+    e_ref, g_ref = run(0, False)
+    for sink in (False, True):
+        e_blk, g_blk = run(1, sink)
+        assert rel_err(e_blk, e_ref) < 2e-6
+        assert set(g_blk) == set(g_ref)
+        for k in g_ref:
+            assert rel_err(g_blk[k], g_ref[k]) < 2e-5, (k, sink)
+    # and the oracle
+    data, attrs = batch_to_oracle(batch)
+    out_ref, _ = orc(data, attrs)
+    assert rel_err(e_blk, out_ref["total_energy"]) < TOL
+    monkeypatch.setattr(conv_block, "ENABLED", 1)
+    assert prod.layer1._forward_block.__self__ is prod.layer1 and prod.layer0._block_plan() is not None
+
+
 def _noise_bank(shapes_gen, n, seed):
     gen = torch.Generator().manual_seed(seed)
     return [torch.randn(shapes_gen, dtype=torch.float64, generator=gen) for _ in range(n)]

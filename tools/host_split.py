@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""Host-side cost of one config_energy training step split into forward / backward / optimizer enqueue time
-(no device sync inside the loop: the GPU runs behind).  python tools/host_split.py [B]"""
+"""Host-side cost of one config_energy training step, split into batch prep (fresh device copy of a resident batch) /
+forward / backward / optimizer enqueue time.  With a small batch (python tools/host_split.py 16) the GPU work is
+negligible and wall = host: the per-step Python + launch cost, which does not depend on the batch size.
+    python tools/host_split.py [B] [--same]      (--same: re-step one batch object, topology prebuilt)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
@@ -11,19 +13,26 @@ from e3_layers_amd.configs import config_energy
 from e3_layers_amd.data.synthetic import synth_qm9
 from e3_layers_amd.run.optim import FusedAdamEMA
 from e3_layers_amd.utils import build
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if args else 256
+same = "--same" in sys.argv
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
 model = build(config_energy.get_config(l_max=2).model_config).to(dev)
-opt = FusedAdamEMA(model.parameters(), lr=1e-2)
+opt = FusedAdamEMA(model.parameters(), lr=1e-2, ema_decay=0.99)
 opt.grads.enable_direct_accumulation()
-batch = synth_qm9(1000, B, config_energy.QM9_SHIFTS).to(dev)
-batch.update(build_topology(batch["edge_index"], batch["pos"].shape[0]).as_dict())
-target = batch["total_energy"]
-acc = [0.0, 0.0, 0.0]
+resident = [synth_qm9(1000 + k, B, config_energy.QM9_SHIFTS).to(dev) for k in range(4)]
+if same:
+    resident[0].update(build_topology(resident[0]["edge_index"], resident[0]["pos"].shape[0]).as_dict())
+acc = [0.0, 0.0, 0.0, 0.0]
+count = [0]
 def step(rec):
     t0 = time.perf_counter()
-    out = model(batch.view())
+    batch = resident[0].view() if same else resident[count[0] % 4].clone()
+    count[0] += 1
+    target = batch["total_energy"]
+    ta = time.perf_counter()
+    out = model(batch)
     loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
     t1 = time.perf_counter()
     opt.zero_grad(); loss.backward()
@@ -31,7 +40,7 @@ def step(rec):
     opt.step()
     t3 = time.perf_counter()
     if rec:
-        acc[0] += t1 - t0; acc[1] += t2 - t1; acc[2] += t3 - t2
+        acc[0] += ta - t0; acc[1] += t1 - ta; acc[2] += t2 - t1; acc[3] += t3 - t2
 for _ in range(5): step(False)
 torch.cuda.synchronize()
 n = 20
@@ -40,5 +49,5 @@ for _ in range(n): step(True)
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"B={B}: forward {1e3*acc[0]/n:.2f} ms, backward {1e3*acc[1]/n:.2f} ms, optimizer {1e3*acc[2]/n:.2f} ms host per step; "
-      f"enqueue {1e3*(t1-t0)/n:.2f}, wall {1e3*(t2-t0)/n:.2f} ms/step")
+print(f"B={B} {'same batch' if same else 'fresh batch'}: prep {1e3*acc[0]/n:.2f} ms, forward {1e3*acc[1]/n:.2f} ms, backward {1e3*acc[2]/n:.2f} ms, "
+      f"optimizer {1e3*acc[3]/n:.2f} ms host per step; enqueue {1e3*(t1-t0)/n:.2f}, wall {1e3*(t2-t0)/n:.2f} ms/step")
