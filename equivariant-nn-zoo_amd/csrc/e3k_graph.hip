@@ -160,3 +160,84 @@ extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, in
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
+
+// ------------------------------------------------------------------------------------------
+// rows grouped by a small categorical key (the keyed self-connection: nodes by species)
+// ------------------------------------------------------------------------------------------
+// perm = row ids sorted by key, STABLE (ascending row id inside a key); bounds[k] = {start, count}; reps[k] = first row of
+// key k (row 0 for an absent key).  One workgroup, one launch, no host sync: replaces a stable argsort (radix sort:
+// ~8 launches), a scatter_add, a cumsum, a gather and their dtype conversions per batch.  Rows are placed chunk by
+// chunk (1024 rows): every wave ranks its lanes per key with ballots (no barrier), the 16 x K per-wave counts are
+// prefixed by one thread each, and a running offset per key carries over to the next chunk.
+namespace e3k {
+constexpr int GR_MAXK = 64;
+
+__global__ __launch_bounds__(1024) void group_rows_kernel(const int64_t* __restrict__ key, int32_t R, int32_t K,
+                                                          int32_t* __restrict__ perm, int32_t* __restrict__ bounds,
+                                                          int64_t* __restrict__ reps, int32_t* __restrict__ bad) {
+  __shared__ int32_t count[GR_MAXK], start[GR_MAXK], running[GR_MAXK];
+  __shared__ int32_t hist[16][GR_MAXK];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < GR_MAXK) count[t] = 0, running[t] = 0;
+  __syncthreads();
+  for (int i = t; i < R; i += 1024) {
+    const int64_t k = key[i];
+    if (k < 0 || k >= K) *bad = 1;
+    else atomicAdd(&count[(int)k], 1);
+  }
+  __syncthreads();
+  if (t == 0) {
+    int acc = 0;
+    for (int k = 0; k < K; ++k) {
+      start[k] = acc;
+      bounds[2 * k] = acc;
+      bounds[2 * k + 1] = count[k];
+      acc += count[k];
+    }
+  }
+  __syncthreads();
+  for (int base = 0; base < R; base += 1024) {
+    const int i = base + t;
+    int k = -1;
+    if (i < R) {
+      const int64_t kk = key[i];
+      k = (kk >= 0 && kk < K) ? (int)kk : -1;
+    }
+    int rank = 0;
+    for (int q = 0; q < K; ++q) {
+      const unsigned long long b = __ballot(k == q);
+      if (k == q) rank = __popcll(b & ((1ull << lane) - 1ull));
+      if (lane == 0) hist[w][q] = __popcll(b);
+    }
+    __syncthreads();
+    // thread (w, q): rows of key q in the waves before w  (one thread per table entry: 16 x K <= 1024)
+    int before = 0;
+    const int tw = t / GR_MAXK, tq = t % GR_MAXK;
+    if (tq < K) {
+      for (int v = 0; v < tw; ++v) before += hist[v][tq];
+    }
+    __syncthreads();
+    int total_q = 0;
+    if (tq < K && tw == 15) total_q = before + hist[15][tq];
+    if (tq < K) hist[tw][tq] = before;       // now: offset of wave tw inside the chunk's rows of key tq
+    __syncthreads();
+    if (k >= 0) perm[start[k] + running[k] + hist[w][k] + rank] = i;
+    __syncthreads();
+    if (tq < K && tw == 15) running[tq] += total_q;
+    __syncthreads();
+  }
+  if (t < K) reps[t] = count[t] > 0 ? perm[start[t]] : 0;
+}
+}  // namespace e3k
+
+extern "C" int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int32_t* bounds, int64_t* reps,
+                              int32_t* bad_flag, void* stream) {
+  if (R < 0 || K <= 0) return E3K_ERR_INVALID;
+  if (K > e3k::GR_MAXK || R >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
+  if (!bounds || !reps || !bad_flag || (R > 0 && (!key || !perm))) return E3K_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  hipLaunchKernelGGL(e3k::group_rows_kernel, dim3(1), dim3(1024), 0, st, key, (int32_t)R, K, perm, bounds, reps, bad_flag);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}

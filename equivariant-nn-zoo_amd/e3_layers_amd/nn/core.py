@@ -72,12 +72,25 @@ def row_groups(index: torch.Tensor, n_keys: int) -> "ops.RowGroups":
     if hit is not None and hit[0]() is index and hit[1] == n_keys:
         return hit[2]
     idx = index.reshape(-1)
-    perm = torch.argsort(idx, stable=True)
-    counts = torch.zeros(n_keys, dtype=torch.long, device=idx.device).scatter_add_(0, idx, torch.ones_like(idx))
-    starts = torch.cumsum(counts, 0) - counts
-    reps = perm[starts.clamp(max=max(idx.numel() - 1, 0))]
-    bounds = torch.stack([starts, counts], dim=1).to(torch.int32).contiguous()
-    groups = ops.RowGroups(perm.to(torch.int32), bounds, reps, n_keys)
+    if idx.is_cuda and n_keys <= 64 and idx.dtype == torch.int64:
+        # csrc/e3k_graph.hip: one single-workgroup launch (a radix sort + scatter_add + cumsum + gather otherwise)
+        from ..backend import lib as L
+
+        idx = idx.contiguous()
+        buf = torch.empty(idx.numel() + 2 * n_keys + 1, dtype=torch.int32, device=idx.device)
+        perm, bounds, flag = buf[:idx.numel()], buf[idx.numel():idx.numel() + 2 * n_keys].view(n_keys, 2), buf[-1:]
+        reps = torch.empty(n_keys, dtype=torch.int64, device=idx.device)
+        with torch.cuda.device(idx.device):
+            L.check(L.load().e3k_group_rows(L.ptr(idx), idx.numel(), n_keys, L.ptr(perm), L.ptr(bounds), L.ptr(reps), L.ptr(flag),
+                                            L.stream_ptr()), "e3k_group_rows")
+        groups = ops.RowGroups(perm, bounds, reps, n_keys)
+    else:
+        perm = torch.argsort(idx, stable=True)
+        counts = torch.zeros(n_keys, dtype=torch.long, device=idx.device).scatter_add_(0, idx, torch.ones_like(idx))
+        starts = torch.cumsum(counts, 0) - counts
+        reps = perm[starts.clamp(max=max(idx.numel() - 1, 0))]
+        bounds = torch.stack([starts, counts], dim=1).to(torch.int32).contiguous()
+        groups = ops.RowGroups(perm.to(torch.int32), bounds, reps, n_keys)
     if len(_groups_cache) > 16:
         _groups_cache.clear()
     _groups_cache[id(index)] = (weakref.ref(index), n_keys, groups)

@@ -212,6 +212,13 @@ int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile,
                   int32_t* dst_ptr, int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* dst_own0,
                   int32_t* src_own0, int32_t* workspace, int32_t* bad_flag, void* stream);
 
+/* Rows grouped by a small categorical key (the keyed self-connection groups nodes by species: node_attrs =
+ * Linear(one_hot(species)), layer_configs.py:104-118 feeding nn/message_passing.py:81-87,100): perm [R] int32 = row ids
+ * sorted by key, stable; bounds [K,2] int32 = {start, count} per key; reps [K] int64 = first row of each key (0 for an
+ * absent key).  K <= 64.  bad_flag [1]: set when a key is outside [0, K). */
+int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int32_t* bounds, int64_t* reps,
+                   int32_t* bad_flag, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Radial-fused tensor product (csrc/e3k_rtp.hip): SURVEY.md 8d "variant B".
  * Replaces the LAST layer of the radial FullyConnectedNet (nn/message_passing.py:74-79,93: weight = fc(edge_radial))

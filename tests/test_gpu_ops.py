@@ -296,6 +296,24 @@ def test_device_csr_build_is_the_stable_sort(dev, n, deg, shuffle):
             G.check_indices()
 
 
+@pytest.mark.parametrize("rows,n_keys", [(4623, 10), (1000, 64), (70, 3), (1, 5), (5000, 1)])
+def test_group_rows_kernel_is_the_stable_sort(dev, rows, n_keys):
+    """e3k_group_rows (one single-workgroup launch) against the torch construction (stable argsort + counts + cumsum):
+    the same permutation, bounds and representatives -- absent keys included."""
+    from e3_layers_amd.nn.core import row_groups
+
+    gen = torch.Generator().manual_seed(rows + n_keys)
+    key = torch.randint(0, n_keys, (rows,), generator=gen)
+    if n_keys > 2:
+        key[key == 1] = 0                      # key 1 is absent
+    ref = row_groups(key.clone(), n_keys)      # CPU tensor: the torch path
+    got = row_groups(key.to(dev), n_keys)
+    assert torch.equal(ref.perm, got.perm.cpu()) and torch.equal(ref.bounds, got.bounds.cpu())
+    present = ref.bounds[:, 1] > 0
+    assert torch.equal(ref.reps[present], got.reps.cpu()[present])
+    assert int(got.reps.min()) >= 0 and int(got.reps.max()) < rows
+
+
 def test_batch_from_device_resident_samples(dev):
     """Batch.from_data_list on samples that already live in HBM: same Batch as collating on the host and copying."""
     from e3_layers_amd.data import Batch
