@@ -21,7 +21,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import lib as L
-from . import ops
+from . import ops, radial_table
 from .graph import GraphTopo
 
 ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
@@ -82,7 +82,10 @@ def _grad_buffer(weight, need: bool):
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo: GraphTopo, groups, in_cf: bool, out_cf: bool,
-                fork: bool, w_lin1, w_post, w_sc, w_last, *w_hidden):
+                fork: bool, table, w_lin1, w_post, w_sc, w_last, *w_hidden):
+        """``table`` = (centre knot int32 [E], offset [E], knot CSR pointers, knot CSR edge ids, knots) when the radial MLP
+        is evaluated on a knot table (backend/radial_table.py): ``edge_radial`` is then the radial basis ON THE KNOTS
+        ([knots + 1, n_basis]), the MLP runs on those rows and every edge interpolates its weights."""
         L.require_cuda(x, edge_radial, sh)
         x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
         dev = x.device
@@ -101,6 +104,8 @@ class ConvBlockFn(torch.autograd.Function):
             w = torch.empty(h.shape[0], plan.last_spec.d_out, device=dev, dtype=torch.float32)
             with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
                 ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
+            if table is not None:      # w so far: the MLP on the knots; every edge interpolates between its three knots
+                w = radial_table.interp_fwd_raw(w, table)
         _rec(edge_radial, side, main)
         # --- node side
         x_cf = x if in_cf else ops._relayout_raw(x, plan.in_blocks, True)
@@ -130,19 +135,19 @@ class ConvBlockFn(torch.autograd.Function):
         if keep:
             ctx.save_for_backward(x_cf, edge_radial, sh, h, w, x1, mid, conv, a_rep, m, w_lin1, w_post, w_sc, w_last,
                                   *w_hidden, *zs)
-            ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden))
+            ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table)
             ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
         return y
 
     @staticmethod
     def backward(ctx, gy):
-        plan, topo, groups, in_cf, out_cf, fork, n_hidden = ctx.cfg
+        plan, topo, groups, in_cf, out_cf, fork, n_hidden, table = ctx.cfg
         saved = ctx.saved_tensors
         x_cf, edge_radial, sh, h, w, x1, mid, conv, a_rep, m, w_lin1, w_post, w_sc, w_last = saved[:14]
         w_hidden, zs = saved[14:14 + n_hidden], saved[14 + n_hidden:]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
-        p0 = 10
+        p0 = 11
         need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
         need_hidden = need[p0 + 4:]
         if torch.is_grad_enabled() or need_sh:
@@ -209,6 +214,9 @@ class ConvBlockFn(torch.autograd.Function):
                     side.wait_event(ev_mid)
                 with _on(side, main):
                     g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
+            if table is not None:      # transpose of the interpolation: the gradient of the MLP's output on the knots
+                with _on(side, main):
+                    g_w = radial_table.interp_bwd_raw(g_w, table)
             if need_last:      # the [64, W] weight gradient (K = E: the longest reduction of the layer) joins the other
                 if side3 is not side:          # weight gradients on their stream; the radial chain continues beside it
                     side3.wait_stream(side)
@@ -256,11 +264,11 @@ class ConvBlockFn(torch.autograd.Function):
             _wait(main, side2)
         if any(r is not None for r in ret_hidden):
             _wait(main, side)
-        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None,
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None,
                 ret_lin1, ret_post, ret_sc, ret_last, *ret_hidden)
 
 
 def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups, in_cf: bool, out_cf: bool, fork: bool,
-               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor]):
-    return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork,
+               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None):
+    return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
                              w_lin1, w_post, w_sc, w_last, *w_hidden)

@@ -67,6 +67,9 @@ def _csr(index: torch.Tensor, num_nodes: int):
 
 
 _pending_flags: list = []      # (event, pinned host flag) of device builds whose index check has not been read yet
+_FLAG_RING = 256               # slots of ONE pinned buffer, allocated once: a pinned allocation per build stalled the host
+_flag_ring = None              # until the device had drained (hipHostMalloc synchronises) -- 3 ms per forward when it
+_flag_next = 0                 # happened mid-step
 
 
 def _check_pending_flags() -> None:
@@ -104,14 +107,18 @@ def _build_topology_device(edge_index: torch.Tensor, num_nodes: int) -> GraphTop
                                   L.ptr(src_ptr), L.ptr(src_perm), L.ptr(dst_own0), L.ptr(src_own0), L.ptr(work), L.ptr(flag),
                                   L.stream_ptr()), "e3k_csr_build")
         if not torch.cuda.is_current_stream_capturing():
+            global _flag_ring, _flag_next
             _check_pending_flags()
-            host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+            if len(_pending_flags) >= _FLAG_RING - 1:
+                check_indices()
+            if _flag_ring is None:
+                _flag_ring = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
+            host = _flag_ring[_flag_next:_flag_next + 1]
+            _flag_next = (_flag_next + 1) % _FLAG_RING
             host.copy_(flag, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record()
             _pending_flags.append((ev, host))
-            if len(_pending_flags) > 256:
-                check_indices()
     return GraphTopo(src, dst, dst_ptr, dst_perm, src_ptr, src_perm, dst_own0, src_own0)
 
 

@@ -12,7 +12,7 @@ from typing import Dict, Tuple
 import torch
 from torch import Tensor, nn
 
-from ..backend import ops
+from ..backend import ops, radial_table
 from ..o3 import Irreps
 from ..utils.utils import build
 from .core import set_row_key
@@ -93,7 +93,12 @@ class RadialBasisEncoding(Module):
         b, c = self.basis, self.cutoff
         out = ops.radial_basis(x.reshape(-1), b.bessel_weights, b.r_max, b.r_min, c.p, b.one_over_r, c.cutoff.kind)
         per_row = x.numel() // x.shape[0] if x.shape[0] else (x.shape[1] if x.dim() > 1 else 1)
-        return ({"radial_embedding": out.view(x.shape[0], per_row * out.shape[-1])},
+        out = out.view(x.shape[0], per_row * out.shape[-1])
+        if per_row == 1 and c.cutoff.kind == 0 and b.r_min == 0.0:
+            # a pure function of one radius per row, constant beyond r_max: the convolutions may evaluate their radial MLPs
+            # on a knot table instead of per edge (backend/radial_table.py); any op that builds a new tensor drops the tag
+            out._e3k_radial_src = radial_table.RadialSource(self, x.reshape(-1))
+        return ({"radial_embedding": out},
                 {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])})
 
 

@@ -26,7 +26,7 @@ from typing import Callable, Dict, Optional, Tuple
 import torch
 from torch import Tensor
 
-from ..backend import conv_block, ops
+from ..backend import conv_block, ops, radial_table
 from ..backend.graph import get_topology
 from ..o3 import Irrep, Irreps
 from ..utils.utils import _is_mapping, activations, build, tp_path_exists
@@ -133,6 +133,11 @@ class FactorizedConvolution(Module):
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
         in_cf = bool(getattr(x, "_e3k_cf", False))     # the previous MessagePassing handed its features over in cf
+        table = radial_table.applicable(data["edge_radial"])
+        if table:      # knot bins and the basis on the knots: once per batch / forward, on this stream (the branches wait for it)
+            src = radial_table.source_of(data["edge_radial"])
+            src.bins()
+            src.knot_basis()
         if (FWD_FORK and x.is_cuda and self._fork_pays(data["edge_radial"].shape[0])
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
@@ -148,7 +153,8 @@ class FactorizedConvolution(Module):
                 else:
                     side.wait_stream(main)
                     with ops.on_stream(side, main):
-                        weight = self.fc(_stream_alias(radial, side))
+                        weight = (radial_table.table_weights(self.fc, radial) if table
+                                  else self.fc(_stream_alias(radial, side)))
                         ready = torch.cuda.Event()
                         ready.record(side)
                 nxt = self._next_conv if RADIAL_AHEAD else None
@@ -176,7 +182,7 @@ class FactorizedConvolution(Module):
                     scale = 1.0 if self.avg_num_neighbors is None else float(self.avg_num_neighbors) ** -0.5
                     return self.tp.linear(mid, in_layout="cf", out_layout="cf", base=sc, scale=scale)
         else:
-            weight = self.fc(data["edge_radial"])
+            weight = radial_table.table_weights(self.fc, data["edge_radial"]) if table else self.fc(data["edge_radial"])
             x_cf = x if in_cf else ops.relayout(x, self._in_blocks, True)
             sc = self.sc(x_cf, data["node_attrs"]) if self.sc is not None else None
             x1 = self.linear_1(x_cf, in_layout="cf", out_layout="cf")
@@ -300,6 +306,11 @@ class MessagePassing(Module):
         topo = get_topology(data, x.shape[0])
         fork = bool(FWD_FORK and conv._fork_pays(radial.shape[0])
                     and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
+        table = None
+        if radial_table.applicable(radial):      # the radial MLP on a knot table; every edge interpolates (backend/radial_table.py)
+            src = radial_table.source_of(radial)
+            table = src.bins()
+            radial = src.knot_basis()            # [knots + 1, n_basis]: the block's MLP runs on these rows
         if fork:      # gradient contributions of the shared inputs are summed on the streams that produce them
             main = torch.cuda.current_stream(x.device)
             side = ops.side_stream(x.device)
@@ -312,7 +323,7 @@ class MessagePassing(Module):
         fc = list(conv.fc.children())
         y = conv_block.conv_block(x, attrs, radial, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                   conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,
-                                  fc[-1].weight, [m.weight for m in fc[:-1]])
+                                  fc[-1].weight, [m.weight for m in fc[:-1]], table=table)
         return y
 
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):

@@ -220,6 +220,29 @@ int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int3
                    int32_t* bad_flag, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radial weights through a knot table (csrc/e3k_rtable.hip).
+ * Replaces weight = fc(edge_radial) (nn/message_passing.py:74-79,93) evaluated per edge when edge_radial is
+ * RadialBasisEncoding(edge_length) (nn/embedding.py:210-219): the MLP is evaluated on the K + 1 knots j * r_max / K
+ * (T [K+1, W], by the caller, with the same kernels) and every edge interpolates the three knots around it
+ * (quadratic Lagrange weights; error ~5e-9 relative at K = 4096, below fp32 rounding of the per-edge evaluation).
+ *   e3k_rtable_bin        r [E] -> bin2 int64 [2,E] (centre knot i in [1, K-1], both rows: feed it to e3k_csr_build with
+ *                         N = K + 1 to group the edges by knot; row 0 doubles as the int64 index), t [E] = r/h - i
+ *   e3k_rtable_interp_fwd w[e,:] = t(t-1)/2 T[i-1,:] + (1-t^2) T[i,:] + t(t+1)/2 T[i+1,:]     (bin = int32 copy of the knots;
+ *                         edges are visited in knot order, bin_perm, so that neighbouring waves share table rows)
+ *   e3k_rtable_interp_bwd g_T[j,:] = sum over the edges of bins j-1, j, j+1 (bin_ptr [K+2], bin_perm [E]: CSR by knot,
+ *                         ascending edge id) of their weight of knot j times g_w[e,:]; every row written; no atomics
+ *                         (per-bin partial sums in the workspace, then a fixed-order combination).
+ * W must be a multiple of 4.
+ * ------------------------------------------------------------------------------------------ */
+int e3k_rtable_bin(const float* r, int64_t E, float r_max, int32_t K, int64_t* bin2, float* t, void* stream);
+int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* t, int64_t E, int32_t K,
+                          int32_t W, float* w, void* stream);
+/* workspace: e3k_rtable_bwd_workspace_floats(K, W) floats (per-bin partial sums, combined in a fixed order) */
+int64_t e3k_rtable_bwd_workspace_floats(int32_t K, int32_t W);
+int e3k_rtable_interp_bwd(const float* g_w, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t, int64_t E,
+                          int32_t K, int32_t W, float* workspace, float* g_T, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radial-fused tensor product (csrc/e3k_rtp.hip): SURVEY.md 8d "variant B".
  * Replaces the LAST layer of the radial FullyConnectedNet (nn/message_passing.py:74-79,93: weight = fc(edge_radial))
  * together with the gather + TensorProduct 'uvu' + scatter above (nn/message_passing.py:104-109), so that

@@ -329,6 +329,38 @@ def test_conv_block_equals_composed_layers(dev, monkeypatch, fork):
     assert prod.layer1._forward_block.__self__ is prod.layer1 and prod.layer0._block_plan() is not None
 
 
+@pytest.mark.parametrize("block", [1, 0])
+def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, block):
+    """The energy model with the radial MLPs evaluated through the knot table (a batch with enough edges for it to apply)
+    against the same model with the per-edge MLPs: energies and every parameter gradient; both layer implementations."""
+    from e3_layers_amd.backend import conv_block, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    tree = _energy_tree(2, 64, 3)
+    prod, _ = _build_pair(tree, dev)
+    batch = synth_qm9(41, 96)
+    assert batch["edge_index"].shape[1] >= radial_table.MIN_EDGES_PER_KNOT * (radial_table.KNOTS + 1)
+    target = batch["total_energy"].to(dev)
+    monkeypatch.setattr(conv_block, "ENABLED", block)
+
+    def run(table):
+        monkeypatch.setattr(radial_table, "ENABLED", table)
+        for p in prod.parameters():
+            p.grad = None
+        out = prod(batch.clone().to(dev))
+        e = out["total_energy"]
+        (1e3 * torch.nn.functional.mse_loss(e, target)).backward()
+        torch.cuda.synchronize()
+        return e.detach().clone(), {k: p.grad.detach().clone() for k, p in prod.named_parameters() if p.grad is not None}
+
+    e_ref, g_ref = run(0)
+    e_tab, g_tab = run(1)
+    assert rel_err(e_tab, e_ref) < 2e-6
+    assert set(g_tab) == set(g_ref)
+    for k in g_ref:
+        assert rel_err(g_tab[k], g_ref[k]) < 5e-5, k
+
+
 def _noise_bank(shapes_gen, n, seed):
     gen = torch.Generator().manual_seed(seed)
     return [torch.randn(shapes_gen, dtype=torch.float64, generator=gen) for _ in range(n)]

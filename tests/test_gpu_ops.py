@@ -314,6 +314,53 @@ def test_group_rows_kernel_is_the_stable_sort(dev, rows, n_keys):
     assert int(got.reps.min()) >= 0 and int(got.reps.max()) < rows
 
 
+def test_radial_table_matches_the_per_edge_mlp(dev, monkeypatch):
+    """backend/radial_table.py: the radial MLP evaluated on a knot table + quadratic interpolation per edge against the
+    MLP evaluated per edge (HIP, fp32) and against the float64 oracle; and the backward (ordered per-knot sums + the MLP's
+    backward on the knots) against the per-edge backward, for the MLP weights and the Bessel frequencies."""
+    from e3_layers_amd import nn as pnn
+    from e3_layers_amd.backend import radial_table
+    from e3_layers_amd.nn.core import FullyConnectedNet
+    from e3_layers_amd.utils.utils import activations
+
+    torch.manual_seed(5)
+    e, width = 40_000, 192
+    enc = pnn.RadialBasisEncoding(r_max=4.0, trainable=True, irreps_out=("8x0e", "edge_radial"), irreps_in=("1x0e", "edge_length")).to(dev)
+    fc = FullyConnectedNet([8, 64, 64, 64, width], activations["ssp"]).to(dev)
+    gen = torch.Generator().manual_seed(1)
+    r = (torch.rand(e, generator=gen) * 3.3 + 0.7)
+    r[:5] = torch.tensor([1e-5, 1e-4, 3.99999, 4.0, 4.7])         # the ends of the table and beyond the cutoff
+    rd = r.to(dev)
+    seed = torch.randn(e, width, generator=gen).to(dev)
+    params = [enc.basis.bessel_weights] + list(fc.parameters())
+
+    def run(table):
+        monkeypatch.setattr(radial_table, "ENABLED", 1 if table else 0)
+        emb, _ = enc({"input": rd}, {"input": ("edge", "1x0e")})
+        emb = emb["radial_embedding"]
+        assert radial_table.applicable(emb) == bool(table)
+        w = radial_table.table_weights(fc, emb) if table else fc(emb)
+        grads = torch.autograd.grad(w, params, seed)
+        return w.detach(), [g.detach() for g in grads]
+
+    w_ref, g_ref = run(False)
+    w_tab, g_tab = run(True)
+    assert bool(torch.isfinite(w_tab).all())
+    assert rel_err(w_tab, w_ref) < 5e-6                  # two fp32 evaluations of the same function (the oracle decides below)
+    assert float((w_tab[4] - w_tab[3]).abs().max()) == 0.0        # constant beyond r_max
+    for a, b, p in zip(g_tab, g_ref, params):
+        assert rel_err(a, b) < 2e-5, tuple(p.shape)
+    # float64 oracle of the same function
+    orc_enc = e3ref.RadialBasisEncoding(r_max=4.0, trainable=True, irreps_out=("8x0e", "edge_radial"), irreps_in=("1x0e", "edge_length")).double()
+    orc_fc = e3ref.FullyConnectedNet([8, 64, 64, 64, width], "ssp").double()
+    orc_enc.load_state_dict({k: v.detach().cpu().double() for k, v in enc.state_dict().items()})
+    orc_fc.load_state_dict({k: v.detach().cpu().double() for k, v in fc.state_dict().items()})
+    out, _ = orc_enc({"input": r.double()[5:]}, {"input": ("edge", "1x0e")})
+    w_orc = orc_fc(out[next(iter(out))])
+    err_tab, err_edge = rel_err(w_tab[5:], w_orc), rel_err(w_ref[5:], w_orc)
+    assert err_tab < 5e-6 and err_tab < 1.5 * err_edge + 1e-7       # interpolation adds nothing to the fp32 noise of the MLP
+
+
 def test_batch_from_device_resident_samples(dev):
     """Batch.from_data_list on samples that already live in HBM: same Batch as collating on the host and copying."""
     from e3_layers_amd.data import Batch
