@@ -328,11 +328,25 @@ def main():
         if t_k and k["avg_launch_us"] > 0:
             k["dram_frac"] = round(t_k / (k["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         kernels.append(k)
+    for kind, label in (("rtable_fwd", "interpolation of the radial knot table, forward: E x W written + the table"),
+                        ("rtable_bwd", "its transpose: E x W read + per-knot partial sums written and combined")):
+        recs = (records or {}).get(kind, [])
+        if not recs:
+            continue
+        nbytes = sum((4.0 * e * w + 4.0 * (k + 1) * w * (1 if kind == "rtable_fwd" else 7)) for _, _, (e, k, w) in recs)
+        ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
+        ach = nbytes / (ms * 1e-3) / 1e9
+        kernels.append({"kernel": f"e3k::{kind.replace('rtable_', 'rtable_interp_')}_kernel ({label})", "bound": "hbm",
+                        "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                        "launches": len(recs), "avg_launch_us": round(1e3 * ms / len(recs), 2),
+                        "avg_launch_algorithmic_MB": round(nbytes / len(recs) / 1e6, 2)})
     recs = (records or {}).get("radial_last_fwd", [])
     if recs:
         flops = sum(2.0 * e * k * w for _, _, (e, k, w) in recs)
         ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
-        kernels.append({"kernel": "e3k::gemm_smallk_kernel (radial MLP last layer, forward)", "bound": "mfma",
+        rows = sorted({e for _, _, (e, k, w) in recs})
+        kernels.append({"kernel": "e3k::gemm_smallk_kernel (radial MLP last layer, forward; rows per launch: "
+                                  + ("the knot table" if max(rows) < 10000 else "one per edge") + ")", "bound": "mfma",
                         "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "launches": len(recs),
                         "avg_launch_us": round(1e3 * ms / len(recs), 2)})
