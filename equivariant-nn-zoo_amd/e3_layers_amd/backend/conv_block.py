@@ -25,6 +25,7 @@ from . import ops, radial_table
 from .graph import GraphTopo
 
 ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
+LOOK_AHEAD = int(os.environ.get("E3K_BLOCK_LOOK_AHEAD", "1"))     # the next layer's radial branch issued one layer early
 BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed)
 
 
@@ -38,6 +39,7 @@ class ConvBlockPlan:
         self.tp_plan, self.post_spec, self.scale = tp_plan, post_spec, float(scale)
         self.sc_spec, self.sc_m_off, self.sc_ld_m = sc_spec, tuple(sc_m_off) if sc_m_off is not None else None, sc_ld_m
         self.gate_spec = gate_spec
+        self.prefetched = None     # radial branch of THIS layer issued by the previous layer's forward (look-ahead)
 
 
 class _on:
@@ -79,13 +81,27 @@ def _grad_buffer(weight, need: bool):
     return buf.view(-1), buf
 
 
+def _radial_branch(rows, plan: ConvBlockPlan, w_last, w_hidden, keep: bool, table):
+    """Hidden chain + last layer on ``rows`` (edges, or the knots) -> per-edge path weights (call on the radial stream)."""
+    h, zs = ops._mlp_fwd_raw(rows, w_hidden, plan.mlp_alphas, plan.mlp_act, plan.mlp_cst, keep)
+    w = torch.empty(h.shape[0], plan.last_spec.d_out, device=rows.device, dtype=torch.float32)
+    with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
+        ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
+    if table is not None:      # w so far: the MLP on the knots; every edge interpolates between its three knots
+        w = radial_table.interp_fwd_raw(w, table)
+    return h, zs, w
+
+
 class ConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo: GraphTopo, groups, in_cf: bool, out_cf: bool,
-                fork: bool, table, w_lin1, w_post, w_sc, w_last, *w_hidden):
+                fork: bool, table, nxt, w_lin1, w_post, w_sc, w_last, *w_hidden):
         """``table`` = (centre knot int32 [E], offset [E], knot CSR pointers, knot CSR edge ids, knots) when the radial MLP
         is evaluated on a knot table (backend/radial_table.py): ``edge_radial`` is then the radial basis ON THE KNOTS
-        ([knots + 1, n_basis]), the MLP runs on those rows and every edge interpolates its weights."""
+        ([knots + 1, n_basis]), the MLP runs on those rows and every edge interpolates its weights.
+        ``nxt`` = (plan, last-layer weight, hidden weights) of the NEXT layer when it reads the same radial rows: its
+        radial branch is issued here, on the radial stream, behind this layer's tensor product -- it then runs under this
+        layer's trailing Linear and gate and the next layer's node-side launches instead of in front of its product."""
         L.require_cuda(x, edge_radial, sh)
         x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
         dev = x.device
@@ -98,15 +114,14 @@ class ConvBlockFn(torch.autograd.Function):
         n = x.shape[0]
 
         # --- radial branch: hidden chain + last layer -> per-edge path weights [E, W]
-        _wait(side, main)
-        with _on(side, main):
-            h, zs = ops._mlp_fwd_raw(edge_radial, w_hidden, plan.mlp_alphas, plan.mlp_act, plan.mlp_cst, keep)
-            w = torch.empty(h.shape[0], plan.last_spec.d_out, device=dev, dtype=torch.float32)
-            with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
-                ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
-            if table is not None:      # w so far: the MLP on the knots; every edge interpolates between its three knots
-                w = radial_table.interp_fwd_raw(w, table)
-        _rec(edge_radial, side, main)
+        pref, plan.prefetched = plan.prefetched, None
+        if pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork):
+            h, zs, w = pref[1]                      # issued by the previous layer (look-ahead); `_wait(main, side)` below
+        else:
+            _wait(side, main)
+            with _on(side, main):
+                h, zs, w = _radial_branch(edge_radial, plan, w_last, w_hidden, keep, table)
+            _rec(edge_radial, side, main)
         # --- node side
         x_cf = x if in_cf else ops._relayout_raw(x, plan.in_blocks, True)
         a_rep = m = None
@@ -124,6 +139,13 @@ class ConvBlockFn(torch.autograd.Function):
         _wait(main, side)
         _rec(w, main, side)
         mid = ops._tp_fwd_raw(x1, sh, w, topo, plan.tp_plan)
+        if nxt is not None and fork and LOOK_AHEAD:
+            plan_n, w_last_n, w_hidden_n = nxt
+            side.wait_stream(main)                   # behind this layer's tensor product: both are HBM streams
+            with _on(side, main):
+                # (the rows and the table themselves are the key: held here, their identity cannot be reused by a later batch)
+                plan_n.prefetched = ((edge_radial, table, keep, fork),
+                                     _radial_branch(edge_radial, plan_n, w_last_n, w_hidden_n, keep, table))
         if has_sc:
             _wait(main, side2)
             _rec(conv, main, side2)
@@ -147,7 +169,7 @@ class ConvBlockFn(torch.autograd.Function):
         w_hidden, zs = saved[14:14 + n_hidden], saved[14 + n_hidden:]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
-        p0 = 11
+        p0 = 12
         need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
         need_hidden = need[p0 + 4:]
         if torch.is_grad_enabled() or need_sh:
@@ -264,11 +286,11 @@ class ConvBlockFn(torch.autograd.Function):
             _wait(main, side2)
         if any(r is not None for r in ret_hidden):
             _wait(main, side)
-        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None,
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None,
                 ret_lin1, ret_post, ret_sc, ret_last, *ret_hidden)
 
 
 def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups, in_cf: bool, out_cf: bool, fork: bool,
-               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None):
-    return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
+               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None, nxt=None):
+    return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
                              w_lin1, w_post, w_sc, w_last, *w_hidden)

@@ -321,9 +321,17 @@ class MessagePassing(Module):
                 with ops.on_stream(side2, main):
                     attrs = _stream_alias(attrs, side2)
         fc = list(conv.fc.children())
+        nxt = None
+        nmp = self.__dict__.get("_next_mp")          # set by SequentialGraphNetwork: the next layer reads the same edge embedding
+        if nmp is not None and fork and nmp.conv._fork_pays(data["edge_radial"].shape[0]):
+            plan_n = nmp._block_plan()
+            if plan_n is not None and (nmp.conv.sc is None) == (conv.sc is None):
+                fc_n = list(nmp.conv.fc.children())
+                if fc_n[0].weight.shape[0] == radial.shape[1]:
+                    nxt = (plan_n, fc_n[-1].weight, [m.weight for m in fc_n[:-1]])
         y = conv_block.conv_block(x, attrs, radial, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                   conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,
-                                  fc[-1].weight, [m.weight for m in fc[:-1]], table=table)
+                                  fc[-1].weight, [m.weight for m in fc[:-1]], table=table, nxt=nxt)
         return y
 
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):

@@ -74,7 +74,8 @@ class SequentialGraphNetwork(torch.nn.Sequential):
             src = next((g for g, loc in getattr(layer, "input_key_mapping", {}).items() if loc == "edge_radial"), None)
             if prev is not None and prev[1] == src and src is not None:
                 object.__setattr__(prev[0], "_next_conv", conv)     # a plain reference, not a registered submodule
-            prev = (conv, src)
+                prev[2].__dict__["_next_mp"] = layer                # (the fused block's look-ahead wants the layer)
+            prev = (conv, src, layer)
 
         # cf hand-over between directly consecutive MessagePassing layers on one feature key (nn/message_passing.py):
         # layer i may emit the channel-fastest layout when layer i+1 is the only reader of that key and overwrites it
