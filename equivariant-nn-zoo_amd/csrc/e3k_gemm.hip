@@ -342,6 +342,89 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
 }
 
+// ---------------------------------------------------------------------------------------
+// few rows, long K (the radial MLP's dgrad on the knot table: 4097 x 64 outputs, K ~ 2000): a 64-row tile grid would
+// occupy a quarter of the chip with one serial K loop each.  Here a workgroup owns 32 x 32 outputs and its four waves
+// split K; operands go global -> registers (both k-contiguous, no LDS), the four partial tiles are summed through
+// LDS in wave order (deterministic).
+// ---------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemm_splitk_kernel(const GemmBatch gb) {
+  constexpr int SKC = 64;                       // k per super-chunk: 8 per lane half and MFMA group, 4 groups in flight
+  __shared__ float red[4][32 * 33];
+  __shared__ long long rowA[32];
+  __shared__ long long rowC[32];
+  const BlockProblem bp_ = fetch_problem(gb);
+  const e3k_gemm_problem& P = bp_.P;
+  const int M = P.M1 * P.M2, K = P.K;
+  const int tiles_n = (P.N + 31) / 32;
+  const int row0 = (bp_.local / tiles_n) * 32, n0 = (bp_.local % tiles_n) * 32;
+  if (row0 >= M) return;
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  fill_row_tables<32>(P, row0, M, rowA, rowC);
+  __syncthreads();
+  const int r = lane & 31, hh = lane >> 5;
+  // rows / columns beyond the problem read a valid row instead (their outputs are never stored): no guards in the loop
+  const long long offa = rowA[r] >= 0 ? rowA[r] : rowA[0];
+  const float* arow = P.A + offa;
+  const float* brow = P.B + (int64_t)(n0 + r < P.N ? n0 + r : n0) * P.b_n;
+  const int chunks = K / SKC, per = (chunks + 3) / 4;          // K % 64 == 0 (dispatch condition)
+  const int c_beg = uniform(w * per), c_end = uniform((c_beg + per < chunks) ? c_beg + per : chunks);   // (scalar loop control)
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  float4 a0[8], b0[8], a1[8], b1[8];
+#define SPLITK_LOAD(c, xa, xb)                                                        \
+  _Pragma("unroll") for (int g = 0; g < 4; ++g) _Pragma("unroll") for (int q = 0; q < 2; ++q) { \
+    const int k = (c) * SKC + 16 * g + 8 * hh + 4 * q;                                \
+    xa[2 * g + q] = *reinterpret_cast<const float4*>(arow + k);                       \
+    xb[2 * g + q] = *reinterpret_cast<const float4*>(brow + k);                       \
+  }
+#define SPLITK_MFMA(xa, xb)                                                           \
+  _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                     \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].x, xb[j].x, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].y, xb[j].y, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].z, xb[j].z, acc, 0, 0, 0);       \
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[j].w, xb[j].w, acc, 0, 0, 0);       \
+  }
+  // two chunks per trip, every load and MFMA of the trip unconditional (a conditional load makes the compiler wait for
+  // ALL outstanding loads before the MFMAs of the other buffer); loads past the wave's range re-read its last chunk
+  const int n_chunks = c_end - c_beg;
+  if (n_chunks > 0) {
+    const int last = c_end - 1;
+    SPLITK_LOAD(c_beg, a0, b0)
+    for (int i = 0; i + 1 < n_chunks; i += 2) {
+      const int c1 = c_beg + i + 1, c2 = (c_beg + i + 2 < last) ? c_beg + i + 2 : last;
+      // (the fences keep the scheduler from sinking the loads to their uses: the point is a full chunk in flight)
+      SPLITK_LOAD(c1, a1, b1)
+      __builtin_amdgcn_sched_barrier(0);
+      SPLITK_MFMA(a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      SPLITK_LOAD(c2, a0, b0)
+      __builtin_amdgcn_sched_barrier(0);
+      SPLITK_MFMA(a1, b1)
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (n_chunks & 1) { SPLITK_MFMA(a0, b0) }
+  }
+#undef SPLITK_LOAD
+#undef SPLITK_MFMA
+#pragma unroll
+  for (int i = 0; i < 16; ++i) red[w][((i & 3) + 8 * (i >> 2) + 4 * hh) * 33 + r] = acc[i];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int o = t + 256 * j, row = o >> 5, col = o & 31;
+    const long long offc = rowC[row];
+    const int n = n0 + col;
+    if (offc < 0 || n >= P.N) continue;
+    float v = ((red[0][row * 33 + col] + red[1][row * 33 + col]) + red[2][row * 33 + col]) + red[3][row * 33 + col];
+    v = fmaf(P.alpha, v, P.bias ? P.bias[n] : 0.f);
+    float* c = P.C + offc + (long long)n * P.c_n;
+    if (P.accumulate) v += *c;
+    *c = epilogue_act(P, v);
+  }
+}
+
 // (An fp32 GEMM on the bf16 matrix pipe -- every operand split into three bf16 planes, six 32x32x16 bf16 MFMAs per k-block
 // instead of eight 32x32x2 f32 ones -- was built and measured in round 1: 2.7x cheaper on the matrix pipe and as accurate,
 // but +12 % at best (K = N = 1024) and -12 % on the radial shapes: the split costs VALU per staged element and these GEMMs
@@ -922,7 +1005,7 @@ int b_mode(const e3k_gemm_problem& P) {
   return 0;
 }
 
-enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_KINDS };
+enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_KINDS };
 
 struct Batcher {
   e3k::GemmBatch gb{};
@@ -947,6 +1030,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
   int kind[64];
   int64_t plain_tiles128 = 0;
   static const int64_t sk_min_rows = getenv("E3K_SK_MIN_ROWS") ? atoll(getenv("E3K_SK_MIN_ROWS")) : 1024;
+  static const bool splitk_on = !(getenv("E3K_SPLITK") && atoi(getenv("E3K_SPLITK")) == 0);
   for (int i = 0; i < n_problems; ++i) {
     const e3k_gemm_problem& P = problems[i];
     const int rc = validate(P, false);
@@ -954,6 +1038,8 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
     const int64_t M = (int64_t)P.M1 * P.M2;
     if (P.V > 0) kind[i] = FWD_OUTER;
     else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows) kind[i] = FWD_SMALLK;
+    else if (splitk_on && a_vec(P) && b_mode(P) == 2 && P.K >= 256 && P.K % 64 == 0 && ((M + 63) / 64) * ((P.N + e3k::BN - 1) / e3k::BN) < 128)
+      kind[i] = FWD_SPLITK;
     else {
       kind[i] = FWD_PLAIN;
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);   // keyed: the groups partition these rows
@@ -975,6 +1061,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
           rc = small_grid ? launch_batch(e3k::gemm_kernel<2>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4>, b.gb, b.blocks, st);
           break;
         case FWD_SMALLK: rc = launch_batch(e3k::gemm_smallk_kernel, b.gb, b.blocks, st); break;
+        case FWD_SPLITK: rc = launch_batch(e3k::gemm_splitk_kernel, b.gb, b.blocks, st); break;
         default: rc = launch_batch(e3k::gemm_outer_kernel, b.gb, b.blocks, st); break;
       }
       b.reset();
@@ -996,8 +1083,14 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
       int aux = 0;
       if (k == FWD_SMALLK) {
         static const int sk_ct = getenv("E3K_SK_CT") ? atoi(getenv("E3K_SK_CT")) : e3k::SK_CT;
+        // a block keeps its A tile and walks `aux` column tiles -- unless the problem has too few tiles to fill the chip
+        // that way (the radial MLP's last layer on the knot table: 33 row tiles): then fewer columns per block
+        const int64_t fill = ((M + 127) / 128) * tiles_n / 1024;
         aux = tiles_n < sk_ct ? tiles_n : sk_ct;
+        if (fill < aux) aux = fill < 1 ? 1 : (int)fill;
         blocks = ((M + 127) / 128) * ((tiles_n + aux - 1) / aux);
+      } else if (k == FWD_SPLITK) {
+        blocks = ((M + 31) / 32) * ((P.N + 31) / 32);
       } else if (k == FWD_PLAIN && small_grid) {
         blocks = ((M + 63) / 64) * tiles_n;
       } else {

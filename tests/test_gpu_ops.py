@@ -105,6 +105,30 @@ def test_linear_large_shapes(dev):
     assert rel_err(gw, rw) < GTOL
 
 
+@pytest.mark.parametrize("rows,width", [(4097, 1920), (700, 960), (33, 260)])
+def test_fully_connected_net_few_rows_wide_output(dev, rows, width):
+    """The radial MLP on the knot table: few rows, a wide last layer -- its dgrad is the split-K kernel (K = width),
+    its forward the small-K kernel with one column tile per workgroup."""
+    from e3_layers_amd.nn import FullyConnectedNet
+    from e3_layers_amd.utils import activations
+
+    torch.manual_seed(7)
+    hs = [8, 64, 64, 64, width]
+    net = FullyConnectedNet(hs, activations["ssp"]).to(dev)
+    ref = e3ref.FullyConnectedNet(hs, "ssp").double()
+    ref.load_state_dict({k: v.cpu() for k, v in net.state_dict().items()})
+    x = torch.randn(rows, 8, dtype=torch.float64)
+    xin = x.float().to(dev).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    y, yr = net(xin), ref(xr)
+    assert rel_err(y, yr) < TOL
+    seed = torch.randn_like(yr)
+    g = _grads(y, [xin] + list(net.parameters()), seed.float().to(dev))
+    r = _grads(yr, [xr] + list(ref.parameters()), seed)
+    for a, b in zip(g, r):
+        assert rel_err(a, b) < GTOL
+
+
 def test_fully_connected_net(dev):
     from e3_layers_amd.nn import FullyConnectedNet
     from e3_layers_amd.utils import activations
