@@ -26,6 +26,7 @@ from .graph import GraphTopo
 
 ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
 LOOK_AHEAD = int(os.environ.get("E3K_BLOCK_LOOK_AHEAD", "1"))     # the next layer's radial branch issued one layer early
+AHEAD_STATS = [0]      # look-ahead results consumed (tests)
 BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed)
 
 
@@ -117,6 +118,7 @@ class ConvBlockFn(torch.autograd.Function):
         pref, plan.prefetched = plan.prefetched, None
         if pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork):
             h, zs, w = pref[1]                      # issued by the previous layer (look-ahead); `_wait(main, side)` below
+            AHEAD_STATS[0] += 1
         else:
             _wait(side, main)
             with _on(side, main):

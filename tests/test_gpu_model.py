@@ -329,6 +329,50 @@ def test_conv_block_equals_composed_layers(dev, monkeypatch, fork):
     assert prod.layer1._forward_block.__self__ is prod.layer1 and prod.layer0._block_plan() is not None
 
 
+@pytest.mark.parametrize("table", [1, 0])
+def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
+    """The fused layer issues the NEXT layer's radial branch behind its own tensor product (conv_block.LOOK_AHEAD): same
+    energies and parameter gradients as the in-order schedule; the results are consumed by the next layer of the same
+    forward only (one issued under no_grad is not picked up by a training forward on the same tensors' addresses)."""
+    from e3_layers_amd.backend import conv_block, ops, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    model = build(_energy_tree(2, 64, 4)).to(dev).train()
+    batch = synth_qm9(9, 24).to(dev)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(radial_table, "ENABLED", table)
+    monkeypatch.setattr(radial_table, "KNOTS", 512)        # so that this small batch has enough edges per knot
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+
+    def run(ahead, grad=True):
+        monkeypatch.setattr(conv_block, "LOOK_AHEAD", ahead)
+        conv_block.AHEAD_STATS[0] = 0
+        model.zero_grad(set_to_none=True)
+        with torch.enable_grad() if grad else torch.no_grad():
+            out = model(batch.clone())["total_energy"]
+            if grad:
+                out.square().mean().backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        g = torch.cat([p.grad.reshape(-1) for p in model.parameters() if p.grad is not None]) if grad else None
+        return out.detach().clone(), g, conv_block.AHEAD_STATS[0]
+
+    e0, g0, hits0 = run(0)
+    e1, g1, hits1 = run(1)
+    e_ng, _, hits_ng = run(1, grad=False)
+    e2, g2, hits2 = run(1)
+    assert hits0 == 0 and hits1 == 3 and hits_ng == 3 and hits2 == 3      # four layers: three find their weights waiting
+    assert rel_err(e1, e0) < 1e-6 and rel_err(g1, g0) < 1e-5
+    assert rel_err(e_ng, e0) < 1e-6
+    assert rel_err(e2, e0) < 1e-6 and rel_err(g2, g0) < 1e-5
+    for layer in (model.layer0, model.layer1, model.layer2, model.layer3):
+        plan = layer._block_plan()
+        assert plan is not None and plan.prefetched is None                 # nothing left behind
+
+
 @pytest.mark.parametrize("block", [1, 0])
 def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, block):
     """The energy model with the radial MLPs evaluated through the knot table (a batch with enough edges for it to apply)
