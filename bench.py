@@ -165,6 +165,8 @@ def main():
                        ema_decay=cfg.ema_decay if cfg.use_ema else None, ema_use_num_updates=cfg.ema_use_num_updates)
     flat = opt.grads
     flat.enable_direct_accumulation()
+    if world > 1 and os.environ.get("E3K_OVERLAP_ALLREDUCE", "1") != "0":
+        flat.enable_overlapped_all_reduce()     # a layer's gradient slice is all-reduced while the backward goes on
 
     # every rank owns its own molecules (weak scaling): four distinct seeded batches per rank, resident in HBM
     n_res = 4

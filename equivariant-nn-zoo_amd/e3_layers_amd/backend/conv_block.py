@@ -288,6 +288,11 @@ class ConvBlockFn(torch.autograd.Function):
             _wait(main, side2)
         if any(r is not None for r in ret_hidden):
             _wait(main, side)
+        if ops.GRAD_READY is not None:
+            rets = (ret_lin1, ret_post, ret_sc if has_sc else None, ret_last, *ret_hidden)
+            needs = (need_lin1, need_post, need_sc or not has_sc, need_last, *need_hidden)
+            if all(needs) and all(r is None for r in rets):          # every weight gradient of the layer went to the sink
+                ops.GRAD_READY([w_lin1, w_post, w_last, *w_hidden] + ([w_sc] if has_sc else []))
         return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None,
                 ret_lin1, ret_post, ret_sc, ret_last, *ret_hidden)
 

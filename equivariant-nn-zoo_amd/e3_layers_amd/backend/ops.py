@@ -90,6 +90,10 @@ class on_stream:
         return False
 
 
+def side_streams_of(device_index: int):
+    return [st for key, st in _side_streams.items() if (key if isinstance(key, int) else key[0]) == device_index]
+
+
 def join_side_streams() -> None:
     """Make the current stream wait for every side stream of its device (cheap when they are idle).  The gradient
     sink writes weight gradients without an AccumulateGrad node, so autograd's end-of-backward stream sync does not
@@ -112,6 +116,10 @@ def join_side_streams() -> None:
 # registered it is alive and still lives there (``model.to()``, ``load_state_dict(assign=True)`` move parameters, and
 # the allocator may hand the old address to an unrelated tensor).
 GRAD_SINK: Dict[Tuple[int, int], Tuple[torch.Tensor, "weakref.ref"]] = {}
+# Set by run/parallel.FlatGradients.enable_overlapped_all_reduce: called (from the autograd engine's thread) with the
+# weight tensors of a layer once every kernel that adds into their sunk gradients has been ENQUEUED (on whichever
+# stream) -- the listener starts that slice's all-reduce behind them while the backward of the earlier layers goes on.
+GRAD_READY = None
 WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
 WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
 class _Mode:

@@ -111,7 +111,65 @@ class FlatGradients:
             ops.GRAD_SINK.pop(k, None)
 
     def zero(self) -> None:
+        self._drain()
         self.buffer.zero_()
+
+    # ------------------------------------------------------------------ all-reduce, overlapped with the backward
+    _pending = ()          # [(lo, hi, work)] slices whose all-reduce is in flight
+    _comm = None
+    overlapped_slices = 0  # slices reduced ahead of all_reduce_mean() since construction (tests / logs)
+
+    def enable_overlapped_all_reduce(self) -> None:
+        """Start a layer's slice of the all-reduce as soon as its weight gradients have been enqueued, on a
+        communication stream, while the backward of the earlier layers is still running (needs the gradient sink:
+        ``enable_direct_accumulation``).  The fused convolution layers report through ``ops.GRAD_READY``; whatever was
+        not reduced ahead (embedding, heads, layers on the composed path) goes in ``all_reduce_mean()`` as before.
+        Every rank runs the same model, so the slices and their order are the same on every rank.  xGMI rings are
+        per-link bound: a layer's slice is 4-5 MB here (1.15 M self-connection weights), large enough for the links."""
+        if not (self.buffer.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from ..backend import ops
+
+        self._comm = torch.cuda.Stream(device=self.buffer.device)
+        self._pending = []
+        self._slot = {(p.data_ptr(), p.numel()): (off, -(-p.numel() // FLAT_ALIGN) * FLAT_ALIGN)
+                      for p, off in zip(self.params, self.offsets)}
+        ops.GRAD_READY = self._on_ready
+
+    def disable_overlapped_all_reduce(self) -> None:
+        from ..backend import ops
+
+        self._drain()
+        if getattr(ops.GRAD_READY, "__self__", None) is self:
+            ops.GRAD_READY = None
+
+    def _on_ready(self, weights) -> None:
+        from ..backend import ops
+
+        slots = [self._slot.get((w.data_ptr(), w.numel())) for w in weights]
+        if not slots or any(sl is None for sl in slots):
+            return
+        lo = min(off for off, _ in slots)
+        hi = max(off + size for off, size in slots)
+        if sum(size for _, size in slots) != hi - lo:
+            return                      # not one contiguous run of the flat buffer: leave it to all_reduce_mean()
+        comm = self._comm
+        comm.wait_stream(torch.cuda.current_stream())
+        for st in ops.side_streams_of(self.buffer.device.index):
+            comm.wait_stream(st)        # the weight-gradient kernels of the layer run on the side streams
+        with torch.cuda.stream(comm):
+            work = dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
+        self._pending.append((lo, hi, work))
+        self.overlapped_slices += 1
+
+    def _drain(self):
+        done = sorted(self._pending, key=lambda t: t[0]) if self._pending else []
+        for _, _, work in done:
+            work.wait()                 # the current stream waits for the collective (RCCL: no host block)
+        if self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+            self._pending = []
+        return done
 
     def all_reduce_mean(self) -> None:
         if self.buffer.is_cuda:
@@ -119,7 +177,16 @@ class FlatGradients:
 
             ops.join_side_streams()   # side-stream weight-gradient kernels (gradient sink) must land first
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)
+            pos, rest = 0, []
+            for lo, hi, _ in (sorted(self._pending, key=lambda t: t[0]) if self._pending else []):
+                if lo > pos:
+                    rest.append((pos, lo))
+                pos = max(pos, hi)
+            if pos < self.buffer.numel():
+                rest.append((pos, self.buffer.numel()))
+            for lo, hi in rest:         # what no layer reduced ahead (everything, without the overlap)
+                dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM)
+            self._drain()
             self.buffer.div_(dist.get_world_size())
 
 

@@ -44,8 +44,10 @@ broadcast_parameters(model)                 # ... made identical, as DDP does at
 opt = FusedAdamEMA(model.parameters(), lr=1e-2, ema_decay=0.99)
 flat = opt.grads
 flat.enable_direct_accumulation()
+if len(sys.argv) > 3 and sys.argv[3] == "overlap":
+    flat.enable_overlapped_all_reduce()
 start = opt.flat.clone()
-batch = synth_qm9(5, 8)
+batch = synth_qm9(5, 40)      # > 256 nodes per rank: the keyed self-connection, so the layers run as fused blocks
 mine = shard_batch(batch, rank, world).to(dev)
 target = mine["total_energy"]
 n_mine = len(mine)
@@ -58,7 +60,7 @@ flat.all_reduce_mean()
 grad = flat.gather().clone()
 opt.step()
 torch.cuda.synchronize()
-torch.save({"grad": grad.cpu(), "start": start.cpu(), "after": opt.flat.detach().cpu().clone(), "n": n_mine,
+torch.save({"overlapped": flat.overlapped_slices, "grad": grad.cpu(), "start": start.cpu(), "after": opt.flat.detach().cpu().clone(), "n": n_mine,
             "sink_entries": len(ops.GRAD_SINK)}, out)
 if world > 1:
     dist.barrier()
@@ -72,7 +74,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _launch(world, tmp_path):
+def _launch(world, tmp_path, mode="plain"):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     port = _free_port()
@@ -80,9 +82,9 @@ def _launch(world, tmp_path):
     for rank in range(world):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    E3K_FWD_FORK="0" if world > 1 else os.environ.get("E3K_FWD_FORK", "1"), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        out = tmp_path / f"w{world}_r{rank}.pt"
+        out = tmp_path / f"w{world}_{mode}_r{rank}.pt"
         outs.append(out)
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out)], env=env, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(out), mode], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT))
     logs = []
     for p in procs:
@@ -98,11 +100,15 @@ def _launch(world, tmp_path):
     return [torch.load(o) for o in outs]
 
 
-def test_two_ranks_on_one_gpu_match_the_single_process_step(dev, tmp_path):
-    two = _launch(2, tmp_path)
+@pytest.mark.parametrize("mode", ["plain", "overlap"])
+def test_two_ranks_on_one_gpu_match_the_single_process_step(dev, tmp_path, mode):
+    """mode "overlap": every fused layer's slice of the flat gradient is all-reduced on a communication stream as soon as
+    its weight-gradient kernels are enqueued (FlatGradients.enable_overlapped_all_reduce), the rest at the end."""
+    two = _launch(2, tmp_path, mode)
     one = _launch(1, tmp_path)[0]
     r0, r1 = two
-    assert r0["n"] + r1["n"] == 8 and r0["n"] >= 1 and r1["n"] >= 1
+    assert r0["overlapped"] == r1["overlapped"] == (3 if mode == "overlap" else 0)      # the three convolution layers
+    assert r0["n"] + r1["n"] == 40 and r0["n"] >= 1 and r1["n"] >= 1
     assert r0["sink_entries"] > 20                              # the weight-gradient kernels wrote into the flat buffer
     assert torch.equal(r0["start"], r1["start"])                # broadcast made the replicas identical
     assert torch.equal(r0["grad"], r1["grad"])                  # one all-reduce: both ranks hold the same mean gradient
