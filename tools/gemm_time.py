@@ -6,7 +6,7 @@ for p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
 import torch
 from e3_layers_amd.backend import ops
 dev = torch.device("cuda:0")
-E = 69484
+E = int(os.environ.get("E3K_ROWS", "69484"))
 K, N = int(sys.argv[1]), int(sys.argv[2])
 spec = ops.LinearSpec(K, N, [ops.LinInstr(0, 0, K, N, 1, 0, 1.0)], "e3nn", "e3nn", [], True, True, K * N)
 h = torch.randn(E, K, device=dev); w = torch.randn(K * N, device=dev)
