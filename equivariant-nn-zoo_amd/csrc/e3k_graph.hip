@@ -170,7 +170,8 @@ extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, in
 // chunk (1024 rows): every wave ranks its lanes per key with ballots (no barrier), the 16 x K per-wave counts are
 // prefixed by one thread each, and a running offset per key carries over to the next chunk.
 namespace e3k {
-constexpr int GR_MAXK = 64;
+constexpr int GR_MAXK = 256;
+constexpr int GR_EPT = 16 * GR_MAXK / 1024;      // (wave, key) table entries per thread
 
 __global__ __launch_bounds__(1024) void group_rows_kernel(const int64_t* __restrict__ key, int32_t R, int32_t K,
                                                           int32_t* __restrict__ perm, int32_t* __restrict__ bounds,
@@ -210,20 +211,34 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(const int64_t* __restr
       if (lane == 0) hist[w][q] = __popcll(b);
     }
     __syncthreads();
-    // thread (w, q): rows of key q in the waves before w  (one thread per table entry: 16 x K <= 1024)
-    int before = 0;
-    const int tw = t / GR_MAXK, tq = t % GR_MAXK;
-    if (tq < K) {
-      for (int v = 0; v < tw; ++v) before += hist[v][tq];
+    // table entry (tw, tq): rows of key tq in the waves before tw; 16 x K entries over 1024 threads
+    int before[GR_EPT];
+#pragma unroll
+    for (int j = 0; j < GR_EPT; ++j) {
+      const int e = t + 1024 * j, tw = e / K, tq = e - tw * K;
+      before[j] = 0;
+      if (e < 16 * K)
+        for (int v = 0; v < tw; ++v) before[j] += hist[v][tq];
     }
     __syncthreads();
-    int total_q = 0;
-    if (tq < K && tw == 15) total_q = before + hist[15][tq];
-    if (tq < K) hist[tw][tq] = before;       // now: offset of wave tw inside the chunk's rows of key tq
+    int total_q[GR_EPT];
+#pragma unroll
+    for (int j = 0; j < GR_EPT; ++j) {
+      const int e = t + 1024 * j, tw = e / K, tq = e - tw * K;
+      total_q[j] = 0;
+      if (e < 16 * K) {
+        if (tw == 15) total_q[j] = before[j] + hist[15][tq];
+        hist[tw][tq] = before[j];            // now: offset of wave tw inside the chunk's rows of key tq
+      }
+    }
     __syncthreads();
     if (k >= 0) perm[start[k] + running[k] + hist[w][k] + rank] = i;
     __syncthreads();
-    if (tq < K && tw == 15) running[tq] += total_q;
+#pragma unroll
+    for (int j = 0; j < GR_EPT; ++j) {
+      const int e = t + 1024 * j, tw = e / K, tq = e - tw * K;
+      if (e < 16 * K && tw == 15) running[tq] += total_q[j];
+    }
     __syncthreads();
   }
   if (t < K) reps[t] = count[t] > 0 ? perm[start[t]] : 0;

@@ -300,7 +300,7 @@ class MessagePassing(Module):
         if conv.sc is not None:
             attrs = data["node_attrs"]
             key = get_row_key(attrs)
-            if key is None or key[1] > conv.sc.KEY_MAX or x.shape[0] < conv.sc.KEY_MIN_ROWS:
+            if not conv.sc.keyed_pays(key, x.shape[0]):
                 return None                            # general (un-keyed) attributes: outer-product GEMMs, composed path
             groups = row_groups(key[0], key[1])
         topo = get_topology(data, x.shape[0])

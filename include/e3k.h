@@ -215,7 +215,7 @@ int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile,
 /* Rows grouped by a small categorical key (the keyed self-connection groups nodes by species: node_attrs =
  * Linear(one_hot(species)), layer_configs.py:104-118 feeding nn/message_passing.py:81-87,100): perm [R] int32 = row ids
  * sorted by key, stable; bounds [K,2] int32 = {start, count} per key; reps [K] int64 = first row of each key (0 for an
- * absent key).  K <= 64.  bad_flag [1]: set when a key is outside [0, K). */
+ * absent key).  K <= 256.  bad_flag [1]: set when a key is outside [0, K). */
 int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int32_t* bounds, int64_t* reps,
                    int32_t* bad_flag, void* stream);
 
@@ -335,7 +335,7 @@ int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t d
  * with W_j the [U][V][Wout] weight block of instruction j of FullyConnectedTensorProduct(x, node_attrs)
  * (e3_layers/nn/message_passing.py:81-87, e3nn 'uvw' weight order) at element offset w_off of the flat weight,
  * and its U*Wout columns at m_off of M (columns packed in instruction order, row stride ld_m).
- * a [n_keys, V] (n_keys <= 64, V <= 32).  backward: g_a [n_keys,V] ACCUMULATED (caller zeroes), g_W flat like W:
+ * a [n_keys, V] (V <= 32; the keys are tiled 64 per workgroup).  backward: g_a [n_keys,V] ACCUMULATED (caller zeroes), g_W flat like W:
  * written (accumulate_w = 0) or added to (accumulate_w = 1); either may be NULL.  g_a needs a device `workspace` of
  * e3k_keyed_weights_bwd_workspace(...) floats (per-block partial sums, reduced by a second launch — same-address
  * atomics from every block serialise).  `instr` is a HOST array. */

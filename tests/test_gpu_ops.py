@@ -320,7 +320,7 @@ def test_device_csr_build_is_the_stable_sort(dev, n, deg, shuffle):
             G.check_indices()
 
 
-@pytest.mark.parametrize("rows,n_keys", [(4623, 10), (1000, 64), (70, 3), (1, 5), (5000, 1)])
+@pytest.mark.parametrize("rows,n_keys", [(4623, 10), (1000, 64), (70, 3), (1, 5), (5000, 1), (1536, 80), (3000, 256), (2049, 65)])
 def test_group_rows_kernel_is_the_stable_sort(dev, rows, n_keys):
     """e3k_group_rows (one single-workgroup launch) against the torch construction (stable argsort + counts + cumsum):
     the same permutation, bounds and representatives -- absent keys included."""
