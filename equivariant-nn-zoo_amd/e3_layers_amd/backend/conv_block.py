@@ -27,7 +27,7 @@ from .graph import GraphTopo
 ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
 LOOK_AHEAD = int(os.environ.get("E3K_BLOCK_LOOK_AHEAD", "1"))     # the next layer's radial branch issued one layer early
 AHEAD_STATS = [0]      # look-ahead results consumed (tests)
-BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "0"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: on the radial stream (-0.6 %)
+BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: beside it on the radial stream (-0.3..0.6 % per step, but the two then stretch each other: their event-timed durations double)
 
 
 class ConvBlockPlan:
