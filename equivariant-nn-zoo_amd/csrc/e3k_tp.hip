@@ -26,12 +26,16 @@
 
 namespace e3k {
 
-template <int L1, int L3MAX, int PART>
+// FULL: every group of the plan has a multiple of 64 channels, so no lane is ever idle: the `active` selects and the
+// exec-masked branches around the loads compile away.  Row addresses are formed as (wave-uniform pointer)[lane channel]:
+// the uniform part stays on the scalar unit and the loads take the SGPR-base + 32-bit-lane-offset form (no 64-bit vector
+// add per load); sh[e] is read first so that waiting for it does not mean waiting for the rows issued after it.
+template <int L1, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const bool active = u < g.mul;
   const int mul = g.mul;
+  const bool active = FULL || u < mul;
   const unsigned mask = g.mask;
 
   float acc[S::TOTAL];
@@ -39,50 +43,42 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
   for (int i = 0; i < S::TOTAL; ++i) acc[i] = 0.0f;
 
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
-  if (beg < end) {
-    // no software pipeline (loads of edge t+1 before edge t is consumed): it costs a second register set and
-    // occupancy buys more here -- measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
-    float xn[D1], wn[S::NQ];
-    YRegs yn;
-    auto issue = [&](int t) {
-      const int e = uniform(a.perm[t]);
-      const int s = uniform(a.nbr[e]);
-      const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off + u;
+  // no software pipeline (loads of edge t+1 before edge t is consumed): it costs a second register set and
+  // occupancy buys more here -- measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
+    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W;                    // wave-uniform
+    float xc[D1], wc[S::NQ];
 #pragma unroll
-      for (int i = 0; i < D1; ++i) xn[i] = active ? xr[i * mul] : 0.0f;
-      const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
-      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        if (mask & (1u << Q)) wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
-      });
-      load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
-    };
-    for (int t = beg; t < end; ++t) {
-      issue(t);
-      float (&xc)[D1] = xn;
-      float (&wc)[S::NQ] = wn;
-      YRegs& yc = yn;
-      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-        if (mask & (1u << Q)) {
-          const float wv = wc[Q] * g.coeff[Q];
-          float tt[2 * L3 + 1];
-          CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+    for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      if (mask & (1u << Q)) wc[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
+    });
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
+        const float wv = wc[Q] * g.coeff[Q];
+        float tt[2 * L3 + 1];
+        CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
 #pragma unroll
-          for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
-        }
-      });
-    }
+        for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
+      }
+    });
   }
   if (active) {
-    float* __restrict__ orow = a.out + (int64_t)node * a.d_mid + u;
+    float* __restrict__ orow = a.out + (int64_t)node * a.d_mid;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
       if (mask & (1u << Q)) {
 #pragma unroll
-        for (int k = 0; k < 2 * L3 + 1; ++k) orow[g.out_off[Q] + k * g.out_stride[Q]] = acc[OFF + k];
+        for (int k = 0; k < 2 * L3 + 1; ++k) (orow + g.out_off[Q] + k * g.out_stride[Q])[u] = acc[OFF + k];
       }
     });
   }
@@ -91,38 +87,38 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
-template <int L1, bool WITH_SH, int L3MAX, int PART>
+template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const bool active = u < g.mul;
   const int mul = g.mul;
+  const bool active = FULL || u < mul;
   const unsigned mask = g.mask;
 
   // incoming gradient of this node's group outputs, resident for the whole edge walk
   float go[S::TOTAL];
   {
-    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid + u;
+    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid;      // wave-uniform
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
 #pragma unroll
       for (int k = 0; k < 2 * L3 + 1; ++k)
-        go[OFF + k] = ((mask & (1u << Q)) && active) ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
+        go[OFF + k] = ((mask & (1u << Q)) && active) ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
     });
   }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   for (int t = beg; t < end; ++t) {
     const int e = uniform(a.perm[t]);
     const int s = uniform(a.nbr[e]);
-    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off + u;
-    float xc[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) xc[i] = active ? xr[i * mul] : 0.0f;
     YRegs yc;
     load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
-    float* __restrict__ gwr = a.g_w + (int64_t)e * a.W + u;
-    const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
+    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform
+    float xc[D1];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
+    float* __restrict__ gwr = a.g_w + (int64_t)e * a.W;
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W;
     YRegs gy;
     if constexpr (WITH_SH) {
       gy.y0[0] = 0.0f;
@@ -143,9 +139,9 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
           gk[k] = go[OFF + k];
           dot = fmaf(gk[k], tt[k], dot);
         }
-        if (active && a.g_w) gwr[g.w_off[Q]] = dot * g.coeff[Q];
+        if (active && a.g_w) (gwr + g.w_off[Q])[u] = dot * g.coeff[Q];
         if constexpr (WITH_SH) {
-          const float wv = active ? wr[g.w_off[Q]] * g.coeff[Q] : 0.0f;
+          const float wv = active ? (wr + g.w_off[Q])[u] * g.coeff[Q] : 0.0f;
           CG<L1, L2, L3>::xg(xc, gk, wv, yref<L2>(gy));
         }
       }
@@ -215,62 +211,57 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX, int PART>
+template <int L1, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  const bool active = u < g.mul;
   const int mul = g.mul;
+  const bool active = FULL || u < mul;
   const unsigned mask = g.mask;
 
   float gx[D1];
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
-  if (beg < end) {
-    // (a one-deep software pipeline measured the same: 495 vs 498 us at l_max 2)
+  // (a one-deep software pipeline measured the same: 495 vs 498 us at l_max 2)
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int d = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W;                 // wave-uniform
+    const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid;       // wave-uniform
+    // every row of the edge is requested before the first one is used (registers are not what limits these kernels'
+    // occupancy; a load consumed right behind its issue leaves one row in flight per wave)
     float gn[S::TOTAL], wn[S::NQ];
-    YRegs yn;
-    auto issue = [&](int t) {
-      const int e = uniform(a.perm[t]);
-      const int d = uniform(a.nbr[e]);
-      load_y(yn, a.sh + (int64_t)e * a.d_sh, g);
-      const float* __restrict__ wr = a.w + (int64_t)e * a.W + u;
-      const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid + u;
-      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
-        if (mask & (1u << Q)) {
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
 #pragma unroll
-          for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? grow[g.out_off[Q] + k * g.out_stride[Q]] : 0.0f;
-          wn[Q] = active ? wr[g.w_off[Q]] : 0.0f;
-        }
-      });
-    };
-    for (int t = beg; t < end; ++t) {
-      issue(t);
-      float (&gc)[S::TOTAL] = gn;
-      float (&wc)[S::NQ] = wn;
-      YRegs& yc = yn;
-      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-        constexpr int Q = decltype(qc)::value;
-        constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-        if (mask & (1u << Q)) {
-          float gk[2 * L3 + 1];
+        for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
+        wn[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
+      }
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
+        float gk[2 * L3 + 1];
 #pragma unroll
-          for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gc[OFF + k];
-          CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wc[Q] * g.coeff[Q], gx);
-        }
-      });
-    }
+        for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
+        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * g.coeff[Q], gx);
+      }
+    });
   }
   if (active) {
-    float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off + u;
+    float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
-      if (PART == 2 && !a.x_shared) gxr[i * mul] = gx[i];
-      else atomicAdd(gxr + i * mul, gx[i]);   // two waves per group (a + b is order independent) or several groups on
-                                              // one input block (repeated sh degree): g_x is pre-zeroed
+      if (PART == 2 && !a.x_shared) (gxr + i * mul)[u] = gx[i];
+      else atomicAdd(gxr + i * mul + u, gx[i]);   // two waves per group (a + b is order independent) or several groups on
+                                                  // one input block (repeated sh degree): g_x is pre-zeroed
     }
   }
 }
@@ -295,10 +286,10 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   if constexpr (MAXL >= L) {                                                                         \
     if (l1 == L) {                                                                                   \
       if constexpr (!SPLIT) {                                                                        \
-        BODY<L, __VA_ARGS__, 2>(a, g, node, u);                                                      \
+        BODY<L, __VA_ARGS__, 2, FULL>(a, g, node, u);                                                \
       } else {                                                                                       \
-        if (part == 0) BODY<L, __VA_ARGS__, 0>(a, g, node, u);                                       \
-        else BODY<L, __VA_ARGS__, 1>(a, g, node, u);                                                 \
+        if (part == 0) BODY<L, __VA_ARGS__, 0, FULL>(a, g, node, u);                                 \
+        else BODY<L, __VA_ARGS__, 1, FULL>(a, g, node, u);                                           \
       }                                                                                              \
     }                                                                                                \
   }
@@ -306,26 +297,26 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
 #define E3K_TP_DISPATCH(BODY, ...)                                                                   \
   const int l1 = g.l1;                                                                               \
   (void)part;                                                                                        \
-  if (l1 == 0) BODY<0, __VA_ARGS__, 2>(a, g, node, u);                                               \
+  if (l1 == 0) BODY<0, __VA_ARGS__, 2, FULL>(a, g, node, u);                                         \
   E3K_TP_CASE(1, BODY, __VA_ARGS__)                                                                  \
   E3K_TP_CASE(2, BODY, __VA_ARGS__)                                                                  \
   E3K_TP_CASE(3, BODY, __VA_ARGS__)
 
-template <int MAXL, int L3MAX, bool SPLIT>
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL>
 __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_fwd_body, L3MAX)
 }
 
-template <bool WITH_SH, int MAXL, int L3MAX, bool SPLIT>
+template <bool WITH_SH, int MAXL, int L3MAX, bool SPLIT, bool FULL>
 __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_w_body, WITH_SH, L3MAX)
 }
 
-template <int MAXL, int L3MAX, bool SPLIT>
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL>
 __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
@@ -457,7 +448,9 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     p->max_l3 = 0;
     p->x_cols = 0;
     p->x_shared = 0;
+    p->full64 = 1;
     for (int i = 0; i < n_groups; ++i) {
+      if (groups[i].mul % 64) p->full64 = 0;
       const int lo_i = groups[i].x_off, hi_i = lo_i + (2 * groups[i].l1 + 1) * groups[i].mul;
       for (int j = 0; j < i; ++j) {
         const int lo_j = groups[j].x_off, hi_j = lo_j + (2 * groups[j].l1 + 1) * groups[j].mul;
@@ -549,17 +542,20 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-#define E3K_TP_LAUNCH(ML, L3, SP)                                                                                           \
+#define E3K_TP_LAUNCH_F(ML, L3, SP, FU)                                                                                      \
   switch (kind) {                                                                                                   \
-    case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_W:                                                                                                  \
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
       break;                                                                                                        \
     case TP_BWD_W_SH:                                                                                               \
-      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
+      hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
       break;                                                                                                        \
-    case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
   }
+#define E3K_TP_LAUNCH(ML, L3, SP)                  \
+  if (p->full64) { E3K_TP_LAUNCH_F(ML, L3, SP, true) } \
+  else { E3K_TP_LAUNCH_F(ML, L3, SP, false) }
   // instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3, the latter
   // also in the split form (two waves per group)
   const bool low = p->max_l3 <= p->max_l1;
@@ -571,6 +567,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     default: if (!sp) { E3K_TP_LAUNCH(3, 3, false) } else { E3K_TP_LAUNCH(3, 3, true) } break;
   }
 #undef E3K_TP_LAUNCH
+#undef E3K_TP_LAUNCH_F
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

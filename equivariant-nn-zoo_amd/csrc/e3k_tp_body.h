@@ -112,5 +112,6 @@ struct e3k_tp_plan {
   e3k_rtp_chunk* d_chunks; // NULL when the radial-fused kernels do not serve this plan (a mul that is not a multiple of 64)
   int32_t n_chunks;
   int32_t y_off[3];        // sh column of each degree when every group agrees on it (the radial-fused kernels stage sh rows once per tile)
+  int32_t full64;   // 1: every group has a multiple of 64 channels (the kernels drop their idle-lane handling)
   int32_t x_shared; // 1: two groups read overlapping input columns (an sh degree that repeats opens a second group)
 };
