@@ -26,8 +26,10 @@
 
 namespace e3k {
 
-// FULL: every group of the plan has a multiple of 64 channels, so no lane is ever idle: the `active` selects and the
-// exec-masked branches around the loads compile away.  Row addresses are formed as (wave-uniform pointer)[lane channel]:
+// FULL: every group of the plan has a multiple of 64 channels and every (l2, l3) slot its degrees allow (all output
+// parities present: the inner layers of the shipped models), so no lane is ever idle and no slot is ever skipped: the
+// `active` selects, the exec-masked branches around the loads and the per-slot mask branches compile away, and an
+// edge's loads and arithmetic are one straight-line block.  Row addresses are formed as (wave-uniform pointer)[lane channel]:
 // the uniform part stays on the scalar unit and the loads take the SGPR-base + 32-bit-lane-offset form (no 64-bit vector
 // add per load); sh[e] is read first so that waiting for it does not mean waiting for the rows issued after it.
 template <int L1, int L3MAX, int PART, bool FULL>
@@ -57,12 +59,12 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
     for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
-      if (mask & (1u << Q)) wc[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
+      if (FULL || (mask & (1u << Q))) wc[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
     });
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-      if (mask & (1u << Q)) {
+      if (FULL || (mask & (1u << Q))) {
         const float wv = wc[Q] * g.coeff[Q];
         float tt[2 * L3 + 1];
         CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
@@ -76,7 +78,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
-      if (mask & (1u << Q)) {
+      if (FULL || (mask & (1u << Q))) {
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) (orow + g.out_off[Q] + k * g.out_stride[Q])[u] = acc[OFF + k];
       }
@@ -104,7 +106,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
 #pragma unroll
       for (int k = 0; k < 2 * L3 + 1; ++k)
-        go[OFF + k] = ((mask & (1u << Q)) && active) ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
+        go[OFF + k] = ((FULL || (mask & (1u << Q))) && active) ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
     });
   }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
@@ -130,7 +132,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-      if (mask & (1u << Q)) {
+      if (FULL || (mask & (1u << Q))) {
         float tt[2 * L3 + 1], gk[2 * L3 + 1];
         CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
         float dot = 0.0f;
@@ -237,7 +239,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
-      if (mask & (1u << Q)) {
+      if (FULL || (mask & (1u << Q))) {
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
         wn[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
@@ -247,7 +249,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-      if (mask & (1u << Q)) {
+      if (FULL || (mask & (1u << Q))) {
         float gk[2 * L3 + 1];
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
@@ -363,6 +365,21 @@ void plan_slot_counts(const e3k_tp_group& g, int& n_acc, int& lo, int& hi) {
     default: slot_counts_of<3>(g.mask, n_acc, lo, hi); break;
   }
 }
+template <int L1>
+unsigned full_mask_of(int l3max) {
+  unsigned m = 0;
+  for (int q = 0; q < e3k::Slots<L1>::NQ; ++q)
+    if (e3k::Slots<L1>::L3[q] <= l3max) m |= 1u << q;
+  return m;
+}
+unsigned plan_full_mask(int l1, int l3max) {
+  switch (l1) {
+    case 0: return full_mask_of<0>(l3max);
+    case 1: return full_mask_of<1>(l3max);
+    case 2: return full_mask_of<2>(l3max);
+    default: return full_mask_of<3>(l3max);
+  }
+}
 int plan_max_l3(const e3k_tp_group& g) {
   switch (g.l1) {
     case 0: return max_l3_of<0>(g.mask);
@@ -460,6 +477,11 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
       p->max_l1 = groups[i].l1 > p->max_l1 ? groups[i].l1 : p->max_l1;
       p->max_l3 = plan_max_l3(groups[i]) > p->max_l3 ? plan_max_l3(groups[i]) : p->max_l3;
     }
+    // ... and every slot the kernel instantiation visits is enabled in every group (see launch_all: outputs up to the
+    // largest input degree when the model stops there, else up to 3)
+    const int l3_inst = (p->max_l3 <= p->max_l1) ? p->max_l1 : 3;
+    for (int i = 0; i < n_groups; ++i)
+      if (groups[i].mask != plan_full_mask(groups[i].l1, l3_inst)) p->full64 = 0;
   }
   {
     // chunk list of the radial-fused kernels: the set slots of a group in pairs, per 64-channel chunk
