@@ -20,6 +20,16 @@
 
 namespace e3k {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
+  f32x4 t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
+}
+__device__ __forceinline__ float4 nt_load4(const float4* p) {
+  const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+  return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // centre knot and offset of every edge
 __global__ __launch_bounds__(256) void rtable_bin_kernel(const float* __restrict__ r, int64_t E, float h_inv, int32_t K,
                                                          int64_t* __restrict__ bin2, float* __restrict__ t_out) {
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(256) void rtable_interp_fwd_kernel(const float* __r
     v.y = fmaf(cp, vc.y, fmaf(c0, vb.y, cm * va.y));
     v.z = fmaf(cp, vc.z, fmaf(c0, vb.z, cm * va.z));
     v.w = fmaf(cp, vc.w, fmaf(c0, vb.w, cm * va.w));
-    o[q] = v;
+    nt_store4(o + q, v);      // written once, read by the edge kernels later: streamed past the caches
   }
 }
 
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(256) void rtable_bwd_partial_kernel(const float* __
     const int e = uniform(perm[p]);
     const float t = __uint_as_float(uniform((int)__float_as_uint(tt[e])));
     const float cm = 0.5f * t * (t - 1.f), c0 = 1.f - t * t, cp = 0.5f * t * (t + 1.f);
-    const float4 g = *reinterpret_cast<const float4*>(gw + (int64_t)e * W + col);
+    const float4 g = nt_load4(reinterpret_cast<const float4*>(gw + (int64_t)e * W + col));      // read once
     am.x = fmaf(cm, g.x, am.x); am.y = fmaf(cm, g.y, am.y); am.z = fmaf(cm, g.z, am.z); am.w = fmaf(cm, g.w, am.w);
     a0.x = fmaf(c0, g.x, a0.x); a0.y = fmaf(c0, g.y, a0.y); a0.z = fmaf(c0, g.z, a0.z); a0.w = fmaf(c0, g.w, a0.w);
     ap.x = fmaf(cp, g.x, ap.x); ap.y = fmaf(cp, g.y, ap.y); ap.z = fmaf(cp, g.z, ap.z); ap.w = fmaf(cp, g.w, ap.w);

@@ -24,6 +24,16 @@
 
 #include "e3k_tp_body.h"
 
+// the per-edge weights are read once per pass and the weight gradients written once: streamed past the caches
+// (the cache lines stay for the gathered node rows)
+#ifdef E3K_NO_NT
+#define E3K_STREAM_LOAD(p) (*(p))
+#define E3K_STREAM_STORE(v, p) (*(p) = (v))
+#else
+#define E3K_STREAM_LOAD(p) __builtin_nontemporal_load(p)
+#define E3K_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 namespace e3k {
 
 // FULL: every group of the plan has a multiple of 64 channels and every (l2, l3) slot its degrees allow (all output
@@ -59,7 +69,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
     for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
-      if (FULL || (mask & (1u << Q))) wc[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
+      if (FULL || (mask & (1u << Q))) wc[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + u) : 0.0f;
     });
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
@@ -141,7 +151,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
           gk[k] = go[OFF + k];
           dot = fmaf(gk[k], tt[k], dot);
         }
-        if (active && a.g_w) (gwr + g.w_off[Q])[u] = dot * g.coeff[Q];
+        if (active && a.g_w) E3K_STREAM_STORE(dot * g.coeff[Q], (gwr + g.w_off[Q]) + u);
         if constexpr (WITH_SH) {
           const float wv = active ? (wr + g.w_off[Q])[u] * g.coeff[Q] : 0.0f;
           CG<L1, L2, L3>::xg(xc, gk, wv, yref<L2>(gy));
@@ -242,7 +252,7 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       if (FULL || (mask & (1u << Q))) {
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
-        wn[Q] = active ? (wr + g.w_off[Q])[u] : 0.0f;
+        wn[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + u) : 0.0f;
       }
     });
     __builtin_amdgcn_sched_barrier(0);
