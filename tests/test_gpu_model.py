@@ -343,6 +343,8 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
     model = build(_energy_tree(2, 64, 4)).to(dev).train()
     batch = synth_qm9(9, 24).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FWD_FORK", 1)                 # (the modes this test is about, whatever the environment says)
+    monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(radial_table, "ENABLED", table)
     monkeypatch.setattr(radial_table, "KNOTS", 512)        # so that this small batch has enough edges per knot
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
@@ -852,6 +854,7 @@ def test_radial_look_ahead_equals_in_order(dev, monkeypatch):
     model = build(_energy_tree(2, 16, 3)).to(dev).train()
     batch = synth_qm9(4, 12).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FWD_FORK", 1)          # (the modes this test is about, whatever the environment says)
 
     def run(ahead):
         monkeypatch.setattr(mp, "RADIAL_AHEAD", ahead)
