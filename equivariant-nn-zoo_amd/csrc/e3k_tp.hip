@@ -29,7 +29,9 @@
 #ifdef E3K_NO_NT
 #define E3K_STREAM_LOAD(p) (*(p))
 #define E3K_STREAM_STORE(v, p) (*(p) = (v))
+#define E3K_STREAM_AUX 0
 #else
+#define E3K_STREAM_AUX 2   // buffer-load cache policy bit 1 = nt
 #define E3K_STREAM_LOAD(p) __builtin_nontemporal_load(p)
 #define E3K_STREAM_STORE(v, p) __builtin_nontemporal_store((v), (p))
 #endif
@@ -42,8 +44,88 @@ namespace e3k {
 // edge's loads and arithmetic are one straight-line block.  Row addresses are formed as (wave-uniform pointer)[lane channel]:
 // the uniform part stays on the scalar unit and the loads take the SGPR-base + 32-bit-lane-offset form (no 64-bit vector
 // add per load); sh[e] is read first so that waiting for it does not mean waiting for the rows issued after it.
+// ---- FULL instantiations: buffer addressing ---------------------------------------------------------------------------
+// A row of an edge is addressed as (descriptor of the edge's row block: wave-uniform base, rebuilt per edge with two scalar
+// adds) + (ONE loop-invariant SGPR: the row's byte offset inside the block) + (one loop-invariant VGPR: 4 * lane channel).
+// The flat form `(uniform pointer)[u]` costs an SGPR pair per row, all live at once because every row of an edge is
+// requested before the first is consumed: tp_bwd_x (22-31 gradient rows + 6-8 weight rows per edge) ran out of scalar
+// registers -- 37-74 spilled to VGPR lanes and read back with v_readlane inside the edge loop -- and the k > 0 rows were
+// formed with 64-bit VECTOR adds.  sh[e] is nine unconditional scalar loads (FULL plans keep the degrees 0, 1, 2 at columns
+// 0, 1, 4 of a 9-wide row: checked when the plan is built), no branch on y_off inside the loop.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const float* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_ld_stream(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, E3K_STREAM_AUX));
+}
+__device__ __forceinline__ void load_y_full(YRegs& y, const float* __restrict__ yr) {
+  y.y0[0] = yr[0];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) y.y1[j] = yr[1 + j];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) y.y2[j] = yr[4 + j];
+}
+
+template <int L1, int L3MAX, int PART>
+__device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int u4 = u * 4;
+  const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
+  int woff4[S::NQ];
+  float cf[S::NQ];
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    woff4[Q] = uniform(g.w_off[Q] * 4);
+    cf[Q] = g.coeff[Q];
+  });
+  const int row_x = a.d_in * 4, row_w = a.W * 4;
+  float acc[S::TOTAL];
+#pragma unroll
+  for (int i = 0; i < S::TOTAL; ++i) acc[i] = 0.0f;
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
+    const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
+    float xc[D1], wc[S::NQ];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      wc[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+    });
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      const float wv = wc[Q] * cf[Q];
+      float tt[2 * L3 + 1];
+      CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
+    });
+  }
+  float* __restrict__ orow = a.out + (int64_t)node * a.d_mid;
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+    for (int k = 0; k < 2 * L3 + 1; ++k) (orow + g.out_off[Q] + k * g.out_stride[Q])[u] = acc[OFF + k];
+  });
+}
+
 template <int L1, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  if constexpr (FULL) {
+    tp_fwd_body_full<L1, L3MAX, PART>(a, g, node, u);
+    return;
+  }
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
@@ -99,8 +181,62 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
+template <int L1, int L3MAX, int PART>
+__device__ __forceinline__ void tp_bwd_w_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int u4 = u * 4;
+  const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
+  int woff4[S::NQ];
+  float cf[S::NQ];
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    woff4[Q] = uniform(g.w_off[Q] * 4);
+    cf[Q] = g.coeff[Q];
+  });
+  const int row_x = a.d_in * 4, row_w = a.W * 4;
+  float go[S::TOTAL];
+  {
+    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid;      // wave-uniform
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) go[OFF + k] = (grow + g.out_off[Q] + k * g.out_stride[Q])[u];
+    });
+  }
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
+    const __amdgpu_buffer_rsrc_t rgw = row_rsrc(a.g_w + (int64_t)e * a.W, row_w);
+    float xc[D1];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      float tt[2 * L3 + 1];
+      CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+      float dot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) dot = fmaf(go[OFF + k], tt[k], dot);
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dot * cf[Q]), rgw, u4, woff4[Q], E3K_STREAM_AUX);
+    });
+  }
+}
+
 template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  if constexpr (FULL && !WITH_SH) {
+    if (a.g_w) {      // (always, without grad_sh: the C ABI rejects a call that asks for neither)
+      tp_bwd_w_body_full<L1, L3MAX, PART>(a, g, node, u);
+      return;
+    }
+  }
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
@@ -223,8 +359,66 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
+template <int L1, int L3MAX, int PART>
+__device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int mul = g.mul;
+  const int u4 = u * 4;
+  int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
+  float cf[S::NQ];
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    goff4[Q] = uniform(g.out_off[Q] * 4);
+    gstr4[Q] = uniform(g.out_stride[Q] * 4);
+    woff4[Q] = uniform(g.w_off[Q] * 4);
+    cf[Q] = g.coeff[Q];
+  });
+  const int row_g = a.d_mid * 4, row_w = a.W * 4;
+  float gx[D1];
+#pragma unroll
+  for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int d = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
+    const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
+    float gn[S::TOTAL], wn[S::NQ];
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k)
+        gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+      wn[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      float gk[2 * L3 + 1];
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
+      CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
+    });
+  }
+  float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
+#pragma unroll
+  for (int i = 0; i < D1; ++i) {
+    if (PART == 2 && !a.x_shared) (gxr + i * mul)[u] = gx[i];
+    else atomicAdd(gxr + i * mul + u, gx[i]);
+  }
+}
+
 template <int L1, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  if constexpr (FULL) {
+    tp_bwd_x_body_full<L1, L3MAX, PART>(a, g, node, u);
+    return;
+  }
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
@@ -489,9 +683,12 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
     }
     // ... and every slot the kernel instantiation visits is enabled in every group (see launch_all: outputs up to the
     // largest input degree when the model stops there, else up to 3)
-    const int l3_inst = (p->max_l3 <= p->max_l1) ? p->max_l1 : 3;
-    for (int i = 0; i < n_groups; ++i)
+    const int l3_inst = (p->max_l3 <= p->max_l1 && !p->split) ? p->max_l1 : 3;   // the predicate of launch_all
+    for (int i = 0; i < n_groups; ++i) {
       if (groups[i].mask != plan_full_mask(groups[i].l1, l3_inst)) p->full64 = 0;
+      // FULL kernels read sh[e] at fixed columns: degrees 0, 1, 2 at 0, 1, 4 of a 9-wide row
+      if (d_sh != 9 || groups[i].y_off[0] != 0 || groups[i].y_off[1] != 1 || groups[i].y_off[2] != 4) p->full64 = 0;
+    }
   }
   {
     // chunk list of the radial-fused kernels: the set slots of a group in pairs, per 64-channel chunk

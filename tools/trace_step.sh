@@ -5,3 +5,4 @@ rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/tr -
 cd $GRAFT_REPO_ROOT
 cut -c120-180 gpurun_out/tr.log | tail -1
 python3 tools/trace_gaps.py $(ls -t gpurun_out/tr/*kernel_trace.csv | head -1)
+python3 tools/step_kernels.py $(ls -t gpurun_out/tr/*kernel_trace.csv | head -1) gpurun_out/step_kernels.txt
