@@ -28,7 +28,7 @@
 //                       split over blocks, 64-row chunks staged in natural row-major order (both MFMA
 //                       operands conflict-free), fp32 atomics on the small output.
 //
-// Descriptors: up to 8 problems per launch, passed by value (1.2 KB of kernel arguments); every
+// Descriptors: up to 16 problems per launch, passed by value (3.2 KB of kernel arguments); keyed and plain problems mix; every
 // workgroup finds its problem and pulls it into scalar registers with s_load (the batch is wave-uniform).
 #include <algorithm>
 #include <cstdlib>
@@ -39,13 +39,13 @@ namespace e3k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GEMM_MAXP = 8;
+constexpr int GEMM_MAXP = 16;   // 16 x 168 B of descriptors + tables = 3.2 KB of the 4 KB kernel-argument segment
 struct GemmBatch {
   int n;
-  int reps;               // > 1: every problem stands for `reps` key groups (its tile range is reps equal sub-ranges);
-  long long key_stride;   //      key t uses B + t*key_stride and the device pair group_dev + 2*t
+  int reps[GEMM_MAXP];              // > 1: the problem stands for `reps` key groups (its tile range is reps equal sub-ranges);
+  long long key_stride[GEMM_MAXP];  //      key t uses B + t*key_stride and the device pair group_dev + 2*t
   int tile_start[GEMM_MAXP + 1];
-  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad)
+  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad), bit4: 128-wide output tile (wgrad)
   int aux[GEMM_MAXP];    // wgrad: row splits; smallk: column tiles per block
   e3k_gemm_problem p[GEMM_MAXP];
 };
@@ -104,11 +104,12 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
   out.flags = gb.flags[pi];
   out.aux = gb.aux[pi];
   out.P = gb.p[pi];
-  if (gb.reps > 1) {  // keyed problem: which key group this workgroup belongs to
-    const int per_key = (gb.tile_start[pi + 1] - gb.tile_start[pi]) / gb.reps;
+  const int reps = gb.reps[pi];
+  if (reps > 1) {  // keyed problem: which key group this workgroup belongs to
+    const int per_key = (gb.tile_start[pi + 1] - gb.tile_start[pi]) / reps;
     const int key = out.local / per_key;
     out.local -= key * per_key;
-    out.P.B += (int64_t)key * gb.key_stride;
+    out.P.B += (int64_t)key * gb.key_stride[pi];
     out.P.group_dev += 2 * key;
   }
   if (out.P.row_index && out.P.group_dev) {  // device-side {start, count} of this key group
@@ -688,13 +689,9 @@ struct RowCursor {
 };
 
 template <bool OUTER, int TN>
-__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
+__device__ __forceinline__ void gemm_wgrad_body(const BlockProblem& bp_, float* As, float* Gs, float* Vs) {
   constexpr int WN = 64 * TN;
   constexpr int LDWG = WN + 4;
-  __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
-  __shared__ __attribute__((aligned(16))) float Gs[WR * LDWG];
-  __shared__ float Vs[OUTER ? WR * LDV : 1];
-  const BlockProblem bp_ = fetch_problem(gb);
   const e3k_gemm_problem& P = bp_.P;
   const int flags = bp_.flags, local = bp_.local;
   const int M = P.M1 * P.M2, M2 = P.M2;
@@ -863,6 +860,17 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
   }
 }
 
+// one launch serves problems with 64-wide (N < 128) and 128-wide output tiles: the width is a per-problem flag
+template <bool OUTER>
+__global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
+  __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
+  __shared__ __attribute__((aligned(16))) float Gs[WR * (128 + 4)];
+  __shared__ float Vs[OUTER ? WR * LDV : 1];
+  const BlockProblem bp_ = fetch_problem(gb);
+  if (bp_.flags & 16) gemm_wgrad_body<OUTER, 2>(bp_, As, Gs, Vs);
+  else gemm_wgrad_body<OUTER, 1>(bp_, As, Gs, Vs);
+}
+
 // ---------------------------------------------------------------------------------------
 // small helpers: column sums and the self-connection backward reduction
 // ---------------------------------------------------------------------------------------
@@ -1010,24 +1018,22 @@ enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_KINDS };
 struct Batcher {
   e3k::GemmBatch gb{};
   int blocks = 0;
-  int reps = 1;
-  long long key_stride = 0;
-  Batcher(int reps_, long long key_stride_) : reps(reps_), key_stride(key_stride_) { reset(); }
   void reset() {
     gb = e3k::GemmBatch{};
-    gb.reps = reps;
-    gb.key_stride = key_stride;
     blocks = 0;
   }
 };
+constexpr int MAX_CALL = 64;   // problems per C-ABI call
 }  // namespace
 
-// reps > 1: every problem is a keyed template (row_index = the key-sorted permutation, group_dev = the pair of key 0)
-static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int reps, long long key_stride, void* stream) {
+// reps[i] > 1: problem i is a keyed template (row_index = the key-sorted permutation, group_dev = the pair of key 0,
+// B of key t at B + t * key_stride[i]); reps == nullptr: all plain
+static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const int* reps, const long long* key_stride,
+                         void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
-  if (n_problems > 64) return E3K_ERR_INVALID;
+  if (n_problems > MAX_CALL) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  int kind[64];
+  int kind[MAX_CALL];
   int64_t plain_tiles128 = 0;
   static const int64_t sk_min_rows = getenv("E3K_SK_MIN_ROWS") ? atoll(getenv("E3K_SK_MIN_ROWS")) : 1024;
   static const bool splitk_on = !(getenv("E3K_SPLITK") && atoi(getenv("E3K_SPLITK")) == 0);
@@ -1048,7 +1054,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
   // launches that would leave most of the 256 CUs without a third workgroup use 64-row tiles
   const bool small_grid = plain_tiles128 < 3 * 256;
   for (int k = 0; k < FWD_KINDS; ++k) {
-    Batcher b(reps, key_stride);
+    Batcher b;
     auto flush = [&]() -> int {
       if (!b.blocks) {
         b.reset();
@@ -1069,7 +1075,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
     };
     // longest-processing-time-first: workgroups are dispatched in blockIdx order, so the problems with the longest
     // K loops go first and the short ones fill the tail of the launch
-    int order[64];
+    int order[MAX_CALL];
     for (int i = 0; i < n_problems; ++i) order[i] = i;
     std::stable_sort(order, order + n_problems, [&](int a, int b) { return problems[a].K > problems[b].K; });
     for (int oi = 0; oi < n_problems; ++oi) {
@@ -1078,6 +1084,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
       const e3k_gemm_problem& P = problems[i];
       const int64_t M = (int64_t)P.M1 * P.M2;
       if (M == 0) continue;
+      const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       const int tiles_n = (P.N + e3k::BN - 1) / e3k::BN;
       int64_t blocks;
       int aux = 0;
@@ -1096,10 +1103,12 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
       } else {
         blocks = ((M + 127) / 128) * tiles_n;
       }
-      blocks *= reps;
+      blocks *= rp;
       if (b.blocks + blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
+      gb.reps[gb.n] = rp;
+      gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
       gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1);
       gb.aux[gb.n] = aux;
       gb.tile_start[gb.n] = b.blocks;
@@ -1117,42 +1126,41 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, int r
 }
 
 extern "C" int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream) {
-  return gemm_fwd_impl(problems, n_problems, 1, 0, stream);
+  return gemm_fwd_impl(problems, n_problems, nullptr, nullptr, stream);
 }
 
-static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, int reps, long long key_stride, void* stream) {
+static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, const int* reps, const long long* key_stride,
+                           void* stream) {
   if (n_problems < 0 || (n_problems && !problems)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   for (int i = 0; i < n_problems; ++i) {
     const int rc = validate(problems[i], true);
     if (rc != E3K_OK) return rc;
   }
-  for (int mode = 0; mode < 4; ++mode) {  // (outer?, 128-wide output tile?)
+  for (int mode = 0; mode < 2; ++mode) {  // plain | outer (x (x) attrs formed on the fly)
     const bool outer = mode & 1;
-    const int tn = (mode & 2) ? 2 : 1;
-    Batcher b(reps, key_stride);
+    Batcher b;
     auto flush = [&]() -> int {
       if (!b.blocks) {
         b.reset();
         return E3K_OK;
       }
       b.gb.tile_start[b.gb.n] = b.blocks;
-      int rc;
-      if (!outer) rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<false, 2>, b.gb, b.blocks, st)
-                               : launch_batch(e3k::gemm_wgrad_kernel<false, 1>, b.gb, b.blocks, st);
-      else rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<true, 2>, b.gb, b.blocks, st)
-                        : launch_batch(e3k::gemm_wgrad_kernel<true, 1>, b.gb, b.blocks, st);
+      const int rc = outer ? launch_batch(e3k::gemm_wgrad_kernel<true>, b.gb, b.blocks, st)
+                           : launch_batch(e3k::gemm_wgrad_kernel<false>, b.gb, b.blocks, st);
       b.reset();
       return rc;
     };
     for (int i = 0; i < n_problems; ++i) {
       const e3k_gemm_problem& P = problems[i];
       if ((P.V > 0) != outer) continue;
-      if ((P.N >= 128 ? 2 : 1) != tn) continue;
+      const int tn = P.N >= 128 ? 2 : 1;
       const int64_t M = (int64_t)P.M1 * P.M2;
       if (M == 0) continue;
+      const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       int f = a_vec(P) ? 1 : 0;
       if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C)) f |= 8;
+      if (tn == 2) f |= 16;
       const int wn = 64 * tn;
       const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + wn - 1) / wn);
       int64_t splits = (1024 + tiles - 1) / tiles;
@@ -1161,10 +1169,12 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, int
       if (splits < 1) splits = 1;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
+      gb.reps[gb.n] = rp;
+      gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
       gb.flags[gb.n] = f;
       gb.aux[gb.n] = (int)splits;
       gb.tile_start[gb.n] = b.blocks;
-      b.blocks += tiles * (int)splits * reps;
+      b.blocks += tiles * (int)splits * rp;
       if (++gb.n == e3k::GEMM_MAXP) {
         const int rc = flush();
         if (rc != E3K_OK) return rc;
@@ -1186,71 +1196,92 @@ extern "C" int e3k_debug_stamps(unsigned long long* out, int n) {
 #endif
 
 extern "C" int e3k_gemm_wgrad(const e3k_gemm_problem* problems, int n_problems, void* stream) {
-  return gemm_wgrad_impl(problems, n_problems, 1, 0, stream);
+  return gemm_wgrad_impl(problems, n_problems, nullptr, nullptr, stream);
+}
+
+namespace {
+// resolves one segment's templates into `out` (pointer fields of a template hold byte offsets; A2 / bias offset + 1)
+int resolve_segment(const e3k_gemm_segment& sg, e3k_gemm_problem* out, int* reps, long long* key_stride, int cap) {
+  if (sg.n_templates < 0 || sg.n_templates > cap || (sg.n_templates && !sg.templates)) return -1;
+  if (sg.M1 > 0x7fffffffLL) return -1;
+  const bool keyed = sg.n_keys > 0;
+  if (keyed && (!sg.perm || !sg.groups_dev)) return -1;
+  const auto off = [](const void* q) { return reinterpret_cast<uintptr_t>(q); };
+  for (int i = 0; i < sg.n_templates; ++i) {
+    e3k_gemm_problem p = sg.templates[i];
+    p.A = reinterpret_cast<const float*>(off(sg.a_base) + off(p.A));
+    p.B = reinterpret_cast<const float*>(off(sg.b_base) + off(p.B));
+    p.C = reinterpret_cast<float*>(off(sg.c_base) + off(p.C));
+    if (sg.M1 >= 0) {   // rebased templates (M1 < 0: the templates carry addresses and their own row counts)
+      if (p.A2) {
+        if (!sg.a2_base) return -1;
+        p.A2 = reinterpret_cast<const float*>(off(sg.a2_base) + off(p.A2) - 1);
+      }
+      if (p.bias) {
+        if (!sg.bias_base) return -1;
+        p.bias = reinterpret_cast<const float*>(off(sg.bias_base) + off(p.bias) - 1);
+      }
+      p.M1 = (int32_t)sg.M1;
+    }
+    if (keyed) {
+      p.row_index = sg.perm;
+      p.group_dev = sg.groups_dev;
+    }
+    out[i] = p;
+    reps[i] = keyed ? sg.n_keys : 1;
+    key_stride[i] = keyed ? sg.b_key_stride : 0;
+  }
+  return sg.n_templates;
+}
+}  // namespace
+
+extern "C" int e3k_gemm_multi(const e3k_gemm_segment* segments, int32_t n_segments, int32_t wgrad, void* stream) {
+  if (n_segments < 0 || (n_segments && !segments)) return E3K_ERR_INVALID;
+  e3k_gemm_problem buf[MAX_CALL];
+  int reps[MAX_CALL];
+  long long ks[MAX_CALL];
+  int n = 0;
+  for (int s = 0; s < n_segments; ++s) {
+    const int got = resolve_segment(segments[s], buf + n, reps + n, ks + n, MAX_CALL - n);
+    if (got < 0) return E3K_ERR_INVALID;
+    n += got;
+  }
+  return wgrad ? gemm_wgrad_impl(buf, n, reps, ks, stream) : gemm_fwd_impl(buf, n, reps, ks, stream);
 }
 
 extern "C" int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base,
                                 const void* a2_base, const void* b_base, void* c_base, const void* bias_base,
                                 int64_t M1, int32_t wgrad, void* stream) {
-  if (n_templates < 0 || n_templates > 64 || (n_templates && !templates) || M1 < 0 || M1 > 0x7fffffffLL) return E3K_ERR_INVALID;
-  // the host caches one descriptor array per (layer, pass): pointer fields hold byte offsets, only the bases and the
-  // row count change from call to call
-  e3k_gemm_problem buf[64];
-  for (int i = 0; i < n_templates; ++i) {
-    e3k_gemm_problem p = templates[i];
-    const auto off = [](const void* q) { return reinterpret_cast<uintptr_t>(q); };
-    p.A = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(a_base) + off(p.A));
-    p.B = reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(b_base) + off(p.B));
-    p.C = reinterpret_cast<float*>(reinterpret_cast<uintptr_t>(c_base) + off(p.C));
-    p.A2 = p.A2 ? reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(a2_base) + off(p.A2) - 1) : nullptr;
-    p.bias = p.bias ? reinterpret_cast<const float*>(reinterpret_cast<uintptr_t>(bias_base) + off(p.bias) - 1) : nullptr;
-    if ((p.A2 && !a2_base) || (p.bias && !bias_base)) return E3K_ERR_INVALID;
-    p.M1 = (int32_t)M1;
-    buf[i] = p;
-  }
-  return wgrad ? gemm_wgrad_impl(buf, n_templates, 1, 0, stream) : gemm_fwd_impl(buf, n_templates, 1, 0, stream);
-}
-
-static int gemm_grouped_impl(const e3k_gemm_problem* templates, int n_templates, uintptr_t a_base, uintptr_t b_base,
-                             uintptr_t c_base, int64_t M1, const int32_t* perm, const int32_t* groups_dev, int32_t n_keys,
-                             int64_t b_key_stride, int32_t wgrad, void* stream) {
-  if (n_templates < 0 || n_keys <= 0 || !perm || !groups_dev || (n_templates && !templates)) return E3K_ERR_INVALID;
-  // the keys are not expanded on the host: a template occupies one slot of a launch and the workgroups work out their
-  // key from their position in the template's tile range (fetch_problem) -- launches per call = templates / 8, not
-  // templates * keys / 8
-  e3k_gemm_problem buf[64];
-  int n = 0;
-  for (int i = 0; i < n_templates; ++i) {
-    e3k_gemm_problem& p = buf[n];
-    p = templates[i];
-    p.A = reinterpret_cast<const float*>(a_base + reinterpret_cast<uintptr_t>(p.A));
-    p.B = reinterpret_cast<const float*>(b_base + reinterpret_cast<uintptr_t>(p.B));
-    p.C = reinterpret_cast<float*>(c_base + reinterpret_cast<uintptr_t>(p.C));
-    if (M1 >= 0) p.M1 = (int32_t)M1;
-    p.row_index = perm;
-    p.group_dev = groups_dev;
-    if (++n == 64 || i + 1 == n_templates) {
-      const int rc = wgrad ? gemm_wgrad_impl(buf, n, n_keys, b_key_stride, stream) : gemm_fwd_impl(buf, n, n_keys, b_key_stride, stream);
-      if (rc != E3K_OK) return rc;
-      n = 0;
-    }
-  }
-  return E3K_OK;
+  if (M1 < 0) return E3K_ERR_INVALID;
+  e3k_gemm_segment sg{};
+  sg.templates = templates; sg.n_templates = n_templates;
+  sg.a_base = a_base; sg.a2_base = a2_base; sg.b_base = b_base; sg.c_base = c_base; sg.bias_base = bias_base;
+  sg.M1 = M1;
+  return e3k_gemm_multi(&sg, 1, wgrad, stream);
 }
 
 extern "C" int e3k_gemm_grouped(const e3k_gemm_problem* templates, int n_templates, const int32_t* perm,
                                 const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
                                 void* stream) {
-  return gemm_grouped_impl(templates, n_templates, 0, 0, 0, -1, perm, groups_dev, n_keys, b_key_stride, wgrad, stream);
+  if (n_keys <= 0) return E3K_ERR_INVALID;
+  e3k_gemm_segment sg{};
+  sg.templates = templates; sg.n_templates = n_templates;
+  sg.M1 = -1;
+  sg.perm = perm; sg.groups_dev = groups_dev; sg.n_keys = n_keys; sg.b_key_stride = b_key_stride;
+  return e3k_gemm_multi(&sg, 1, wgrad, stream);
 }
 
 extern "C" int e3k_gemm_grouped_rebased(const e3k_gemm_problem* templates, int n_templates, const void* a_base,
                                         const void* b_base, void* c_base, int64_t M1, const int32_t* perm,
                                         const int32_t* groups_dev, int32_t n_keys, int64_t b_key_stride, int32_t wgrad,
                                         void* stream) {
-  if (M1 < 0 || M1 > 0x7fffffffLL) return E3K_ERR_INVALID;
-  return gemm_grouped_impl(templates, n_templates, reinterpret_cast<uintptr_t>(a_base), reinterpret_cast<uintptr_t>(b_base),
-                           reinterpret_cast<uintptr_t>(c_base), M1, perm, groups_dev, n_keys, b_key_stride, wgrad, stream);
+  if (M1 < 0 || n_keys <= 0) return E3K_ERR_INVALID;
+  e3k_gemm_segment sg{};
+  sg.templates = templates; sg.n_templates = n_templates;
+  sg.a_base = a_base; sg.b_base = b_base; sg.c_base = c_base;
+  sg.M1 = M1;
+  sg.perm = perm; sg.groups_dev = groups_dev; sg.n_keys = n_keys; sg.b_key_stride = b_key_stride;
+  return e3k_gemm_multi(&sg, 1, wgrad, stream);
 }
 
 extern "C" int e3k_colsum(const float* G, int64_t rows, int32_t cols, int64_t ld, float* out, void* stream) {

@@ -27,6 +27,13 @@ from .graph import GraphTopo
 ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
 LOOK_AHEAD = int(os.environ.get("E3K_BLOCK_LOOK_AHEAD", "1"))     # the next layer's radial branch issued one layer early
 AHEAD_STATS = [0]      # look-ahead results consumed (tests)
+# The GEMMs of a layer that share an operand go out in one e3k_gemm_multi call each -- backward: the input gradients of the
+# trailing Linear and of the self-connection (both read the gradient of the convolution output), then linear_1's input
+# gradient accumulated on top, then the weight gradients (forked: trailing Linear + self-connection right behind the gate
+# backward, linear_1's after the tensor product; on one stream: all three together); forward, on one stream: keyed
+# self-connection + linear_1 (both read the node features).  Measured against one call per operator: 256 molecules 5.73
+# vs 5.79 ms, 32 molecules 3.45 vs 3.38 ms (host-bound either way) -- launches per step 263 -> 228.
+MERGE = 1
 BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: beside it on the radial stream (-0.3..0.6 % per step, but the two then stretch each other: their event-timed durations double)
 
 
@@ -127,17 +134,26 @@ class ConvBlockFn(torch.autograd.Function):
         # --- node side
         x_cf = x if in_cf else ops._relayout_raw(x, plan.in_blocks, True)
         a_rep = m = None
-        if has_sc:
-            node_attrs = L.f32c(node_attrs)
-            _wait(side2, main)
-            with _on(side2, main):
-                a_rep = node_attrs.index_select(0, groups.reps)
-                m = ops._kw_fwd_raw(a_rep, w_sc, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m)
-                conv = ops._grp_fwd_raw(x_cf, m, groups, plan.sc_spec, plan.sc_m_off)       # [N, conv_out] cf
-            _rec(x_cf, side2, main)
-            _rec(node_attrs, side2, main)
         x1 = torch.empty(n, plan.lin1_spec.d_out, device=dev, dtype=torch.float32)
-        ops._lin_fwd_raw(x_cf, w_lin1, None, x1, plan.lin1_spec, 1.0, False)
+        if has_sc and MERGE and not fork:      # one stream anyway: the self-connection and linear_1 in one launch
+            node_attrs = L.f32c(node_attrs)
+            a_rep = node_attrs.index_select(0, groups.reps)
+            m = ops._kw_fwd_raw(a_rep, w_sc, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m)
+            conv = (torch.empty if plan.sc_spec.out_covered else torch.zeros)(n, plan.sc_spec.d_out, device=dev, dtype=torch.float32)
+            ops._run_segments([ops._grp_segs("fwd", x_cf, m, conv, groups, plan.sc_spec, plan.sc_m_off),
+                               ops._lin_fwd_segs(x_cf, w_lin1, x1, plan.lin1_spec, 1.0, False)])
+            side2 = main                                 # (the self-connection is already on this stream)
+        else:
+            if has_sc:
+                node_attrs = L.f32c(node_attrs)
+                _wait(side2, main)
+                with _on(side2, main):
+                    a_rep = node_attrs.index_select(0, groups.reps)
+                    m = ops._kw_fwd_raw(a_rep, w_sc, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m)
+                    conv = ops._grp_fwd_raw(x_cf, m, groups, plan.sc_spec, plan.sc_m_off)       # [N, conv_out] cf
+                _rec(x_cf, side2, main)
+                _rec(node_attrs, side2, main)
+            ops._lin_fwd_raw(x_cf, w_lin1, None, x1, plan.lin1_spec, 1.0, False)
         _wait(main, side)
         _rec(w, main, side)
         mid = ops._tp_fwd_raw(x1, sh, w, topo, plan.tp_plan)
@@ -188,69 +204,98 @@ class ConvBlockFn(torch.autograd.Function):
         side3 = ops.side_stream(dev, 2) if (fork and ops.WGRAD_SIDE) else main
         gy = L.f32c(gy)
 
-        # gate -> gradient of the convolution output (cf); the self-connection and the trailing Linear both see it
+        return ConvBlockFn._backward_grouped(ctx, gy, main, side, side2, side3, fork)
+
+    @staticmethod
+    def _backward_grouped(ctx, gy, main, side, side2, side3, fork):
+        """The backward, its GEMMs grouped by shared operand: four or five e3k_gemm_multi calls (round 2: nine calls,
+        fifteen launches)."""
+        plan, topo, groups, in_cf, out_cf, _, n_hidden, table = ctx.cfg
+        saved = ctx.saved_tensors
+        x_cf, edge_radial, sh, h, w, x1, mid, conv, a_rep, m, w_lin1, w_post, w_sc, w_last = saved[:14]
+        w_hidden, zs = saved[14:14 + n_hidden], saved[14 + n_hidden:]
+        need = ctx.needs_input_grad
+        need_x, need_attrs, need_radial = need[0], need[1], need[2]
+        p0 = 12
+        need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
+        need_hidden = need[p0 + 4:]
+        has_sc = plan.sc_spec is not None
+        dev = gy.device
+        n = x_cf.shape[0]
+        need_radial_side = need_last or need_radial or any(need_hidden)
+        need_x1 = need_x or need_lin1
+
         g_conv = ops._gate_bwd_raw(conv, gy, plan.gate_spec, out_cf)
-        ev_conv = None
-        if fork:
-            ev_conv = torch.cuda.Event()
-            ev_conv.record(main)
-        g_mid = ops._lin_dgrad_raw(g_conv, w_post, plan.post_spec, plan.scale)
-        ev_mid = None
-        if fork:
-            ev_mid = torch.cuda.Event()
-            ev_mid.record(main)
-        # weight gradient of the trailing Linear: off the critical path
-        ret_post = None
-        if need_post:
-            if side3 is not main:
-                side3.wait_event(ev_conv)
-            with _on(side3, main):           # (a fresh buffer is zero-filled on the stream that accumulates into it)
+        # (A) both readers of g_conv: the trailing Linear's input gradient and the self-connection's
+        g_mid = (torch.empty if plan.post_spec.in_covered else torch.zeros)(n, plan.post_spec.d_in, device=dev, dtype=torch.float32)
+        segs = [ops._lin_dgrad_segs(g_conv, w_post, g_mid, plan.post_spec, plan.scale, False)]
+        g_xcf = None
+        if need_x:
+            if has_sc:
+                g_xcf = (torch.empty if plan.sc_spec.in_covered else torch.zeros)(n, plan.sc_spec.d_in, device=dev, dtype=torch.float32)
+                segs.append(ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off))
+            else:
+                g_xcf = (torch.empty if plan.lin1_spec.in_covered else torch.zeros)(n, plan.lin1_spec.d_in, device=dev, dtype=torch.float32)
+        ops._run_segments(segs)
+        ret_post = ret_lin1 = ret_sc = g_attrs = None
+        want_sc = has_sc and (need_sc or need_attrs)
+        gm = None
+
+        def weight_grads(with_g_conv: bool, with_lin1: bool):
+            """(C) weight gradients off the critical path, one call: trailing Linear + self-connection (per key) need
+            g_conv, linear_1 needs g_x1.  Forked, the first two start right behind the gate backward and linear_1's
+            follows the tensor product; on one stream all three go out together."""
+            nonlocal ret_post, ret_lin1, gm
+            segs = []
+            if with_g_conv and need_post:
                 gb_post, ret_post = _grad_buffer(w_post, True)
-                ops._lin_wgrad_raw(mid, g_conv, gb_post, plan.post_spec, plan.scale)
-            _rec(g_conv, side3, main)
-            _rec(mid, side3, main)
-        # self-connection branch: per-key weight gradients and the attribute gradient
-        g_attrs = ret_sc = None
-        if has_sc and (need_sc or need_attrs):
-            if side2 is not main:
-                side2.wait_event(ev_conv)
+                segs.append(ops._lin_wgrad_segs(mid, g_conv, gb_post, plan.post_spec, plan.scale))
+            if with_g_conv and want_sc:
+                gm = torch.zeros(tuple(m.shape), device=dev, dtype=torch.float32)
+                segs.append(ops._grp_segs("wgrad", x_cf, gm, g_conv, groups, plan.sc_spec, plan.sc_m_off))
+            if with_lin1 and need_lin1:
+                gb_lin1, ret_lin1 = _grad_buffer(w_lin1, True)
+                segs.append(ops._lin_wgrad_segs(x_cf, g_x1, gb_lin1, plan.lin1_spec, 1.0))
+            if segs:
+                ops._run_segments(segs, wgrad=True)
+
+        def keyed_weight_grads():
+            nonlocal ret_sc, g_attrs
+            # per-key weight gradients -> the flat weight's and the attributes': on the self-connection stream, where
+            # the consumer of g_attrs (the stream alias of node_attrs) lives
+            _wait(side2, side3)
             with _on(side2, main):
-                gm = ops._grp_wgrad_raw(x_cf, g_conv, tuple(m.shape), groups, plan.sc_spec, plan.sc_m_off)
                 gb_sc, ret_sc = _grad_buffer(w_sc, need_sc)
-                acc = 1 if (gb_sc is not None and ret_sc is None) else 0      # a sink accumulates, a fresh buffer is written
+                acc = 1 if (gb_sc is not None and ret_sc is None) else 0
                 ga = ops._kw_bwd_raw(a_rep, w_sc, gm, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m, bool(need_attrs), gb_sc, acc)
                 if need_attrs:
                     g_attrs = torch.zeros(ctx.attrs_shape, device=dev, dtype=torch.float32)
                     g_attrs.index_add_(0, groups.reps, ga)
-            _rec(g_conv, side2, main)
-            _rec(x_cf, side2, main)
-        # tensor product: features on this stream, per-edge weights on the radial stream
-        g_x1 = ops._tp_bwd_x_raw(sh, w, g_mid, topo, plan.tp_plan) if need_x else None
+            _rec(gm, side2, side3)
+            _rec(a_rep, side2, main)
+
+        if fork and (need_post or want_sc):
+            _wait(side3, main)
+            with _on(side3, main):
+                weight_grads(True, False)
+            for t in (g_conv, mid, x_cf):
+                _rec(t, side3, main)
+            if want_sc:
+                keyed_weight_grads()
+        # tensor product: features on this stream, per-edge weights handed to the radial stream
+        g_x1 = ops._tp_bwd_x_raw(sh, w, g_mid, topo, plan.tp_plan) if need_x1 else None
         g_radial = ret_last = None
         ret_hidden: List[Optional[torch.Tensor]] = [None] * n_hidden
-        if need_last or need_radial or any(need_hidden):
-            if BWD_W_ON_MAIN:
-                g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
-                _wait(side, main)
-                _rec(g_w, side, main)
-            else:
-                if side is not main:
-                    side.wait_event(ev_mid)
-                with _on(side, main):
-                    g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
-            if table is not None:      # transpose of the interpolation: the gradient of the MLP's output on the knots
-                with _on(side, main):
+        if need_radial_side:
+            g_w, _ = ops._tp_bwd_w_raw(x1, sh, w, g_mid, topo, plan.tp_plan, False, True)
+            _wait(side, main)
+            _rec(g_w, side, main)
+            with _on(side, main):
+                if table is not None:      # transpose of the interpolation: the gradient of the MLP's output on the knots
                     g_w = radial_table.interp_bwd_raw(g_w, table)
-            if need_last:      # the [64, W] weight gradient (K = E: the longest reduction of the layer) joins the other
-                if side3 is not side:          # weight gradients on their stream; the radial chain continues beside it
-                    side3.wait_stream(side)
-                with _on(side3, main):
+                if need_last:
                     gb_last, ret_last = _grad_buffer(w_last, True)
                     ops._lin_wgrad_raw(h, g_w, gb_last, plan.last_spec, 1.0)
-                if side3 is not side:
-                    g_w.record_stream(side3)
-                    h.record_stream(side3)
-            with _on(side, main):
                 if need_radial or any(need_hidden):
                     g_h = ops._lin_dgrad_raw(g_w, w_last, plan.last_spec, 1.0)
                     gws = []
@@ -260,34 +305,31 @@ class ConvBlockFn(torch.autograd.Function):
                         ret_hidden[i] = ret
                     g_radial = torch.empty_like(edge_radial) if need_radial else None
                     ops._mlp_bwd_raw(edge_radial, w_hidden, zs, plan.mlp_alphas, plan.mlp_act, plan.mlp_cst, g_h, gws, g_radial)
-            for t in (g_mid, x1, sh, edge_radial):      # allocated elsewhere, read on the radial stream until it gets there
+            for t in (g_mid, x1, sh, edge_radial):
                 _rec(t, side, main)
-        # node features: linear_1, then the self-connection's contribution accumulated in place (no separate add)
+        # (B) linear_1's input gradient on top of the self-connection's
         g_x = None
         if need_x:
-            g_xcf = ops._lin_dgrad_raw(g_x1, w_lin1, plan.lin1_spec, 1.0)
-            if has_sc:
-                ops._grp_dgrad_raw(g_conv, m, groups, plan.sc_spec, plan.sc_m_off, out=g_xcf)
-                _rec(m, main, side2)
+            ops._run_segments([ops._lin_dgrad_segs(g_x1, w_lin1, g_xcf, plan.lin1_spec, 1.0, has_sc)])
             g_x = g_xcf if in_cf else ops._relayout_raw(g_xcf, plan.in_blocks, False)
-        ret_lin1 = None
-        if need_lin1:
-            if g_x1 is None:
-                g_x1 = ops._tp_bwd_x_raw(sh, w, g_mid, topo, plan.tp_plan)
-            if side3 is not main:
-                side3.wait_stream(main)
-            with _on(side3, main):
-                gb_lin1, ret_lin1 = _grad_buffer(w_lin1, True)
-                ops._lin_wgrad_raw(x_cf, g_x1, gb_lin1, plan.lin1_spec, 1.0)
-            _rec(g_x1, side3, main)
-            _rec(x_cf, side3, main)
+        if fork:
+            if need_lin1:
+                _wait(side3, main)
+                with _on(side3, main):
+                    weight_grads(False, True)
+                _rec(g_x1, side3, main)
+                _rec(x_cf, side3, main)
+        elif need_post or need_lin1 or want_sc:
+            weight_grads(True, True)
+            if want_sc:
+                keyed_weight_grads()
         # parameter gradients handed back to autograd (no gradient sink) are consumed on THIS stream
-        if ret_post is not None or ret_lin1 is not None or ret_last is not None:
+        if ret_post is not None or ret_lin1 is not None:
             _wait(main, side3)
         if ret_sc is not None:
             _wait(main, side2)
-        if any(r is not None for r in ret_hidden):
-            _wait(main, side)
+        if ret_last is not None or any(r is not None for r in ret_hidden):
+            _wait(main, side)      # (g_radial is consumed by the radial stream's alias of the edge embedding: no wait)
         if ops.GRAD_READY is not None:
             rets = (ret_lin1, ret_post, ret_sc if has_sc else None, ret_last, *ret_hidden)
             needs = (need_lin1, need_post, need_sc or not has_sc, need_last, *need_hidden)

@@ -34,6 +34,15 @@ class GemmProblem(C.Structure):
     ]
 
 
+class GemmSegment(C.Structure):
+    _fields_ = [
+        ("templates", C.POINTER(GemmProblem)), ("n_templates", C.c_int32), ("n_keys", C.c_int32),
+        ("a_base", C.c_void_p), ("a2_base", C.c_void_p), ("b_base", C.c_void_p), ("c_base", C.c_void_p),
+        ("bias_base", C.c_void_p), ("M1", C.c_int64), ("perm", C.c_void_p), ("groups_dev", C.c_void_p),
+        ("b_key_stride", C.c_int64),
+    ]
+
+
 class TpGroup(C.Structure):
     _fields_ = [
         ("l1", C.c_int32), ("x_off", C.c_int32), ("mul", C.c_int32), ("mask", C.c_uint32),
@@ -69,6 +78,7 @@ SIGNATURES = {
     "e3k_gemm_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _P, _P, _I64, _I32, _P]),
     "e3k_gemm_grouped_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _I64, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_gemm_grouped": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _I32, _I64, _I32, _P]),
+    "e3k_gemm_multi": (C.c_int, [C.POINTER(GemmSegment), _I32, _I32, _P]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),

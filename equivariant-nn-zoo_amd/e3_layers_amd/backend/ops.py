@@ -1079,6 +1079,59 @@ def _run_grouped(rounds, a, b, c, rows: int, groups: RowGroups, ld_m: int, wgrad
                                              groups.n_keys, ld_m, int(wgrad), st), "e3k_gemm_grouped_rebased")
 
 
+# ---- several descriptor arrays in one call (e3k_gemm_multi): what a convolution layer issues together -------------------
+def _seg(rounds, a, b, c, rows: int, groups: Optional["RowGroups"] = None, ld_m: int = 0, bias=None):
+    """One segment per round of a cached template set (``_GemmTemplates.rounds`` / ``_grouped_templates``): a list, the
+    rounds of one set write the same blocks and must run in order -- callers merge only single-round sets."""
+    out = []
+    for arr, n in rounds:
+        sg = L.GemmSegment()
+        sg.templates, sg.n_templates = arr, n
+        sg.a_base, sg.a2_base, sg.b_base, sg.c_base = a.data_ptr(), None, b.data_ptr(), c.data_ptr()
+        sg.bias_base = bias.data_ptr() if bias is not None else None
+        sg.M1 = rows
+        if groups is not None:
+            sg.n_keys, sg.perm, sg.groups_dev, sg.b_key_stride = groups.n_keys, groups.perm.data_ptr(), groups.bounds.data_ptr(), ld_m
+        out.append(sg)
+    return out
+
+
+def _run_segments(segment_lists, wgrad: bool = False) -> None:
+    """``segment_lists``: one list per template set (see ``_seg``).  Sets that have a single round go out in ONE call (the
+    library packs up to 16 problems per launch); a multi-round set runs its rounds in order, alone."""
+    lib, st = L.load(), L.stream_ptr()
+    merged = [sl[0] for sl in segment_lists if len(sl) == 1]
+    if merged:
+        arr = (L.GemmSegment * len(merged))(*merged)
+        L.check(lib.e3k_gemm_multi(arr, len(merged), int(wgrad), st), "e3k_gemm_multi")
+    for sl in segment_lists:
+        if len(sl) > 1:
+            for sg in sl:
+                arr = (L.GemmSegment * 1)(sg)
+                L.check(lib.e3k_gemm_multi(arr, 1, int(wgrad), st), "e3k_gemm_multi")
+
+
+def _lin_fwd_segs(x, weight, y, spec: "LinearSpec", scale: float, accumulate: bool):
+    t = _templates(spec, ("fwd", scale, bool(accumulate), 0, 1.0, False),
+                   lambda: _lin_fwd_templates(spec, scale, bool(accumulate), 0, 1.0, False))
+    return _seg(t.rounds, x, weight, y, x.shape[0])
+
+
+def _lin_dgrad_segs(gy, weight, gx, spec: "LinearSpec", scale: float, accumulate: bool):
+    t = _templates(spec, ("dgrad", scale, bool(accumulate)), lambda: _lin_dgrad_templates(spec, scale, bool(accumulate)))
+    return _seg(t.rounds, gy, weight, gx, gy.shape[0])
+
+
+def _lin_wgrad_segs(x, gy, gw, spec: "LinearSpec", scale: float):
+    t = _templates(spec, ("wgrad", scale), lambda: _lin_wgrad_templates(spec, scale))
+    return _seg(t.rounds, x, gw, gy, x.shape[0])
+
+
+def _grp_segs(mode: str, a, m, c, groups, spec, m_off):
+    """mode 'fwd': c = a . M[key];  'dgrad' / 'dgrad_acc': c (+)= a . M[key]^T;  'wgrad': m += a^T . c (c = gradient rows)."""
+    return _seg(_grouped_templates(spec, m_off, mode), a, m, c, a.shape[0], groups, m.shape[1])
+
+
 def _grp_fwd_raw(x, m, groups, spec, m_off):
     rows, ld_m = x.shape[0], m.shape[1]
     # rows of absent keys do not exist, every node belongs to exactly one key: full coverage

@@ -89,6 +89,30 @@ int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const v
                      const void* b_base, void* c_base, const void* bias_base, int64_t M1, int32_t wgrad,
                      void* stream);
 
+/* Several descriptor arrays in ONE call (as few launches as the kernel kinds allow; up to 16 problems per launch, keyed
+ * and plain problems mixed): what a convolution layer issues together -- linear_1 with the keyed self-connection
+ * (e3_layers/nn/message_passing.py:100,102: both read the node features), the input gradients of the trailing Linear
+ * and of the self-connection (both read the gradient of the convolution output), the three weight gradients.
+ * A segment is a template array as for e3k_gemm_rebased (byte offsets in the pointer fields, M1 >= 0 overwrites the
+ * templates' row count; M1 < 0: the templates carry addresses and row counts) and, with n_keys > 0, the key expansion
+ * of e3k_gemm_grouped (row_index = perm, group_dev = groups_dev + 2 t, B += t * b_key_stride for key t).
+ * At most 64 problems per call. */
+typedef struct {
+  const e3k_gemm_problem* templates;
+  int32_t n_templates;
+  int32_t n_keys;            /* 0: plain problems */
+  const void* a_base;
+  const void* a2_base;
+  const void* b_base;
+  void* c_base;
+  const void* bias_base;
+  int64_t M1;
+  const int32_t* perm;
+  const int32_t* groups_dev;
+  int64_t b_key_stride;
+} e3k_gemm_segment;
+int e3k_gemm_multi(const e3k_gemm_segment* segments, int32_t n_segments, int32_t wgrad, void* stream);
+
 /* Grouped launch over key groups: every template problem is expanded into n_keys problems, one per
  * key t, with  B += t * b_key_stride,  row_index = perm,  group_dev = groups_dev + 2*t  and M1 kept as the
  * (host-known) upper bound of the group size.  wgrad != 0 runs e3k_gemm_wgrad semantics (B accumulated).

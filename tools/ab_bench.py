@@ -6,7 +6,8 @@ Each variant runs bench.py --no-cpu-baseline in a child process `rounds` times, 
 minimum ms/step per variant."""
 import json, os, statistics, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-args = [a for a in sys.argv[1:] if not a.startswith("--")]
+argv = sys.argv[1:sys.argv.index("--")] if "--" in sys.argv else sys.argv[1:]
+args = [a for i, a in enumerate(argv) if not a.startswith("--") and (i == 0 or argv[i - 1] not in ("--rounds", "--steps"))]
 rounds = int(sys.argv[sys.argv.index("--rounds") + 1]) if "--rounds" in sys.argv else 4
 steps = int(sys.argv[sys.argv.index("--steps") + 1]) if "--steps" in sys.argv else 30
 extra = sys.argv[sys.argv.index("--") + 1:] if "--" in sys.argv else []
