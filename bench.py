@@ -51,8 +51,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=256, help="molecules per GPU")
+    ap.add_argument("--config", default="energy", choices=["energy", "energy_force", "diffusion", "diffusion_CA"],
+                    help="BASELINE.json configuration: energy = configs[1] (the metric's workload, default); energy_force = "
+                         "configs[2] (64 molecules, energy + force loss: double backward); diffusion = configs[3] (128 fully "
+                         "connected molecules, VP-SDE loss); diffusion_CA = configs[4] (4 x 384 residues)")
+    ap.add_argument("--batch", type=int, default=None, help="graphs per GPU (default: 256 / 64 / 128 / 4 by --config)")
     ap.add_argument("--lmax", type=int, default=2)
+    ap.add_argument("--loader", action="store_true",
+                    help="feed the step from the prefetching loader (data/loader.py: collate of fresh samples on a worker thread, "
+                         "pinned buffers, async H2D) instead of HBM-resident batches; reported beside the resident figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) on ONE resident batch in a HIP graph and "
@@ -89,7 +96,7 @@ def _cpu_model_times(tree, batch, target, reps_fwd, reps_bwd, budget_s):
         return statistics.median(f), None, (len(f), 0)
     warm = fwd_bwd()                                         # warm-up
     left = budget_s - (time.perf_counter() - t_start)
-    n = max(1, min(reps_bwd, int(left / max(warm, 1e-3))))   # bounded: the default run must finish within minutes
+    n = max(3, min(reps_bwd, int(left / max(warm, 1e-3))))   # bounded (the default run must finish within minutes), median of >= 3
     b = [fwd_bwd() for _ in range(n)]
     return statistics.median(f), statistics.median(b), (len(f), len(b))
 
@@ -101,16 +108,17 @@ def cpu_baseline(budget_s):
     from e3_layers_amd.configs import config_energy
     from e3_layers_amd.data.synthetic import synth_qm9
 
-    cores = min(os.cpu_count() or 1, 32)  # more threads than this only adds fork/join overhead on these op sizes
+    host_cores = os.cpu_count() or 1
+    cores = min(host_cores, 32)  # more threads than this only adds fork/join overhead on these op sizes
     torch.set_num_threads(cores)
     n_mol = 32
     batch = synth_qm9(0, n_mol, config_energy.QM9_SHIFTS)
     target = batch["total_energy"]
-    f3, b3, (nf3, nb3) = _cpu_model_times(config_energy.get_config(l_max=3).model_config, batch, target, 5, 10, 0.75 * budget_s)
+    f3, b3, (nf3, nb3) = _cpu_model_times(config_energy.get_config(l_max=3).model_config, batch, target, 3, 10, 0.75 * budget_s)
     f2, _, (nf2, _) = _cpu_model_times(config_energy.get_config(l_max=2).model_config, batch, target, 3, 0, 0.25 * budget_s)
     return {
-        "value": round(n_mol / b3, 4), "unit": "molecules/s", "cores": cores, "kind": "port",
-        "sample": (f"oracle/e3ref.py fp32 on {cores} threads, BASELINE configs[0]: config_energy l_max 3, synth_qm9(seed 0, "
+        "value": round(n_mol / b3, 4), "unit": "molecules/s", "cores": cores, "host_cpu_count": host_cores, "kind": "port",
+        "sample": (f"oracle/e3ref.py fp32 on {cores} threads (os.cpu_count() = {host_cores}), BASELINE configs[0]: config_energy l_max 3, synth_qm9(seed 0, "
                    f"{n_mol} molecules): fwd+bwd 1 warm-up + median of {nb3} ({b3:.2f} s/step), forward 1 warm-up + median of "
                    f"{nf3} ({f3:.2f} s); second field: forward of the l_max 2 model on the same molecules, median of {nf2}"),
         "forward_only_value": round(n_mol / f3, 4),
@@ -149,57 +157,106 @@ def main():
 
     from e3_layers_amd.backend import ops
     from e3_layers_amd.backend.graph import build_topology
-    from e3_layers_amd.configs import config_energy
-    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.configs import config_diffusion, config_diffusion_CA, config_energy, config_energy_force
+    from e3_layers_amd.data.synthetic import synth_protein, synth_qm9, synth_qm9_diffusion
     from e3_layers_amd.run.optim import FusedAdamEMA
-    from e3_layers_amd.run.parallel import broadcast_parameters
+    from e3_layers_amd.run.parallel import backward_parameters, broadcast_parameters
+    from e3_layers_amd.run.sde_utils import VPSDE, sde_loss
     from e3_layers_amd.utils import build, countParameters
 
-    cfg = config_energy.get_config(l_max=args.lmax)
+    # ---- the workload: BASELINE.json configs[1] by default; configs[2..4] by --config (tools/config_bench.py folded in) ----
+    cfg_kind = args.config
+    if args.batch is None:
+        args.batch = {"energy": 256, "energy_force": 64, "diffusion": 128, "diffusion_CA": 4}[cfg_kind]
+    n_res = 4
+    unit = "proteins" if cfg_kind == "diffusion_CA" else "molecules"
+    if cfg_kind == "energy":
+        cfg = config_energy.get_config(l_max=args.lmax)
+        make = lambda k: synth_qm9(1000 + 17 * k + rank, args.batch, config_energy.QM9_SHIFTS)
+        opt_kw = dict(ema_decay=cfg.ema_decay if cfg.use_ema else None, ema_use_num_updates=cfg.ema_use_num_updates)
+    elif cfg_kind == "energy_force":
+        cfg = config_energy_force.get_config()
+        make = lambda k: synth_qm9(2000 + 17 * k + rank, args.batch, r_max=5.0)
+        opt_kw = {}
+    elif cfg_kind == "diffusion":
+        cfg = config_diffusion.get_config()
+        make = lambda k: synth_qm9_diffusion(1 + 17 * k + rank, args.batch)
+        opt_kw = dict(max_grad_norm=1.0)
+    else:
+        cfg = config_diffusion_CA.get_config()
+        make = lambda k: synth_protein(1 + 17 * k + rank, args.batch, n_res=384)
+        opt_kw = dict(max_grad_norm=1.0)
     tree = cfg.model_config
     torch.manual_seed(0)
     model = build(tree).to(dev)
     broadcast_parameters(model)
     # parameters, gradients, Adam moments and the EMA shadow as flat vectors: one all-reduce, one fused optimizer launch
-    opt = FusedAdamEMA(model.parameters(), lr=cfg.learning_rate,
-                       ema_decay=cfg.ema_decay if cfg.use_ema else None, ema_use_num_updates=cfg.ema_use_num_updates)
+    opt = FusedAdamEMA(model.parameters(), lr=cfg.learning_rate, **opt_kw)
     flat = opt.grads
     flat.enable_direct_accumulation()
     if world > 1 and os.environ.get("E3K_OVERLAP_ALLREDUCE", "1") != "0":
-        flat.enable_overlapped_all_reduce()     # a layer's gradient slice is all-reduced while the backward goes on
+        flat.enable_overlapped_all_reduce(model)     # a layer's gradient slice is all-reduced while the backward goes on
 
-    # every rank owns its own molecules (weak scaling): four distinct seeded batches per rank, resident in HBM
-    n_res = 4
-    resident = [synth_qm9(1000 + 17 * k + rank, args.batch, config_energy.QM9_SHIFTS).to(dev) for k in range(n_res)]
-    n_nodes = [b["pos"].shape[0] for b in resident]
-    n_edges = [b["edge_index"].shape[1] for b in resident]
+    # every rank owns its own graphs (weak scaling): four distinct seeded batches per rank, resident in HBM
+    host_batches = [make(k) for k in range(n_res)]
+    resident = [b.to(dev) for b in host_batches]
+    n_nodes = [b["pos"].shape[0] if "pos" in b else b["_n_nodes"].sum().item() for b in resident]
+    n_edges = [b["edge_index"].shape[1] if "edge_index" in b else 0 for b in resident]
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    if cfg_kind == "energy_force":
+        for b in resident:      # synthetic force targets (the generator has none): one fixed draw per resident batch
+            b["forces_target"] = torch.randn(b["pos"].shape, device=dev, generator=gen)
+            b.attrs["forces_target"] = ("node", "1x1o")
+    sde = VPSDE({"pos": 3}) if cfg_kind == "diffusion" else (VPSDE({"CA": 3}) if cfg_kind == "diffusion_CA" else None)
+
+    def loss_of(batch):
+        if cfg_kind == "energy":
+            target = batch["total_energy"]          # the model writes its prediction under the same key of the same Batch
+            return 1e3 * torch.nn.functional.mse_loss(model(batch)["total_energy"], target)
+        if cfg_kind == "energy_force":                  # config_energy_force.py:18 loss_coeffs
+            e_t, f_t = batch["total_energy"], batch["forces_target"]
+            out = model(batch)
+            return 1e3 * ((out["total_energy"] - e_t) ** 2).mean() + 3e4 * ((out["forces"] - f_t) ** 2).mean()
+        return sde_loss(sde, model, batch, generator=gen)[0]
 
     # setup, not a step of the workload: libe3k.so is loaded, the TP plans are created and the code objects of every
-    # kernel on the path are paged in by one forward/backward over EIGHT molecules (no optimizer step, gradients zeroed
+    # kernel on the path are paged in by one forward/backward over a SMALL batch (no optimizer step, gradients zeroed
     # after) -- otherwise the first timed-or-warm-up step carries 0.2 s of lazy initialisation
-    tiny = synth_qm9(7, 8, config_energy.QM9_SHIFTS).to(dev)
-    (1e3 * torch.nn.functional.mse_loss(model(tiny)["total_energy"], tiny["total_energy"])).backward()
-    ops.join_side_streams()
-    flat.zero()
-    torch.cuda.synchronize()
-    del tiny
+    if cfg_kind == "energy":
+        tiny = synth_qm9(7, 8, config_energy.QM9_SHIFTS).to(dev)
+        loss_of(tiny).backward()
+        ops.join_side_streams()
+        flat.zero()
+        torch.cuda.synchronize()
+        del tiny
 
     counter = [0]
+    loader = None
+    if args.loader:
+        from e3_layers_amd.data.loader import PrefetchLoader, samples_of
+
+        pool = [s for b in host_batches for s in samples_of(b)]
+        loader = iter(PrefetchLoader(pool, batch_size=args.batch, device=dev, shuffle=True, seed=rank, epochs=None))
 
     def next_batch():
         """A batch the framework has never seen: fresh device copies of the next resident batch's tensors (what a
-        collated batch arriving from the loader is), so no per-batch memo (topology, key groups) can hit."""
+        collated batch arriving from the loader is), so no per-batch memo (topology, key groups) can hit; with
+        --loader: the next batch collated by the loader's worker from individual samples."""
+        if loader is not None:
+            return next(loader)
         b = resident[counter[0] % n_res].clone()
         counter[0] += 1
         return b
 
     def step(batch=None):
         batch = next_batch() if batch is None else batch
-        target = batch["total_energy"]          # the model writes its prediction under the same key of the same Batch
-        out = model(batch)
-        loss = 1e3 * torch.nn.functional.mse_loss(out["total_energy"], target)
+        loss = loss_of(batch)
         flat.zero()
-        loss.backward()
+        if cfg_kind == "energy":
+            loss.backward()
+        else:
+            backward_parameters(loss, opt.params)
         flat.all_reduce_mean()
         opt.step()
         return loss
@@ -212,6 +269,8 @@ def main():
     run = step
     graph = None
     if args.graph:
+        if cfg_kind != "energy" or args.loader:
+            raise SystemExit("--graph replays the config_energy step on one resident batch")
         from e3_layers_amd.run.graph_step import CapturedStep
 
         fixed = resident[0]
@@ -275,15 +334,16 @@ def main():
         with torch.no_grad():
             model(next_batch())
 
-    forward_only()
-    fwd_ms = event_ms(forward_only, 10)
-
     def prep_only():
         b = next_batch()
         build_topology(b["edge_index"], b["pos"].shape[0])
 
-    prep_only()
-    prep_ms = event_ms(prep_only, 10)
+    fwd_ms = prep_ms = None
+    if cfg_kind == "energy":      # (the other configurations' forward needs the loss wrapper's inputs: t, noise)
+        forward_only()
+        fwd_ms = event_ms(forward_only, 10)
+        prep_only()
+        prep_ms = event_ms(prep_only, 10)
 
     # ---- roofline blocks (rank 0's launches in the timed region) ---------------------------------------------------
     def tp_bytes(kind, n, e, plan):
@@ -308,7 +368,7 @@ def main():
 
     traffic = {}
     tfile = os.path.join(ROOT, TRAFFIC_FILE)
-    if os.path.exists(tfile) and args.batch == 256 and args.lmax == 2:
+    if os.path.exists(tfile) and cfg_kind == "energy" and args.batch == 256 and args.lmax == 2:
         try:
             traffic = json.load(open(tfile))
         except Exception:
@@ -355,30 +415,41 @@ def main():
     roofline["kernels"] = kernels
 
     if rank == 0:
+        workloads = {
+            "energy": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU",
+            "energy_force": f"config_energy_force (BASELINE configs[2]): n_dim 64, l_max 2, r_max 5, {args.batch} molecules per GPU, "
+                            "loss on energies and forces (double backward through every kernel)",
+            "diffusion": f"config_diffusion (BASELINE configs[3]): VP-SDE score net, n_dim 32, 4 layers, {args.batch} fully "
+                         "connected molecules per GPU",
+            "diffusion_CA": f"config_diffusion_CA (BASELINE configs[4]): residue-level score net, n_dim 64, 8 layers, {args.batch} x 384 "
+                            "residues per GPU",
+        }
         result = {
-            "metric": "molecules/s forward+backward, QM9 config_energy batch",
+            "metric": ("molecules/s forward+backward, QM9 config_energy batch" if cfg_kind == "energy"
+                       else f"{unit}/s forward+backward, {cfg_kind} batch (not the BASELINE metric's workload)"),
             "value": round(world * args.batch * args.steps / elapsed, 2),
-            "unit": "molecules/s",
+            "unit": f"{unit}/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {
-                "workload": f"config_energy QM9-like, l_max={args.lmax}, n_dim 64, 5 layers, {args.batch} molecules per GPU "
-                            f"(rank 0: {n_res} resident batches, a fresh copy per step, N={min(n_nodes)}-{max(n_nodes)} nodes, "
-                            f"E={min(n_edges)}-{max(n_edges)} edges), fwd + 1e3*MSE + bwd + Adam + EMA",
+                "workload": workloads[cfg_kind] + (f" (rank 0: {n_res} resident batches, a fresh copy per step, N={min(n_nodes)}-{max(n_nodes)} "
+                                               f"nodes, E={min(n_edges)}-{max(n_edges)} edges), fwd + loss + bwd + Adam"
+                                               + (" + EMA" if cfg_kind == "energy" else "")),
+                "input": "prefetching loader (collate of fresh samples + pinned H2D inside the loop)" if args.loader else "HBM-resident batches",
                 "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
                 "ranks": dist.get_world_size() if world > 1 else 1,
                 "launch": "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager",
                 "parameters": countParameters(model), "final_loss": round(float(loss.detach()), 4),
                 "retimed_after_stall": retimed,
             },
-            "per_batch_prep_ms": round(prep_ms, 3),
-            "gpu_forward_only_ms": round(fwd_ms, 3),
-            "gpu_forward_only_molecules_per_s": round(args.batch / (fwd_ms * 1e-3), 1),
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if fwd_ms is not None:
+            result.update({"per_batch_prep_ms": round(prep_ms, 3), "gpu_forward_only_ms": round(fwd_ms, 3),
+                           "gpu_forward_only_molecules_per_s": round(args.batch / (fwd_ms * 1e-3), 1)})
+        if world == 1 and not args.no_cpu_baseline and cfg_kind == "energy":
             cb = cpu_baseline(args.cpu_budget)
             result["cpu_baseline"] = cb
             result["gpu_vs_cpu_forward"] = round(result["gpu_forward_only_molecules_per_s"] / cb["lmax2_forward_only_value"], 1)

@@ -115,61 +115,129 @@ class FlatGradients:
         self.buffer.zero_()
 
     # ------------------------------------------------------------------ all-reduce, overlapped with the backward
-    _pending = ()          # [(lo, hi, work)] slices whose all-reduce is in flight
+    # The collective sequence is STATIC: ``enable_overlapped_all_reduce(model)`` fixes, from the model's structure alone, a
+    # schedule of contiguous slices of the flat buffer -- one per message-passing layer in reverse layer order (the order
+    # their backward passes finish), then whatever lies between and around them in ascending order -- and every step every
+    # rank issues exactly these all-reduces in exactly this order.  A layer that reports through ``ops.GRAD_READY`` only
+    # moves the START of its slice's collective forward (to behind the kernels that write it, on the communication stream);
+    # a slice whose layer never reports on this rank (its batch took the composed path: too few rows per key, forces,
+    # graph capture) is issued by ``all_reduce_mean()``, at its place in the sequence.  Which collectives run, their sizes
+    # and their order never depend on the rank's data -- ranks whose shards fall on either side of a path threshold stay in
+    # step (an RCCL sequence that differs between ranks hangs or pairs the wrong buffers).
     _comm = None
-    overlapped_slices = 0  # slices reduced ahead of all_reduce_mean() since construction (tests / logs)
+    _schedule = ()         # [(lo, hi)] in issue order
+    _layer_of = None       # (data_ptr, numel) -> (schedule position, weakref to the Parameter)
+    _issued = 0            # schedule entries issued this step
+    _ready = None          # schedule positions whose layer has reported this step
+    _works = ()
+    overlapped_slices = 0  # slices whose collective started ahead of all_reduce_mean() since construction (tests / logs)
 
-    def enable_overlapped_all_reduce(self) -> None:
-        """Start a layer's slice of the all-reduce as soon as its weight gradients have been enqueued, on a
-        communication stream, while the backward of the earlier layers is still running (needs the gradient sink:
-        ``enable_direct_accumulation``).  The fused convolution layers report through ``ops.GRAD_READY``; whatever was
-        not reduced ahead (embedding, heads, layers on the composed path) goes in ``all_reduce_mean()`` as before.
-        Every rank runs the same model, so the slices and their order are the same on every rank.  xGMI rings are
-        per-link bound: a layer's slice is 4-5 MB here (1.15 M self-connection weights), large enough for the links."""
-        if not (self.buffer.is_cuda and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    def enable_overlapped_all_reduce(self, model: "torch.nn.Module" = None, layer_params=None) -> None:
+        """``model``: its ``MessagePassing`` sub-modules define the layer slices (``layer_params``: an explicit list of
+        parameter lists instead).  Needs the gradient sink (``enable_direct_accumulation``).  xGMI rings are per-link
+        bound: a layer's slice is 4-5 MB here (1.15 M self-connection weights), large enough for the links."""
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return
-        from ..backend import ops
+        if layer_params is None:
+            layer_params = []
+            if model is not None:
+                from ..nn.message_passing import MessagePassing
 
-        self._comm = torch.cuda.Stream(device=self.buffer.device)
-        self._pending = []
-        self._slot = {(p.data_ptr(), p.numel()): (off, -(-p.numel() // FLAT_ALIGN) * FLAT_ALIGN)
-                      for p, off in zip(self.params, self.offsets)}
-        ops.GRAD_READY = self._on_ready
+                layer_params = [list(mod.parameters()) for mod in model.modules() if isinstance(mod, MessagePassing)]
+        slot = {id(p): (off, -(-p.numel() // FLAT_ALIGN) * FLAT_ALIGN) for p, off in zip(self.params, self.offsets)}
+        layers = []
+        for group in layer_params:
+            sl = [slot.get(id(p)) for p in group if p.requires_grad]
+            if not sl or any(x is None for x in sl):
+                continue
+            lo, hi = min(o for o, _ in sl), max(o + n for o, n in sl)
+            if sum(n for _, n in sl) != hi - lo:
+                continue                      # not one contiguous run of the flat buffer: stays in the remainder
+            layers.append((lo, hi, [p for p in group if p.requires_grad]))
+        layers.sort(key=lambda t: -t[0])      # reverse layer order = the order the backward reaches them
+        schedule, self._layer_of = [], {}
+        for pos, (lo, hi, group) in enumerate(layers):
+            if any(lo < h and l < hi for l, h in schedule):
+                continue                      # nested MessagePassing modules: the outer one already covers it
+            schedule.append((lo, hi))
+            for p in group:
+                self._layer_of[(p.data_ptr(), p.numel())] = (len(schedule) - 1, weakref.ref(p))
+        covered, pos = sorted(schedule), 0
+        for lo, hi in covered:
+            if lo > pos:
+                schedule.append((pos, lo))
+            pos = max(pos, hi)
+        if pos < self.buffer.numel():
+            schedule.append((pos, self.buffer.numel()))
+        self._schedule = schedule
+        self._issued, self._ready, self._works = 0, set(), []
+        if self.buffer.is_cuda:
+            from ..backend import ops
+
+            self._comm = torch.cuda.Stream(device=self.buffer.device)
+            ops.GRAD_READY = self._on_ready      # (CPU buffers -- the gloo tests -- call _on_ready themselves)
 
     def disable_overlapped_all_reduce(self) -> None:
-        from ..backend import ops
-
         self._drain()
-        if getattr(ops.GRAD_READY, "__self__", None) is self:
-            ops.GRAD_READY = None
+        if self.buffer.is_cuda:
+            from ..backend import ops
+
+            if getattr(ops.GRAD_READY, "__self__", None) is self:
+                ops.GRAD_READY = None
+        self._schedule, self._layer_of = (), None
+
+    def _issue(self, upto: int, early: bool) -> None:
+        """Issues schedule entries [issued, upto) in order on the communication stream, behind everything enqueued so far
+        on the current stream and the side streams (the weight-gradient kernels of the gradient sink)."""
+        if upto <= self._issued:
+            return
+        if self._comm is not None:
+            from ..backend import ops
+
+            comm = self._comm
+            comm.wait_stream(torch.cuda.current_stream())
+            for st in ops.side_streams_of(self.buffer.device.index):
+                comm.wait_stream(st)
+            with torch.cuda.stream(comm):
+                for lo, hi in self._schedule[self._issued:upto]:
+                    self._works.append(dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        else:
+            for lo, hi in self._schedule[self._issued:upto]:
+                self._works.append(dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+        if early:
+            self.overlapped_slices += upto - self._issued
+        self._issued = upto
 
     def _on_ready(self, weights) -> None:
-        from ..backend import ops
-
-        slots = [self._slot.get((w.data_ptr(), w.numel())) for w in weights]
-        if not slots or any(sl is None for sl in slots):
+        if self._layer_of is None or (self.buffer.is_cuda and torch.cuda.is_current_stream_capturing()):
             return
-        lo = min(off for off, _ in slots)
-        hi = max(off + size for off, size in slots)
-        if sum(size for _, size in slots) != hi - lo:
-            return                      # not one contiguous run of the flat buffer: leave it to all_reduce_mean()
-        comm = self._comm
-        comm.wait_stream(torch.cuda.current_stream())
-        for st in ops.side_streams_of(self.buffer.device.index):
-            comm.wait_stream(st)        # the weight-gradient kernels of the layer run on the side streams
-        with torch.cuda.stream(comm):
-            work = dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM, async_op=True)
-        self._pending.append((lo, hi, work))
-        self.overlapped_slices += 1
+        pos = None
+        for w in weights:
+            hit = self._layer_of.get((w.data_ptr(), w.numel()))
+            if hit is None:
+                return
+            p = hit[1]()
+            if p is None or p.data_ptr() != w.data_ptr():
+                return                        # the parameter moved after enable_overlapped_all_reduce(): no early start
+            if pos is not None and hit[0] != pos:
+                return
+            pos = hit[0]
+        if pos is None:
+            return
+        self._ready.add(pos)
+        upto = self._issued
+        while upto in self._ready:            # only ever the next entries of the fixed sequence
+            upto += 1
+        self._issue(upto, early=True)
 
     def _drain(self):
-        done = sorted(self._pending, key=lambda t: t[0]) if self._pending else []
-        for _, _, work in done:
+        for work in self._works:
             work.wait()                 # the current stream waits for the collective (RCCL: no host block)
-        if self._comm is not None:
+        if self._comm is not None and self._works:
             torch.cuda.current_stream().wait_stream(self._comm)
-            self._pending = []
-        return done
+        self._works = []
+        self._issued = 0
+        self._ready = set()
 
     def all_reduce_mean(self) -> None:
         if self.buffer.is_cuda:
@@ -177,16 +245,11 @@ class FlatGradients:
 
             ops.join_side_streams()   # side-stream weight-gradient kernels (gradient sink) must land first
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            pos, rest = 0, []
-            for lo, hi, _ in (sorted(self._pending, key=lambda t: t[0]) if self._pending else []):
-                if lo > pos:
-                    rest.append((pos, lo))
-                pos = max(pos, hi)
-            if pos < self.buffer.numel():
-                rest.append((pos, self.buffer.numel()))
-            for lo, hi in rest:         # what no layer reduced ahead (everything, without the overlap)
-                dist.all_reduce(self.buffer[lo:hi], op=dist.ReduceOp.SUM)
-            self._drain()
+            if self._schedule:
+                self._issue(len(self._schedule), early=False)      # the rest of the fixed sequence, in order
+                self._drain()
+            else:
+                dist.all_reduce(self.buffer, op=dist.ReduceOp.SUM)
             self.buffer.div_(dist.get_world_size())
 
 
