@@ -345,6 +345,9 @@ def main():
         prep_only()
         prep_ms = event_ms(prep_only, 10)
 
+    if loader is not None:
+        loader.close()
+
     # ---- roofline blocks (rank 0's launches in the timed region) ---------------------------------------------------
     def tp_bytes(kind, n, e, plan):
         """Algorithmic bytes of one launch (SURVEY.md 8d variant A)."""

@@ -366,10 +366,16 @@ class Batch(Data):
         (the reference's ``Batch.index_select``, e3_layers/data/batch.py:133-162, rebuilds Data objects one by one)."""
         n_nodes = self.data["_n_nodes"].reshape(-1)
         dev = n_nodes.device
-        ids = torch.as_tensor(idx, dtype=torch.long, device=dev).reshape(-1)
-        if ids.numel() and (int(ids.min()) < -self.n_graphs or int(ids.max()) >= self.n_graphs):
-            raise IndexError("graph index out of range")
-        ids = torch.where(ids < 0, ids + self.n_graphs, ids)
+        if dev.type == "cpu":
+            ids_np = np.asarray(idx, dtype=np.int64).reshape(-1)
+            if ids_np.size and (int(ids_np.min()) < -self.n_graphs or int(ids_np.max()) >= self.n_graphs):
+                raise IndexError("graph index out of range")
+            ids = torch.from_numpy(np.where(ids_np < 0, ids_np + self.n_graphs, ids_np))
+        else:
+            ids = torch.as_tensor(idx, dtype=torch.long, device=dev).reshape(-1)
+            if ids.numel() and (int(ids.min()) < -self.n_graphs or int(ids.max()) >= self.n_graphs):
+                raise IndexError("graph index out of range")
+            ids = torch.where(ids < 0, ids + self.n_graphs, ids)
 
         host = dev.type == "cpu"     # host batches: numpy index arithmetic (no intra-op thread pool, see segment_ids)
 
@@ -409,7 +415,10 @@ class Batch(Data):
                 if edge_index_sel is None:
                     raise KeyError("edge_index without _n_edges")
                 shift = (new_node_off - node_off[sel])[edge_seg]
-                out[key] = take(value, edge_index_sel, 1) + (torch.from_numpy(shift) if host else shift)
+                if host:      # numpy add: a torch CPU op of this size spins up the intra-op thread pool (see segment_ids)
+                    out[key] = torch.from_numpy(np.take(value.detach().numpy(), edge_index_sel, axis=1) + shift)
+                else:
+                    out[key] = take(value, edge_index_sel, 1) + shift
                 continue
             if key not in self.attrs:
                 continue

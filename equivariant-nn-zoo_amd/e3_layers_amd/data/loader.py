@@ -256,22 +256,42 @@ class _PrefetchIter:
         self.thread = threading.Thread(target=self._work, name="e3k-prefetch", daemon=True)
         self.thread.start()
 
+    def _stage(self, slot: dict, key: str, t: torch.Tensor) -> torch.Tensor:
+        """``t`` copied into the slot's pinned buffer for ``key`` (grown geometrically; pinned allocations cost
+        milliseconds each, so they happen a handful of times per run, not ten times per batch)."""
+        buf = slot.get(key)
+        if buf is None or buf.dtype != t.dtype or buf.numel() < t.numel():
+            buf = slot[key] = torch.empty(max(int(t.numel() * 1.25), 16), dtype=t.dtype).pin_memory()
+        view = buf[:t.numel()].view(t.shape)
+        np.copyto(view.numpy(), t.numpy())      # (numpy: a torch CPU copy of this size wakes the intra-op thread pool)
+        return view
+
     def _work(self):
         loader = self.loader
         try:
             if self.cuda:
                 torch.cuda.set_device(loader.device)
+            # a ring of pinned staging sets: one more than the batches that can be in flight, each guarded by the event of
+            # the copies last issued from it
+            ring = [({}, None) for _ in range(max(loader.depth, 1) + 2)]
+            turn = 0
             for ids in loader.id_batches():
                 if self.stop.is_set():
                     return
                 batch = loader.assemble(ids)
                 ready = None
                 if self.cuda:
-                    batch.pin_memory()
+                    slot, busy = ring[turn % len(ring)]
+                    if busy is not None:
+                        busy.synchronize()           # (this worker thread only: the copies from this slot have landed)
                     with torch.cuda.stream(self.copy_stream):
-                        batch.to(loader.device, non_blocking=True)
+                        for key in list(batch.data.keys()):
+                            batch.data[key] = self._stage(slot, key, batch.data[key]).to(loader.device, non_blocking=True)
+                        batch.device = loader.device
                         ready = torch.cuda.Event()
                         ready.record(self.copy_stream)
+                    ring[turn % len(ring)] = (slot, ready)
+                    turn += 1
                 elif loader.device is not None:
                     batch.to(loader.device)
                 while not self.stop.is_set():
@@ -301,10 +321,22 @@ class _PrefetchIter:
         return batch
 
     def close(self):
+        """Stops the worker and waits for it (an endless loader must be closed before the interpreter exits: a thread
+        that still holds a HIP stream at shutdown aborts the process)."""
         self.stop.set()
+        try:
+            while True:
+                self.q.get_nowait()
+        except queue.Empty:
+            pass
+        if self.thread.is_alive() and threading.current_thread() is not self.thread:
+            self.thread.join(timeout=10)
 
     def __del__(self):
-        self.stop.set()
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---------------------------------------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ elif model_kind == "force":
     tree = config_energy_force.get_config().model_config
     batch = synth_qm9(6, 12, r_max=5.0)
 else:
-    tree = config_diffusion_CA.get_config(num_layers=2, n_dim=32).model_config
+    tree = config_diffusion_CA.get_config(num_layers=3).model_config
     batch = synth_protein(3, 4, n_res=48)
 torch.manual_seed(100 + rank)               # different initial weights per rank ...
 model = build(tree).to(dev)
@@ -189,7 +189,7 @@ def test_two_ranks_force_training_step_matches_the_single_process_step(dev, tmp_
 
 
 def test_two_ranks_protein_score_net_stay_in_step(dev, tmp_path):
-    """BASELINE configs[4] (reduced depth / width) under a process group: composed layers, LayerNormalization, the keyed
+    """BASELINE configs[4] (reduced depth) under a process group: composed layers, LayerNormalization, the keyed
     (residue type x protein) self-connection; both ranks must hold the same finite mean gradient and the same update."""
     r0, r1 = _launch(2, tmp_path, "overlap", "protein")
     assert r0["n"] + r1["n"] == 4
