@@ -8,7 +8,6 @@
 //   scan    one workgroup per CSR: exclusive scan of the histogram into the row pointers (+ a cursor copy)
 //   fill    one thread per edge: claims a slot in its source row and its destination row (order arbitrary)
 //   sort    one wave per (node, CSR): ranks the row's edge ids -> ascending order (rows are short: a node's degree)
-//   own0    one thread per tile border: lower bound of the border in the row starts
 // The result does not depend on the order in which the atomics of `fill` land.
 #include "e3k_common.h"
 
@@ -104,45 +103,25 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int32_t* __restrict
   }
 }
 
-// own0[t] = number of rows that start before position t * tile (lower bound of t * tile in ptr[0..N)); own0[n_tiles] = N
-__global__ __launch_bounds__(256) void csr_own0_kernel(const int32_t* __restrict__ dst_ptr, const int32_t* __restrict__ src_ptr,
-                                                       int32_t N, int32_t n_tiles, int32_t tile, int32_t* __restrict__ dst_own0,
-                                                       int32_t* __restrict__ src_own0) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= 2 * (n_tiles + 1)) return;
-  const bool by_src = i > n_tiles;
-  const int t = by_src ? i - (n_tiles + 1) : i;
-  const int32_t* ptr = by_src ? src_ptr : dst_ptr;
-  int32_t* own = by_src ? src_own0 : dst_own0;
-  if (t == n_tiles) {
-    own[t] = N;
-    return;
-  }
-  const int32_t key = t * tile;
-  int lo = 0, hi = N;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (ptr[mid] < key) lo = mid + 1; else hi = mid;
-  }
-  own[t] = lo;
-}
-
 }  // namespace e3k
 
 extern "C" int64_t e3k_csr_workspace_ints(int64_t N, int64_t E) { return 2 * N + 2 * E + 2; }
 
-extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile, int32_t* src, int32_t* dst,
-                             int32_t* dst_ptr, int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* dst_own0,
-                             int32_t* src_own0, int32_t* workspace, int32_t* bad_flag, void* stream) {
-  if (N < 0 || E < 0 || tile <= 0) return E3K_ERR_INVALID;
+extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* src, int32_t* dst, int32_t* dst_ptr,
+                             int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* workspace, int32_t* bad_flag,
+                             void* stream) {
+  if (N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N >= 0x7fffffffLL || E >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
-  if (!dst_ptr || !src_ptr || !dst_own0 || !src_own0 || !bad_flag) return E3K_ERR_INVALID;
+  if (!dst_ptr || !src_ptr || !bad_flag) return E3K_ERR_INVALID;
   if (E > 0 && (!edge_index || !src || !dst || !dst_perm || !src_perm || !workspace)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
-  if (hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
-  if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
-  const int32_t n_tiles = (int32_t)((E + tile - 1) / tile);
+  if (dst_ptr == bad_flag + 1 && src_ptr == dst_ptr + (N + 1)) {   // one block [flag | dst_ptr | src_ptr]: one fill
+    if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t) * (2 * (N + 1) + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  } else {
+    if (hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+    if (hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+    if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  }
   if (E > 0 && N > 0) {
     int32_t* dst_cur = workspace;
     int32_t* src_cur = workspace + N;
@@ -155,8 +134,6 @@ extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, in
     hipLaunchKernelGGL(e3k::csr_sort_kernel, dim3((unsigned)((2 * N + 3) / 4)), dim3(256), 0, st, dst_ptr, src_ptr, dst_tmp, src_tmp,
                        dst_perm, src_perm, (int32_t)N);
   }
-  hipLaunchKernelGGL(e3k::csr_own0_kernel, dim3((unsigned)((2 * (n_tiles + 1) + 255) / 256)), dim3(256), 0, st, dst_ptr, src_ptr,
-                     (int32_t)N, n_tiles, tile, dst_own0, src_own0);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -611,8 +611,6 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
   p->d_groups = nullptr;
   p->d_gc = nullptr;
   p->n_gc = 0;
-  p->d_chunks = nullptr;
-  p->n_chunks = 0;
   if (hipMalloc(&p->d_groups, sizeof(e3k_tp_group) * n_groups) != hipSuccess) {
     delete p;
     return E3K_ERR_LAUNCH;
@@ -690,58 +688,6 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
       if (d_sh != 9 || groups[i].y_off[0] != 0 || groups[i].y_off[1] != 1 || groups[i].y_off[2] != 4) p->full64 = 0;
     }
   }
-  {
-    // chunk list of the radial-fused kernels: the set slots of a group in pairs, per 64-channel chunk
-    bool ok = true;
-    int64_t n = 0;
-    for (int l = 0; l < 3; ++l) p->y_off[l] = -1;
-    for (int i = 0; i < n_groups; ++i) {
-      for (int l = 0; l < 3; ++l) {
-        if (groups[i].y_off[l] < 0) continue;
-        if (p->y_off[l] >= 0 && p->y_off[l] != groups[i].y_off[l]) ok = false;   // an sh degree that repeats
-        p->y_off[l] = groups[i].y_off[l];
-      }
-      if (groups[i].mul % 64) ok = false;
-      n += (int64_t)((groups[i].mul + 63) / 64) * ((__builtin_popcount(groups[i].mask) + 1) / 2);
-    }
-    if (ok && n > 0 && n < (1 << 16)) {
-      e3k_rtp_chunk* hc = new e3k_rtp_chunk[n];
-      int cnt = 0;
-      for (int i = 0; i < n_groups; ++i) {
-        for (int c = 0; c < groups[i].mul / 64; ++c) {
-          e3k_rtp_chunk blank{};
-          blank.group = i;
-          blank.cchunk = c;
-          blank.l1 = groups[i].l1;
-          blank.x_off = groups[i].x_off;
-          blank.mul = groups[i].mul;
-          for (int t = 0; t < 3; ++t) blank.y_off[t] = groups[i].y_off[t];
-          e3k_rtp_chunk cur = blank;
-          for (int q = 0; q < E3K_TP_MAXQ; ++q) {
-            if (!(groups[i].mask & (1u << q))) continue;
-            cur.mask |= 1u << q;
-            cur.col[cur.np] = groups[i].w_off[q] + 64 * c;
-            cur.out_off[cur.np] = groups[i].out_off[q];
-            cur.out_stride[cur.np] = groups[i].out_stride[q];
-            cur.coeff[cur.np] = groups[i].coeff[q];
-            if (++cur.np == 2) {
-              hc[cnt++] = cur;
-              cur = blank;
-            }
-          }
-          if (cur.np) hc[cnt++] = cur;
-        }
-      }
-      hipError_t e1 = hipMalloc(&p->d_chunks, sizeof(e3k_rtp_chunk) * cnt);
-      hipError_t e2 = e1 == hipSuccess ? hipMemcpy(p->d_chunks, hc, sizeof(e3k_rtp_chunk) * cnt, hipMemcpyHostToDevice) : e1;
-      delete[] hc;
-      if (e2 != hipSuccess) {
-        e3k_tp_plan_destroy(p);
-        return E3K_ERR_LAUNCH;
-      }
-      p->n_chunks = cnt;
-    }
-  }
   *out = p;
   return E3K_OK;
 }
@@ -755,7 +701,6 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
   if (!p) return;
   if (p->d_groups) (void)hipFree(p->d_groups);
   if (p->d_gc) (void)hipFree(p->d_gc);
-  if (p->d_chunks) (void)hipFree(p->d_chunks);
   delete p;
 }
 

@@ -1,6 +1,5 @@
-// Pieces shared by the tensor-product kernels (e3k_tp.hip: per-edge weights read from HBM; e3k_rtp.hip: per-edge
-// weights formed in the kernel from the radial hidden activations): compile-time loops over the (l2, l3) slots of an
-// input degree, the spherical-harmonics registers, the plan object.
+// Pieces of the tensor-product kernels (e3k_tp.hip): compile-time loops over the (l2, l3) slots of an input degree, the
+// spherical-harmonics registers, the plan object.
 #pragma once
 #include <type_traits>
 
@@ -88,18 +87,6 @@ __device__ __forceinline__ void slot_for_part(F&& f) {
 
 }  // namespace e3k
 
-// radial-fused kernels (e3k_rtp.hip): at most two paths of one group and one 64-channel chunk per matrix phase
-// (self-contained: the vector phase reads nothing of the group table, the whole descriptor sits in scalar registers)
-struct e3k_rtp_chunk {
-  int32_t group, cchunk, np;
-  uint32_t mask;          // the chunk's slots (a subset of the group's mask)
-  int32_t col[2];         // first weight column of each path: w_off[q] + 64 * cchunk
-  int32_t l1, x_off, mul;
-  int32_t y_off[3];
-  int32_t out_off[2], out_stride[2];
-  float coeff[2];
-};
-
 struct e3k_tp_plan {
   int32_t n_groups, d_in, d_sh, w_numel, d_mid;
   e3k_tp_group* d_groups;
@@ -109,9 +96,6 @@ struct e3k_tp_plan {
   int32_t max_l3; // largest output degree any group's mask enables
   int32_t split;  // 1: groups with l1 >= 1 are walked by two waves (slot parts 0 / 1)
   int32_t x_cols; // input columns owned by some group: sum over groups of (2 l1 + 1) * mul
-  e3k_rtp_chunk* d_chunks; // NULL when the radial-fused kernels do not serve this plan (a mul that is not a multiple of 64)
-  int32_t n_chunks;
-  int32_t y_off[3];        // sh column of each degree when every group agrees on it (the radial-fused kernels stage sh rows once per tile)
   int32_t full64;   // 1: every group has a multiple of 64 channels (the kernels drop their idle-lane handling)
   int32_t x_shared; // 1: two groups read overlapping input columns (an sh degree that repeats opens a second group)
 };

@@ -48,6 +48,7 @@ class ConvBlockPlan:
         self.sc_spec, self.sc_m_off, self.sc_ld_m = sc_spec, tuple(sc_m_off) if sc_m_off is not None else None, sc_ld_m
         self.gate_spec = gate_spec
         self.prefetched = None     # radial branch of THIS layer issued by the previous layer's forward (look-ahead)
+        self.guard_key = None      # the radial MLP's last-layer Parameter: key of its knot-table guard (radial_table.guard)
 
 
 class _on:
@@ -96,6 +97,7 @@ def _radial_branch(rows, plan: ConvBlockPlan, w_last, w_hidden, keep: bool, tabl
     with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
         ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
     if table is not None:      # w so far: the MLP on the knots; every edge interpolates between its three knots
+        radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, w)
         w = radial_table.interp_fwd_raw(w, table)
     return h, zs, w
 
@@ -330,6 +332,14 @@ class ConvBlockFn(torch.autograd.Function):
             _wait(main, side2)
         if ret_last is not None or any(r is not None for r in ret_hidden):
             _wait(main, side)      # (g_radial is consumed by the radial stream's alias of the edge embedding: no wait)
+        if fork:      # buffers zero-filled on a side stream and handed to autograd are read (and later freed) on this one
+            for r in (ret_post, ret_lin1, ret_sc, ret_last, *ret_hidden):
+                if r is not None:
+                    r.record_stream(main)
+            if table is not None:
+                for t in table:      # the knot bins were built on the main stream and read on the radial one
+                    if isinstance(t, torch.Tensor):
+                        _rec(t, side, main)
         if ops.GRAD_READY is not None:
             rets = (ret_lin1, ret_post, ret_sc if has_sc else None, ret_last, *ret_hidden)
             needs = (need_lin1, need_post, need_sc or not has_sc, need_last, *need_hidden)

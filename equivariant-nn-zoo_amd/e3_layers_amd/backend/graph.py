@@ -8,8 +8,8 @@ in-edges; building that list with a *stable* sort keeps the ascending-edge-id or
 segment, so the sum order (and hence fp32 rounding) follows the reference's CPU path, with no
 atomics.  The by-source CSR serves the backward pass (grad wrt node features, grad wrt pos).
 
-On the device the lists are built by ``csrc/e3k_graph.hip`` (count -> scan -> fill -> per-row rank sort: five small
-launches, no host sync); the torch construction below (stable argsort / bincount / cumsum) serves CPU tensors (host
+On the device the lists are built by ``csrc/e3k_graph.hip`` (count -> scan -> fill -> per-row rank sort: four small
+launches and one fill, no host sync); the torch construction below (stable argsort / bincount / cumsum) serves CPU tensors (host
 logic tests, gloo runs) and is the reference the device build is tested bit-exact against.
 """
 from __future__ import annotations
@@ -20,9 +20,7 @@ from typing import Dict, Optional
 
 import torch
 
-TOPO_KEYS = ("_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm",
-             "_e3k_dst_own0", "_e3k_src_own0")
-RTP_TILE = 64      # edges per tile of the radial-fused kernels (csrc/e3k_rtp.hip: RT_TE; checked against the library)
+TOPO_KEYS = ("_e3k_src", "_e3k_dst", "_e3k_dst_ptr", "_e3k_dst_perm", "_e3k_src_ptr", "_e3k_src_perm")
 
 
 @dataclass
@@ -33,8 +31,6 @@ class GraphTopo:
     dst_perm: torch.Tensor  # int32 [E]
     src_ptr: torch.Tensor   # int32 [N+1]
     src_perm: torch.Tensor  # int32 [E]
-    dst_own0: torch.Tensor  # int32 [ceil(E / RTP_TILE) + 1]: nodes whose dst segment starts before each tile border
-    src_own0: torch.Tensor  # the same for the CSR by source
 
     @property
     def num_nodes(self) -> int:
@@ -59,11 +55,7 @@ def _csr(index: torch.Tensor, num_nodes: int):
     counts = torch.bincount(index, minlength=num_nodes)
     ptr = torch.zeros(num_nodes + 1, dtype=torch.int32, device=index.device)
     ptr[1:] = torch.cumsum(counts, 0).to(torch.int32)
-    borders = torch.arange(0, index.numel(), RTP_TILE, device=index.device, dtype=torch.int32)
-    own0 = torch.empty(borders.numel() + 1, dtype=torch.int32, device=index.device)
-    own0[:-1] = torch.searchsorted(ptr[:-1], borders, right=False)
-    own0[-1] = num_nodes
-    return ptr, perm.to(torch.int32), own0
+    return ptr, perm.to(torch.int32)
 
 
 _pending_flags: list = []      # (event, pinned host flag) of device builds whose index check has not been read yet
@@ -72,54 +64,70 @@ _flag_ring = None              # until the device had drained (hipHostMalloc syn
 _flag_next = 0                 # happened mid-step
 
 
+_EDGE_MSG = ("an earlier batch's edge_index held node ids outside [0, num_nodes): its topology is invalid (such edges were "
+             "attached to node 0)")
+
+
 def _check_pending_flags() -> None:
-    """Out-of-range endpoints are detected by the device build without a host sync: the flag travels to pinned memory
-    asynchronously and is looked at by the NEXT build (or by ``check_indices()``) once its copy has landed."""
+    """Out-of-range indices are detected on the device without a host sync: the flag travels to pinned memory
+    asynchronously and is looked at once its copy has landed -- by the next build, by the optimizer step
+    (``FusedAdamEMA.step`` polls), or by ``check_indices()`` (blocking: evaluation, before a graph capture, tests)."""
     while _pending_flags and _pending_flags[0][0].query():
-        _, host = _pending_flags.pop(0)
+        _, host, msg = _pending_flags.pop(0)
         if int(host[0]) != 0:
-            raise ValueError("an earlier batch's edge_index held node ids outside [0, num_nodes): its topology is invalid")
+            raise ValueError(msg)
+
+
+def poll_indices() -> None:
+    """Non-blocking look at the flags that have arrived (called once per optimizer step)."""
+    if _pending_flags:
+        _check_pending_flags()
 
 
 def check_indices() -> None:
-    """Block until every device-built topology so far has been validated (tests; debugging)."""
+    """Block until every device-side index check so far (edge endpoints, row keys) has been read."""
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     _check_pending_flags()
 
 
+def defer_flag(flag: torch.Tensor, message: str) -> None:
+    """Registers a device int32 [1] error flag (non-zero = bad input) to be read back without a sync."""
+    global _flag_ring, _flag_next
+    if torch.cuda.is_current_stream_capturing():
+        return
+    _check_pending_flags()
+    if len(_pending_flags) >= _FLAG_RING - 1:
+        check_indices()
+    if _flag_ring is None:
+        _flag_ring = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
+    host = _flag_ring[_flag_next:_flag_next + 1]
+    _flag_next = (_flag_next + 1) % _FLAG_RING
+    host.copy_(flag, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record()
+    _pending_flags.append((ev, host, message))
+
+
 def _build_topology_device(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
-    """csrc/e3k_graph.hip: five small launches, no host sync, bit-identical to the stable-sort construction."""
+    """csrc/e3k_graph.hip: four small launches + one fill, no host sync, bit-identical to the stable-sort construction."""
     from . import lib as L
 
     lib = L.load()
     dev = edge_index.device
     e = edge_index.shape[1]
     ei = edge_index if (edge_index.dtype == torch.int64 and edge_index.is_contiguous()) else edge_index.long().contiguous()
-    n_tiles = (e + RTP_TILE - 1) // RTP_TILE
     i32 = dict(dtype=torch.int32, device=dev)
-    # one allocation for every output and the workspace (row pointers first: they are zero-filled by the library)
-    sizes = [num_nodes + 1, num_nodes + 1, e, e, e, e, n_tiles + 1, n_tiles + 1, 1, int(lib.e3k_csr_workspace_ints(num_nodes, e))]
+    # one allocation for every output and the workspace; [flag | dst_ptr | src_ptr] first and adjacent: the library
+    # zero-fills them with one memset
+    sizes = [1, num_nodes + 1, num_nodes + 1, e, e, e, e, int(lib.e3k_csr_workspace_ints(num_nodes, e))]
     buf = torch.empty(sum(sizes), **i32)
-    dst_ptr, src_ptr, src, dst, dst_perm, src_perm, dst_own0, src_own0, flag, work = torch.split(buf, sizes)
+    flag, dst_ptr, src_ptr, src, dst, dst_perm, src_perm, work = torch.split(buf, sizes)
     with torch.cuda.device(dev):
-        L.check(lib.e3k_csr_build(L.ptr(ei), num_nodes, e, RTP_TILE, L.ptr(src), L.ptr(dst), L.ptr(dst_ptr), L.ptr(dst_perm),
-                                  L.ptr(src_ptr), L.ptr(src_perm), L.ptr(dst_own0), L.ptr(src_own0), L.ptr(work), L.ptr(flag),
-                                  L.stream_ptr()), "e3k_csr_build")
-        if not torch.cuda.is_current_stream_capturing():
-            global _flag_ring, _flag_next
-            _check_pending_flags()
-            if len(_pending_flags) >= _FLAG_RING - 1:
-                check_indices()
-            if _flag_ring is None:
-                _flag_ring = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
-            host = _flag_ring[_flag_next:_flag_next + 1]
-            _flag_next = (_flag_next + 1) % _FLAG_RING
-            host.copy_(flag, non_blocking=True)
-            ev = torch.cuda.Event()
-            ev.record()
-            _pending_flags.append((ev, host))
-    return GraphTopo(src, dst, dst_ptr, dst_perm, src_ptr, src_perm, dst_own0, src_own0)
+        L.check(lib.e3k_csr_build(L.ptr(ei), num_nodes, e, L.ptr(src), L.ptr(dst), L.ptr(dst_ptr), L.ptr(dst_perm),
+                                  L.ptr(src_ptr), L.ptr(src_perm), L.ptr(work), L.ptr(flag), L.stream_ptr()), "e3k_csr_build")
+        defer_flag(flag, _EDGE_MSG)
+    return GraphTopo(src, dst, dst_ptr, dst_perm, src_ptr, src_perm)
 
 
 def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
@@ -131,9 +139,9 @@ def build_topology(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:
     if edge_index.is_cuda:
         return _build_topology_device(edge_index, int(num_nodes))
     src64, dst64 = edge_index[0].contiguous(), edge_index[1].contiguous()
-    dst_ptr, dst_perm, dst_own0 = _csr(dst64, num_nodes)
-    src_ptr, src_perm, src_own0 = _csr(src64, num_nodes)
-    return GraphTopo(src64.to(torch.int32), dst64.to(torch.int32), dst_ptr, dst_perm, src_ptr, src_perm, dst_own0, src_own0)
+    dst_ptr, dst_perm = _csr(dst64, num_nodes)
+    src_ptr, src_perm = _csr(src64, num_nodes)
+    return GraphTopo(src64.to(torch.int32), dst64.to(torch.int32), dst_ptr, dst_perm, src_ptr, src_perm)
 
 
 _cache: "Dict[int, tuple]" = {}

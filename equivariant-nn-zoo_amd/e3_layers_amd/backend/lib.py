@@ -104,15 +104,12 @@ SIGNATURES = {
     "e3k_tp_bwd_x_overwrites": (C.c_int, [_P]),
     "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_csr_workspace_ints": (C.c_int64, [_I64, _I64]),
-    "e3k_csr_build": (C.c_int, [_P, _I64, _I64, _I32, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "e3k_csr_build": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "e3k_group_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
     "e3k_rtable_bin": (C.c_int, [_P, _I64, _F, _I32, _P, _P, _P]),
     "e3k_rtable_interp_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I32, _I32]),
     "e3k_rtable_interp_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
-    "e3k_rtp_supported": (C.c_int, [_P]),
-    "e3k_rtp_tile_edges": (C.c_int, []),
-    "e3k_rtp_fwd": (C.c_int, [_P, _P, _P, _I32, _F, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),

@@ -1248,10 +1248,6 @@ class TpPlan:
             self._handles[idx] = h
         return h
 
-    def rtp_supported(self, device: torch.device) -> bool:
-        """The radial-fused kernels serve this plan (every multiplicity a multiple of 64)."""
-        return bool(L.load().e3k_rtp_supported(self.handle(device)))
-
     def bwd_x_overwrites(self, device: torch.device) -> bool:
         """g_x needs no zero-fill: the backward w.r.t. x stores every element (see e3k_tp_bwd_x_overwrites)."""
         if self._bwd_x_overwrites is None:
@@ -1300,20 +1296,6 @@ def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool,
                                       L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(gw), L.ptr(gsh),
                                       L.stream_ptr()), "e3k_tp_bwd_w")
     return gw, gsh
-
-
-def _rtp_fwd_raw(h, wl, w_scale: float, x, sh, topo: GraphTopo, plan: TpPlan):
-    """Radial-fused forward (csrc/e3k_rtp.hip): w = w_scale * h @ wl is formed per 64-edge tile in LDS."""
-    n, e = x.shape[0], sh.shape[0]
-    assert x.shape[1] == plan.d_in and sh.shape[1] == plan.d_sh and h.shape[0] == e and wl.shape == (h.shape[1], plan.w_numel)
-    assert topo.num_nodes == n and topo.num_edges == e
-    out = torch.empty(n, plan.d_mid, device=x.device, dtype=torch.float32)
-    handle = plan.handle(x.device)
-    with timed_launch("rtp_fwd", (n, e, plan)):
-        L.check(L.load().e3k_rtp_fwd(handle, L.ptr(h), L.ptr(wl), h.shape[1], float(w_scale), L.ptr(x), L.ptr(sh),
-                                     L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), L.ptr(topo.dst_own0), n, e,
-                                     L.ptr(out), L.stream_ptr()), "e3k_rtp_fwd")
-    return out
 
 
 class TpFn(torch.autograd.Function):

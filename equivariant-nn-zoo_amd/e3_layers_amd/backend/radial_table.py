@@ -32,12 +32,14 @@ MIN_EDGES_PER_KNOT = 4                                            # below this t
 
 
 class RadialSource:
-    """What ``RadialBasisEncoding`` knows about an edge embedding it produced: the module and the radii."""
+    """What ``RadialBasisEncoding`` knows about an edge embedding it produced: the module, the radii, and the version
+    counter of the embedding tensor when it was tagged (an in-place op on the embedding bumps it: the tag then no longer
+    describes the tensor's contents and the table is not used)."""
 
-    __slots__ = ("module", "r", "_bins", "_knot_basis", "__weakref__")
+    __slots__ = ("module", "r", "version", "_bins", "_knot_basis", "__weakref__")
 
-    def __init__(self, module, r: torch.Tensor):
-        self.module, self.r = weakref.ref(module), r
+    def __init__(self, module, r: torch.Tensor, version: int = 0):
+        self.module, self.r, self.version = weakref.ref(module), r, int(version)
         self._bins = None
         self._knot_basis = None
 
@@ -84,13 +86,106 @@ def source_of(edge_radial) -> Optional[RadialSource]:
     return getattr(edge_radial, "_e3k_radial_src", None)
 
 
-def applicable(edge_radial) -> bool:
+def applicable(edge_radial, w_last=None) -> bool:
+    """``w_last``: the last-layer weight of the radial MLP that would run on the table -- its a-posteriori error guard
+    (``guard`` below) can veto the table for that MLP."""
     if not ENABLED or not edge_radial.is_cuda:
         return False
     src = source_of(edge_radial)
     if src is None or src.module() is None or src.r.requires_grad:
         return False
+    if edge_radial._version != src.version:
+        return False                       # modified in place since RadialBasisEncoding produced it
+    if w_last is not None and not guard_ok(w_last):
+        return False
     return edge_radial.shape[0] >= MIN_EDGES_PER_KNOT * (KNOTS + 1)
+
+
+# ---- a-posteriori guard of the interpolation error ---------------------------------------------------------------------
+# Quadratic Lagrange interpolation on knots h apart is off by at most h^3 max|f(3)| / (9 sqrt 3) (f(3): third derivative);
+# on the table itself h^3 f(3) is the third finite difference, so
+#     err <= max|T[i+3] - 3 T[i+2] + 3 T[i+1] - T[i]| / (9 sqrt 3)
+# -- read off the 4 097 rows the forward has just computed, relative to max|T|.  5e-9 for the shipped models at random
+# init (8 Bessel functions through a smooth MLP); it grows like (frequency x weight scale)^3, so a 32-function basis, grown
+# Bessel frequencies or large trained weights can push it towards the 1e-5 parity budget.  The bound is evaluated on the
+# device the first time an MLP's table is built and every GUARD_EVERY-th time after (a few elementwise passes over 31 MB
+# on the radial stream), copied to pinned memory without a sync and looked at on a later call: above GUARD_TOL the table
+# is switched off for that MLP (per-edge evaluation from then on) with a warning.
+GUARD_TOL = float(os.environ.get("E3K_RADIAL_TABLE_TOL", "1e-6"))
+GUARD_EVERY = int(os.environ.get("E3K_RADIAL_TABLE_CHECK_EVERY", "64"))
+_C3 = 1.0 / (9.0 * 3.0 ** 0.5)
+
+
+class _Guard:
+    __slots__ = ("calls", "pending", "ok", "last", "__weakref__")
+
+    def __init__(self):
+        self.calls, self.pending, self.ok, self.last = 0, [], True, None
+
+
+_GUARDS: dict = {}      # id(weight) -> (weak reference to the weight, its guard): tensors compare elementwise, so they cannot
+                        # key a WeakKeyDictionary; the entry is dropped when the weight dies
+
+
+def _guard_of(w_last, create: bool = False):
+    hit = _GUARDS.get(id(w_last))
+    if hit is not None and hit[0]() is w_last:
+        return hit[1]
+    if not create:
+        return None
+    key = id(w_last)
+    g = _Guard()
+    _GUARDS[key] = (weakref.ref(w_last, lambda _r, key=key: _GUARDS.pop(key, None)), g)
+    return g
+
+
+def _poll(g: _Guard) -> None:
+    while g.pending and g.pending[0][0].query():
+        _, host = g.pending.pop(0)
+        g.last = float(host[0])
+        if not (g.last <= GUARD_TOL):       # (also catches NaN)
+            if g.ok:
+                import warnings
+
+                warnings.warn(f"radial knot table: interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e} "
+                              f"({KNOTS} knots): this radial MLP is evaluated per edge from now on "
+                              "(E3K_RADIAL_KNOTS raises the resolution)")
+            g.ok = False
+
+
+def guard_ok(w_last) -> bool:
+    g = _guard_of(w_last)
+    if g is None:
+        return True
+    _poll(g)
+    return g.ok
+
+
+def guard_error(w_last):
+    """Last error bound read back for this MLP (None before the first one arrived)."""
+    g = _guard_of(w_last)
+    if g is None:
+        return None
+    _poll(g)
+    return g.last
+
+
+def guard(w_last, table: torch.Tensor) -> None:
+    """Call with the table just computed (on the stream that computed it)."""
+    g = _guard_of(w_last, create=True)
+    g.calls += 1
+    _poll(g)
+    if (g.calls - 1) % max(GUARD_EVERY, 1) != 0 or torch.cuda.is_current_stream_capturing() or table.shape[0] < 4:
+        return
+    with torch.no_grad():
+        t = table.detach()
+        d3 = t[3:] - 3.0 * t[2:-1] + 3.0 * t[1:-2] - t[:-3]
+        est = (d3.abs().amax() * _C3 / t.abs().amax().clamp_min(1e-30)).reshape(1)
+        host = torch.empty(1, dtype=torch.float32).pin_memory()
+        host.copy_(est, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+    g.pending.append((ev, host))
 
 
 def interp_fwd_raw(table: torch.Tensor, bins) -> torch.Tensor:
@@ -129,8 +224,14 @@ class RadialTableFn(torch.autograd.Function):
         return interp_bwd_raw(L.f32c(g_w), ctx.src.bins()), None
 
 
+def last_weight(fc):
+    """The last-layer weight Parameter of a FullyConnectedNet: the key of its guard."""
+    return list(fc.children())[-1].weight
+
+
 def table_weights(fc, edge_radial) -> torch.Tensor:
-    """``fc(edge_radial)`` through the knot table (call only when ``applicable(edge_radial)``)."""
+    """``fc(edge_radial)`` through the knot table (call only when ``applicable(edge_radial, last_weight(fc))``)."""
     src = source_of(edge_radial)
     table = fc(src.knot_basis())            # the MLP on KNOTS + 1 rows: its forward AND backward shrink with it
+    guard(last_weight(fc), table)
     return RadialTableFn.apply(table, src)

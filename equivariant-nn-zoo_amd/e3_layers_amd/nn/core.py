@@ -83,6 +83,10 @@ def row_groups(index: torch.Tensor, n_keys: int) -> "ops.RowGroups":
         with torch.cuda.device(idx.device):
             L.check(L.load().e3k_group_rows(L.ptr(idx), idx.numel(), n_keys, L.ptr(perm), L.ptr(bounds), L.ptr(reps), L.ptr(flag),
                                             L.stream_ptr()), "e3k_group_rows")
+            from ..backend.graph import defer_flag
+
+            # rows whose key is outside [0, n_keys) are left out of perm / bounds: reported like bad edge endpoints
+            defer_flag(flag, f"a row key outside [0, {n_keys}) reached the keyed self-connection (species index beyond num_types?)")
         groups = ops.RowGroups(perm, bounds, reps, n_keys)
     else:
         perm = torch.argsort(idx, stable=True)

@@ -97,7 +97,7 @@ class RadialBasisEncoding(Module):
         if per_row == 1 and c.cutoff.kind == 0 and b.r_min == 0.0:
             # a pure function of one radius per row, constant beyond r_max: the convolutions may evaluate their radial MLPs
             # on a knot table instead of per edge (backend/radial_table.py); any op that builds a new tensor drops the tag
-            out._e3k_radial_src = radial_table.RadialSource(self, x.reshape(-1))
+            out._e3k_radial_src = radial_table.RadialSource(self, x.reshape(-1), out._version)
         return ({"radial_embedding": out},
                 {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])})
 

@@ -133,7 +133,7 @@ class FactorizedConvolution(Module):
         x = data["input_features"]
         topo = get_topology(data, x.shape[0])
         in_cf = bool(getattr(x, "_e3k_cf", False))     # the previous MessagePassing handed its features over in cf
-        table = radial_table.applicable(data["edge_radial"])
+        table = radial_table.applicable(data["edge_radial"], radial_table.last_weight(self.fc))
         if table:      # knot bins and the basis on the knots: once per batch / forward, on this stream (the branches wait for it)
             src = radial_table.source_of(data["edge_radial"])
             src.bins()
@@ -282,6 +282,7 @@ class MessagePassing(Module):
                 last_spec=last._spec, tp_plan=conv.tp.tp.plan, post_spec=conv.tp.linear.spec("cf", "cf"),
                 scale=1.0 if conv.avg_num_neighbors is None else float(conv.avg_num_neighbors) ** -0.5,
                 sc_spec=sc_spec, sc_m_off=sc_m_off, sc_ld_m=sc_ld, gate_spec=self.equivariant_nonlin._spec)
+            plan.guard_key = last.weight
         self.__dict__["_cb_plan"] = plan
         return plan
 
@@ -307,7 +308,8 @@ class MessagePassing(Module):
         fork = bool(FWD_FORK and conv._fork_pays(radial.shape[0])
                     and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         table = None
-        if radial_table.applicable(radial):      # the radial MLP on a knot table; every edge interpolates (backend/radial_table.py)
+        fc = list(conv.fc.children())
+        if radial_table.applicable(radial, fc[-1].weight):      # the radial MLP on a knot table; every edge interpolates (backend/radial_table.py)
             src = radial_table.source_of(radial)
             table = src.bins()
             radial = src.knot_basis()            # [knots + 1, n_basis]: the block's MLP runs on these rows
@@ -320,14 +322,15 @@ class MessagePassing(Module):
                 side2 = ops.side_stream(x.device, 1)
                 with ops.on_stream(side2, main):
                     attrs = _stream_alias(attrs, side2)
-        fc = list(conv.fc.children())
         nxt = None
         nmp = self.__dict__.get("_next_mp")          # set by SequentialGraphNetwork: the next layer reads the same edge embedding
         if nmp is not None and fork and nmp.conv._fork_pays(data["edge_radial"].shape[0]):
             plan_n = nmp._block_plan()
             if plan_n is not None and (nmp.conv.sc is None) == (conv.sc is None):
                 fc_n = list(nmp.conv.fc.children())
-                if fc_n[0].weight.shape[0] == radial.shape[1]:
+                # (the next layer must take the same radial path as this one: its guard may have vetoed the table)
+                same_path = (table is not None) == radial_table.applicable(data["edge_radial"], fc_n[-1].weight)
+                if fc_n[0].weight.shape[0] == radial.shape[1] and same_path:
                     nxt = (plan_n, fc_n[-1].weight, [m.weight for m in fc_n[:-1]])
         y = conv_block.conv_block(x, attrs, radial, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                   conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,

@@ -36,6 +36,9 @@ class CapturedStep:
         torch.cuda.current_stream(dev).wait_stream(side)
         del out
         torch.cuda.synchronize(dev)
+        from ..backend.graph import check_indices
+
+        check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = fn()

@@ -68,6 +68,9 @@ class FusedAdamEMA:
         """(all-reduce of the flat gradient is the caller's: ``self.grads.all_reduce_mean()``)"""
         from ..backend import ops
 
+        from ..backend.graph import poll_indices
+
+        poll_indices()               # device-side index checks of the batches so far (edge endpoints, row keys): no sync
         ops.join_side_streams()      # weight gradients written by side-stream kernels (gradient sink) are complete
         L.check(L.load().e3k_adam_ema_step(
             L.ptr(self.flat), L.ptr(self.grads.buffer), L.ptr(self.exp_avg), L.ptr(self.exp_avg_sq), L.ptr(self.ema),
@@ -96,6 +99,9 @@ class FusedAdamEMA:
     def average_parameters(self):
         """``with opt.average_parameters(): validate(model)`` — torch_ema's context manager
         (``e3_layers/run/trainer.py:438-439``): parameters hold the EMA inside, are restored after."""
+        from ..backend.graph import check_indices
+
+        check_indices()              # a natural sync point: every batch so far had valid indices
         if self.ema is None:
             yield
             return

@@ -227,14 +227,13 @@ int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const
  * bookkeeping (data/batch.py:164-178): from edge_index int64 [2,E] (row 0 sources, row 1 destinations) builds
  *   src, dst [E] int32; dst_ptr/src_ptr [N+1] row pointers; dst_perm/src_perm [E] edge ids grouped by endpoint,
  *   ASCENDING inside a row (= a stable sort by endpoint, the reference's CPU summation order);
- *   dst_own0/src_own0 [ceil(E/tile)+1]: rows that start before each tile border (e3k_rtp_*), last entry N.
  * workspace: e3k_csr_workspace_ints(N, E) int32.  bad_flag [1]: set to 1 when an endpoint is outside [0, N)
  * (such edges are attached to node 0; the caller reads the flag when it chooses to).
  * ------------------------------------------------------------------------------------------ */
 int64_t e3k_csr_workspace_ints(int64_t N, int64_t E);
-int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t tile, int32_t* src, int32_t* dst,
-                  int32_t* dst_ptr, int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* dst_own0,
-                  int32_t* src_own0, int32_t* workspace, int32_t* bad_flag, void* stream);
+int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* src, int32_t* dst, int32_t* dst_ptr,
+                  int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* workspace, int32_t* bad_flag,
+                  void* stream);
 
 /* Rows grouped by a small categorical key (the keyed self-connection groups nodes by species: node_attrs =
  * Linear(one_hot(species)), layer_configs.py:104-118 feeding nn/message_passing.py:81-87,100): perm [R] int32 = row ids
@@ -265,26 +264,6 @@ int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t
 int64_t e3k_rtable_bwd_workspace_floats(int32_t K, int32_t W);
 int e3k_rtable_interp_bwd(const float* g_w, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t, int64_t E,
                           int32_t K, int32_t W, float* workspace, float* g_T, void* stream);
-
-/* ------------------------------------------------------------------------------------------
- * Radial-fused tensor product (csrc/e3k_rtp.hip): SURVEY.md 8d "variant B".
- * Replaces the LAST layer of the radial FullyConnectedNet (nn/message_passing.py:74-79,93: weight = fc(edge_radial))
- * together with the gather + TensorProduct 'uvu' + scatter above (nn/message_passing.py:104-109), so that
- * weight[E, weight_numel] never exists in HBM:
- *     w[e, c] = w_scale * sum_k h[e, k] wl[k, c]           (formed tile by tile on the matrix pipe, kept in LDS)
- *     out     = e3k_tp_fwd(x, sh, w)
- * h [E,k]: activations of the last hidden layer (k = 64); wl [k, weight_numel] row-major (e3nn's weight of the last
- * layer); w_scale = 1/sqrt(k).  Tiles are runs of e3k_rtp_tile_edges() consecutive positions of the CSR order;
- * own0 [n_tiles+1] (int32): own0[t] = number of nodes whose segment starts before position t * tile
- * (= lower bound of t * tile in ptr[0..N)), own0[n_tiles] = N.
- * e3k_rtp_supported(plan): 1 when these kernels serve the plan (every mul a multiple of 64), else the caller forms
- * w with e3k_gemm and uses e3k_tp_*.
- * ------------------------------------------------------------------------------------------ */
-int e3k_rtp_supported(const e3k_tp_plan* plan);
-int e3k_rtp_tile_edges(void);
-int e3k_rtp_fwd(const e3k_tp_plan* plan, const float* h, const float* wl, int32_t k, float w_scale, const float* x,
-                const float* sh, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm,
-                const int32_t* dst_own0, int64_t N, int64_t E, float* out, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-side elementwise kernels.

@@ -482,41 +482,6 @@ def test_tp_repeated_sh_degree_shares_an_input_block(dev):
     assert rel_err(gsh, rsh) < GTOL
 
 
-@pytest.mark.parametrize("left,out,n,deg", [
-    ("64x0e+64x1o+64x2e", "64x0e+64x1o+64x2e", 41, 9),                 # E not a multiple of the 64-edge tile
-    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", 30, 15),
-    ("64x0e+64x1o+64x2e+64x3o", "64x0e+64x1o+64x2e+64x3o+64x1e", 12, 150),    # l = 3; nodes whose in-edges span several tiles
-    ("128x0e+64x1o", "128x0e+64x1o", 50, 3),                           # a two-chunk block (mul 128)
-])
-def test_radial_fused_tp_forward_equals_gemm_plus_tp(dev, left, out, n, deg):
-    """SURVEY 8d "variant B" (csrc/e3k_rtp.hip, opt-in): the radial last layer formed tile by tile on the matrix pipe and
-    consumed from LDS by the CG stage == e3k_gemm + e3k_tp_fwd; tile-border nodes (float atomics into pre-zeroed rows),
-    isolated nodes (exact zeros) and a ragged last tile included."""
-    from e3_layers_amd.backend import ops
-    from e3_layers_amd.backend.graph import build_topology
-    from e3_layers_amd.nn import TensorProductExpansion
-
-    torch.manual_seed(n + deg)
-    mod = TensorProductExpansion(left, ("1x0e+1x1o+1x2e", "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
-    plan = mod.tp.plan
-    assert plan.rtp_supported(dev)
-    gen = torch.Generator().manual_seed(3)
-    e = n * deg
-    ei = torch.stack([torch.randint(0, n, (e,), generator=gen), torch.randint(0, n, (e,), generator=gen)])
-    ei[1, : e // 2] = ei[1, 0]                            # a hub with e/2 in-edges
-    ei = ei[:, ei[1] != n - 1]                            # and an isolated last node
-    topo = build_topology(ei.to(dev), n)
-    e = ei.shape[1]
-    x = torch.randn(n, plan.d_in, device=dev)
-    sh = torch.randn(e, 9, device=dev)
-    h = torch.randn(e, 64, device=dev)
-    wl = torch.randn(64, plan.w_numel, device=dev)
-    ref = ops._tp_fwd_raw(x, sh, (h @ wl) * 0.125, topo, plan)
-    got = ops._rtp_fwd_raw(h, wl, 0.125, x, sh, topo, plan)
-    assert rel_err(got, ref) < 2e-6
-    assert float(got[n - 1].abs().max()) == 0.0
-
-
 def test_tp_empty_and_isolated(dev):
     """No edges at all, and nodes without in-edges: outputs are exact zeros."""
     from e3_layers_amd.backend.graph import build_topology

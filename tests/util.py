@@ -56,3 +56,14 @@ def batch_to_oracle(batch, dtype=torch.float64):
     data = {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu())
             for k, v in batch.data.items() if not k.startswith("_e3k_")}
     return data, dict(batch.attrs)
+
+
+def record_measured(test: str, **values) -> None:
+    """Appends measured errors to the JSON-lines file named by E3K_PARITY_LOG (DESIGN.md quotes them); no-op otherwise."""
+    import json
+    import os
+
+    path = os.environ.get("E3K_PARITY_LOG")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps({"test": test, **{k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}}) + "\n")
