@@ -1,0 +1,444 @@
+// A convolution layer as ONE call: FactorizedConvolution + Gate forward and backward
+// (reference: e3_layers/nn/message_passing.py:91-124 forward, :249 gate; their autograd backward).
+//
+// This file launches nothing of its own except two row gather / scatter kernels: it is the HOST side of a layer in native
+// code.  The kernels are the library's (e3k_tp, e3k_gemm, e3k_node, e3k_mlp, e3k_rtable); what used to sit between them was
+// Python -- one ctypes call, a descriptor rebase, a stream switch and an output allocation per launch: 0.22 ms forward
+// and 0.30 ms backward per layer, ~2.6 ms of a training step that takes 3.4 ms at 32 molecules (host-bound up to 128
+// molecules per GPU: every batch size the reference ships) and as long as the GPU time at 256.  Here the whole sequence
+// is issued back to back on the caller's streams:
+//
+//   forward   side : radial MLP hidden chain -> last layer (-> table interpolation)          -> w [E, W]
+//             side2: per-key self-connection weights M, keyed self-connection GEMM           -> conv [N, d_conv]
+//             main : (relayout) -> linear_1 -> [wait side] tensor product + reduce -> [wait side2]
+//                    conv += scale * Linear(mid) -> gate                                     -> y
+//             side : (look-ahead) the NEXT layer's radial branch behind this layer's tensor product
+//   backward  main : gate' -> {trailing Linear dgrad, self-connection dgrad} -> tp_bwd_x -> tp_bwd_w -> linear_1 dgrad
+//             side3: {trailing Linear wgrad, self-connection wgrad} behind gate'; linear_1 wgrad behind tp_bwd_x
+//             side2: per-key weight gradient -> flat weight gradient + attribute gradient
+//             side : (table^T) -> last-layer wgrad / dgrad -> hidden chain backward
+//
+// Cross-stream edges are hipEvents owned by the layer object (no timing, re-recorded every call).  Without `fork` all
+// streams are the same and the events are skipped.  GEMMs that share an operand go out in one e3k_gemm_multi call.
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "e3k_common.h"
+
+namespace e3k {
+
+// a_rep[k, :] = attrs[reps[k], :]
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ rows, int n_rows,
+                                                          int width, float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows * width) return;
+  const int r = i / width, c = i - r * width;
+  dst[i] = src[rows[r] * width + c];
+}
+
+// g_attrs[reps[k], :] += ga[k, :]   (g_attrs zero-filled before; keys with no rows carry ga = 0 and reps = 0: harmless adds)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int64_t* __restrict__ rows,
+                                                           const int32_t* __restrict__ bounds, int n_rows, int width,
+                                                           float* __restrict__ dst) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_rows * width) return;
+  const int r = i / width, c = i - r * width;
+  if (bounds[2 * r + 1] > 0) atomicAdd(dst + rows[r] * width + c, src[i]);   // distinct representatives: no contention
+}
+
+}  // namespace e3k
+
+// per-kernel timing (bench.py's roofline block): event pairs around the edge kernels, on the stream that runs them
+constexpr int PROF_KINDS = 6;   // E3K_PROF_* in e3k.h
+struct ProfRing {
+  std::vector<hipEvent_t> beg, end;
+  std::vector<int64_t> n, e;
+  int count = 0;
+};
+
+struct e3k_layer {
+  e3k_layer_desc d;
+  std::vector<e3k_gemm_problem> sets[13];
+  int rounds[13];
+  int round_start[13][5];
+  std::vector<e3k_gate_seg> gate;
+  std::vector<e3k_block> in_blocks;
+  std::vector<e3k_kw_instr> kw;
+  hipEvent_t ev[8];
+  int n_ev;
+  mutable ProfRing prof[PROF_KINDS];
+  int prof_cap = 0;
+};
+
+namespace {
+struct Timed {   // records an event pair around one launch when the layer is being profiled
+  const e3k_layer* L;
+  int kind, slot;
+  hipStream_t st;
+  Timed(const e3k_layer* L_, int kind_, void* st_, int64_t n, int64_t e) : L(L_), kind(kind_), slot(-1), st((hipStream_t)st_) {
+    if (L->prof_cap <= 0) return;
+    ProfRing& r = L->prof[kind];
+    if (r.count >= L->prof_cap) return;
+    slot = r.count++;
+    r.n[slot] = n;
+    r.e[slot] = e;
+    (void)hipEventRecord(r.beg[slot], st);
+  }
+  ~Timed() {
+    if (slot >= 0) (void)hipEventRecord(L->prof[kind].end[slot], st);
+  }
+};
+}  // namespace
+
+namespace {
+
+enum SetId { LIN1_FWD, LIN1_DGRAD, LIN1_DGRAD_ACC, LIN1_WGRAD, POST_FWD, POST_DGRAD, POST_WGRAD, SC_FWD, SC_DGRAD, SC_WGRAD,
+             LAST_FWD, LAST_DGRAD, LAST_WGRAD, N_SETS };
+
+#define E3K_TRY(call)              \
+  do {                             \
+    const int rc_ = (call);        \
+    if (rc_ != E3K_OK) return rc_; \
+  } while (0)
+
+// template sets that go out together: round r of every set in one e3k_gemm_multi call, the rounds in order
+struct Seg {
+  e3k_gemm_segment s[4];
+  const e3k_layer* layer[4];
+  int id[4];
+  int n = 0;
+  void add(const e3k_layer* L, SetId set, const void* a, const void* b, void* c, int64_t rows) {
+    e3k_gemm_segment sg{};
+    sg.a_base = a; sg.b_base = b; sg.c_base = c;
+    sg.M1 = rows;
+    layer[n] = L;
+    id[n] = set;
+    s[n++] = sg;
+  }
+  void add_keyed(const e3k_layer* L, SetId set, const void* a, const void* b, void* c, int64_t rows, const int32_t* perm,
+                 const int32_t* bounds, int32_t n_keys) {
+    add(L, set, a, b, c, rows);
+    e3k_gemm_segment& sg = s[n - 1];
+    sg.n_keys = n_keys; sg.perm = perm; sg.groups_dev = bounds; sg.b_key_stride = L->d.ld_m;
+  }
+  int run(int wgrad, void* st) {
+    for (int r = 0;; ++r) {
+      e3k_gemm_segment round[4];
+      int m = 0;
+      for (int i = 0; i < n; ++i) {
+        const e3k_layer* L = layer[i];
+        if (r >= L->rounds[id[i]]) continue;
+        e3k_gemm_segment sg = s[i];
+        const int beg = L->round_start[id[i]][r], end = L->round_start[id[i]][r + 1];
+        sg.templates = L->sets[id[i]].data() + beg;
+        sg.n_templates = end - beg;
+        round[m++] = sg;
+      }
+      if (!m) return E3K_OK;
+      const int rc = e3k_gemm_multi(round, m, wgrad, st);
+      if (rc != E3K_OK) return rc;
+    }
+  }
+};
+
+// consumer waits for everything enqueued on producer so far
+int edge(const e3k_layer* L, int slot, void* producer, void* consumer) {
+  if (producer == consumer) return E3K_OK;
+  hipEvent_t ev = L->ev[slot];
+  if (hipEventRecord(ev, (hipStream_t)producer) != hipSuccess) return E3K_ERR_LAUNCH;
+  if (hipStreamWaitEvent((hipStream_t)consumer, ev, 0) != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
+  const e3k_layer_desc& d = L->d;
+  if (r.R == 0 || r.E == 0) return E3K_OK;
+  float* zs[4] = {r.z[0], r.z[1], r.z[2], r.z[3]};
+  E3K_TRY(e3k_mlp_hidden_fwd(r.radial, r.R, d.k0, d.h, d.n_hidden, r.w_hidden, d.alphas, d.act, d.cst, r.keep ? zs : nullptr, r.h, st));
+  {
+    Timed t(L, E3K_PROF_RADIAL_LAST_FWD, st, r.R, r.E);
+    Seg g;
+    g.add(L, LAST_FWD, r.h, r.w_last, r.use_table ? r.T : r.w, r.R);
+    E3K_TRY(g.run(0, st));
+  }
+  if (r.use_table) {
+    Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
+    E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
+  }
+  return E3K_OK;
+}
+
+}  // namespace
+
+extern "C" int e3k_layer_create(const e3k_layer_desc* desc, e3k_layer** out) {
+  if (!desc || !out || !desc->tp) return E3K_ERR_INVALID;
+  if (desc->n_hidden < 1 || desc->n_hidden > 4) return E3K_ERR_UNSUPPORTED;
+  e3k_layer* L = new (std::nothrow) e3k_layer();
+  if (!L) return E3K_ERR_LAUNCH;
+  L->d = *desc;
+  const e3k_gemm_set* src[N_SETS] = {&desc->lin1_fwd, &desc->lin1_dgrad, &desc->lin1_dgrad_acc, &desc->lin1_wgrad, &desc->post_fwd,
+                                     &desc->post_dgrad, &desc->post_wgrad, &desc->sc_fwd, &desc->sc_dgrad, &desc->sc_wgrad,
+                                     &desc->last_fwd, &desc->last_dgrad, &desc->last_wgrad};
+  for (int i = 0; i < N_SETS; ++i) {
+    const e3k_gemm_set& gs = *src[i];
+    bool ok = gs.n >= 0 && (gs.n == 0 || gs.p) && gs.n_rounds >= 0 && gs.n_rounds <= 4 && (gs.n == 0 || gs.n_rounds >= 1);
+    for (int r = 0; ok && r < gs.n_rounds; ++r) ok = gs.round_start[r] <= gs.round_start[r + 1];
+    ok = ok && (gs.n_rounds == 0 || (gs.round_start[0] == 0 && gs.round_start[gs.n_rounds] == gs.n));
+    if (!ok) {
+      delete L;
+      return E3K_ERR_INVALID;
+    }
+    L->sets[i].assign(gs.p, gs.p + gs.n);
+    L->rounds[i] = gs.n_rounds;
+    for (int r = 0; r < 5; ++r) L->round_start[i][r] = gs.round_start[r];
+  }
+  if (desc->gate) L->gate.assign(desc->gate, desc->gate + desc->n_gate);
+  if (desc->in_blocks) L->in_blocks.assign(desc->in_blocks, desc->in_blocks + desc->n_in_blocks);
+  if (desc->kw) L->kw.assign(desc->kw, desc->kw + desc->n_kw);
+  L->n_ev = 0;
+  for (int i = 0; i < 8; ++i) {
+    if (hipEventCreateWithFlags(&L->ev[i], hipEventDisableTiming) != hipSuccess) {
+      e3k_layer_destroy(L);
+      return E3K_ERR_LAUNCH;
+    }
+    L->n_ev = i + 1;
+  }
+  *out = L;
+  return E3K_OK;
+}
+
+static void prof_free(e3k_layer* L) {
+  for (int k = 0; k < PROF_KINDS; ++k) {
+    for (hipEvent_t ev : L->prof[k].beg) (void)hipEventDestroy(ev);
+    for (hipEvent_t ev : L->prof[k].end) (void)hipEventDestroy(ev);
+    L->prof[k] = ProfRing();
+  }
+  L->prof_cap = 0;
+}
+
+extern "C" void e3k_layer_destroy(e3k_layer* L) {
+  if (!L) return;
+  prof_free(L);
+  for (int i = 0; i < L->n_ev; ++i) (void)hipEventDestroy(L->ev[i]);
+  delete L;
+}
+
+extern "C" int e3k_layer_profile(e3k_layer* L, int32_t capacity) {
+  if (!L || capacity < 0) return E3K_ERR_INVALID;
+  prof_free(L);
+  for (int k = 0; k < PROF_KINDS && capacity > 0; ++k) {
+    ProfRing& r = L->prof[k];
+    r.beg.resize(capacity);
+    r.end.resize(capacity);
+    r.n.assign(capacity, 0);
+    r.e.assign(capacity, 0);
+    for (int i = 0; i < capacity; ++i)
+      if (hipEventCreate(&r.beg[i]) != hipSuccess || hipEventCreate(&r.end[i]) != hipSuccess) return E3K_ERR_LAUNCH;
+  }
+  L->prof_cap = capacity;
+  return E3K_OK;
+}
+
+extern "C" int e3k_layer_profile_read(e3k_layer* L, int32_t kind, float* ms, int64_t* n, int64_t* e, int32_t cap) {
+  if (!L || kind < 0 || kind >= PROF_KINDS || cap < 0) return E3K_ERR_INVALID;
+  const ProfRing& r = L->prof[kind];
+  const int cnt = r.count < cap ? r.count : cap;
+  for (int i = 0; i < cnt; ++i) {
+    if (hipEventSynchronize(r.end[i]) != hipSuccess) return E3K_ERR_LAUNCH;
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, r.beg[i], r.end[i]) != hipSuccess) return E3K_ERR_LAUNCH;
+    ms[i] = t;
+    n[i] = r.n[i];
+    e[i] = r.e[i];
+  }
+  return cnt;
+}
+
+extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
+  if (!L || !a || a->N < 0 || a->E < 0) return E3K_ERR_INVALID;
+  const e3k_layer_desc& d = L->d;
+  const bool has_sc = !L->sets[SC_FWD].empty();
+  void* main = a->main;
+  void* side = a->fork ? a->side : main;
+  void* side2 = a->fork ? a->side2 : main;
+  if (a->N == 0) return E3K_OK;
+  if (!a->x || !a->sh || !a->x1 || !a->mid || !a->conv || !a->y || !a->rad.w) return E3K_ERR_INVALID;
+  // --- radial branch (unless the previous layer's look-ahead already issued it)
+  if (!a->has_w) {
+    E3K_TRY(edge(L, 0, main, side));
+    E3K_TRY(radial_fwd(L, a->rad, side));
+  }
+  // --- node side
+  const float* x_cf = a->x;
+  if (!a->in_cf && !L->in_blocks.empty()) {
+    E3K_TRY(e3k_relayout(a->x, a->N, d.d_in, L->in_blocks.data(), (int32_t)L->in_blocks.size(), 1, a->x_cf, main));
+    x_cf = a->x_cf;
+  }
+  if (has_sc) {
+    if (!a->node_attrs || !a->a_rep || !a->m || !a->reps || !a->perm || !a->bounds || a->n_keys <= 0) return E3K_ERR_INVALID;
+    E3K_TRY(edge(L, 1, main, side2));        // x_cf (and the attributes) are ready
+    const int tot = a->n_keys * d.V;
+    hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->node_attrs, a->reps,
+                       a->n_keys, d.V, a->a_rep);
+    E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
+    if (!d.sc_out_covered && hipMemsetAsync(a->conv, 0, sizeof(float) * a->N * d.d_conv, (hipStream_t)side2) != hipSuccess)
+      return E3K_ERR_LAUNCH;
+    Seg g;
+    g.add_keyed(L, SC_FWD, x_cf, a->m, a->conv, a->N, a->perm, a->bounds, a->n_keys);
+    if (side2 == main) g.add(L, LIN1_FWD, x_cf, a->w_lin1, a->x1, a->N);      // one stream: both readers of x_cf in one launch
+    E3K_TRY(g.run(0, side2));
+    if (side2 != main) {
+      Seg g1;
+      g1.add(L, LIN1_FWD, x_cf, a->w_lin1, a->x1, a->N);
+      E3K_TRY(g1.run(0, main));
+    }
+  } else {
+    if (!d.post_out_covered && hipMemsetAsync(a->conv, 0, sizeof(float) * a->N * d.d_conv, (hipStream_t)main) != hipSuccess)
+      return E3K_ERR_LAUNCH;
+    Seg g1;
+    g1.add(L, LIN1_FWD, x_cf, a->w_lin1, a->x1, a->N);
+    E3K_TRY(g1.run(0, main));
+  }
+  E3K_TRY(edge(L, 2, side, main));           // the per-edge weights
+  {
+    Timed t(L, E3K_PROF_TP_FWD, main, a->N, a->E);
+    E3K_TRY(e3k_tp_fwd(d.tp, a->x1, a->sh, a->rad.w, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->mid, main));
+  }
+  if (a->next && a->next_rad && side != main) {
+    E3K_TRY(edge(L, 3, main, side));         // behind this layer's tensor product: both are HBM streams
+    E3K_TRY(radial_fwd(a->next, *a->next_rad, side));
+  }
+  if (has_sc) E3K_TRY(edge(L, 4, side2, main));
+  {
+    Seg g;
+    g.add(L, POST_FWD, a->mid, a->w_post, a->conv, a->N);
+    E3K_TRY(g.run(0, main));
+  }
+  E3K_TRY(e3k_gate_fwd(a->conv, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->y, main));
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
+  if (!L || !a || a->N < 0 || a->E < 0) return E3K_ERR_INVALID;
+  const e3k_layer_desc& d = L->d;
+  const bool has_sc = !L->sets[SC_FWD].empty();
+  if (a->N == 0) return E3K_OK;
+  void* main = a->main;
+  void* side = a->fork ? a->side : main;
+  void* side2 = a->fork ? a->side2 : main;
+  void* side3 = a->fork ? a->side3 : main;
+  const e3k_layer_radial& r = a->rad;
+  const bool need_last = a->gb_last != nullptr;
+  bool need_hidden = false;
+  for (int i = 0; i < d.n_hidden; ++i) need_hidden = need_hidden || a->gb_hidden[i];
+  const bool need_radial_side = need_last || need_hidden || a->need_radial;
+  const bool need_post = a->gb_post != nullptr, need_lin1 = a->gb_lin1 != nullptr;
+  const bool want_sc = has_sc && (a->gb_sc || a->need_attrs);
+  const bool need_x1 = a->need_x || need_lin1;
+  if (!a->gy || !a->g_conv || !a->g_mid || !a->conv) return E3K_ERR_INVALID;
+
+  // gate' -> gradient of the convolution output; both readers of it in one call
+  E3K_TRY(e3k_gate_bwd(a->conv, a->gy, nullptr, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->g_conv,
+                       main));
+  if (!d.post_in_covered && hipMemsetAsync(a->g_mid, 0, sizeof(float) * a->N * d.d_mid, (hipStream_t)main) != hipSuccess)
+    return E3K_ERR_LAUNCH;
+  {
+    Seg g;
+    g.add(L, POST_DGRAD, a->g_conv, a->w_post, a->g_mid, a->N);
+    if (a->need_x) {
+      if (!a->g_xcf) return E3K_ERR_INVALID;
+      const bool covered = has_sc ? d.sc_in_covered : d.lin1_in_covered;
+      if (!covered && hipMemsetAsync(a->g_xcf, 0, sizeof(float) * a->N * d.d_in, (hipStream_t)main) != hipSuccess) return E3K_ERR_LAUNCH;
+      if (has_sc) g.add_keyed(L, SC_DGRAD, a->g_conv, a->m, a->g_xcf, a->N, a->perm, a->bounds, a->n_keys);
+    }
+    E3K_TRY(g.run(0, main));
+  }
+  // weight gradients that only need g_conv: off the critical path (forked) or together with linear_1's below
+  auto keyed_weight_grads = [&]() -> int {
+    E3K_TRY(edge(L, 1, side3, side2));
+    if (a->need_attrs && hipMemsetAsync(a->ga, 0, sizeof(float) * a->n_keys * d.V, (hipStream_t)side2) != hipSuccess) return E3K_ERR_LAUNCH;
+    E3K_TRY(e3k_keyed_weights_bwd(a->a_rep, a->w_sc, a->gm, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m,
+                                  a->need_attrs ? a->ga : nullptr, a->gb_sc, a->acc_sc, a->kw_ws, side2));
+    if (a->need_attrs) {
+      if (hipMemsetAsync(a->g_attrs, 0, sizeof(float) * a->N * d.V, (hipStream_t)side2) != hipSuccess) return E3K_ERR_LAUNCH;
+      const int tot = a->n_keys * d.V;
+      hipLaunchKernelGGL(e3k::scatter_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->ga, a->reps, a->bounds,
+                         a->n_keys, d.V, a->g_attrs);
+    }
+    return E3K_OK;
+  };
+  auto weight_grads = [&](bool with_g_conv, bool with_lin1, void* st) -> int {
+    Seg g;
+    if (with_g_conv && need_post) g.add(L, POST_WGRAD, a->mid, a->gb_post, const_cast<float*>(a->g_conv), a->N);
+    if (with_g_conv && want_sc) {
+      if (hipMemsetAsync(a->gm, 0, sizeof(float) * a->n_keys * d.ld_m, (hipStream_t)st) != hipSuccess) return E3K_ERR_LAUNCH;
+      g.add_keyed(L, SC_WGRAD, a->x_cf, a->gm, const_cast<float*>(a->g_conv), a->N, a->perm, a->bounds, a->n_keys);
+    }
+    if (with_lin1 && need_lin1) g.add(L, LIN1_WGRAD, a->x_cf, a->gb_lin1, a->g_x1, a->N);
+    return g.run(1, st);
+  };
+  if (side3 != main && (need_post || want_sc)) {
+    E3K_TRY(edge(L, 0, main, side3));
+    E3K_TRY(weight_grads(true, false, side3));
+    if (want_sc) E3K_TRY(keyed_weight_grads());
+  }
+  // tensor product
+  if (need_x1) {
+    if (!a->g_x1) return E3K_ERR_INVALID;
+    if (!d.tp_bwd_x_overwrites && hipMemsetAsync(a->g_x1, 0, sizeof(float) * a->N * d.d_x1, (hipStream_t)main) != hipSuccess)
+      return E3K_ERR_LAUNCH;
+    Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
+    E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+  }
+  if (need_radial_side && a->E > 0) {
+    if (!a->g_w) return E3K_ERR_INVALID;
+    {
+      Timed t(L, E3K_PROF_TP_BWD_W, main, a->N, a->E);
+      E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, main));
+    }
+    E3K_TRY(edge(L, 2, main, side));
+    const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
+    if (r.use_table) {
+      Timed t(L, E3K_PROF_RTABLE_BWD, side, r.R, r.E);
+      E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
+      g_rows = a->g_T;
+    }
+    if (need_last) {
+      Seg g;
+      g.add(L, LAST_WGRAD, r.h, a->gb_last, const_cast<float*>(g_rows), r.R);
+      E3K_TRY(g.run(1, side));
+    }
+    if (need_hidden || a->need_radial) {
+      Seg g;
+      g.add(L, LAST_DGRAD, g_rows, r.w_last, a->g_h, r.R);
+      E3K_TRY(g.run(0, side));
+      float* gws[4] = {a->gb_hidden[0], a->gb_hidden[1], a->gb_hidden[2], a->gb_hidden[3]};
+      const float* zs[4] = {r.z[0], r.z[1], r.z[2], r.z[3]};
+      E3K_TRY(e3k_mlp_hidden_bwd(r.radial, r.R, d.k0, d.h, d.n_hidden, r.w_hidden, d.alphas, d.act, d.cst, zs, a->g_h, gws,
+                                 a->need_radial ? a->g_radial : nullptr, side));
+    }
+  }
+  // linear_1's input gradient on top of the self-connection's
+  if (a->need_x) {
+    Seg g;
+    g.add(L, has_sc ? LIN1_DGRAD_ACC : LIN1_DGRAD, a->g_x1, a->w_lin1, a->g_xcf, a->N);
+    E3K_TRY(g.run(0, main));
+    if (!a->in_cf && !L->in_blocks.empty()) {
+      if (!a->g_x) return E3K_ERR_INVALID;
+      E3K_TRY(e3k_relayout(a->g_xcf, a->N, d.d_in, L->in_blocks.data(), (int32_t)L->in_blocks.size(), 0, a->g_x, main));
+    }
+  }
+  if (side3 != main) {
+    if (need_lin1) {
+      E3K_TRY(edge(L, 3, main, side3));
+      E3K_TRY(weight_grads(false, true, side3));
+    }
+  } else if (need_post || need_lin1 || want_sc) {
+    E3K_TRY(weight_grads(true, true, main));
+    if (want_sc) E3K_TRY(keyed_weight_grads());
+  }
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}

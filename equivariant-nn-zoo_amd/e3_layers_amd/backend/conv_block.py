@@ -40,10 +40,11 @@ BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w
 class ConvBlockPlan:
     """Static description of one layer (specs own their cached launch descriptors)."""
 
-    def __init__(self, *, in_blocks, lin1_spec, mlp_alphas, mlp_act, mlp_cst, last_spec, tp_plan, post_spec, scale,
+    def __init__(self, *, in_blocks, lin1_spec, mlp_alphas, mlp_act, mlp_cst, mlp_k0, last_spec, tp_plan, post_spec, scale,
                  sc_spec, sc_m_off, sc_ld_m, gate_spec):
         self.in_blocks, self.lin1_spec = in_blocks, lin1_spec
         self.mlp_alphas, self.mlp_act, self.mlp_cst, self.last_spec = tuple(mlp_alphas), mlp_act, float(mlp_cst), last_spec
+        self.mlp_k0 = int(mlp_k0)
         self.tp_plan, self.post_spec, self.scale = tp_plan, post_spec, float(scale)
         self.sc_spec, self.sc_m_off, self.sc_ld_m = sc_spec, tuple(sc_m_off) if sc_m_off is not None else None, sc_ld_m
         self.gate_spec = gate_spec
@@ -351,5 +352,10 @@ class ConvBlockFn(torch.autograd.Function):
 
 def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups, in_cf: bool, out_cf: bool, fork: bool,
                w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None, nxt=None):
+    from . import conv_native
+
+    if conv_native.ENABLED and conv_native.native_layer(plan) is not None:      # the same sequence issued by csrc/e3k_layer.hip
+        return conv_native.NativeConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
+                                                   nxt, w_lin1, w_post, w_sc, w_last, *w_hidden)
     return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
                              w_lin1, w_post, w_sc, w_last, *w_hidden)

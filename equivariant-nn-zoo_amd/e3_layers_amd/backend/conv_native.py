@@ -1,0 +1,464 @@
+"""The fused convolution block through the native layer executor (``csrc/e3k_layer.hip``).
+
+Same arithmetic, same kernels and the same stream layout as ``backend/conv_block.py`` -- which stays as the readable
+definition of the sequence and serves whatever this path declines -- but the launches of a layer's forward (and of its
+backward) are issued by ONE C call: Python allocates the outputs (two or three buffers per pass instead of twenty
+tensors), fills one argument struct and returns.  Reference: ``FactorizedConvolution.forward`` + ``Gate``
+(``e3_layers/nn/message_passing.py:91-124, 249``).
+
+Host time per layer: 0.22 -> 0.05 ms forward, 0.30 -> 0.07 ms backward (32 molecules, where the step is host-bound).
+``E3K_LAYER_NATIVE=0`` keeps the Python sequence.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional
+
+import torch
+
+from . import lib as L
+from . import ops, radial_table
+
+ENABLED = int(os.environ.get("E3K_LAYER_NATIVE", "1"))
+AHEAD_STATS = [0]
+PROF_KINDS = {"tp_fwd": 0, "tp_bwd_x": 1, "tp_bwd_w": 2, "rtable_fwd": 3, "rtable_bwd": 4, "radial_last_fwd": 5}
+_LAYERS: List["NativeLayer"] = []      # every layer object created (bench.py arms / reads their per-kernel timers)
+
+
+MAX_ROUNDS = 4
+
+
+class NativeLayer:
+    """The static description of one layer handed to ``e3k_layer_create`` (the ctypes arrays stay referenced here)."""
+
+    def __init__(self, plan):
+        self.plan = plan
+        self.handles = {}          # device index -> e3k_layer*
+        self.keep = []             # ctypes arrays referenced by the descriptor until create() has copied them
+        self.ok = True
+        try:
+            self.desc = self._describe(plan)
+        except NotImplementedError:
+            self.ok = False
+        _LAYERS.append(self)
+
+    def _set(self, rounds) -> L.GemmSet:
+        """``rounds``: [(ctypes problem array, n)] -- concatenated round-major (problems of one round write distinct
+        blocks, a later round accumulates on top of the earlier ones: the executor issues them in order)."""
+        if not 1 <= len(rounds) <= MAX_ROUNDS:
+            raise NotImplementedError("template set with more rounds than the executor takes")
+        total = sum(n for _, n in rounds)
+        arr = (L.GemmProblem * total)()
+        gs = L.GemmSet()
+        pos = 0
+        for r, (src, n) in enumerate(rounds):
+            gs.round_start[r] = pos
+            for i in range(n):
+                C.memmove(C.byref(arr, (pos + i) * C.sizeof(L.GemmProblem)), C.byref(src, i * C.sizeof(L.GemmProblem)),
+                          C.sizeof(L.GemmProblem))
+            pos += n
+        gs.round_start[len(rounds)] = pos
+        self.keep.append(arr)
+        gs.p, gs.n, gs.n_rounds = arr, total, len(rounds)
+        return gs
+
+    def _describe(self, plan) -> L.LayerDesc:
+        d = L.LayerDesc()
+        lin1, post, last, sc = plan.lin1_spec, plan.post_spec, plan.last_spec, plan.sc_spec
+        has_sc = sc is not None
+        T = ops._templates
+        d.lin1_fwd = self._set(T(lin1, ("fwd", 1.0, False, 0, 1.0, False), lambda: ops._lin_fwd_templates(lin1, 1.0, False, 0, 1.0, False)).rounds)
+        d.lin1_dgrad = self._set(T(lin1, ("dgrad", 1.0, False), lambda: ops._lin_dgrad_templates(lin1, 1.0, False)).rounds)
+        d.lin1_dgrad_acc = self._set(T(lin1, ("dgrad", 1.0, True), lambda: ops._lin_dgrad_templates(lin1, 1.0, True)).rounds)
+        d.lin1_wgrad = self._set(T(lin1, ("wgrad", 1.0), lambda: ops._lin_wgrad_templates(lin1, 1.0)).rounds)
+        sc_ = plan.scale
+        d.post_fwd = self._set(T(post, ("fwd", sc_, has_sc, 0, 1.0, False), lambda: ops._lin_fwd_templates(post, sc_, has_sc, 0, 1.0, False)).rounds)
+        d.post_dgrad = self._set(T(post, ("dgrad", sc_, False), lambda: ops._lin_dgrad_templates(post, sc_, False)).rounds)
+        d.post_wgrad = self._set(T(post, ("wgrad", sc_), lambda: ops._lin_wgrad_templates(post, sc_)).rounds)
+        if has_sc:
+            d.sc_fwd = self._set(ops._grouped_templates(sc, plan.sc_m_off, "fwd"))
+            d.sc_dgrad = self._set(ops._grouped_templates(sc, plan.sc_m_off, "dgrad"))
+            d.sc_wgrad = self._set(ops._grouped_templates(sc, plan.sc_m_off, "wgrad"))
+            kw = ops._kw_array(sc, plan.sc_m_off)
+            self.keep.append(kw)
+            d.kw, d.n_kw, d.V, d.ld_m = kw, len(sc.instr), sc.v, plan.sc_ld_m
+        d.last_fwd = self._set(T(last, ("fwd", 1.0, False, 0, 1.0, False), lambda: ops._lin_fwd_templates(last, 1.0, False, 0, 1.0, False)).rounds)
+        d.last_dgrad = self._set(T(last, ("dgrad", 1.0, False), lambda: ops._lin_dgrad_templates(last, 1.0, False)).rounds)
+        d.last_wgrad = self._set(T(last, ("wgrad", 1.0), lambda: ops._lin_wgrad_templates(last, 1.0)).rounds)
+        gate = plan.gate_spec.c_array()
+        self.keep.append(gate)
+        d.gate, d.n_gate = gate, len(plan.gate_spec.segs)
+        blocks = tuple(b for b in plan.in_blocks if b[1] > 1 and b[2] > 1)
+        if blocks:
+            arr = ops._blocks(blocks)
+            self.keep.append(arr)
+            d.in_blocks, d.n_in_blocks = arr, len(blocks)
+        n_hidden = len(plan.mlp_alphas)
+        if not (1 <= n_hidden <= 4) or plan.mlp_act not in ops.ACT_IDS:
+            raise NotImplementedError("radial MLP shape")
+        d.k0, d.h, d.n_hidden, d.act, d.cst = plan.mlp_k0, last.d_in, n_hidden, ops.ACT_IDS[plan.mlp_act], plan.mlp_cst
+        for i, al in enumerate(plan.mlp_alphas):
+            d.alphas[i] = al
+        d.d_in, d.d_x1, d.d_mid, d.d_conv, d.d_out, d.W = lin1.d_in, lin1.d_out, post.d_in, post.d_out, plan.gate_spec.out_dim, last.d_out
+        d.post_in_covered, d.lin1_in_covered, d.post_out_covered = int(post.in_covered), int(lin1.in_covered), int(post.out_covered)
+        d.sc_in_covered = int(sc.in_covered) if has_sc else 1
+        d.sc_out_covered = int(sc.out_covered) if has_sc else 1
+        if plan.gate_spec.in_dim != post.d_out or (has_sc and (sc.d_out != post.d_out or sc.d_in != lin1.d_in)):
+            raise NotImplementedError("layer dims")
+        return d
+
+    def handle(self, device) -> Optional[int]:
+        if not self.ok:
+            return None
+        idx = device.index if device.index is not None else torch.cuda.current_device()
+        h = self.handles.get(idx)
+        if h is None:
+            self.desc.tp = self.plan.tp_plan.handle(device)
+            self.desc.tp_bwd_x_overwrites = int(self.plan.tp_plan.bwd_x_overwrites(device))
+            out = C.c_void_p()
+            with torch.cuda.device(idx):
+                L.check(L.load().e3k_layer_create(C.byref(self.desc), C.byref(out)), "e3k_layer_create")
+            h = self.handles[idx] = out.value
+        return h
+
+    # ---- per-kernel timers (bench.py) ----
+    def profile(self, capacity: int) -> None:
+        for h in self.handles.values():
+            L.check(L.load().e3k_layer_profile(h, capacity), "e3k_layer_profile")
+
+    def profile_read(self, kind: str):
+        out = []
+        cap = 4096
+        ms, n, e = (C.c_float * cap)(), (C.c_int64 * cap)(), (C.c_int64 * cap)()
+        for h in self.handles.values():
+            cnt = L.load().e3k_layer_profile_read(h, PROF_KINDS[kind], ms, n, e, cap)
+            if cnt < 0:
+                L.check(cnt, "e3k_layer_profile_read")
+            out += [(float(ms[i]), int(n[i]), int(e[i])) for i in range(cnt)]
+        return out
+
+    def __del__(self):
+        try:
+            lib = L.load()
+            for h in self.handles.values():
+                lib.e3k_layer_destroy(h)
+        except Exception:
+            pass
+
+
+def native_layer(plan) -> Optional[NativeLayer]:
+    nl = plan.__dict__.get("_native")
+    if nl is None:
+        nl = plan.__dict__["_native"] = NativeLayer(plan)
+    return nl if nl.ok else None
+
+
+def _ptr(t, off: int = 0):
+    return None if t is None else t.data_ptr() + 4 * off
+
+
+class _Carve:
+    """Offsets (in floats, 64-float aligned) of the pieces of one buffer."""
+
+    __slots__ = ("total", "off")
+
+    def __init__(self):
+        self.total, self.off = 0, {}
+
+    def add(self, name: str, numel: int) -> None:
+        self.off[name] = self.total
+        self.total += -(-int(numel) // 64) * 64
+
+    def alloc(self, dev) -> torch.Tensor:
+        return torch.empty(max(self.total, 64), device=dev, dtype=torch.float32)
+
+
+def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, keep: bool, w_last, w_hidden, buf, carve, w, t_tab):
+    r = edge_radial.shape[0]
+    rad.R, rad.E, rad.keep = r, n_edges, int(keep)
+    rad.use_table = int(table is not None)
+    rad.radial = edge_radial.data_ptr()
+    if table is not None:
+        bin32, t, ptr, perm = table
+        rad.knots = radial_table.KNOTS
+        rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
+        rad.T = t_tab.data_ptr()
+    rad.w_last = w_last.data_ptr()
+    for i, wh in enumerate(w_hidden):
+        rad.w_hidden[i] = wh.data_ptr()
+    rad.h = _ptr(buf, carve.off["h"])
+    if keep:
+        for i in range(len(w_hidden)):
+            rad.z[i] = _ptr(buf, carve.off[f"z{i}"])
+    rad.w = w.data_ptr()
+
+
+def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
+    """Buffers of one radial branch: (activations buffer, its carve, w [E, W], table rows [R, W] or None)."""
+    r, hdim, width = edge_radial.shape[0], plan.last_spec.d_in, plan.last_spec.d_out
+    carve = _Carve()
+    carve.add("h", r * hdim)
+    if keep:
+        for i in range(len(plan.mlp_alphas)):
+            carve.add(f"z{i}", r * hdim)
+    buf = carve.alloc(dev)
+    w = torch.empty(n_edges, width, device=dev, dtype=torch.float32)
+    t_tab = torch.empty(r, width, device=dev, dtype=torch.float32) if table is not None else None
+    return buf, carve, w, t_tab
+
+
+class NativeConvBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf: bool, out_cf: bool, fork: bool, table, nxt,
+                w_lin1, w_post, w_sc, w_last, *w_hidden):
+        from . import conv_block
+
+        L.require_cuda(x, edge_radial, sh)
+        x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
+        dev = x.device
+        layer = native_layer(plan).handle(dev)
+        main = torch.cuda.current_stream(dev)
+        fork = bool(fork) and not torch.cuda.is_current_stream_capturing()
+        side = ops.side_stream(dev, 0) if fork else main
+        side2 = ops.side_stream(dev, 1) if fork else main
+        keep = any(ctx.needs_input_grad)
+        has_sc = plan.sc_spec is not None
+        n, e = x.shape[0], sh.shape[0]
+        a = L.LayerFwdArgs()
+        a.N, a.E = n, e
+        a.in_cf, a.out_cf, a.keep, a.fork = int(in_cf), int(out_cf), int(keep), int(fork)
+        a.main, a.side, a.side2 = main.cuda_stream, side.cuda_stream, side2.cuda_stream
+        a.x, a.sh = x.data_ptr(), sh.data_ptr()
+        a.src, a.dst_ptr, a.dst_perm = topo.src.data_ptr(), topo.dst_ptr.data_ptr(), topo.dst_perm.data_ptr()
+        a.w_lin1, a.w_post = w_lin1.data_ptr(), w_post.data_ptr()
+        # --- radial branch: this layer's (or the look-ahead's result), and the next layer's look-ahead
+        pref, plan.prefetched = plan.prefetched, None
+        if pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork, "native"):
+            rbuf, rcarve, w, t_tab = pref[1]
+            own_table = None
+            a.has_w = 1
+            AHEAD_STATS[0] += 1
+            conv_block.AHEAD_STATS[0] += 1
+        else:
+            with conv_block._on(side, main):       # (buffers used on the radial stream are allocated on it)
+                rbuf, rcarve, w, t_tab = _radial_alloc(plan, edge_radial, table, e, keep, dev)
+            own_table = t_tab
+        _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab)
+        nxt_keep = None
+        if nxt is not None and fork and conv_block.LOOK_AHEAD:
+            plan_n, w_last_n, w_hidden_n = nxt
+            nl_n = native_layer(plan_n)
+            if nl_n is not None:
+                with conv_block._on(side, main):
+                    nbuf, ncarve, w_n, t_n = _radial_alloc(plan_n, edge_radial, table, e, keep, dev)
+                rad_n = L.LayerRadial()
+                _radial_struct(rad_n, plan_n, edge_radial, table, e, keep, w_last_n, w_hidden_n, nbuf, ncarve, w_n, t_n)
+                a.next, a.next_rad = nl_n.handle(dev), C.pointer(rad_n)
+                nxt_keep = (rad_n, nbuf, ncarve, w_n, t_n, plan_n, w_last_n)
+        # --- node side buffers: one allocation
+        carve = _Carve()
+        need_relayout = (not in_cf) and bool(tuple(b for b in plan.in_blocks if b[1] > 1 and b[2] > 1))
+        if need_relayout:
+            carve.add("x_cf", n * plan.lin1_spec.d_in)
+        if has_sc:
+            carve.add("a_rep", groups.n_keys * plan.sc_spec.v)
+            carve.add("m", groups.n_keys * plan.sc_ld_m)
+        carve.add("conv", n * plan.post_spec.d_out)
+        carve.add("x1", n * plan.lin1_spec.d_out)
+        carve.add("mid", n * plan.post_spec.d_in)
+        buf = carve.alloc(dev)
+        y = torch.empty(n, plan.gate_spec.out_dim, device=dev, dtype=torch.float32)
+        off = carve.off
+        if need_relayout:
+            a.x_cf = _ptr(buf, off["x_cf"])
+        if has_sc:
+            node_attrs = L.f32c(node_attrs)
+            a.node_attrs, a.w_sc = node_attrs.data_ptr(), w_sc.data_ptr()
+            a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
+            a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
+        a.conv, a.x1, a.mid, a.y = _ptr(buf, off["conv"]), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
+        L.check(L.load().e3k_layer_fwd(layer, C.byref(a)), "e3k_layer_fwd")
+        if own_table is not None:      # the a-posteriori error guard of the table just built (radial stream)
+            with conv_block._on(side, main):
+                radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, own_table)
+        if fork:      # what the side streams touched must not return to the allocator before they are done with it
+            for t in (buf, x, node_attrs if has_sc else None):
+                if t is not None:
+                    t.record_stream(side2)
+            for t in (edge_radial, w, rbuf, t_tab):
+                if t is not None:
+                    t.record_stream(side)
+                    t.record_stream(main)
+            if table is not None:
+                for t in table:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)
+        if nxt_keep is not None:
+            rad_n, nbuf, ncarve, w_n, t_n, plan_n, w_last_n = nxt_keep
+            if t_n is not None:
+                with conv_block._on(side, main):
+                    radial_table.guard(plan_n.guard_key if plan_n.guard_key is not None else w_last_n, t_n)
+            # (the rows and the table themselves are the key: held here, their identity cannot be reused by a later batch)
+            plan_n.prefetched = ((edge_radial, table, keep, fork, "native"), (nbuf, ncarve, w_n, t_n))
+        if keep:
+            ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
+                                  w_last, *w_hidden)
+            ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
+            ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        from . import conv_block
+
+        plan, topo, groups, in_cf, out_cf, fork, n_hidden, table, carve, rcarve, need_relayout = ctx.cfg
+        saved = ctx.saved_tensors
+        x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last = saved[:10]
+        w_hidden = saved[10:10 + n_hidden]
+        need = ctx.needs_input_grad
+        need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
+        p0 = 12
+        need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
+        need_hidden = need[p0 + 4:]
+        if torch.is_grad_enabled() or need_sh:
+            raise RuntimeError(
+                "the fused convolution block serves first-order training only (no gradient w.r.t. the spherical harmonics, "
+                "no create_graph=True): MessagePassing takes the composed path for those by itself; set E3K_CONV_BLOCK=0 "
+                "if this was reached another way")
+        has_sc = plan.sc_spec is not None
+        dev = gy.device
+        layer = native_layer(plan).handle(dev)
+        main = torch.cuda.current_stream(dev)
+        fork = fork and not torch.cuda.is_current_stream_capturing()
+        side = ops.side_stream(dev, 0) if fork else main
+        side2 = ops.side_stream(dev, 1) if fork else main
+        side3 = ops.side_stream(dev, 2) if (fork and ops.WGRAD_SIDE) else main
+        gy = L.f32c(gy)
+        n, e, r = gy.shape[0], sh.shape[0], edge_radial.shape[0]
+        lin1, post, last, sc = plan.lin1_spec, plan.post_spec, plan.last_spec, plan.sc_spec
+        off = carve.off
+        a = L.LayerBwdArgs()
+        a.N, a.E = n, e
+        a.in_cf, a.out_cf, a.fork = int(in_cf), int(out_cf), int(fork)
+        a.need_x, a.need_attrs, a.need_radial = int(need_x), int(bool(need_attrs and has_sc)), int(need_radial)
+        a.main, a.side, a.side2, a.side3 = main.cuda_stream, side.cuda_stream, side2.cuda_stream, side3.cuda_stream
+        a.x_cf = _ptr(buf, off["x_cf"]) if need_relayout else x_in.data_ptr()
+        a.sh, a.x1, a.mid, a.conv = sh.data_ptr(), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), _ptr(buf, off["conv"])
+        a.src, a.dst, a.dst_ptr, a.dst_perm = topo.src.data_ptr(), topo.dst.data_ptr(), topo.dst_ptr.data_ptr(), topo.dst_perm.data_ptr()
+        a.src_ptr, a.src_perm = topo.src_ptr.data_ptr(), topo.src_perm.data_ptr()
+        a.w_lin1, a.w_post = w_lin1.data_ptr(), w_post.data_ptr()
+        if has_sc:
+            a.a_rep, a.m, a.w_sc = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"]), w_sc.data_ptr()
+            a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
+        keep_z = True
+        _radial_struct(a.rad, plan, edge_radial, table, e, keep_z, w_last, w_hidden, rbuf, rcarve, w, None if table is None else w)
+        a.rad.T = None
+        a.gy = gy.data_ptr()
+        # ---- gradient buffers: the flat gradient buffer (sink) or zero-filled temporaries handed back to autograd
+        rets = {}
+
+        def grad_buffer(name, weight, needed):
+            if not needed:
+                return None
+            sink = ops._sink_for(weight)
+            if sink is not None:
+                return sink
+            rets[name] = torch.zeros_like(weight)
+            return rets[name].view(-1)
+
+        gb_lin1, gb_post = grad_buffer("lin1", w_lin1, need_lin1), grad_buffer("post", w_post, need_post)
+        gb_last = grad_buffer("last", w_last, need_last)
+        gb_hidden = [grad_buffer(f"h{i}", wh, need_hidden[i]) for i, wh in enumerate(w_hidden)]
+        gb_sc = None
+        if has_sc and need_sc:
+            sink = ops._sink_for(w_sc)
+            if sink is not None:
+                gb_sc, a.acc_sc = sink, 1
+            else:
+                rets["sc"] = ops._kw_weight_buffer(w_sc, sc)
+                gb_sc, a.acc_sc = rets["sc"].view(-1), 0
+        a.gb_lin1, a.gb_post, a.gb_sc, a.gb_last = _ptr(gb_lin1), _ptr(gb_post), _ptr(gb_sc), _ptr(gb_last)
+        for i, g in enumerate(gb_hidden):
+            a.gb_hidden[i] = _ptr(g)
+        need_radial_side = need_last or need_radial or any(need_hidden)
+        want_sc = has_sc and (need_sc or need_attrs)
+        # ---- scratch: one allocation
+        sc_ = _Carve()
+        sc_.add("g_conv", n * post.d_out)
+        sc_.add("g_mid", n * post.d_in)
+        if need_x or need_lin1:
+            sc_.add("g_x1", n * lin1.d_out)
+        g_x = None
+        if need_x:
+            if need_relayout:
+                sc_.add("g_xcf", n * lin1.d_in)
+                g_x = torch.empty(n, lin1.d_in, device=dev, dtype=torch.float32)
+            else:
+                g_x = torch.empty(n, lin1.d_in, device=dev, dtype=torch.float32)
+        if need_radial_side:
+            sc_.add("g_w", e * last.d_out)
+            if table is not None:
+                sc_.add("g_T", r * last.d_out)
+                sc_.add("table_ws", int(L.load().e3k_rtable_bwd_workspace_floats(radial_table.KNOTS, last.d_out)))
+            if need_radial or any(need_hidden):
+                sc_.add("g_h", r * last.d_in)
+        if want_sc:
+            sc_.add("gm", groups.n_keys * plan.sc_ld_m)
+            if need_attrs:
+                sc_.add("ga", groups.n_keys * sc.v)
+                sc_.add("kw_ws", int(L.load().e3k_keyed_weights_bwd_workspace(ops._kw_array(sc, plan.sc_m_off), len(sc.instr),
+                                                                               groups.n_keys, sc.v)))
+        work = sc_.alloc(dev)
+        so = sc_.off
+        a.g_conv, a.g_mid = _ptr(work, so["g_conv"]), _ptr(work, so["g_mid"])
+        if "g_x1" in so:
+            a.g_x1 = _ptr(work, so["g_x1"])
+        if need_x:
+            if need_relayout:
+                a.g_xcf, a.g_x = _ptr(work, so["g_xcf"]), g_x.data_ptr()
+            else:
+                a.g_xcf = g_x.data_ptr()
+        for k in ("g_w", "g_T", "table_ws", "g_h", "gm", "ga", "kw_ws"):
+            if k in so:
+                setattr(a, k, _ptr(work, so[k]))
+        g_attrs = g_radial = None
+        if need_attrs and has_sc:
+            with conv_block._on(side2, main):
+                g_attrs = torch.empty(ctx.attrs_shape, device=dev, dtype=torch.float32)
+            a.g_attrs = g_attrs.data_ptr()
+        if need_radial:
+            with conv_block._on(side, main):
+                g_radial = torch.empty_like(edge_radial)
+            a.g_radial = g_radial.data_ptr()
+        L.check(L.load().e3k_layer_bwd(layer, C.byref(a)), "e3k_layer_bwd")
+        if fork:
+            for st in (side, side2, side3):
+                if st is not main:
+                    work.record_stream(st)
+            for t in (buf, gy, x_in):
+                if t is not None:
+                    t.record_stream(side3)
+                    t.record_stream(side2)
+            for t in (rbuf, w, sh, edge_radial):
+                t.record_stream(side)
+            if table is not None:
+                for t in table:
+                    if isinstance(t, torch.Tensor):
+                        t.record_stream(side)
+        # parameter gradients handed back to autograd (no gradient sink) are consumed on THIS stream
+        if "post" in rets or "lin1" in rets:
+            conv_block._wait(main, side3)
+        if "sc" in rets:
+            conv_block._wait(main, side2)
+        if "last" in rets or any(f"h{i}" in rets for i in range(n_hidden)):
+            conv_block._wait(main, side)
+        if fork:
+            for t in rets.values():
+                t.record_stream(main)
+        if ops.GRAD_READY is not None:
+            needs = (need_lin1, need_post, need_sc or not has_sc, need_last, *need_hidden)
+            if all(needs) and not rets:          # every weight gradient of the layer went to the sink
+                ops.GRAD_READY([w_lin1, w_post, w_last, *w_hidden] + ([w_sc] if has_sc else []))
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None,
+                rets.get("lin1"), rets.get("post"), rets.get("sc"), rets.get("last"), *[rets.get(f"h{i}") for i in range(n_hidden)])

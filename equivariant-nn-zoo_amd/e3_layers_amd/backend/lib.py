@@ -67,6 +67,52 @@ class GateSeg(C.Structure):
     ]
 
 
+class GemmSet(C.Structure):
+    _fields_ = [("p", C.POINTER(GemmProblem)), ("n", C.c_int32), ("n_rounds", C.c_int32), ("round_start", C.c_int32 * 5),
+                ("_pad", C.c_int32)]
+
+
+class LayerDesc(C.Structure):
+    _fields_ = ([("tp", C.c_void_p)]
+                + [(k, GemmSet) for k in ("lin1_fwd", "lin1_dgrad", "lin1_dgrad_acc", "lin1_wgrad", "post_fwd", "post_dgrad",
+                                          "post_wgrad", "sc_fwd", "sc_dgrad", "sc_wgrad", "last_fwd", "last_dgrad", "last_wgrad")]
+                + [("gate", C.POINTER(GateSeg)), ("n_gate", C.c_int32), ("n_in_blocks", C.c_int32), ("in_blocks", C.POINTER(Block)),
+                   ("kw", C.POINTER(KwInstr)), ("n_kw", C.c_int32), ("V", C.c_int32), ("ld_m", C.c_int64),
+                   ("k0", C.c_int32), ("h", C.c_int32), ("n_hidden", C.c_int32), ("act", C.c_int32), ("cst", C.c_float),
+                   ("alphas", C.c_float * 4)]
+                + [(k, C.c_int32) for k in ("d_in", "d_x1", "d_mid", "d_conv", "d_out", "W", "post_in_covered", "sc_in_covered",
+                                            "lin1_in_covered", "sc_out_covered", "post_out_covered", "tp_bwd_x_overwrites")])
+
+
+class LayerRadial(C.Structure):
+    _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
+                ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
+                ("bin_t", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
+                ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p)]
+
+
+class LayerFwdArgs(C.Structure):
+    _fields_ = ([("N", C.c_int64), ("E", C.c_int64)]
+                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "keep", "fork", "has_w", "n_keys")]
+                + [(k, C.c_void_p) for k in ("main", "side", "side2", "x", "node_attrs", "sh", "src", "dst_ptr", "dst_perm", "perm",
+                                             "bounds", "reps", "w_lin1", "w_post", "w_sc")]
+                + [("rad", LayerRadial), ("next", C.c_void_p), ("next_rad", C.POINTER(LayerRadial))]
+                + [(k, C.c_void_p) for k in ("x_cf", "a_rep", "m", "conv", "x1", "mid", "y")])
+
+
+class LayerBwdArgs(C.Structure):
+    _fields_ = ([("N", C.c_int64), ("E", C.c_int64)]
+                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "fork", "n_keys", "need_x", "need_attrs", "need_radial", "acc_sc")]
+                + [(k, C.c_void_p) for k in ("main", "side", "side2", "side3", "x_cf", "sh", "x1", "mid", "conv", "a_rep", "m",
+                                             "src", "dst", "dst_ptr", "dst_perm", "src_ptr", "src_perm", "perm", "bounds", "reps",
+                                             "w_lin1", "w_post", "w_sc")]
+                + [("rad", LayerRadial), ("gy", C.c_void_p)]
+                + [(k, C.c_void_p) for k in ("gb_lin1", "gb_post", "gb_sc", "gb_last")]
+                + [("gb_hidden", C.c_void_p * 4)]
+                + [(k, C.c_void_p) for k in ("g_x", "g_attrs", "g_radial", "g_conv", "g_mid", "g_x1", "g_xcf", "g_w", "g_T",
+                                             "table_ws", "g_h", "gm", "ga", "kw_ws")])
+
+
 # name -> (restype, argtypes); every symbol include/e3k.h declares must appear here (tests check it)
 _P, _I32, _I64, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 SIGNATURES = {
@@ -79,6 +125,12 @@ SIGNATURES = {
     "e3k_gemm_grouped_rebased": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _P, _I64, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_gemm_grouped": (C.c_int, [C.POINTER(GemmProblem), C.c_int, _P, _P, _I32, _I64, _I32, _P]),
     "e3k_gemm_multi": (C.c_int, [C.POINTER(GemmSegment), _I32, _I32, _P]),
+    "e3k_layer_create": (C.c_int, [C.POINTER(LayerDesc), C.POINTER(C.c_void_p)]),
+    "e3k_layer_destroy": (None, [_P]),
+    "e3k_layer_fwd": (C.c_int, [_P, C.POINTER(LayerFwdArgs)]),
+    "e3k_layer_bwd": (C.c_int, [_P, C.POINTER(LayerBwdArgs)]),
+    "e3k_layer_profile": (C.c_int, [_P, _I32]),
+    "e3k_layer_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),

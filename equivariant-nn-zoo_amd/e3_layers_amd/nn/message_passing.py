@@ -279,6 +279,7 @@ class MessagePassing(Module):
             plan = conv_block.ConvBlockPlan(
                 in_blocks=conv._in_blocks, lin1_spec=conv.linear_1.spec("cf", "cf"),
                 mlp_alphas=[1.0 / math.sqrt(m.h_in) for m in hidden], mlp_act=conv.fc.act_name, mlp_cst=hidden[0].cst,
+                mlp_k0=hidden[0].h_in,
                 last_spec=last._spec, tp_plan=conv.tp.tp.plan, post_spec=conv.tp.linear.spec("cf", "cf"),
                 scale=1.0 if conv.avg_num_neighbors is None else float(conv.avg_num_neighbors) ** -0.5,
                 sc_spec=sc_spec, sc_m_off=sc_m_off, sc_ld_m=sc_ld, gate_spec=self.equivariant_nonlin._spec)

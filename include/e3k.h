@@ -400,6 +400,122 @@ int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg, float* ex
                       int32_t ema_use_num_updates, float max_grad_norm, int32_t skip_nonfinite, float* state,
                       void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * A convolution layer as ONE call (csrc/e3k_layer.hip): FactorizedConvolution + Gate
+ * (e3_layers/nn/message_passing.py:91-124, 249) forward and backward -- the launch sequence of
+ * backend/conv_block.py issued from native code on the caller's streams, with the library's own events
+ * for the cross-stream edges.  The arithmetic is the kernels above, unchanged; what this removes is
+ * the host: ~15 ctypes calls, ~12 stream switches and ~20 tensor allocations per layer and pass
+ * (0.22 ms forward / 0.30 ms backward of Python per layer: at <= 128 molecules the whole training
+ * step was bound by it, at 256 it equalled the GPU time).
+ *
+ * A layer is described once (template sets as for e3k_gemm_rebased / e3k_gemm_grouped_rebased: byte
+ * offsets in the pointer fields; the arrays are copied).  Every buffer is the caller's (PyTorch's
+ * allocator): inputs, outputs, saved activations and scratch arrive as device pointers.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const e3k_gemm_problem* p;   /* n problems, round-major: round r = p[round_start[r] .. round_start[r + 1]) */
+  int32_t n;
+  int32_t n_rounds;            /* problems of one round write distinct blocks; round r + 1 accumulates on top of round r */
+  int32_t round_start[5];      /* (a Linear whose input block feeds two output blocks -- scalars and gates -- has a */
+  int32_t _pad;                /*  two-round input gradient) */
+} e3k_gemm_set;
+
+typedef struct {
+  const e3k_tp_plan* tp;
+  e3k_gemm_set lin1_fwd, lin1_dgrad, lin1_dgrad_acc, lin1_wgrad;
+  e3k_gemm_set post_fwd, post_dgrad, post_wgrad; /* post_fwd: conv (+)= scale * Linear(mid); accumulates iff a self-connection exists */
+  e3k_gemm_set sc_fwd, sc_dgrad, sc_wgrad;       /* keyed (e3k_gemm_grouped) templates; sc_fwd.n == 0: no self-connection */
+  e3k_gemm_set last_fwd, last_dgrad, last_wgrad; /* last layer of the radial MLP: [rows, h] -> [rows, W] */
+  const e3k_gate_seg* gate;
+  int32_t n_gate;
+  int32_t n_in_blocks;
+  const e3k_block* in_blocks;                    /* e3nn <-> cf relayout of the layer input */
+  const e3k_kw_instr* kw;
+  int32_t n_kw, V;
+  int64_t ld_m;
+  int32_t k0, h, n_hidden, act;                  /* radial MLP hidden chain (e3k_mlp_hidden_*) */
+  float cst;
+  float alphas[4];
+  int32_t d_in, d_x1, d_mid, d_conv, d_out, W;
+  int32_t post_in_covered, sc_in_covered, lin1_in_covered, sc_out_covered, post_out_covered, tp_bwd_x_overwrites;
+} e3k_layer_desc;
+
+typedef struct e3k_layer e3k_layer;
+int e3k_layer_create(const e3k_layer_desc* desc, e3k_layer** out);
+void e3k_layer_destroy(e3k_layer* layer);
+
+/* radial branch of a layer: hidden chain + last layer on R rows (R = E edges, or knots + 1 table rows) and, with the
+ * table, the interpolation to the E edges */
+typedef struct {
+  int64_t R, E;
+  int32_t use_table, keep, knots, _pad;
+  const float* radial;       /* [R, k0] */
+  const int32_t* bin;        /* table: centre knot per edge, */
+  const int32_t* bin_ptr;    /*        CSR by knot (backward), */
+  const int32_t* bin_perm;
+  const float* bin_t;        /*        offset per edge */
+  const float* w_last;
+  const float* w_hidden[4];
+  float* h;                  /* [R, h] out */
+  float* z[4];               /* [R, h] pre-activations (keep) */
+  float* T;                  /* table: [R, W] out; without the table unused */
+  float* w;                  /* [E, W] out */
+} e3k_layer_radial;
+
+typedef struct {
+  int64_t N, E;
+  int32_t in_cf, out_cf, keep, fork, has_w, n_keys;
+  void *main, *side, *side2;
+  const float *x, *node_attrs, *sh;
+  const int32_t *src, *dst_ptr, *dst_perm;
+  const int32_t *perm, *bounds;
+  const int64_t* reps;
+  const float *w_lin1, *w_post, *w_sc;
+  e3k_layer_radial rad;              /* this layer's radial branch (skipped when has_w: rad.w already holds the weights) */
+  const e3k_layer* next;             /* look-ahead: the next layer's radial branch, issued behind this layer's tensor product */
+  const e3k_layer_radial* next_rad;
+  float *x_cf, *a_rep, *m, *conv, *x1, *mid, *y;
+} e3k_layer_fwd_args;
+int e3k_layer_fwd(const e3k_layer* layer, const e3k_layer_fwd_args* a);
+
+typedef struct {
+  int64_t N, E;
+  int32_t in_cf, out_cf, fork, n_keys, need_x, need_attrs, need_radial, acc_sc;
+  void *main, *side, *side2, *side3;
+  /* saved by the forward */
+  const float *x_cf, *sh, *x1, *mid, *conv, *a_rep, *m;
+  const int32_t *src, *dst, *dst_ptr, *dst_perm, *src_ptr, *src_perm;
+  const int32_t *perm, *bounds;
+  const int64_t* reps;
+  const float *w_lin1, *w_post, *w_sc;
+  e3k_layer_radial rad;              /* as in the forward (h, z, w, radial, bins, weights) */
+  const float* gy;
+  /* gradient buffers (NULL = not needed); accumulated (gradient sink) or written into zero-filled temporaries */
+  float *gb_lin1, *gb_post, *gb_sc, *gb_last;
+  float* gb_hidden[4];
+  /* outputs */
+  float *g_x;        /* [N, d_in] in the layer input's layout (need_x) */
+  float *g_attrs;    /* [N, V] (need_attrs): zero-filled here, the per-key rows scattered to the keys' representatives */
+  float *g_radial;   /* [R, k0] (need_radial) */
+  /* scratch */
+  float *g_conv, *g_mid, *g_x1, *g_xcf, *g_w, *g_T, *table_ws, *g_h, *gm, *ga, *kw_ws;
+} e3k_layer_bwd_args;
+int e3k_layer_bwd(const e3k_layer* layer, const e3k_layer_bwd_args* a);
+
+/* Per-kernel timing of a layer's edge kernels (bench.py's roofline block: HIP events on the stream that runs the kernel).
+ * e3k_layer_profile(layer, capacity): capacity > 0 arms `capacity` event pairs per kind, 0 disarms.
+ * e3k_layer_profile_read: waits for the recorded pairs of `kind` and returns their count (<= cap), filling the elapsed
+ * milliseconds and the node / edge counts (table kinds: table rows / edges) of each launch. */
+#define E3K_PROF_TP_FWD 0
+#define E3K_PROF_TP_BWD_X 1
+#define E3K_PROF_TP_BWD_W 2
+#define E3K_PROF_RTABLE_FWD 3
+#define E3K_PROF_RTABLE_BWD 4
+#define E3K_PROF_RADIAL_LAST_FWD 5
+int e3k_layer_profile(e3k_layer* layer, int32_t capacity);
+int e3k_layer_profile_read(e3k_layer* layer, int32_t kind, float* ms, int64_t* n, int64_t* e, int32_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,9 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
         'printf("%zu %zu %zu %zu\\n", sizeof(e3k_gemm_problem), sizeof(e3k_tp_group), sizeof(e3k_block), sizeof(e3k_gate_seg));\n'
         'printf("%zu %zu %zu %zu\\n", offsetof(e3k_gemm_problem, M1), offsetof(e3k_gemm_problem, a_r1), offsetof(e3k_gemm_problem, alpha), offsetof(e3k_tp_group, coeff));\n'
         'printf("%zu %zu\\n", sizeof(e3k_kw_instr), offsetof(e3k_kw_instr, u));\n'
+        'printf("%zu %zu %zu %zu %zu\\n", sizeof(e3k_gemm_segment), sizeof(e3k_layer_desc), sizeof(e3k_layer_radial), sizeof(e3k_layer_fwd_args), sizeof(e3k_layer_bwd_args));\n'
+        'printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(e3k_gemm_segment, M1), offsetof(e3k_layer_desc, gate), offsetof(e3k_layer_desc, alphas), offsetof(e3k_layer_desc, tp_bwd_x_overwrites), offsetof(e3k_layer_fwd_args, rad), offsetof(e3k_layer_bwd_args, gb_hidden));\n'
+        'printf("%zu %zu %zu\\n", offsetof(e3k_layer_fwd_args, x_cf), offsetof(e3k_layer_bwd_args, kw_ws), offsetof(e3k_layer_radial, z));\n'
         "return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -53,6 +56,11 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
     assert sizes[:4] == [C.sizeof(L.GemmProblem), C.sizeof(L.TpGroup), C.sizeof(L.Block), C.sizeof(L.GateSeg)]
     assert sizes[4:8] == [L.GemmProblem.M1.offset, L.GemmProblem.a_r1.offset, L.GemmProblem.alpha.offset, L.TpGroup.coeff.offset]
     assert sizes[8:10] == [C.sizeof(L.KwInstr), L.KwInstr.u.offset]
+    assert sizes[10:15] == [C.sizeof(L.GemmSegment), C.sizeof(L.LayerDesc), C.sizeof(L.LayerRadial), C.sizeof(L.LayerFwdArgs),
+                            C.sizeof(L.LayerBwdArgs)]
+    assert sizes[15:21] == [L.GemmSegment.M1.offset, L.LayerDesc.gate.offset, L.LayerDesc.alphas.offset,
+                            L.LayerDesc.tp_bwd_x_overwrites.offset, L.LayerFwdArgs.rad.offset, L.LayerBwdArgs.gb_hidden.offset]
+    assert sizes[21:24] == [L.LayerFwdArgs.x_cf.offset, L.LayerBwdArgs.kw_ws.offset, L.LayerRadial.z.offset]
 
 
 def test_limits_agree_with_generated_header():
