@@ -297,8 +297,37 @@ def main():
     fence()
     ref_step = max_over_ranks(time.perf_counter() - t0) / n_ref if n_ref else None
 
+    from e3_layers_amd.backend import conv_native, radial_table
+
+    class _Ms:
+        """An elapsed time read back from the native layer executor's event pairs, in the shape of a torch event pair."""
+
+        def __init__(self, ms):
+            self.ms = ms
+
+        def elapsed_time(self, other):
+            return other.ms
+
+    def native_records(recs):
+        """Launches issued by csrc/e3k_layer.hip (HIP event pairs recorded there, on the launching stream)."""
+        for nl in conv_native._LAYERS:
+            plan = nl.plan
+            for kind in ("tp_fwd", "tp_bwd_x", "tp_bwd_w"):
+                for ms, n, e in nl.profile_read(kind):
+                    recs.setdefault(kind, []).append((_Ms(0.0), _Ms(ms), (n, e, plan.tp_plan)))
+            for kind in ("rtable_fwd", "rtable_bwd"):
+                for ms, rows, e in nl.profile_read(kind):
+                    recs.setdefault(kind, []).append((_Ms(0.0), _Ms(ms), (e, rows - 1, plan.last_spec.d_out)))
+            for ms, rows, e in nl.profile_read("radial_last_fwd"):
+                recs.setdefault("radial_last_fwd", []).append((_Ms(0.0), _Ms(ms), (rows, plan.last_spec.d_in, plan.last_spec.d_out)))
+            nl.profile(0)
+        return recs
+
     def timed_region():
         ops.PROFILE = {} if graph is None else None
+        if graph is None:
+            for nl in conv_native._LAYERS:
+                nl.profile(args.steps + 8)
         fence()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -306,6 +335,8 @@ def main():
         fence()
         seconds = time.perf_counter() - t0
         recs, ops.PROFILE = ops.PROFILE, None
+        if graph is None:
+            recs = native_records(recs)
         return max_over_ranks(seconds), recs, out
 
     elapsed, records, loss = timed_region()
@@ -316,10 +347,13 @@ def main():
         elapsed, records, loss = timed_region()
     if graph is not None:  # per-kernel events cannot be read back from a replayed graph: eager pass for the roofline block
         ops.PROFILE = {}
+        for nl in conv_native._LAYERS:
+            nl.profile(16)
         for _ in range(min(args.steps, 5)):
             step()
         torch.cuda.synchronize()
         records, ops.PROFILE = ops.PROFILE, None
+        records = native_records(records)
 
     # ---- outside the timed region: the pieces of a step on their own (rank 0 reports them) -------------------------
     def event_ms(fn, n):

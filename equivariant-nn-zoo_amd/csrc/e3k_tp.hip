@@ -181,62 +181,10 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX, int PART>
-__device__ __forceinline__ void tp_bwd_w_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  using S = Slots<L1>;
-  constexpr int D1 = 2 * L1 + 1;
-  const int u4 = u * 4;
-  const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
-  int woff4[S::NQ];
-  float cf[S::NQ];
-  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-    constexpr int Q = decltype(qc)::value;
-    woff4[Q] = uniform(g.w_off[Q] * 4);
-    cf[Q] = g.coeff[Q];
-  });
-  const int row_x = a.d_in * 4, row_w = a.W * 4;
-  float go[S::TOTAL];
-  {
-    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid;      // wave-uniform
-    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
-#pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k) go[OFF + k] = (grow + g.out_off[Q] + k * g.out_stride[Q])[u];
-    });
-  }
-  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int s = uniform(a.nbr[e]);
-    YRegs yc;
-    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
-    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
-    const __amdgpu_buffer_rsrc_t rgw = row_rsrc(a.g_w + (int64_t)e * a.W, row_w);
-    float xc[D1];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
-    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-      float tt[2 * L3 + 1];
-      CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
-      float dot = 0.0f;
-#pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k) dot = fmaf(go[OFF + k], tt[k], dot);
-      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, dot * cf[Q]), rgw, u4, woff4[Q], E3K_STREAM_AUX);
-    });
-  }
-}
-
 template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  if constexpr (FULL && !WITH_SH) {
-    if (a.g_w) {      // (always, without grad_sh: the C ABI rejects a call that asks for neither)
-      tp_bwd_w_body_full<L1, L3MAX, PART>(a, g, node, u);
-      return;
-    }
-  }
+  // (the buffer-addressed form of tp_fwd / tp_bwd_x was tried here too: 71 instead of 60 VGPRs, 7 instead of 8 waves per SIMD,
+  //  the step 3-5 % slower -- this kernel keeps the flat row pointers; it has no scalar-register spills to begin with)
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
