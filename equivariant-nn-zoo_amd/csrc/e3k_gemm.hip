@@ -45,7 +45,7 @@ struct GemmBatch {
   int reps[GEMM_MAXP];              // > 1: the problem stands for `reps` key groups (its tile range is reps equal sub-ranges);
   long long key_stride[GEMM_MAXP];  //      key t uses B + t*key_stride and the device pair group_dev + 2*t
   int tile_start[GEMM_MAXP + 1];
-  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad), bit4: 128-wide output tile (wgrad)
+  int flags[GEMM_MAXP];  // bit0: A float4-loadable, bits1-2: B mode (0 scalar, 1 n-contiguous vec, 2 k-contiguous vec), bit3: G float4-loadable (wgrad)
   int aux[GEMM_MAXP];    // wgrad: row splits; smallk: column tiles per block
   e3k_gemm_problem p[GEMM_MAXP];
 };
@@ -860,15 +860,15 @@ __device__ __forceinline__ void gemm_wgrad_body(const BlockProblem& bp_, float* 
   }
 }
 
-// one launch serves problems with 64-wide (N < 128) and 128-wide output tiles: the width is a per-problem flag
-template <bool OUTER>
+// (one kernel serving both tile widths by a per-problem flag was built and measured: 164 VGPRs and 51 KB of LDS for every
+//  problem -- three workgroups per CU -- made the 64-wide problems 55 % slower; a call issues one launch per width)
+template <bool OUTER, int TN>
 __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float As[WR * LDWA];
-  __shared__ __attribute__((aligned(16))) float Gs[WR * (128 + 4)];
+  __shared__ __attribute__((aligned(16))) float Gs[WR * (64 * TN + 4)];
   __shared__ float Vs[OUTER ? WR * LDV : 1];
   const BlockProblem bp_ = fetch_problem(gb);
-  if (bp_.flags & 16) gemm_wgrad_body<OUTER, 2>(bp_, As, Gs, Vs);
-  else gemm_wgrad_body<OUTER, 1>(bp_, As, Gs, Vs);
+  gemm_wgrad_body<OUTER, TN>(bp_, As, Gs, Vs);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1137,8 +1137,9 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
     const int rc = validate(problems[i], true);
     if (rc != E3K_OK) return rc;
   }
-  for (int mode = 0; mode < 2; ++mode) {  // plain | outer (x (x) attrs formed on the fly)
+  for (int mode = 0; mode < 4; ++mode) {  // (outer: x (x) attrs formed on the fly?, 128-wide output tile?)
     const bool outer = mode & 1;
+    const int tn = (mode & 2) ? 2 : 1;
     Batcher b;
     auto flush = [&]() -> int {
       if (!b.blocks) {
@@ -1146,21 +1147,23 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
         return E3K_OK;
       }
       b.gb.tile_start[b.gb.n] = b.blocks;
-      const int rc = outer ? launch_batch(e3k::gemm_wgrad_kernel<true>, b.gb, b.blocks, st)
-                           : launch_batch(e3k::gemm_wgrad_kernel<false>, b.gb, b.blocks, st);
+      int rc;
+      if (!outer) rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<false, 2>, b.gb, b.blocks, st)
+                               : launch_batch(e3k::gemm_wgrad_kernel<false, 1>, b.gb, b.blocks, st);
+      else rc = tn == 2 ? launch_batch(e3k::gemm_wgrad_kernel<true, 2>, b.gb, b.blocks, st)
+                        : launch_batch(e3k::gemm_wgrad_kernel<true, 1>, b.gb, b.blocks, st);
       b.reset();
       return rc;
     };
     for (int i = 0; i < n_problems; ++i) {
       const e3k_gemm_problem& P = problems[i];
       if ((P.V > 0) != outer) continue;
-      const int tn = P.N >= 128 ? 2 : 1;
+      if ((P.N >= 128 ? 2 : 1) != tn) continue;
       const int64_t M = (int64_t)P.M1 * P.M2;
       if (M == 0) continue;
       const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       int f = a_vec(P) ? 1 : 0;
       if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C)) f |= 8;
-      if (tn == 2) f |= 16;
       const int wn = 64 * tn;
       const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + wn - 1) / wn);
       int64_t splits = (1024 + tiles - 1) / tiles;
