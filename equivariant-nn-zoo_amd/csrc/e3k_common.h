@@ -30,6 +30,22 @@ __device__ __forceinline__ int xcd_remap(int b, int nblocks) {
   return start + i;
 }
 
+// Zero-fill as a KERNEL, not hipMemsetAsync: memset nodes recorded while a stream is being captured did not replay
+// correctly here (a HIP graph holding e3k_csr_build faulted on its second replay with "write access to a read-only
+// page"; with this kernel in place of the three memsets it replays) -- and one launch path is one thing less to reason about.
+static __global__ __launch_bounds__(256) void zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) p[i] = 0u;
+}
+static inline int zero_fill(void* p, int64_t bytes, hipStream_t st) {
+  if (bytes <= 0) return 0;
+  if ((reinterpret_cast<uintptr_t>(p) & 3) || (bytes & 3)) return -1;
+  const int64_t n = bytes / 4;
+  int64_t blocks = (n + 255) / 256;
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<uint32_t*>(p), n);
+  return 0;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

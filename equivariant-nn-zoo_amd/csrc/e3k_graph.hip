@@ -116,11 +116,11 @@ extern "C" int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, in
   if (E > 0 && (!edge_index || !src || !dst || !dst_perm || !src_perm || !workspace)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
   if (dst_ptr == bad_flag + 1 && src_ptr == dst_ptr + (N + 1)) {   // one block [flag | dst_ptr | src_ptr]: one fill
-    if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t) * (2 * (N + 1) + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
+    if (e3k::zero_fill(bad_flag, sizeof(int32_t) * (2 * (N + 1) + 1), st)) return E3K_ERR_INVALID;
   } else {
-    if (hipMemsetAsync(dst_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
-    if (hipMemsetAsync(src_ptr, 0, sizeof(int32_t) * (N + 1), st) != hipSuccess) return E3K_ERR_LAUNCH;
-    if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
+    if (e3k::zero_fill(dst_ptr, sizeof(int32_t) * (N + 1), st) || e3k::zero_fill(src_ptr, sizeof(int32_t) * (N + 1), st) ||
+        e3k::zero_fill(bad_flag, sizeof(int32_t), st))
+      return E3K_ERR_INVALID;
   }
   if (E > 0 && N > 0) {
     int32_t* dst_cur = workspace;
@@ -228,7 +228,7 @@ extern "C" int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t*
   if (K > e3k::GR_MAXK || R >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
   if (!bounds || !reps || !bad_flag || (R > 0 && (!key || !perm))) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(bad_flag, 0, sizeof(int32_t), st) != hipSuccess) return E3K_ERR_LAUNCH;
+  if (e3k::zero_fill(bad_flag, sizeof(int32_t), st)) return E3K_ERR_LAUNCH;
   hipLaunchKernelGGL(e3k::group_rows_kernel, dim3(1), dim3(1024), 0, st, key, (int32_t)R, K, perm, bounds, reps, bad_flag);
   E3K_CHECK_LAUNCH();
   return E3K_OK;

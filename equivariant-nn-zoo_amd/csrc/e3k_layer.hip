@@ -282,7 +282,7 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
     hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->node_attrs, a->reps,
                        a->n_keys, d.V, a->a_rep);
     E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
-    if (!d.sc_out_covered && hipMemsetAsync(a->conv, 0, sizeof(float) * a->N * d.d_conv, (hipStream_t)side2) != hipSuccess)
+    if (!d.sc_out_covered && e3k::zero_fill(a->conv, sizeof(float) * a->N * d.d_conv, (hipStream_t)side2))
       return E3K_ERR_LAUNCH;
     Seg g;
     g.add_keyed(L, SC_FWD, x_cf, a->m, a->conv, a->N, a->perm, a->bounds, a->n_keys);
@@ -294,7 +294,7 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
       E3K_TRY(g1.run(0, main));
     }
   } else {
-    if (!d.post_out_covered && hipMemsetAsync(a->conv, 0, sizeof(float) * a->N * d.d_conv, (hipStream_t)main) != hipSuccess)
+    if (!d.post_out_covered && e3k::zero_fill(a->conv, sizeof(float) * a->N * d.d_conv, (hipStream_t)main))
       return E3K_ERR_LAUNCH;
     Seg g1;
     g1.add(L, LIN1_FWD, x_cf, a->w_lin1, a->x1, a->N);
@@ -342,7 +342,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // gate' -> gradient of the convolution output; both readers of it in one call
   E3K_TRY(e3k_gate_bwd(a->conv, a->gy, nullptr, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->g_conv,
                        main));
-  if (!d.post_in_covered && hipMemsetAsync(a->g_mid, 0, sizeof(float) * a->N * d.d_mid, (hipStream_t)main) != hipSuccess)
+  if (!d.post_in_covered && e3k::zero_fill(a->g_mid, sizeof(float) * a->N * d.d_mid, (hipStream_t)main))
     return E3K_ERR_LAUNCH;
   {
     Seg g;
@@ -350,7 +350,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (a->need_x) {
       if (!a->g_xcf) return E3K_ERR_INVALID;
       const bool covered = has_sc ? d.sc_in_covered : d.lin1_in_covered;
-      if (!covered && hipMemsetAsync(a->g_xcf, 0, sizeof(float) * a->N * d.d_in, (hipStream_t)main) != hipSuccess) return E3K_ERR_LAUNCH;
+      if (!covered && e3k::zero_fill(a->g_xcf, sizeof(float) * a->N * d.d_in, (hipStream_t)main)) return E3K_ERR_LAUNCH;
       if (has_sc) g.add_keyed(L, SC_DGRAD, a->g_conv, a->m, a->g_xcf, a->N, a->perm, a->bounds, a->n_keys);
     }
     E3K_TRY(g.run(0, main));
@@ -358,11 +358,11 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // weight gradients that only need g_conv: off the critical path (forked) or together with linear_1's below
   auto keyed_weight_grads = [&]() -> int {
     E3K_TRY(edge(L, 1, side3, side2));
-    if (a->need_attrs && hipMemsetAsync(a->ga, 0, sizeof(float) * a->n_keys * d.V, (hipStream_t)side2) != hipSuccess) return E3K_ERR_LAUNCH;
+    if (a->need_attrs && e3k::zero_fill(a->ga, sizeof(float) * a->n_keys * d.V, (hipStream_t)side2)) return E3K_ERR_LAUNCH;
     E3K_TRY(e3k_keyed_weights_bwd(a->a_rep, a->w_sc, a->gm, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m,
                                   a->need_attrs ? a->ga : nullptr, a->gb_sc, a->acc_sc, a->kw_ws, side2));
     if (a->need_attrs) {
-      if (hipMemsetAsync(a->g_attrs, 0, sizeof(float) * a->N * d.V, (hipStream_t)side2) != hipSuccess) return E3K_ERR_LAUNCH;
+      if (e3k::zero_fill(a->g_attrs, sizeof(float) * a->N * d.V, (hipStream_t)side2)) return E3K_ERR_LAUNCH;
       const int tot = a->n_keys * d.V;
       hipLaunchKernelGGL(e3k::scatter_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->ga, a->reps, a->bounds,
                          a->n_keys, d.V, a->g_attrs);
@@ -373,7 +373,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     Seg g;
     if (with_g_conv && need_post) g.add(L, POST_WGRAD, a->mid, a->gb_post, const_cast<float*>(a->g_conv), a->N);
     if (with_g_conv && want_sc) {
-      if (hipMemsetAsync(a->gm, 0, sizeof(float) * a->n_keys * d.ld_m, (hipStream_t)st) != hipSuccess) return E3K_ERR_LAUNCH;
+      if (e3k::zero_fill(a->gm, sizeof(float) * a->n_keys * d.ld_m, (hipStream_t)st)) return E3K_ERR_LAUNCH;
       g.add_keyed(L, SC_WGRAD, a->x_cf, a->gm, const_cast<float*>(a->g_conv), a->N, a->perm, a->bounds, a->n_keys);
     }
     if (with_lin1 && need_lin1) g.add(L, LIN1_WGRAD, a->x_cf, a->gb_lin1, a->g_x1, a->N);
@@ -387,7 +387,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // tensor product
   if (need_x1) {
     if (!a->g_x1) return E3K_ERR_INVALID;
-    if (!d.tp_bwd_x_overwrites && hipMemsetAsync(a->g_x1, 0, sizeof(float) * a->N * d.d_x1, (hipStream_t)main) != hipSuccess)
+    if (!d.tp_bwd_x_overwrites && e3k::zero_fill(a->g_x1, sizeof(float) * a->N * d.d_x1, (hipStream_t)main))
       return E3K_ERR_LAUNCH;
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
     E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));

@@ -770,8 +770,7 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
     const unsigned tiles = (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT);
     if (tiles > 1 && !accumulate_w) {   // the key tiles add with atomics: start from zero
       for (int i = 0; i < n_instr; ++i)
-        if (hipMemsetAsync(g_W + instr[i].w_off, 0, sizeof(float) * (size_t)instr[i].u * V * instr[i].w_out,
-                           (hipStream_t)stream) != hipSuccess)
+        if (e3k::zero_fill(g_W + instr[i].w_off, sizeof(float) * (size_t)instr[i].u * V * instr[i].w_out, (hipStream_t)stream))
           return E3K_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(e3k::keyed_weights_kernel<1>, dim3((unsigned)((ka.total + 255) / 256), tiles), dim3(256), 0,

@@ -1130,3 +1130,43 @@ def test_radial_table_guard_vetoes_a_table_that_would_miss_the_parity_budget(dev
     assert radial_table.applicable(radial)
     radial.mul_(1.0)
     assert not radial_table.applicable(radial)
+
+
+def test_captured_energy_step_with_the_knot_table_replays(dev):
+    """A config_energy training step on a batch large enough for the radial knot table (its bins are grouped by a CSR
+    build INSIDE the step) captured in a HIP graph and replayed: every replay must reproduce the eager step.  Round 2
+    shipped this broken -- the CSR build zero-filled with hipMemsetAsync, whose graph nodes did not replay (the second
+    replay faulted with a write to a read-only page); every zero-fill of the library is a kernel now."""
+    from e3_layers_amd.backend import ops, radial_table
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import CapturedStep
+
+    torch.manual_seed(0)
+    tree = _energy_tree(2, 64, 3)
+    from e3_layers_amd.utils import build
+
+    model = build(tree).to(dev).train()
+    fixed = synth_qm9(1000, 96).to(dev)
+    assert fixed["edge_index"].shape[1] >= radial_table.MIN_EDGES_PER_KNOT * (radial_table.KNOTS + 1)
+    fixed.update(build_topology(fixed["edge_index"], fixed["pos"].shape[0]).as_dict())
+    target = fixed["total_energy"].clone()
+
+    def step():
+        out = model(fixed.view())["total_energy"]
+        for p in model.parameters():
+            p.grad = None
+        (out - target).square().mean().backward()
+        return out
+
+    eager = step().detach().clone()
+    ops.join_side_streams()
+    torch.cuda.synchronize()
+    g_eager = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone()
+    captured = CapturedStep(step, warmup=2)
+    for _ in range(3):
+        out = captured()
+        torch.cuda.synchronize()
+        assert rel_err(out, eager) < 1e-6
+    g_graph = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    assert rel_err(g_graph, g_eager) < 1e-5
