@@ -20,6 +20,7 @@
 //
 // Cross-stream edges are hipEvents owned by the layer object (no timing, re-recorded every call).  Without `fork` all
 // streams are the same and the events are skipped.  GEMMs that share an operand go out in one e3k_gemm_multi call.
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <vector>
@@ -93,6 +94,12 @@ struct Timed {   // records an event pair around one launch when the layer is be
 
 namespace {
 
+// timing-only ablation (tools/ablate.sh): E3K_ABLATE is a bitmask of launches to SKIP -- the results are wrong with any
+// bit set; it answers "what would the step gain if this kernel family were free" before anyone optimises it.
+// 1: keyed-weight kernels (fwd + bwd), 2: weight-gradient GEMMs, 4: gate fwd + bwd, 8: table interpolation fwd + bwd,
+// 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
+static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
+
 enum SetId { LIN1_FWD, LIN1_DGRAD, LIN1_DGRAD_ACC, LIN1_WGRAD, POST_FWD, POST_DGRAD, POST_WGRAD, SC_FWD, SC_DGRAD, SC_WGRAD,
              LAST_FWD, LAST_DGRAD, LAST_WGRAD, N_SETS };
 
@@ -155,14 +162,15 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   const e3k_layer_desc& d = L->d;
   if (r.R == 0 || r.E == 0) return E3K_OK;
   float* zs[4] = {r.z[0], r.z[1], r.z[2], r.z[3]};
-  E3K_TRY(e3k_mlp_hidden_fwd(r.radial, r.R, d.k0, d.h, d.n_hidden, r.w_hidden, d.alphas, d.act, d.cst, r.keep ? zs : nullptr, r.h, st));
-  {
+  if (!(ABLATE & 16))
+    E3K_TRY(e3k_mlp_hidden_fwd(r.radial, r.R, d.k0, d.h, d.n_hidden, r.w_hidden, d.alphas, d.act, d.cst, r.keep ? zs : nullptr, r.h, st));
+  if (!(ABLATE & 16)) {
     Timed t(L, E3K_PROF_RADIAL_LAST_FWD, st, r.R, r.E);
     Seg g;
     g.add(L, LAST_FWD, r.h, r.w_last, r.use_table ? r.T : r.w, r.R);
     E3K_TRY(g.run(0, st));
   }
-  if (r.use_table) {
+  if (r.use_table && !(ABLATE & 8)) {
     Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
     E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
   }
@@ -281,7 +289,8 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
     const int tot = a->n_keys * d.V;
     hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->node_attrs, a->reps,
                        a->n_keys, d.V, a->a_rep);
-    E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
+    if (!(ABLATE & 1))
+      E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
     if (!d.sc_out_covered && e3k::zero_fill(a->conv, sizeof(float) * a->N * d.d_conv, (hipStream_t)side2))
       return E3K_ERR_LAUNCH;
     Seg g;
@@ -315,7 +324,8 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
     g.add(L, POST_FWD, a->mid, a->w_post, a->conv, a->N);
     E3K_TRY(g.run(0, main));
   }
-  E3K_TRY(e3k_gate_fwd(a->conv, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->y, main));
+  if (!(ABLATE & 4))
+    E3K_TRY(e3k_gate_fwd(a->conv, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->y, main));
   if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
   return E3K_OK;
 }
@@ -340,8 +350,9 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   if (!a->gy || !a->g_conv || !a->g_mid || !a->conv) return E3K_ERR_INVALID;
 
   // gate' -> gradient of the convolution output; both readers of it in one call
-  E3K_TRY(e3k_gate_bwd(a->conv, a->gy, nullptr, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf, a->g_conv,
-                       main));
+  if (!(ABLATE & 4))
+    E3K_TRY(e3k_gate_bwd(a->conv, a->gy, nullptr, a->N, d.d_conv, d.d_out, L->gate.data(), (int32_t)L->gate.size(), a->out_cf,
+                         a->g_conv, main));
   if (!d.post_in_covered && e3k::zero_fill(a->g_mid, sizeof(float) * a->N * d.d_mid, (hipStream_t)main))
     return E3K_ERR_LAUNCH;
   {
@@ -353,14 +364,15 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
       if (!covered && e3k::zero_fill(a->g_xcf, sizeof(float) * a->N * d.d_in, (hipStream_t)main)) return E3K_ERR_LAUNCH;
       if (has_sc) g.add_keyed(L, SC_DGRAD, a->g_conv, a->m, a->g_xcf, a->N, a->perm, a->bounds, a->n_keys);
     }
-    E3K_TRY(g.run(0, main));
+    if (!(ABLATE & 64)) E3K_TRY(g.run(0, main));
   }
   // weight gradients that only need g_conv: off the critical path (forked) or together with linear_1's below
   auto keyed_weight_grads = [&]() -> int {
     E3K_TRY(edge(L, 1, side3, side2));
     if (a->need_attrs && e3k::zero_fill(a->ga, sizeof(float) * a->n_keys * d.V, (hipStream_t)side2)) return E3K_ERR_LAUNCH;
-    E3K_TRY(e3k_keyed_weights_bwd(a->a_rep, a->w_sc, a->gm, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m,
-                                  a->need_attrs ? a->ga : nullptr, a->gb_sc, a->acc_sc, a->kw_ws, side2));
+    if (!(ABLATE & 1))
+      E3K_TRY(e3k_keyed_weights_bwd(a->a_rep, a->w_sc, a->gm, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m,
+                                    a->need_attrs ? a->ga : nullptr, a->gb_sc, a->acc_sc, a->kw_ws, side2));
     if (a->need_attrs) {
       if (e3k::zero_fill(a->g_attrs, sizeof(float) * a->N * d.V, (hipStream_t)side2)) return E3K_ERR_LAUNCH;
       const int tot = a->n_keys * d.V;
@@ -377,6 +389,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
       g.add_keyed(L, SC_WGRAD, a->x_cf, a->gm, const_cast<float*>(a->g_conv), a->N, a->perm, a->bounds, a->n_keys);
     }
     if (with_lin1 && need_lin1) g.add(L, LIN1_WGRAD, a->x_cf, a->gb_lin1, a->g_x1, a->N);
+    if (ABLATE & 2) return E3K_OK;
     return g.run(1, st);
   };
   if (side3 != main && (need_post || want_sc)) {
@@ -390,7 +403,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (!d.tp_bwd_x_overwrites && e3k::zero_fill(a->g_x1, sizeof(float) * a->N * d.d_x1, (hipStream_t)main))
       return E3K_ERR_LAUNCH;
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
-    E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+    if (!(ABLATE & 32)) E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
   }
   if (need_radial_side && a->E > 0) {
     if (!a->g_w) return E3K_ERR_INVALID;
@@ -402,15 +415,15 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
     if (r.use_table) {
       Timed t(L, E3K_PROF_RTABLE_BWD, side, r.R, r.E);
-      E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
+      if (!(ABLATE & 8)) E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
       g_rows = a->g_T;
     }
-    if (need_last) {
+    if (need_last && !(ABLATE & 16)) {
       Seg g;
       g.add(L, LAST_WGRAD, r.h, a->gb_last, const_cast<float*>(g_rows), r.R);
       E3K_TRY(g.run(1, side));
     }
-    if (need_hidden || a->need_radial) {
+    if ((need_hidden || a->need_radial) && !(ABLATE & 16)) {
       Seg g;
       g.add(L, LAST_DGRAD, g_rows, r.w_last, a->g_h, r.R);
       E3K_TRY(g.run(0, side));
@@ -424,7 +437,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   if (a->need_x) {
     Seg g;
     g.add(L, has_sc ? LIN1_DGRAD_ACC : LIN1_DGRAD, a->g_x1, a->w_lin1, a->g_xcf, a->N);
-    E3K_TRY(g.run(0, main));
+    if (!(ABLATE & 64)) E3K_TRY(g.run(0, main));
     if (!a->in_cf && !L->in_blocks.empty()) {
       if (!a->g_x) return E3K_ERR_INVALID;
       E3K_TRY(e3k_relayout(a->g_xcf, a->N, d.d_in, L->in_blocks.data(), (int32_t)L->in_blocks.size(), 0, a->g_x, main));

@@ -537,6 +537,64 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     atomicAdd(g_std + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// Double backward of the normalisation (force training through LayerNormalization, e3_layers/nn/pointwise.py:32-51 under
+// GradientOutput's create_graph=True): cotangents h (of g_x) and hs (of g_std, may be NULL) in, gradients of
+//   S = <h, g_x(x, g, s)> + <hs, g_std(x, g)>      with   g_x_i = s v g_i - s v^3 D x_i / m,   g_std = sum_rows D v,
+//   v = (Q / m + eps)^-1/2,  Q = sum x^2,  D = sum g x,  A = sum h g,  B = sum h x   (sums over the irrep block of one row)
+// out:  dS/dg_j = s v h_j - s v^3 B x_j / m + hs v x_j
+//       dS/dx_j = -s A v^3 x_j / m + 3 s v^5 D B x_j / m^2 - s v^3 (g_j B + D h_j) / m + hs (g_j v - D v^3 x_j / m)
+//       dS/ds   = sum_rows (v A - v^3 D B / m)
+__global__ __launch_bounds__(256) void layernorm_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                              const float* __restrict__ h, const float* __restrict__ hs,
+                                                              const float* __restrict__ inv_norm, int64_t rows, int row_dim,
+                                                              BlockArgs ba, const float* __restrict__ stdv, float* __restrict__ g_g,
+                                                              float* __restrict__ g_x, float* __restrict__ g_std) {
+  __shared__ float part[4][MAXBLK];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  float gs[MAXBLK];
+#pragma unroll
+  for (int k = 0; k < MAXBLK; ++k) gs[k] = 0.f;
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += (int64_t)gridDim.x * 4) {
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k) {
+      if (k < ba.n) {
+        const e3k_block& b = ba.b[k];
+        const int len = b.mul * b.dim;
+        const float* xb = x + r * row_dim + b.off;
+        const float* gb = g + r * row_dim + b.off;
+        const float* hb = h + r * row_dim + b.off;
+        float A = 0.f, B = 0.f, D = 0.f;
+        for (int j = lane; j < len; j += 64) {
+          A = fmaf(hb[j], gb[j], A);
+          B = fmaf(hb[j], xb[j], B);
+          D = fmaf(gb[j], xb[j], D);
+        }
+        A = wave_sum(A);
+        B = wave_sum(B);
+        D = wave_sum(D);
+        const float v = inv_norm[r * ba.n + k], sc = stdv[k], m = (float)b.mul;
+        const float v3 = v * v * v, hsk = hs ? hs[k] : 0.f;
+        const float cg_x = -sc * v3 * B / m + hsk * v;                                             // dS/dg: coefficient of x_j
+        const float cx_x = -sc * A * v3 / m + 3.f * sc * v3 * v * v * D * B / (m * m) - hsk * D * v3 / m;   // dS/dx: of x_j
+        const float cx_g = -sc * v3 * B / m + hsk * v, cx_h = -sc * v3 * D / m;                    //        of g_j and h_j
+        for (int j = lane; j < len; j += 64) {
+          if (g_g) g_g[r * row_dim + b.off + j] = fmaf(sc * v, hb[j], cg_x * xb[j]);
+          if (g_x) g_x[r * row_dim + b.off + j] = fmaf(cx_x, xb[j], fmaf(cx_g, gb[j], cx_h * hb[j]));
+        }
+        gs[k] += v * A - v3 * D * B / m;
+      }
+    }
+  }
+  if (g_std) {
+#pragma unroll
+    for (int k = 0; k < MAXBLK; ++k)
+      if (k < ba.n && lane == 0) part[wv][k] = gs[k];
+    __syncthreads();
+    if ((int)threadIdx.x < ba.n)
+      atomicAdd(g_std + threadIdx.x, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
+  }
+}
+
 // ---------------------------------------------------------------------------------------
 // sorted segment sum
 // ---------------------------------------------------------------------------------------
@@ -848,6 +906,23 @@ extern "C" int e3k_layernorm_bwd(const float* x, const float* g_y, const float* 
   if (lblocks > 512) lblocks = 512;
   hipLaunchKernelGGL(e3k::layernorm_bwd_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, x, g_y,
                      inv_norm, rows, row_dim, ba, std, g_x, g_std);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_layernorm_bwd2(const float* x, const float* g_y, const float* h, const float* h_std, const float* inv_norm,
+                                  int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks, const float* std,
+                                  float* g_gy, float* g_x, float* g_std, void* stream) {
+  e3k::BlockArgs ba{};
+  const int rc = make_blocks(blocks, n_blocks, row_dim, ba);
+  if (rc != E3K_OK) return rc;
+  if (rows < 0 || n_blocks == 0) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!x || !g_y || !h || !inv_norm || !std || (!g_gy && !g_x && !g_std)) return E3K_ERR_INVALID;
+  int64_t lblocks = (rows + 3) / 4;
+  if (lblocks > 512) lblocks = 512;
+  hipLaunchKernelGGL(e3k::layernorm_bwd2_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, x, g_y, h, h_std,
+                     inv_norm, rows, row_dim, ba, std, g_gy, g_x, g_std);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -154,6 +154,19 @@ def native_layer(plan) -> Optional[NativeLayer]:
     return nl if nl.ok else None
 
 
+def _record_once(t, stream) -> None:
+    """``t.record_stream(stream)`` the first time this tensor meets this stream (tensors shared by every layer of a pass)."""
+    seen = getattr(t, "_e3k_rec", None)
+    key = stream.cuda_stream
+    if seen is None:
+        t._e3k_rec = {key}
+    elif key in seen:
+        return
+    else:
+        seen.add(key)
+    t.record_stream(stream)
+
+
 def _ptr(t, off: int = 0):
     return None if t is None else t.data_ptr() + 4 * off
 
@@ -282,18 +295,20 @@ class NativeConvBlockFn(torch.autograd.Function):
         if own_table is not None:      # the a-posteriori error guard of the table just built (radial stream)
             with conv_block._on(side, main):
                 radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, own_table)
-        if fork:      # what the side streams touched must not return to the allocator before they are done with it
-            for t in (buf, x, node_attrs if has_sc else None):
-                if t is not None:
-                    t.record_stream(side2)
-            for t in (edge_radial, w, rbuf, t_tab):
-                if t is not None:
-                    t.record_stream(side)
-                    t.record_stream(main)
+        if fork:      # what a stream other than the allocating one touched must not return to the allocator before that
+            # stream is done with it.  record_stream costs ~5 us a call: only the pairs that need it -- the radial buffers
+            # live on the radial stream (w is also read by the tensor product on this one), tensors every layer of a
+            # forward shares (edge embedding, attributes, knot bins) are recorded once per tensor, not once per layer
+            if has_sc:
+                buf.record_stream(side2)
+                x.record_stream(side2)
+                _record_once(node_attrs, side2)
+            w.record_stream(main)
+            _record_once(edge_radial, side)
             if table is not None:
                 for t in table:
                     if isinstance(t, torch.Tensor):
-                        t.record_stream(side)
+                        _record_once(t, side)
         if nxt_keep is not None:
             rad_n, nbuf, ncarve, w_n, t_n, plan_n, w_last_n = nxt_keep
             if t_n is not None:
@@ -432,20 +447,15 @@ class NativeConvBlockFn(torch.autograd.Function):
                 g_radial = torch.empty_like(edge_radial)
             a.g_radial = g_radial.data_ptr()
         L.check(L.load().e3k_layer_bwd(layer, C.byref(a)), "e3k_layer_bwd")
-        if fork:
+        if fork:      # (see the forward: only the stream / tensor pairs that need it)
             for st in (side, side2, side3):
                 if st is not main:
                     work.record_stream(st)
-            for t in (buf, gy, x_in):
-                if t is not None:
-                    t.record_stream(side3)
-                    t.record_stream(side2)
-            for t in (rbuf, w, sh, edge_radial):
-                t.record_stream(side)
-            if table is not None:
-                for t in table:
-                    if isinstance(t, torch.Tensor):
-                        t.record_stream(side)
+            if side3 is not main:
+                buf.record_stream(side3)          # mid, x_cf: operands of the weight gradients
+                if x_in is not None:
+                    x_in.record_stream(side3)
+            _record_once(sh, side)                # (tp_bwd_w runs on this stream; the radial chain only reads rows it wrote)
         # parameter gradients handed back to autograd (no gradient sink) are consumed on THIS stream
         if "post" in rets or "lin1" in rets:
             conv_block._wait(main, side3)

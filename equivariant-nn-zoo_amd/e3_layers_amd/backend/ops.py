@@ -746,8 +746,90 @@ class FctpSpec:
     rounds = LinearSpec.rounds
 
 
+def _fctp_problems(x, attrs, b, c, spec: FctpSpec, rows: int, wgrad: bool):
+    """Outer-mode problems  C[(n,k), w] (+)= alpha * sum_{u,v} x[n,u,k] attrs[n,v] B[(u,v), w]  (forward: B = weight, C = out;
+    wgrad: B = the weight gradient, accumulated, C = the incoming gradient), one list per round."""
+    rounds = spec.rounds("i_out") if not wgrad else [list(spec.instr)]
+    out = []
+    for r, group in enumerate(rounds):
+        probs = []
+        for ins in group:
+            a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
+            c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+            p = L.GemmProblem()
+            p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), _addr(attrs), _addr(b, ins.w_off), _addr(c, ins.out_off), None
+            p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in * spec.v, spec.v
+            p.accumulate = 1 if (wgrad or r > 0) else 0
+            p.a_r1, p.a_r2, p.a_k, p.a2_r1 = spec.d_in, a_r2, a_k, spec.v
+            p.b_k, p.b_n = ins.mul_out, 1
+            p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
+            p.alpha = ins.alpha
+            probs.append(p)
+        out.append(probs)
+    return out
+
+
+def _fctp_fwd_raw(x, attrs, weight, spec: FctpSpec):
+    rows = x.shape[0]
+    y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
+    for probs in _fctp_problems(x, attrs, weight, y, spec, rows, False):
+        _run_gemm(probs)
+    return y
+
+
+def _fctp_wgrad_raw(x, attrs, gy, gw, spec: FctpSpec) -> None:
+    """gw += alpha * sum_n (x (x) attrs)^T gy  (gw zero-filled or a gradient sink)."""
+    for probs in _fctp_problems(x, attrs, gw, gy, spec, x.shape[0], True):
+        _run_gemm(probs, wgrad=True)
+
+
+def _fctp_bwd_inputs_raw(gy, x, attrs, weight, spec: FctpSpec, want_x: bool, want_a: bool):
+    """(gx, ga): H = gy . W^T per instruction ([rows, (u, v)], one plain GEMM), then gx[n,u,k] = sum_v attrs[n,v] H and
+    ga[n,v] = sum_{u,k} x[n,u,k] H in one reduction kernel.  ``x`` / ``attrs`` may be None when the gradient that needs
+    them is not wanted (a zero operand stands in: the kernel always forms both)."""
+    if spec.in_layout != "cf":
+        raise NotImplementedError("self-connection backward expects the channel-fastest input layout")
+    rows, dev = gy.shape[0], gy.device
+    lib = L.load()
+    if x is None:
+        x = torch.zeros(rows, spec.d_in, device=dev, dtype=torch.float32)
+    if attrs is None:
+        attrs = torch.zeros(rows, spec.v, device=dev, dtype=torch.float32)
+    gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=dev, dtype=torch.float32)
+    ga = torch.zeros(rows, spec.v, device=dev, dtype=torch.float32)
+    hmax = max(ins.dim * ins.mul_in for ins in spec.instr) * spec.v
+    H = torch.empty(rows * hmax, device=dev, dtype=torch.float32)
+    seen_in = set()
+    for ins in spec.instr:
+        a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
+        uv = ins.mul_in * spec.v
+        p = L.GemmProblem()
+        p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(H), None
+        p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, uv, ins.mul_out, 0
+        p.accumulate = 0
+        p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
+        p.b_k, p.b_n = 1, ins.mul_out  # W viewed [(u,v), w] transposed
+        p.c_r1, p.c_r2, p.c_n = ins.dim * uv, uv, 1
+        p.alpha = ins.alpha
+        _run_gemm([p])
+        L.check(
+            lib.e3k_fctp_reduce_bwd(_addr(H), _addr(x, ins.in_off), _addr(attrs), rows, ins.dim, ins.mul_in, spec.v,
+                                    spec.d_in, ins.mul_in, spec.v, _addr(gx, ins.in_off),
+                                    1 if ins.i_in in seen_in else 0, _addr(ga), L.stream_ptr()),
+            "e3k_fctp_reduce_bwd",
+        )
+        seen_in.add(ins.i_in)
+    return (gx if want_x else None), (ga if want_a else None)
+
+
 class FctpFn(torch.autograd.Function):
-    """out[n, w, k] = alpha * sum_{u,v} W[u,v,w] x[n,u,k] attrs[n,v]   per instruction."""
+    """out[n, w, k] = alpha * sum_{u,v} W[u,v,w] x[n,u,k] attrs[n,v]   per instruction.
+
+    F = <g, out(x, a, W)> is linear in each of (x, a, W, g), so every derivative of every order is the same form with
+    some slots open: open g = this forward; open x = ``FctpDxFn`` (g . W^T reduced with a); open a = ``FctpDaFn``
+    (g . W^T reduced with x); open W = ``FctpDwFn`` (the outer-mode weight-gradient GEMM).  The backward of each is the
+    other three with the cotangent put in the slot the output stood for -- the double backward of force training runs the
+    same HIP kernels (round 2 differentiated a torch restatement here)."""
 
     @staticmethod
     def forward(ctx, x, attrs, weight, spec: FctpSpec):
@@ -756,22 +838,7 @@ class FctpFn(torch.autograd.Function):
         x, attrs, weight = L.f32c(x), L.f32c(attrs), L.f32c(weight)
         rows = x.shape[0]
         assert x.shape[1] == spec.d_in and attrs.shape == (rows, spec.v)
-        y = (torch.empty if spec.out_covered else torch.zeros)(rows, spec.d_out, device=x.device, dtype=torch.float32)
-        for r, group in enumerate(spec.rounds("i_out")):
-            probs = []
-            for ins in group:
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                p = L.GemmProblem()
-                p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), _addr(attrs), _addr(weight, ins.w_off), _addr(y, ins.out_off), None
-                p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in * spec.v, spec.v
-                p.accumulate = 1 if r > 0 else 0
-                p.a_r1, p.a_r2, p.a_k, p.a2_r1 = spec.d_in, a_r2, a_k, spec.v
-                p.b_k, p.b_n = ins.mul_out, 1
-                p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                p.alpha = ins.alpha
-                probs.append(p)
-            _run_gemm(probs)
+        y = _fctp_fwd_raw(x, attrs, weight, spec)
         ctx.save_for_backward(x, attrs, weight)
         ctx.spec = spec
         ctx.in_fork = bool(IN_FORK)
@@ -783,97 +850,101 @@ class FctpFn(torch.autograd.Function):
         x, attrs, weight = ctx.saved_tensors
         spec: FctpSpec = ctx.spec
         if torch.is_grad_enabled():
-            # double backward of the un-keyed self-connection: differentiate a torch restatement of the
-            # same trilinear form on the device (rare path — keyed node attributes take GroupedLinearFn)
-            wrt = [t for t, nd in zip((x, attrs, weight), need[:3]) if nd]
-            with torch.enable_grad():
-                y = _fctp_composed(x, attrs, weight, spec)
-                grads = list(torch.autograd.grad(y, wrt, gy, create_graph=True, allow_unused=True))
-            out = [grads.pop(0) if nd else None for nd in need[:3]]
-            return out[0], out[1], out[2], None
+            gx = FctpDxFn.apply(gy, attrs, weight, spec) if need[0] else None
+            ga = FctpDaFn.apply(gy, x, weight, spec) if need[1] else None
+            gw = FctpDwFn.apply(x, attrs, gy, spec, weight.numel()).view_as(weight) if need[2] else None
+            return gx, ga, gw, None
         gy = L.f32c(gy)
         rows = x.shape[0]
-        lib = L.load()
         gx = ga = gw = None
         if need[0] or need[1]:
-            if spec.in_layout != "cf":
-                raise NotImplementedError("self-connection backward expects the channel-fastest input layout")
-            gx = (torch.empty if spec.in_covered else torch.zeros)(rows, spec.d_in, device=x.device, dtype=torch.float32)
-            ga = torch.zeros(rows, spec.v, device=x.device, dtype=torch.float32)
-            hmax = max(ins.dim * ins.mul_in for ins in spec.instr) * spec.v
-            H = torch.empty(rows * hmax, device=x.device, dtype=torch.float32)
-            seen_in = set()
-            for ins in spec.instr:
-                a_r2, a_k = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                uv = ins.mul_in * spec.v
-                p = L.GemmProblem()
-                p.A, p.A2, p.B, p.C, p.bias = _addr(gy, ins.out_off), None, _addr(weight, ins.w_off), _addr(H), None
-                p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, uv, ins.mul_out, 0
-                p.accumulate = 0
-                p.a_r1, p.a_r2, p.a_k = spec.d_out, a_r2, a_k
-                p.b_k, p.b_n = 1, ins.mul_out  # W viewed [(u,v), w] transposed
-                p.c_r1, p.c_r2, p.c_n = ins.dim * uv, uv, 1
-                p.alpha = ins.alpha
-                _run_gemm([p])
-                L.check(
-                    lib.e3k_fctp_reduce_bwd(_addr(H), _addr(x, ins.in_off), _addr(attrs), rows, ins.dim, ins.mul_in, spec.v,
-                                            spec.d_in, ins.mul_in, spec.v, _addr(gx, ins.in_off),
-                                            1 if ins.i_in in seen_in else 0, _addr(ga), L.stream_ptr()),
-                    "e3k_fctp_reduce_bwd",
-                )
-                seen_in.add(ins.i_in)
+            gx, ga = _fctp_bwd_inputs_raw(gy, x, attrs, weight, spec, bool(need[0]), bool(need[1]))
         sunk = False
         if need[2]:
             gw = _sink_for(weight)
             sunk = gw is not None
             if not sunk:
                 gw = torch.zeros_like(weight)
-            probs = []
-            for ins in spec.instr:
-                a_r2, a_k = _layout_strides(spec.in_layout, ins.mul_in, ins.dim)
-                c_r2, c_n = _layout_strides(spec.out_layout, ins.mul_out, ins.dim)
-                p = L.GemmProblem()
-                p.A, p.A2, p.B, p.C, p.bias = _addr(x, ins.in_off), _addr(attrs), _addr(gw, ins.w_off), _addr(gy, ins.out_off), None
-                p.M1, p.M2, p.N, p.K, p.V = rows, ins.dim, ins.mul_out, ins.mul_in * spec.v, spec.v
-                p.accumulate = 1
-                p.a_r1, p.a_r2, p.a_k, p.a2_r1 = spec.d_in, a_r2, a_k, spec.v
-                p.b_k, p.b_n = ins.mul_out, 1
-                p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
-                p.alpha = ins.alpha
-                probs.append(p)
             if (sunk and WGRAD_SIDE and ctx.in_fork and rows >= WGRAD_SIDE_MIN_ROWS
                     and not torch.cuda.is_current_stream_capturing()):
                 cur = torch.cuda.current_stream(x.device)   # off the critical path: see StridedLinearFn.backward
                 st = side_stream(x.device, 2)
                 st.wait_stream(cur)
                 with on_stream(st, cur):
-                    _run_gemm(probs, wgrad=True)
+                    _fctp_wgrad_raw(x, attrs, gy, gw, spec)
                 for t_ in (x, attrs, gy):
                     t_.record_stream(st)
             else:
-                _run_gemm(probs, wgrad=True)
-        if not need[0]:
-            gx = None
-        if not need[1]:
-            ga = None
+                _fctp_wgrad_raw(x, attrs, gy, gw, spec)
         if sunk:
             gw = None
         return gx, ga, gw, None
 
 
-def _fctp_composed(x, attrs, weight, spec: FctpSpec):
-    """torch-op restatement of FctpFn.forward (same layouts), used only to build a double-backward graph."""
-    rows = x.shape[0]
-    y = torch.zeros(rows, spec.d_out, device=x.device, dtype=x.dtype)
-    for ins in spec.instr:
-        xb = x[:, ins.in_off:ins.in_off + ins.mul_in * ins.dim]
-        xb = xb.reshape(rows, ins.dim, ins.mul_in) if spec.in_layout == "cf" else xb.reshape(rows, ins.mul_in, ins.dim).transpose(1, 2)
-        wb = weight.reshape(-1)[ins.w_off:ins.w_off + ins.mul_in * spec.v * ins.mul_out].reshape(ins.mul_in, spec.v, ins.mul_out)
-        ob = ins.alpha * torch.einsum("nku,nv,uvw->nkw", xb, attrs, wb)
-        if spec.out_layout != "cf":
-            ob = ob.transpose(1, 2)
-        y[:, ins.out_off:ins.out_off + ins.mul_out * ins.dim] += ob.reshape(rows, ins.mul_out * ins.dim)
-    return y
+class FctpDxFn(torch.autograd.Function):
+    """gx = dF/dx (g, a, W)."""
+
+    @staticmethod
+    def forward(ctx, gy, attrs, weight, spec: FctpSpec):
+        gy, attrs, weight = L.f32c(gy), L.f32c(attrs), L.f32c(weight)
+        ctx.save_for_backward(gy, attrs, weight)
+        ctx.spec = spec
+        return _fctp_bwd_inputs_raw(gy, None, attrs, weight, spec, True, False)[0]
+
+    @staticmethod
+    def backward(ctx, hx):      # hx ~ x
+        gy, attrs, weight = ctx.saved_tensors
+        spec = ctx.spec
+        n = ctx.needs_input_grad
+        g_g = FctpFn.apply(hx, attrs, weight, spec) if n[0] else None
+        g_a = FctpDaFn.apply(gy, hx, weight, spec) if n[1] else None
+        g_w = FctpDwFn.apply(hx, attrs, gy, spec, weight.numel()).view_as(weight) if n[2] else None
+        return g_g, g_a, g_w, None
+
+
+class FctpDaFn(torch.autograd.Function):
+    """ga = dF/da (g, x, W)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, weight, spec: FctpSpec):
+        gy, x, weight = L.f32c(gy), L.f32c(x), L.f32c(weight)
+        ctx.save_for_backward(gy, x, weight)
+        ctx.spec = spec
+        return _fctp_bwd_inputs_raw(gy, x, None, weight, spec, False, True)[1]
+
+    @staticmethod
+    def backward(ctx, ha):      # ha ~ attrs
+        gy, x, weight = ctx.saved_tensors
+        spec = ctx.spec
+        n = ctx.needs_input_grad
+        g_g = FctpFn.apply(x, ha, weight, spec) if n[0] else None
+        g_x = FctpDxFn.apply(gy, ha, weight, spec) if n[1] else None
+        g_w = FctpDwFn.apply(x, ha, gy, spec, weight.numel()).view_as(weight) if n[2] else None
+        return g_g, g_x, g_w, None
+
+
+class FctpDwFn(torch.autograd.Function):
+    """gW = dF/dW (x, a, g)  (flat, the weight's layout)."""
+
+    @staticmethod
+    def forward(ctx, x, attrs, gy, spec: FctpSpec, w_numel: int):
+        x, attrs, gy = L.f32c(x), L.f32c(attrs), L.f32c(gy)
+        ctx.save_for_backward(x, attrs, gy)
+        ctx.spec = spec
+        gw = torch.zeros(w_numel, device=x.device, dtype=torch.float32)
+        _fctp_wgrad_raw(x, attrs, gy, gw, spec)
+        return gw
+
+    @staticmethod
+    def backward(ctx, hw):      # hw ~ W
+        x, attrs, gy = ctx.saved_tensors
+        spec = ctx.spec
+        hw = hw.reshape(-1)
+        n = ctx.needs_input_grad
+        g_x = FctpDxFn.apply(gy, attrs, hw, spec) if n[0] else None
+        g_a = FctpDaFn.apply(gy, x, hw, spec) if n[1] else None
+        g_g = FctpFn.apply(x, attrs, hw, spec) if n[2] else None
+        return g_x, g_a, g_g, None, None
 
 
 def fctp(x, attrs, weight, spec: FctpSpec):
@@ -1669,23 +1740,9 @@ class LayerNormFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         x, std, inv = ctx.saved_tensors
-        if torch.is_grad_enabled():
-            # double backward: differentiate a torch restatement on the device (no shipped config combines
-            # LayerNormalization with GradientOutput training; kept correct rather than fast)
-            with torch.enable_grad():
-                parts, pos = [], 0
-                for k, (off, mul, dim) in enumerate(ctx.blocks):
-                    assert off == pos, "normalisation blocks must tile the row"
-                    xb = x[:, off:off + mul * dim]
-                    parts.append(xb * torch.rsqrt(xb.pow(2).sum(1, keepdim=True) / mul + 1e-6) * std[k])
-                    pos += mul * dim
-                y = torch.cat(parts, 1)
-                wrt = [t for t, nd in zip((x, std), ctx.needs_input_grad[:2]) if nd]
-                grads = list(torch.autograd.grad(y, wrt, gy[:, :pos], create_graph=True))
-            out = [grads.pop(0) if need else None for need in ctx.needs_input_grad[:2]]
-            if out[0] is not None and pos < x.shape[1]:
-                out[0] = torch.cat([out[0][:, :pos], gy.new_zeros(x.shape[0], x.shape[1] - pos)], 1)
-            return out[0], out[1], None
+        if torch.is_grad_enabled():      # double backward (force training): e3k_layernorm_bwd2
+            gx, gstd = LayerNormBwdFn.apply(x, std, inv, gy, ctx.blocks)
+            return (gx if ctx.needs_input_grad[0] else None), (gstd if ctx.needs_input_grad[1] else None), None
         gy = L.f32c(gy)
         gx = torch.empty_like(x)
         gstd = torch.zeros_like(std)
@@ -1693,6 +1750,50 @@ class LayerNormFn(torch.autograd.Function):
                                            len(ctx.blocks), L.ptr(std), L.ptr(gx), L.ptr(gstd), L.stream_ptr()),
                 "e3k_layernorm_bwd")
         return gx, gstd, None
+
+
+def _layer_norm_bwd_raw(x, std, inv, gy, blocks):
+    gx = torch.empty_like(x) if _blocks_cover(blocks, x.shape[1]) else torch.zeros_like(x)
+    gstd = torch.zeros_like(std)
+    L.check(L.load().e3k_layernorm_bwd(L.ptr(x), L.ptr(gy), L.ptr(inv), x.shape[0], x.shape[1], _blocks(blocks), len(blocks),
+                                       L.ptr(std), L.ptr(gx), L.ptr(gstd), L.stream_ptr()), "e3k_layernorm_bwd")
+    return gx, gstd
+
+
+def _blocks_cover(blocks, row_dim: int) -> bool:
+    return sum(mul * dim for _, mul, dim in blocks) == row_dim
+
+
+class LayerNormBwdFn(torch.autograd.Function):
+    """(g_x, g_std) of the normalisation as a differentiable op; its backward is e3k_layernorm_bwd2."""
+
+    @staticmethod
+    def forward(ctx, x, std, inv, gy, blocks):
+        x, std, gy = L.f32c(x), L.f32c(std), L.f32c(gy)
+        ctx.save_for_backward(x, std, inv, gy)
+        ctx.blocks = blocks
+        return _layer_norm_bwd_raw(x, std, inv, gy, blocks)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h, hs):
+        x, std, inv, gy = ctx.saved_tensors
+        blocks = ctx.blocks
+        need_x, need_std, _, need_g = ctx.needs_input_grad[:4]
+        if h is None:
+            h = torch.zeros_like(x)
+        h = L.f32c(h)
+        hs = L.f32c(hs) if hs is not None else None
+        cover = _blocks_cover(blocks, x.shape[1])
+        alloc = torch.empty_like if cover else torch.zeros_like
+        g_x = alloc(x) if need_x else None
+        g_g = alloc(x) if need_g else None
+        g_s = torch.zeros_like(std) if need_std else None
+        if g_x is not None or g_g is not None or g_s is not None:
+            L.check(L.load().e3k_layernorm_bwd2(L.ptr(x), L.ptr(gy), L.ptr(h), L.ptr(hs), L.ptr(inv), x.shape[0], x.shape[1],
+                                                _blocks(blocks), len(blocks), L.ptr(std), L.ptr(g_g), L.ptr(g_x), L.ptr(g_s),
+                                                L.stream_ptr()), "e3k_layernorm_bwd2")
+        return g_x, g_s, None, g_g, None
 
 
 def layer_norm(x, std, blocks):

@@ -327,6 +327,12 @@ int e3k_layernorm_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_b
 int e3k_layernorm_bwd(const float* x, const float* g_y, const float* inv_norm, int64_t rows, int32_t row_dim,
                       const e3k_block* blocks, int32_t n_blocks, const float* std, float* g_x, float* g_std,
                       void* stream);
+/* double backward: h [rows,row_dim] is the cotangent of e3k_layernorm_bwd's g_x, h_std [n_blocks] that of its g_std (may
+ * be NULL); g_gy, g_x [rows,row_dim] written on the block columns (the caller zero-fills uncovered columns), g_std
+ * [n_blocks] ACCUMULATED (any of the three may be NULL). */
+int e3k_layernorm_bwd2(const float* x, const float* g_y, const float* h, const float* h_std, const float* inv_norm,
+                       int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks, const float* std,
+                       float* g_gy, float* g_x, float* g_std, void* stream);
 
 /* sorted-segment sum (Pooling, nn/output.py:66-74): out[s, :] = sum_{r in [ptr[s], ptr[s+1])} x[r, :] (* 1/count if mean) */
 int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t dim, int32_t mean, float* out,

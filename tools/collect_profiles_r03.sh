@@ -1,0 +1,34 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: the rocprofv3 evidence of round 3 into gpurun_out/r03/
+# (kernel-trace stats; separate --pmc passes, no trace domains beside --pmc), then
+#   python3 tools/summarize_profiles_r03.py        (runs anywhere)
+cd /tmp && export TMPDIR=/tmp
+cd "$GRAFT_REPO_ROOT" || exit 1
+OUT=gpurun_out/r03
+rm -rf $OUT; mkdir -p $OUT
+B="python3 bench.py --no-cpu-baseline"
+# 1. default workload: kernel stats + one step's launch sequence, PMC traffic, calibration probe
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+python3 tools/step_kernels.py $(ls -t $OUT/stats/*kernel_trace.csv | head -1) $OUT/step_kernels.txt
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o p -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o p -- $B --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/probe_fetch -o p -- python3 tools/pmc_probe.py > $OUT/pmc_probe.json 2>/dev/null
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/probe_write -o p -- python3 tools/pmc_probe.py > /dev/null 2>&1
+# 2. config_energy as shipped (l_max 3): kernel stats + PMC traffic
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l3_stats -o s -- $B --lmax 3 --steps 10 --warmup 3 > $OUT/l3_bench_under_rocprof.json 2> $OUT/l3.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/l3_pmc_fetch -o p -- $B --lmax 3 --steps 3 --warmup 1 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/l3_pmc_write -o p -- $B --lmax 3 --steps 3 --warmup 1 > /dev/null 2>&1
+# 3. MFMA busy of the GEMM kernels (default workload)
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel-trace --output-format csv -d $OUT/pmc_mfma -o p -- $B --steps 4 --warmup 1 > /dev/null 2>&1
+# 4. the other BASELINE configurations
+for c in energy_force diffusion diffusion_CA; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_$c -o s -- $B --config $c --steps 10 --warmup 3 > $OUT/cfg_$c.json 2> $OUT/cfg_$c.err
+done
+# 5. the lines themselves (no profiler)
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+$B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
+for b in 32 64 128 512; do $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done
+$B --loader > $OUT/bench_loader.json 2>/dev/null
+$B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
+for c in energy_force diffusion diffusion_CA; do $B --config $c > $OUT/bench_$c.json 2>/dev/null; done
+ls $OUT; tail -c 600 $OUT/bench_default.json
