@@ -43,7 +43,8 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (the clock an MFMA loop sustains is lower)
-TRAFFIC_FILE = "profiles/r02_tp_traffic.json"   # rocprofv3 --pmc passes over this command (tools/collect_profiles.sh)
+# rocprofv3 --pmc passes over this command at the two l_max values (tools/collect_profiles_r03.sh, tools/summarize_profiles_r03.py)
+TRAFFIC_FILES = {2: "profiles/r03_tp_traffic.json", 3: "profiles/r03_lmax3_tp_traffic.json"}
 
 
 def parse():
@@ -404,8 +405,9 @@ def main():
                 "avg_launch_algorithmic_MB": round(tot_b / n / 1e6, 2)}
 
     traffic = {}
+    TRAFFIC_FILE = TRAFFIC_FILES.get(args.lmax, "")
     tfile = os.path.join(ROOT, TRAFFIC_FILE)
-    if os.path.exists(tfile) and cfg_kind == "energy" and args.batch == 256 and args.lmax == 2:
+    if TRAFFIC_FILE and os.path.exists(tfile) and cfg_kind == "energy" and args.batch == 256:
         try:
             traffic = json.load(open(tfile))
         except Exception:
