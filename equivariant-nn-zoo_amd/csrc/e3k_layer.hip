@@ -161,6 +161,13 @@ int edge(const e3k_layer* L, int slot, void* producer, void* consumer) {
 int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   const e3k_layer_desc& d = L->d;
   if (r.R == 0 || r.E == 0) return E3K_OK;
+  if (r.have_rows) {      // the stack computed T (table) or w (per edge) already
+    if (r.use_table && !(ABLATE & 8)) {
+      Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
+      E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
+    }
+    return E3K_OK;
+  }
   float* zs[4] = {r.z[0], r.z[1], r.z[2], r.z[3]};
   if (!(ABLATE & 16))
     E3K_TRY(e3k_mlp_hidden_fwd(r.radial, r.R, d.k0, d.h, d.n_hidden, r.w_hidden, d.alphas, d.act, d.cst, r.keep ? zs : nullptr, r.h, st));
@@ -273,7 +280,7 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   if (a->N == 0) return E3K_OK;
   if (!a->x || !a->sh || !a->x1 || !a->mid || !a->conv || !a->y || !a->rad.w) return E3K_ERR_INVALID;
   // --- radial branch (unless the previous layer's look-ahead already issued it)
-  if (!a->has_w) {
+  if (!a->has_w && !(a->rad.have_rows && !a->rad.use_table)) {
     E3K_TRY(edge(L, 0, main, side));
     E3K_TRY(radial_fwd(L, a->rad, side));
   }
@@ -343,7 +350,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   const bool need_last = a->gb_last != nullptr;
   bool need_hidden = false;
   for (int i = 0; i < d.n_hidden; ++i) need_hidden = need_hidden || a->gb_hidden[i];
-  const bool need_radial_side = need_last || need_hidden || a->need_radial;
+  const bool need_radial_side = need_last || need_hidden || a->need_radial || (r.have_rows && a->g_w);
   const bool need_post = a->gb_post != nullptr, need_lin1 = a->gb_lin1 != nullptr;
   const bool want_sc = has_sc && (a->gb_sc || a->need_attrs);
   const bool need_x1 = a->need_x || need_lin1;
@@ -418,12 +425,12 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
       if (!(ABLATE & 8)) E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
       g_rows = a->g_T;
     }
-    if (need_last && !(ABLATE & 16)) {
+    if (need_last && !(ABLATE & 16) && !r.have_rows) {
       Seg g;
       g.add(L, LAST_WGRAD, r.h, a->gb_last, const_cast<float*>(g_rows), r.R);
       E3K_TRY(g.run(1, side));
     }
-    if ((need_hidden || a->need_radial) && !(ABLATE & 16)) {
+    if ((need_hidden || a->need_radial) && !(ABLATE & 16) && !r.have_rows) {
       Seg g;
       g.add(L, LAST_DGRAD, g_rows, r.w_last, a->g_h, r.R);
       E3K_TRY(g.run(0, side));
@@ -452,6 +459,85 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     E3K_TRY(weight_grads(true, true, main));
     if (want_sc) E3K_TRY(keyed_weight_grads());
   }
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+// ---- the radial MLPs of several layers, batched ------------------------------------------------------------------------
+extern "C" int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, void* stream) {
+  if (!layers || !rads || n <= 0 || n > 16) return E3K_ERR_INVALID;
+  const e3k_layer_desc& d0 = layers[0]->d;
+  e3k_mlp_net nets[16];
+  for (int i = 0; i < n; ++i) {
+    const e3k_layer_desc& d = layers[i]->d;
+    const e3k_layer_radial& r = rads[i];
+    if (d.k0 != d0.k0 || d.h != d0.h || d.n_hidden != d0.n_hidden || d.act != d0.act || d.cst != d0.cst) return E3K_ERR_UNSUPPORTED;
+    for (int l = 0; l < d.n_hidden; ++l)
+      if (d.alphas[l] != d0.alphas[l]) return E3K_ERR_UNSUPPORTED;
+    if (r.R != rads[0].R || r.radial != rads[0].radial) return E3K_ERR_INVALID;
+    e3k_mlp_net nt{};
+    for (int l = 0; l < 4; ++l) {
+      nt.weights[l] = r.w_hidden[l];
+      nt.z[l] = r.keep ? r.z[l] : nullptr;
+    }
+    nt.out = r.h;
+    nets[i] = nt;
+  }
+  if (rads[0].R == 0) return E3K_OK;
+  if (!(ABLATE & 16)) {
+    E3K_TRY(e3k_mlp_hidden_fwd_multi(nets, n, rads[0].radial, rads[0].R, d0.k0, d0.h, d0.n_hidden, d0.alphas, d0.act, d0.cst, stream));
+    for (int base = 0; base < n; base += 4) {      // last layers: one e3k_gemm_multi call per four layers
+      Seg g;
+      for (int i = base; i < n && i < base + 4; ++i) {
+        const e3k_layer_radial& r = rads[i];
+        g.add(layers[i], LAST_FWD, r.h, r.w_last, r.use_table ? r.T : r.w, r.R);
+      }
+      Timed t(layers[base], E3K_PROF_RADIAL_LAST_FWD, stream, rads[0].R, rads[0].E);
+      E3K_TRY(g.run(0, stream));
+    }
+  }
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, void* stream) {
+  if (!layers || !items || n <= 0 || n > 16) return E3K_ERR_INVALID;
+  const e3k_layer_desc& d0 = layers[0]->d;
+  const int64_t R = items[0].rad.R;
+  if (R == 0) return E3K_OK;
+  if (ABLATE & 16) return E3K_OK;
+  e3k_mlp_net nets[16];
+  int n_nets = 0;
+  for (int base = 0; base < n; base += 4) {        // weight gradients of the last layers
+    Seg g;
+    for (int i = base; i < n && i < base + 4; ++i)
+      if (items[i].gb_last && items[i].g_rows)
+        g.add(layers[i], LAST_WGRAD, items[i].rad.h, items[i].gb_last, const_cast<float*>(items[i].g_rows), R);
+    E3K_TRY(g.run(1, stream));
+  }
+  for (int base = 0; base < n; base += 4) {        // their input gradients, then the hidden chains
+    Seg g;
+    for (int i = base; i < n && i < base + 4; ++i) {
+      const e3k_radial_stack_item& it = items[i];
+      bool need_hidden = it.g_radial != nullptr;
+      for (int l = 0; l < d0.n_hidden; ++l) need_hidden = need_hidden || it.gb_hidden[l];
+      if (!need_hidden || !it.g_rows) continue;
+      if (!it.g_h) return E3K_ERR_INVALID;
+      g.add(layers[i], LAST_DGRAD, it.g_rows, it.rad.w_last, it.g_h, R);
+      e3k_mlp_net nt{};
+      for (int l = 0; l < 4; ++l) {
+        nt.weights[l] = it.rad.w_hidden[l];
+        nt.z[l] = it.rad.z[l];
+        nt.g_weights[l] = it.gb_hidden[l];
+      }
+      nt.g_out = it.g_h;
+      nt.g_x = it.g_radial;
+      nets[n_nets++] = nt;
+    }
+    E3K_TRY(g.run(0, stream));
+  }
+  if (n_nets)
+    E3K_TRY(e3k_mlp_hidden_bwd_multi(nets, n_nets, items[0].rad.radial, R, d0.k0, d0.h, d0.n_hidden, d0.alphas, d0.act, d0.cst, stream));
   if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
   return E3K_OK;
 }

@@ -39,6 +39,14 @@ struct MlpArgs {
   float* gx;            // backward: [E,k0] or NULL
 };
 
+// several MLPs over the SAME input rows in one launch (the radial MLPs of all the layers of a network read one edge
+// embedding): blockIdx.y picks the net
+constexpr int MLP_MAXNETS = 8;
+struct MlpBatch {
+  int n;
+  MlpArgs a[MLP_MAXNETS];
+};
+
 __device__ __forceinline__ int acc_row(int i, int lane) { return (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5); }
 
 // rows x cols tile, global row-major (ld = cols) -> LDS (row stride MLP_LD); rows beyond E and columns beyond cols
@@ -62,7 +70,8 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ src, int64_t
   }
 }
 
-__global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
+__global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpBatch mb) {
+  const MlpArgs& a = mb.a[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float As[MLP_BM * MLP_LD];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w & 1, wn = w >> 1;
@@ -122,7 +131,8 @@ __global__ __launch_bounds__(256) void mlp_hidden_fwd_kernel(const MlpArgs a) {
 }
 
 template <int NL>   // number of hidden layers: one register-resident weight-gradient tile each
-__global__ __launch_bounds__(256, 3) void mlp_hidden_bwd_kernel(const MlpArgs a, int n_tiles) {
+__global__ __launch_bounds__(256, 3) void mlp_hidden_bwd_kernel(const MlpBatch mb, int n_tiles) {
+  const MlpArgs& a = mb.a[blockIdx.y];
   __shared__ __attribute__((aligned(16))) float Gs[MLP_BM * MLP_LD];   // gradient wrt h_l, then gz_l
   __shared__ __attribute__((aligned(16))) float Ds[MLP_BM * MLP_LD];   // cst act'(z_l)
   __shared__ __attribute__((aligned(16))) float Hs[MLP_BM * MLP_LD];   // layer input: h_{l-1} = cst act(z_{l-1}) or x
@@ -267,28 +277,55 @@ int fill_args(e3k::MlpArgs& a, const float* x, int64_t E, int32_t k0, int32_t h,
 }
 }  // namespace
 
+namespace {
+int launch_fwd(const e3k::MlpBatch& mb, int64_t E, hipStream_t st) {
+  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
+  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::mlp_hidden_fwd_kernel, dim3((unsigned)tiles, (unsigned)mb.n), dim3(256), 0, st, mb);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+int launch_bwd(const e3k::MlpBatch& mb, int64_t E, int n_layers, hipStream_t st) {
+  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
+  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
+  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 768;
+  int64_t blocks = max_blocks / mb.n;      // persistent: two to three workgroups per CU share the weight-gradient atomics
+  if (blocks < 1) blocks = 1;
+  if (tiles < blocks) blocks = tiles;
+  const dim3 grid((unsigned)blocks, (unsigned)mb.n);
+  switch (n_layers) {
+    case 1: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<1>, grid, dim3(256), 0, st, mb, (int)tiles); break;
+    case 2: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<2>, grid, dim3(256), 0, st, mb, (int)tiles); break;
+    case 3: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<3>, grid, dim3(256), 0, st, mb, (int)tiles); break;
+    default: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<4>, grid, dim3(256), 0, st, mb, (int)tiles); break;
+  }
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+}  // namespace
+
 extern "C" int e3k_mlp_hidden_fwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
                                   const float* const* weights, const float* alphas, int32_t act, float cst,
                                   float* const* z, float* out, void* stream) {
-  e3k::MlpArgs a{};
-  const int rc = fill_args(a, x, E, k0, h, n_layers, weights, alphas, act, cst);
+  e3k::MlpBatch mb{};
+  mb.n = 1;
+  const int rc = fill_args(mb.a[0], x, E, k0, h, n_layers, weights, alphas, act, cst);
   if (rc != E3K_OK) return rc;
   if (E == 0) return E3K_OK;
   if (!out) return E3K_ERR_INVALID;
-  for (int l = 0; l < n_layers; ++l) a.z[l] = z ? z[l] : nullptr;
-  a.out = out;
-  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
-  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::mlp_hidden_fwd_kernel, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, a);
-  E3K_CHECK_LAUNCH();
-  return E3K_OK;
+  for (int l = 0; l < n_layers; ++l) mb.a[0].z[l] = z ? z[l] : nullptr;
+  mb.a[0].out = out;
+  return launch_fwd(mb, E, (hipStream_t)stream);
 }
 
 extern "C" int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t n_layers,
                                   const float* const* weights, const float* alphas, int32_t act, float cst,
                                   const float* const* z, const float* g_out, float* const* g_weights, float* g_x,
                                   void* stream) {
-  e3k::MlpArgs a{};
+  e3k::MlpBatch mb{};
+  mb.n = 1;
+  e3k::MlpArgs& a = mb.a[0];
   const int rc = fill_args(a, x, E, k0, h, n_layers, weights, alphas, act, cst);
   if (rc != E3K_OK) return rc;
   if (E == 0) return E3K_OK;
@@ -300,16 +337,54 @@ extern "C" int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t
   }
   a.g = g_out;
   a.gx = g_x;
-  const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
-  if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
-  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 768;
-  int64_t blocks = tiles < max_blocks ? tiles : max_blocks;   // persistent: two workgroups per CU share the weight-gradient atomics
-  switch (n_layers) {
-    case 1: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
-    case 2: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<2>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
-    case 3: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<3>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
-    default: hipLaunchKernelGGL(e3k::mlp_hidden_bwd_kernel<4>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a, (int)tiles); break;
+  return launch_bwd(mb, E, n_layers, (hipStream_t)stream);
+}
+
+// n_nets MLPs of one shape over the same input rows (e3k_mlp_net: the per-net pointers), one launch
+extern "C" int e3k_mlp_hidden_fwd_multi(const e3k_mlp_net* nets, int32_t n_nets, const float* x, int64_t E, int32_t k0, int32_t h,
+                                        int32_t n_layers, const float* alphas, int32_t act, float cst, void* stream) {
+  if (!nets || n_nets <= 0) return E3K_ERR_INVALID;
+  for (int base = 0; base < n_nets; base += e3k::MLP_MAXNETS) {
+    e3k::MlpBatch mb{};
+    mb.n = n_nets - base < e3k::MLP_MAXNETS ? n_nets - base : e3k::MLP_MAXNETS;
+    for (int i = 0; i < mb.n; ++i) {
+      const e3k_mlp_net& nt = nets[base + i];
+      const int rc = fill_args(mb.a[i], x, E, k0, h, n_layers, nt.weights, alphas, act, cst);
+      if (rc != E3K_OK) return rc;
+      if (E > 0 && !nt.out) return E3K_ERR_INVALID;
+      for (int l = 0; l < n_layers; ++l) mb.a[i].z[l] = nt.z[l];
+      mb.a[i].out = nt.out;
+    }
+    if (E == 0) return E3K_OK;
+    const int rc = launch_fwd(mb, E, (hipStream_t)stream);
+    if (rc != E3K_OK) return rc;
   }
-  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_mlp_hidden_bwd_multi(const e3k_mlp_net* nets, int32_t n_nets, const float* x, int64_t E, int32_t k0, int32_t h,
+                                        int32_t n_layers, const float* alphas, int32_t act, float cst, void* stream) {
+  if (!nets || n_nets <= 0) return E3K_ERR_INVALID;
+  for (int base = 0; base < n_nets; base += e3k::MLP_MAXNETS) {
+    e3k::MlpBatch mb{};
+    mb.n = n_nets - base < e3k::MLP_MAXNETS ? n_nets - base : e3k::MLP_MAXNETS;
+    for (int i = 0; i < mb.n; ++i) {
+      const e3k_mlp_net& nt = nets[base + i];
+      e3k::MlpArgs& a = mb.a[i];
+      const int rc = fill_args(a, x, E, k0, h, n_layers, nt.weights, alphas, act, cst);
+      if (rc != E3K_OK) return rc;
+      if (E > 0 && !nt.g_out) return E3K_ERR_INVALID;
+      for (int l = 0; l < n_layers; ++l) {
+        if (E > 0 && !nt.z[l]) return E3K_ERR_INVALID;
+        a.z[l] = nt.z[l];
+        a.gw[l] = nt.g_weights[l];
+      }
+      a.g = nt.g_out;
+      a.gx = nt.g_x;
+    }
+    if (E == 0) return E3K_OK;
+    const int rc = launch_bwd(mb, E, n_layers, (hipStream_t)stream);
+    if (rc != E3K_OK) return rc;
+  }
   return E3K_OK;
 }

@@ -16,6 +16,7 @@ import os
 from typing import List, Optional
 
 import torch
+from torch.autograd.function import once_differentiable
 
 from . import lib as L
 from . import ops, radial_table
@@ -207,6 +208,135 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
     rad.w = w.data_ptr()
 
 
+def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
+    """Radial argument block of a layer whose MLP rows ``pre`` came from the stack: with the table the layer interpolates
+    ``pre`` (= T) into ``w``; without, ``pre`` is ``w``."""
+    rad.R, rad.E, rad.keep, rad.have_rows = pre.shape[0], n_edges, 0, 1
+    rad.use_table = int(table is not None)
+    if table is not None:
+        bin32, t, ptr, perm = table
+        rad.knots = radial_table.KNOTS
+        rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
+        rad.T = pre.data_ptr()
+        rad.w = w.data_ptr()
+    else:
+        rad.w = pre.data_ptr()
+
+
+STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
+
+
+class RadialStackFn(torch.autograd.Function):
+    """The radial MLPs of ALL the layers that read one edge embedding, in one op: ``rows`` [R, k0] (the radial basis on
+    the knots, or per edge) -> per layer its output rows [R, W_l] (``fc(edge_radial)`` of ``nn/message_passing.py:74-79,93``,
+    evaluated for every layer at once).  Forward: the hidden chains in one launch, the last layers in one call; backward
+    (runs once the gradients of all layers' rows have arrived, i.e. behind the first layer's backward): last-layer weight
+    gradients in one call, their input gradients in one, the hidden chains in one.  Per layer that was 2 launches forward
+    and 4-5 backward over the same 4 097 knot rows: latency, not work."""
+
+    @staticmethod
+    def forward(ctx, rows, plans, use_table: bool, *weights):
+        L.require_cuda(rows)
+        rows = L.f32c(rows)
+        dev = rows.device
+        n = len(plans)
+        n_hidden = len(plans[0].mlp_alphas)
+        per = 1 + n_hidden
+        assert len(weights) == n * per
+        keep = any(ctx.needs_input_grad)
+        r, hdim = rows.shape[0], plans[0].last_spec.d_in
+        handles = (C.c_void_p * n)(*[native_layer(p).handle(dev) for p in plans])
+        rads = (L.LayerRadial * n)()
+        outs, bufs, carves = [], [], []
+        for i, plan in enumerate(plans):
+            w_last, w_hidden = weights[i * per], weights[i * per + 1:(i + 1) * per]
+            carve = _Carve()
+            carve.add("h", r * hdim)
+            if keep:
+                for l in range(n_hidden):
+                    carve.add(f"z{l}", r * hdim)
+            buf = carve.alloc(dev)
+            out = torch.empty(r, plan.last_spec.d_out, device=dev, dtype=torch.float32)
+            rad = rads[i]
+            rad.R, rad.E, rad.keep, rad.use_table = r, r, int(keep), int(use_table)
+            rad.radial, rad.w_last = rows.data_ptr(), w_last.data_ptr()
+            for l, wh in enumerate(w_hidden):
+                rad.w_hidden[l] = wh.data_ptr()
+                if keep:
+                    rad.z[l] = _ptr(buf, carve.off[f"z{l}"])
+            rad.h = _ptr(buf, carve.off["h"])
+            if use_table:
+                rad.T = out.data_ptr()
+            else:
+                rad.w = out.data_ptr()
+            outs.append(out)
+            bufs.append(buf)
+            carves.append(carve)
+        L.check(L.load().e3k_radial_stack_fwd(handles, rads, n, L.stream_ptr()), "e3k_radial_stack_fwd")
+        STACK_STATS[0] += 1
+        STACK_STATS[1] = n
+        if use_table:
+            for plan, out, i in zip(plans, outs, range(n)):
+                radial_table.guard(plan.guard_key if plan.guard_key is not None else weights[i * per], out)
+        if keep:
+            ctx.save_for_backward(rows, *bufs, *weights)
+            ctx.cfg = (plans, use_table, carves, n_hidden)
+        return tuple(outs)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *g_rows):
+        plans, use_table, carves, n_hidden = ctx.cfg
+        n, per = len(plans), 1 + n_hidden
+        saved = ctx.saved_tensors
+        rows, bufs, weights = saved[0], saved[1:1 + n], saved[1 + n:]
+        dev = rows.device
+        r, hdim, k0 = rows.shape[0], plans[0].last_spec.d_in, rows.shape[1]
+        need = ctx.needs_input_grad
+        need_rows = need[0]
+        live = [i for i in range(n) if g_rows[i] is not None]
+        rets = [None] * (n * per)
+        g_in = None
+        if live:
+            handles = (C.c_void_p * len(live))(*[native_layer(plans[i]).handle(dev) for i in live])
+            items = (L.RadialStackItem * len(live))()
+            g_h = torch.empty(len(live), r, hdim, device=dev, dtype=torch.float32)
+            g_rad = torch.empty(len(live), r, k0, device=dev, dtype=torch.float32) if need_rows else None
+            keepalive = []
+            for j, i in enumerate(live):
+                it = items[j]
+                g = L.f32c(g_rows[i])
+                keepalive.append(g)
+                rad = it.rad
+                rad.R, rad.E, rad.keep, rad.use_table = r, r, 1, int(use_table)
+                rad.radial, rad.w_last = rows.data_ptr(), weights[i * per].data_ptr()
+                rad.h = _ptr(bufs[i], carves[i].off["h"])
+                for l in range(n_hidden):
+                    rad.w_hidden[l] = weights[i * per + 1 + l].data_ptr()
+                    rad.z[l] = _ptr(bufs[i], carves[i].off[f"z{l}"])
+                it.g_rows = g.data_ptr()
+                for l in range(per):
+                    if not need[3 + i * per + l]:
+                        continue
+                    w = weights[i * per + l]
+                    sink = ops._sink_for(w)
+                    if sink is None:
+                        rets[i * per + l] = torch.zeros_like(w)
+                        sink = rets[i * per + l].view(-1)
+                    if l == 0:
+                        it.gb_last = sink.data_ptr()
+                    else:
+                        it.gb_hidden[l - 1] = sink.data_ptr()
+                it.g_h = g_h[j].data_ptr()
+                if g_rad is not None:
+                    it.g_radial = g_rad[j].data_ptr()
+            L.check(L.load().e3k_radial_stack_bwd(handles, items, len(live), L.stream_ptr()), "e3k_radial_stack_bwd")
+            if g_rad is not None:
+                g_in = g_rad[0] if len(live) == 1 else g_rad.sum(0)
+            del keepalive
+        return (g_in, None, None, *rets)
+
+
 def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
     """Buffers of one radial branch: (activations buffer, its carve, w [E, W], table rows [R, W] or None)."""
     r, hdim, width = edge_radial.shape[0], plan.last_spec.d_in, plan.last_spec.d_out
@@ -224,9 +354,17 @@ def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
 class NativeConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf: bool, out_cf: bool, fork: bool, table, nxt,
-                w_lin1, w_post, w_sc, w_last, *w_hidden):
+                pre, w_lin1, w_post, w_sc, w_last, *w_hidden):
+        """``pre`` (stack mode, ``RadialStackFn``): the radial MLP's output rows of this layer, computed for all layers of
+        the network at once -- the knot table [knots + 1, W] (``table`` given: the layer interpolates) or the per-edge
+        weights [E, W] themselves; ``edge_radial`` / ``w_last`` / ``w_hidden`` are then unused (None) and ``nxt`` =
+        (next plan, next layer's ``pre``) lets this layer issue the next one's interpolation early."""
         from . import conv_block
 
+        stack = pre is not None
+        if stack:
+            pre = L.f32c(pre)
+            edge_radial = pre          # (stands in wherever only identity / residency matters)
         L.require_cuda(x, edge_radial, sh)
         x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
         dev = x.device
@@ -247,19 +385,40 @@ class NativeConvBlockFn(torch.autograd.Function):
         a.w_lin1, a.w_post = w_lin1.data_ptr(), w_post.data_ptr()
         # --- radial branch: this layer's (or the look-ahead's result), and the next layer's look-ahead
         pref, plan.prefetched = plan.prefetched, None
-        if pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork, "native"):
+        mode = "stack" if stack else "native"
+        own_table = rbuf = rcarve = None
+        if stack and table is None:
+            w = pre                                  # per-edge weights straight from the stack
+            _stack_radial_struct(a.rad, plan, pre, None, e, None)
+        elif pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork, mode):
             rbuf, rcarve, w, t_tab = pref[1]
-            own_table = None
             a.has_w = 1
             AHEAD_STATS[0] += 1
             conv_block.AHEAD_STATS[0] += 1
+            if stack:
+                _stack_radial_struct(a.rad, plan, pre, table, e, w)
+        elif stack:
+            with conv_block._on(side, main):
+                w = torch.empty(e, plan.last_spec.d_out, device=dev, dtype=torch.float32)
+            _stack_radial_struct(a.rad, plan, pre, table, e, w)
         else:
             with conv_block._on(side, main):       # (buffers used on the radial stream are allocated on it)
                 rbuf, rcarve, w, t_tab = _radial_alloc(plan, edge_radial, table, e, keep, dev)
             own_table = t_tab
-        _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab)
+        if not stack:
+            _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab)
         nxt_keep = None
-        if nxt is not None and fork and conv_block.LOOK_AHEAD:
+        if stack and nxt is not None and fork and conv_block.LOOK_AHEAD and table is not None:
+            plan_n, pre_n = nxt
+            nl_n = native_layer(plan_n)
+            if nl_n is not None:
+                with conv_block._on(side, main):
+                    w_n = torch.empty(e, plan_n.last_spec.d_out, device=dev, dtype=torch.float32)
+                rad_n = L.LayerRadial()
+                _stack_radial_struct(rad_n, plan_n, pre_n, table, e, w_n)
+                a.next, a.next_rad = nl_n.handle(dev), C.pointer(rad_n)
+                nxt_keep = (rad_n, None, None, w_n, None, plan_n, pre_n)
+        elif nxt is not None and fork and conv_block.LOOK_AHEAD and not stack:
             plan_n, w_last_n, w_hidden_n = nxt
             nl_n = native_layer(plan_n)
             if nl_n is not None:
@@ -303,7 +462,10 @@ class NativeConvBlockFn(torch.autograd.Function):
                 buf.record_stream(side2)
                 x.record_stream(side2)
                 _record_once(node_attrs, side2)
-            w.record_stream(main)
+            if w is not pre:
+                w.record_stream(main)
+            else:
+                pre.record_stream(main)        # (allocated by the stack on the radial stream, read by the tensor product here)
             _record_once(edge_radial, side)
             if table is not None:
                 for t in table:
@@ -314,12 +476,14 @@ class NativeConvBlockFn(torch.autograd.Function):
             if t_n is not None:
                 with conv_block._on(side, main):
                     radial_table.guard(plan_n.guard_key if plan_n.guard_key is not None else w_last_n, t_n)
-            # (the rows and the table themselves are the key: held here, their identity cannot be reused by a later batch)
-            plan_n.prefetched = ((edge_radial, table, keep, fork, "native"), (nbuf, ncarve, w_n, t_n))
+            # (the rows and the table themselves are the key: held here, their identity cannot be reused by a later batch;
+            #  in stack mode the key is the next layer's own rows, w_last_n stands for them)
+            plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))
         if keep:
             ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
                                   w_last, *w_hidden)
             ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
+            ctx.stack = stack
             ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
         return y
 
@@ -333,9 +497,13 @@ class NativeConvBlockFn(torch.autograd.Function):
         w_hidden = saved[10:10 + n_hidden]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
-        p0 = 12
+        stack, need_pre = ctx.stack, need[12]
+        p0 = 13
         need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
         need_hidden = need[p0 + 4:]
+        if stack:
+            need_radial = need_last = False
+            need_hidden = ()
         if torch.is_grad_enabled() or need_sh:
             raise RuntimeError(
                 "the fused convolution block serves first-order training only (no gradient w.r.t. the spherical harmonics, "
@@ -366,9 +534,11 @@ class NativeConvBlockFn(torch.autograd.Function):
         if has_sc:
             a.a_rep, a.m, a.w_sc = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"]), w_sc.data_ptr()
             a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
-        keep_z = True
-        _radial_struct(a.rad, plan, edge_radial, table, e, keep_z, w_last, w_hidden, rbuf, rcarve, w, None if table is None else w)
-        a.rad.T = None
+        if stack:
+            _stack_radial_struct(a.rad, plan, edge_radial, table, e, w)      # (edge_radial: the layer's pre-computed rows)
+        else:
+            _radial_struct(a.rad, plan, edge_radial, table, e, True, w_last, w_hidden, rbuf, rcarve, w, None if table is None else w)
+            a.rad.T = None
         a.gy = gy.data_ptr()
         # ---- gradient buffers: the flat gradient buffer (sink) or zero-filled temporaries handed back to autograd
         rets = {}
@@ -396,8 +566,9 @@ class NativeConvBlockFn(torch.autograd.Function):
         a.gb_lin1, a.gb_post, a.gb_sc, a.gb_last = _ptr(gb_lin1), _ptr(gb_post), _ptr(gb_sc), _ptr(gb_last)
         for i, g in enumerate(gb_hidden):
             a.gb_hidden[i] = _ptr(g)
-        need_radial_side = need_last or need_radial or any(need_hidden)
+        need_radial_side = need_last or need_radial or any(need_hidden) or (stack and need_pre)
         want_sc = has_sc and (need_sc or need_attrs)
+        g_pre = None
         # ---- scratch: one allocation
         sc_ = _Carve()
         sc_.add("g_conv", n * post.d_out)
@@ -412,9 +583,16 @@ class NativeConvBlockFn(torch.autograd.Function):
             else:
                 g_x = torch.empty(n, lin1.d_in, device=dev, dtype=torch.float32)
         if need_radial_side:
-            sc_.add("g_w", e * last.d_out)
+            if stack and table is None:
+                g_pre = torch.empty(e, last.d_out, device=dev, dtype=torch.float32)      # g_w IS the gradient of the layer's rows
+            else:
+                sc_.add("g_w", e * last.d_out)
             if table is not None:
-                sc_.add("g_T", r * last.d_out)
+                if stack:
+                    with conv_block._on(side, main):
+                        g_pre = torch.empty(r, last.d_out, device=dev, dtype=torch.float32)
+                else:
+                    sc_.add("g_T", r * last.d_out)
                 sc_.add("table_ws", int(L.load().e3k_rtable_bwd_workspace_floats(radial_table.KNOTS, last.d_out)))
             if need_radial or any(need_hidden):
                 sc_.add("g_h", r * last.d_in)
@@ -437,6 +615,11 @@ class NativeConvBlockFn(torch.autograd.Function):
         for k in ("g_w", "g_T", "table_ws", "g_h", "gm", "ga", "kw_ws"):
             if k in so:
                 setattr(a, k, _ptr(work, so[k]))
+        if g_pre is not None:
+            if table is None:
+                a.g_w = g_pre.data_ptr()
+            else:
+                a.g_T = g_pre.data_ptr()
         g_attrs = g_radial = None
         if need_attrs and has_sc:
             with conv_block._on(side2, main):
@@ -467,8 +650,12 @@ class NativeConvBlockFn(torch.autograd.Function):
             for t in rets.values():
                 t.record_stream(main)
         if ops.GRAD_READY is not None:
-            needs = (need_lin1, need_post, need_sc or not has_sc, need_last, *need_hidden)
+            needs = (need_lin1, need_post, need_sc or not has_sc) + (() if stack else (need_last, *need_hidden))
             if all(needs) and not rets:          # every weight gradient of the layer went to the sink
-                ops.GRAD_READY([w_lin1, w_post, w_last, *w_hidden] + ([w_sc] if has_sc else []))
-        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None,
+                # (stack mode: the radial MLP's gradients arrive with RadialStackFn's backward, after the last layer -- the
+                #  layer's slice of the all-reduce schedule is then its node-side weights, see run/parallel.py)
+                ops.GRAD_READY([w_lin1, w_post] + ([] if stack else [w_last, *w_hidden]) + ([w_sc] if has_sc else []))
+        if g_pre is not None and fork and table is None:
+            g_pre.record_stream(side)          # (allocated here, consumed by the stack's backward on the radial stream)
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None, g_pre,
                 rets.get("lin1"), rets.get("post"), rets.get("sc"), rets.get("last"), *[rets.get(f"h{i}") for i in range(n_hidden)])

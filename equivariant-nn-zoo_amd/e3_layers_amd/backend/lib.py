@@ -86,9 +86,19 @@ class LayerDesc(C.Structure):
 
 class LayerRadial(C.Structure):
     _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
-                ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
+                ("have_rows", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
                 ("bin_t", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
                 ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p)]
+
+
+class RadialStackItem(C.Structure):
+    _fields_ = [("rad", LayerRadial), ("g_rows", C.c_void_p), ("gb_last", C.c_void_p), ("gb_hidden", C.c_void_p * 4),
+                ("g_h", C.c_void_p), ("g_radial", C.c_void_p)]
+
+
+class MlpNet(C.Structure):
+    _fields_ = [("weights", C.c_void_p * 4), ("z", C.c_void_p * 4), ("out", C.c_void_p), ("g_out", C.c_void_p),
+                ("g_weights", C.c_void_p * 4), ("g_x", C.c_void_p)]
 
 
 class LayerFwdArgs(C.Structure):
@@ -129,6 +139,10 @@ SIGNATURES = {
     "e3k_layer_destroy": (None, [_P]),
     "e3k_layer_fwd": (C.c_int, [_P, C.POINTER(LayerFwdArgs)]),
     "e3k_layer_bwd": (C.c_int, [_P, C.POINTER(LayerBwdArgs)]),
+    "e3k_radial_stack_fwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(LayerRadial), _I32, _P]),
+    "e3k_radial_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(RadialStackItem), _I32, _P]),
+    "e3k_mlp_hidden_fwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
+    "e3k_mlp_hidden_bwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
     "e3k_layer_profile": (C.c_int, [_P, _I32]),
     "e3k_layer_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),

@@ -36,12 +36,13 @@ class RadialSource:
     counter of the embedding tensor when it was tagged (an in-place op on the embedding bumps it: the tag then no longer
     describes the tensor's contents and the table is not used)."""
 
-    __slots__ = ("module", "r", "version", "_bins", "_knot_basis", "__weakref__")
+    __slots__ = ("module", "r", "version", "_bins", "_knot_basis", "_stack", "__weakref__")
 
     def __init__(self, module, r: torch.Tensor, version: int = 0):
         self.module, self.r, self.version = weakref.ref(module), r, int(version)
         self._bins = None
         self._knot_basis = None
+        self._stack = {}      # id(MessagePassing) -> (its radial MLP's rows on the knots, mode): nn/message_passing.py:_stack_rows
 
     def bins(self):
         """(centre knot int32 [E], offset t [E], CSR by knot) -- once per batch, shared by the layers."""

@@ -55,6 +55,12 @@ RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "0"))
 # 1: consecutive MessagePassing layers pass their node features in the channel-fastest layout (MessagePassing._emit_cf)
 CF_CHAIN = int(os.environ.get("E3K_CF_CHAIN", "1"))
 AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
+# 1: the radial MLPs of all the layers that read one edge embedding run as one batch on the knot table (first layer of
+# the chain), see MessagePassing._stack_rows
+RADIAL_STACK = int(os.environ.get("E3K_RADIAL_STACK", "1"))
+# ... while the step is launch-bound: with more edges than this every layer runs its own MLP (its backward then overlaps
+# the earlier layers' backward instead of forming one tail behind the first layer's; measured cross-over)
+STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
 
 
 def _stream_alias(t: Tensor, stream) -> Tensor:
@@ -287,6 +293,51 @@ class MessagePassing(Module):
         self.__dict__["_cb_plan"] = plan
         return plan
 
+    def _stack_rows(self, cache: dict, rows, edge_radial, plan, fork: bool, use_table: bool):
+        """This layer's radial-MLP output rows (on the knots of the table, or per edge), from one batched evaluation of the
+        MLPs of every layer that follows on the same edge embedding (``_next_mp`` chain) -- or None when the stack does not
+        apply.  The first layer of a chain computes it (on the radial stream when forked) and leaves the others' rows in
+        ``cache`` (which lives as long as this forward pass's edge embedding); every layer takes its own entry out."""
+        from ..backend import conv_native
+
+        if not conv_native.ENABLED or conv_native.native_layer(plan) is None:
+            return None
+        grad = torch.is_grad_enabled()
+        hit = cache.pop(id(self), None)
+        if hit is not None and hit[1] == (grad, fork):
+            return hit[0]
+        sig = (plan.mlp_k0, plan.last_spec.d_in, tuple(plan.mlp_alphas), plan.mlp_act, plan.mlp_cst)
+        chain, m = [], self
+        n_edges = edge_radial.shape[0]
+        while m is not None and len(chain) < 16:
+            pl = m._block_plan() if m is not self else plan
+            if pl is None or conv_native.native_layer(pl) is None:
+                break
+            fc = list(m.conv.fc.children())
+            if (pl.mlp_k0, pl.last_spec.d_in, tuple(pl.mlp_alphas), pl.mlp_act, pl.mlp_cst) != sig:
+                break
+            if m is not self and (radial_table.applicable(edge_radial, fc[-1].weight) != use_table
+                                  or bool(FWD_FORK and m.conv._fork_pays(n_edges)) != bool(FWD_FORK and self.conv._fork_pays(n_edges))):
+                break
+            chain.append((m, pl, fc))
+            m = m.__dict__.get("_next_mp")
+        weights = []
+        for _, _, fc in chain:
+            weights.append(fc[-1].weight)
+            weights.extend(mod.weight for mod in fc[:-1])
+        plans = [pl for _, pl, _ in chain]
+        if fork:
+            main = torch.cuda.current_stream(rows.device)
+            side = ops.side_stream(rows.device)
+            side.wait_stream(main)              # (the knot basis was evaluated on this stream)
+            with ops.on_stream(side, main):     # forward AND backward of the stack live on the radial stream
+                outs = conv_native.RadialStackFn.apply(rows, plans, use_table, *weights)
+        else:
+            outs = conv_native.RadialStackFn.apply(rows, plans, use_table, *weights)
+        for (m, _, _), out in zip(chain[1:], outs[1:]):
+            cache[id(m)] = (out, (grad, fork))
+        return outs[0]
+
     def _forward_block(self, data, out_cf: bool):
         """The layer through ``conv_block`` when it applies to this call, else None (composed path)."""
         if not conv_block.ENABLED:
@@ -325,6 +376,23 @@ class MessagePassing(Module):
                     attrs = _stream_alias(attrs, side2)
         nxt = None
         nmp = self.__dict__.get("_next_mp")          # set by SequentialGraphNetwork: the next layer reads the same edge embedding
+        pre = None
+        if RADIAL_STACK and data["edge_radial"].shape[0] <= STACK_MAX_EDGES:
+            if table is not None:
+                cache = src._stack
+            else:      # per-edge MLPs: the rows of the layers wait on the edge embedding of this forward pass
+                cache = getattr(data["edge_radial"], "_e3k_stack", None)
+                if cache is None:
+                    cache = data["edge_radial"]._e3k_stack = {}
+            pre = self._stack_rows(cache, radial, data["edge_radial"], plan, fork, table is not None)
+        if pre is not None:      # the MLPs of all the layers on this edge embedding ran as one batch (conv_native.RadialStackFn)
+            if nmp is not None and fork and table is not None:
+                pre_n = cache.get(id(nmp))
+                if pre_n is not None:
+                    nxt = (nmp._block_plan(), pre_n[0])
+            return conv_block.conv_block(x, attrs, None, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
+                                         conv.linear_1.weight, conv.tp.linear.weight,
+                                         conv.sc.weight if conv.sc is not None else None, None, (), table=table, nxt=nxt, pre=pre)
         if nmp is not None and fork and nmp.conv._fork_pays(data["edge_radial"].shape[0]):
             plan_n = nmp._block_plan()
             if plan_n is not None and (nmp.conv.sc is None) == (conv.sc is None):

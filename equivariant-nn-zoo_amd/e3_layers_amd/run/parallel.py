@@ -74,6 +74,29 @@ def backward_parameters(loss: torch.Tensor, params: Iterable[torch.nn.Parameter]
         loss.backward(inputs=[p for p in params if p.requires_grad])
 
 
+def _radial_mlp_params(mp) -> list:
+    conv = getattr(mp, "conv", None)
+    fc = getattr(conv, "fc", None)
+    return list(fc.parameters()) if fc is not None else []
+
+
+def flat_param_order(model: torch.nn.Module) -> list:
+    """``model.parameters()`` with the radial MLPs of the message-passing layers moved to the tail.  With this order
+    in ``FlatGradients`` / ``FusedAdamEMA`` every layer's node-side weights (linear_1, tp.linear, sc) are one contiguous
+    slice whose all-reduce starts behind that layer's backward, and the radial MLPs -- whose gradients are written by
+    one batched backward at the end (``backend/conv_native.RadialStackFn``) -- are one slice of the remainder."""
+    from ..nn.message_passing import MessagePassing
+
+    tail, tail_ids = [], set()
+    for mod in model.modules():
+        if isinstance(mod, MessagePassing):
+            for p in _radial_mlp_params(mod):
+                if id(p) not in tail_ids:
+                    tail_ids.add(id(p))
+                    tail.append(p)
+    return [p for p in model.parameters() if id(p) not in tail_ids] + tail
+
+
 class FlatGradients:
     """Points every ``p.grad`` at a slice of one contiguous buffer."""
 
@@ -127,6 +150,7 @@ class FlatGradients:
     _comm = None
     _schedule = ()         # [(lo, hi)] in issue order
     _layer_of = None       # (data_ptr, numel) -> (schedule position, weakref to the Parameter)
+    _layer_size = ()       # schedule position -> number of parameters in that layer's slice
     _issued = 0            # schedule entries issued this step
     _ready = None          # schedule positions whose layer has reported this step
     _works = ()
@@ -143,23 +167,34 @@ class FlatGradients:
             if model is not None:
                 from ..nn.message_passing import MessagePassing
 
-                layer_params = [list(mod.parameters()) for mod in model.modules() if isinstance(mod, MessagePassing)]
+                # per layer: its node-side weights alone (contiguous when the buffer was laid out by ``flat_param_order``:
+                # the radial MLPs' gradients arrive together at the END of the backward when the MLPs run as one stack, so
+                # they belong to the remainder), else all its parameters
+                for mod in model.modules():
+                    if isinstance(mod, MessagePassing):
+                        radial = {id(p) for p in _radial_mlp_params(mod)}
+                        layer_params.append(([p for p in mod.parameters() if id(p) not in radial], list(mod.parameters())))
         slot = {id(p): (off, -(-p.numel() // FLAT_ALIGN) * FLAT_ALIGN) for p, off in zip(self.params, self.offsets)}
         layers = []
-        for group in layer_params:
-            sl = [slot.get(id(p)) for p in group if p.requires_grad]
-            if not sl or any(x is None for x in sl):
-                continue
-            lo, hi = min(o for o, _ in sl), max(o + n for o, n in sl)
-            if sum(n for _, n in sl) != hi - lo:
-                continue                      # not one contiguous run of the flat buffer: stays in the remainder
-            layers.append((lo, hi, [p for p in group if p.requires_grad]))
+        for candidates in layer_params:
+            if not isinstance(candidates, tuple):
+                candidates = (candidates,)
+            for group in candidates:
+                sl = [slot.get(id(p)) for p in group if p.requires_grad]
+                if not sl or any(x is None for x in sl):
+                    continue
+                lo, hi = min(o for o, _ in sl), max(o + n for o, n in sl)
+                if sum(n for _, n in sl) != hi - lo:
+                    continue                      # not one contiguous run of the flat buffer: stays in the remainder
+                layers.append((lo, hi, [p for p in group if p.requires_grad]))
+                break
         layers.sort(key=lambda t: -t[0])      # reverse layer order = the order the backward reaches them
-        schedule, self._layer_of = [], {}
+        schedule, self._layer_of, self._layer_size = [], {}, []
         for pos, (lo, hi, group) in enumerate(layers):
             if any(lo < h and l < hi for l, h in schedule):
                 continue                      # nested MessagePassing modules: the outer one already covers it
             schedule.append((lo, hi))
+            self._layer_size.append(len(group))
             for p in group:
                 self._layer_of[(p.data_ptr(), p.numel())] = (len(schedule) - 1, weakref.ref(p))
         covered, pos = sorted(schedule), 0
@@ -211,19 +246,22 @@ class FlatGradients:
     def _on_ready(self, weights) -> None:
         if self._layer_of is None or (self.buffer.is_cuda and torch.cuda.is_current_stream_capturing()):
             return
-        pos = None
+        pos, seen = None, set()
         for w in weights:
-            hit = self._layer_of.get((w.data_ptr(), w.numel()))
+            key = (w.data_ptr(), w.numel())
+            hit = self._layer_of.get(key)
             if hit is None:
-                return
+                continue                      # not part of a layer slice (the remainder is issued by all_reduce_mean())
             p = hit[1]()
             if p is None or p.data_ptr() != w.data_ptr():
                 return                        # the parameter moved after enable_overlapped_all_reduce(): no early start
             if pos is not None and hit[0] != pos:
                 return
             pos = hit[0]
-        if pos is None:
-            return
+            seen.add(key)
+        if pos is None or len(seen) != self._layer_size[pos]:
+            return                            # the slice holds parameters this report does not cover: their gradients may
+                                              # still be on their way (e.g. a radial MLP evaluated in the stack): no early start
         self._ready.add(pos)
         upto = self._issued
         while upto in self._ready:            # only ever the next entries of the fixed sequence

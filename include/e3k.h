@@ -375,6 +375,21 @@ int e3k_mlp_hidden_bwd(const float* x, int64_t E, int32_t k0, int32_t h, int32_t
                        const float* alphas, int32_t act, float cst, const float* const* z, const float* g_out,
                        float* const* g_weights, float* g_x, void* stream);
 
+/* Several MLPs of ONE shape over the SAME input rows in one launch each way (the radial MLPs of all the layers of a
+ * network read one edge embedding: nn/message_passing.py:74-79,93 per layer).  g_x is per net (the caller sums). */
+typedef struct {
+  const float* weights[4];
+  float* z[4];            /* forward: pre-activations out (NULL entries: not kept); backward: in */
+  float* out;             /* forward: [E, h] */
+  const float* g_out;     /* backward: gradient w.r.t. out */
+  float* g_weights[4];    /* backward: accumulated (NULL entries: skipped) */
+  float* g_x;             /* backward: [E, k0] or NULL */
+} e3k_mlp_net;
+int e3k_mlp_hidden_fwd_multi(const e3k_mlp_net* nets, int32_t n_nets, const float* x, int64_t E, int32_t k0, int32_t h,
+                             int32_t n_layers, const float* alphas, int32_t act, float cst, void* stream);
+int e3k_mlp_hidden_bwd_multi(const e3k_mlp_net* nets, int32_t n_nets, const float* x, int64_t E, int32_t k0, int32_t h,
+                             int32_t n_layers, const float* alphas, int32_t act, float cst, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Radius graph on the device.
  * Replaces computeEdgeIndex (e3_layers/data/compute_edge.py:38-113) for the criteria-free case: per graph all
@@ -455,7 +470,10 @@ void e3k_layer_destroy(e3k_layer* layer);
  * table, the interpolation to the E edges */
 typedef struct {
   int64_t R, E;
-  int32_t use_table, keep, knots, _pad;
+  int32_t use_table, keep, knots;
+  int32_t have_rows;         /* the MLP's output rows (T with the table, else w) were computed by e3k_radial_stack_fwd:
+                                the layer only interpolates (table) / uses w as it is; its backward stops at the gradient
+                                of those rows (g_T resp. g_w), which e3k_radial_stack_bwd takes from there */
   const float* radial;       /* [R, k0] */
   const int32_t* bin;        /* table: centre knot per edge, */
   const int32_t* bin_ptr;    /*        CSR by knot (backward), */
@@ -508,6 +526,22 @@ typedef struct {
   float *g_conv, *g_mid, *g_x1, *g_xcf, *g_w, *g_T, *table_ws, *g_h, *gm, *ga, *kw_ws;
 } e3k_layer_bwd_args;
 int e3k_layer_bwd(const e3k_layer* layer, const e3k_layer_bwd_args* a);
+
+/* The radial MLPs of several layers that read the same rows (one edge embedding / one knot basis), batched: hidden
+ * chains in ONE launch (e3k_mlp_hidden_fwd_multi), last layers in ONE e3k_gemm_multi call -> rads[i].T (table) or
+ * rads[i].w (per edge); backward: last-layer weight gradients in one call, input gradients in one, hidden chains in
+ * one.  Per layer this was 2 launches forward and 4-5 backward on 4 097 knot rows -- latency, not work: 0.6 ms of a
+ * 3.4 ms step at 64 molecules.  All layers must share k0 / h / depth / activation (the shipped models do). */
+typedef struct {
+  e3k_layer_radial rad;      /* radial rows, weights, h, z as in the forward */
+  const float* g_rows;       /* [R, W] gradient of the MLP's output rows (from e3k_layer_bwd: g_T or g_w) */
+  float* gb_last;            /* weight-gradient buffers (NULL = not needed), accumulated */
+  float* gb_hidden[4];
+  float* g_h;                /* scratch [R, h] */
+  float* g_radial;           /* [R, k0] per layer (the caller sums) or NULL */
+} e3k_radial_stack_item;
+int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, void* stream);
+int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, void* stream);
 
 /* Per-kernel timing of a layer's edge kernels (bench.py's roofline block: HIP events on the stream that runs the kernel).
  * e3k_layer_profile(layer, capacity): capacity > 0 arms `capacity` event pairs per kind, 0 disarms.

@@ -365,6 +365,9 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
     monkeypatch.setattr(radial_table, "KNOTS", 512)        # so that this small batch has enough edges per knot
     monkeypatch.setattr(radial_table, "GUARD_TOL", 1.0)    # (512 knots: bound 4e-6 -- this test is about launch order, not accuracy)
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+    # table: the MLPs ran as one stack on the knots, the look-ahead is the next layer's interpolation; per edge: the stacked
+    # MLPs leave nothing to issue ahead, so the look-ahead is exercised with every layer running its own
+    monkeypatch.setattr(mp, "RADIAL_STACK", table)
 
     def run(ahead, grad=True):
         monkeypatch.setattr(conv_block, "LOOK_AHEAD", ahead)
@@ -390,6 +393,73 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
     for layer in (model.layer0, model.layer1, model.layer2, model.layer3):
         plan = layer._block_plan()
         assert plan is not None and plan.prefetched is None                 # nothing left behind
+
+
+@pytest.mark.parametrize("table", [1, 0])
+@pytest.mark.parametrize("fork", [True, False])
+def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table):
+    """The radial MLPs of all layers evaluated as one batch on the knot table (MessagePassing._stack_rows ->
+    conv_native.RadialStackFn: one launch for the hidden chains, one for the last layers, the same backward) against each
+    layer running its own: energies and every parameter gradient (Bessel frequencies included -- their gradient is the sum
+    over the layers' MLP input gradients), with the gradient sink and without, forked and on one stream."""
+    from e3_layers_amd.backend import conv_block, conv_native, ops, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients, flat_param_order
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(3)
+    model = build(_energy_tree(2, 64, 4)).to(dev).train()
+    batch = synth_qm9(13, 24).to(dev)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0 if fork else 10 ** 9)
+    monkeypatch.setattr(mp, "FWD_FORK", 1)
+    monkeypatch.setattr(conv_block, "ENABLED", 1)
+    monkeypatch.setattr(conv_native, "ENABLED", 1)
+    monkeypatch.setattr(mp, "STACK_MAX_EDGES", 10 ** 9)
+    monkeypatch.setattr(radial_table, "ENABLED", table)      # (0: the per-edge MLPs, stacked the same way)
+    monkeypatch.setattr(radial_table, "KNOTS", 512)
+    monkeypatch.setattr(radial_table, "GUARD_TOL", 1.0)
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+
+    def run(stack, sink):
+        monkeypatch.setattr(mp, "RADIAL_STACK", stack)
+        model.zero_grad(set_to_none=True)
+        flat = None
+        if sink:
+            flat = FlatGradients(flat_param_order(model))
+            flat.enable_direct_accumulation()
+            flat.zero()
+        try:
+            n0 = conv_native.STACK_STATS[0]
+            out = model(batch.clone())["total_energy"]
+            (out * torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)).sum().backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            n_calls = conv_native.STACK_STATS[0] - n0
+        finally:
+            if flat is not None:
+                flat.disable_direct_accumulation()
+                model.zero_grad(set_to_none=True)
+        return out.detach().clone(), grads, n_calls
+
+    e0, g0, c0 = run(0, False)
+    assert c0 == 0
+    for sink in (False, True):
+        e1, g1, c1 = run(1, sink)
+        assert c1 == 1 and conv_native.STACK_STATS[1] == 4          # ONE stack evaluation for the four layers
+        assert rel_err(e1, e0) < 1e-6
+        assert set(g1) == set(g0)
+        for k in g0:
+            assert rel_err(g1[k], g0[k]) < 1e-5, (k, sink)
+    with torch.no_grad():
+        monkeypatch.setattr(mp, "RADIAL_STACK", 1)
+        e_ng = model(batch.clone())["total_energy"]
+    assert rel_err(e_ng, e0) < 1e-6
+    monkeypatch.setattr(mp, "STACK_MAX_EDGES", 10)             # more edges than the stack is for: every layer its own MLP
+    n0 = conv_native.STACK_STATS[0]
+    e_big = model(batch.clone())["total_energy"]
+    assert conv_native.STACK_STATS[0] == n0 and rel_err(e_big, e0) < 1e-6
 
 
 @pytest.mark.parametrize("block", [1, 0])

@@ -36,7 +36,7 @@ from e3_layers_amd.configs import config_diffusion_CA, config_energy_force
 from e3_layers_amd.configs.layer_configs import addEnergyOutput, featureModel
 from e3_layers_amd.data.synthetic import synth_protein, synth_qm9
 from e3_layers_amd.run.optim import FusedAdamEMA
-from e3_layers_amd.run.parallel import backward_parameters, broadcast_parameters, shard_batch
+from e3_layers_amd.run.parallel import backward_parameters, broadcast_parameters, flat_param_order, shard_batch
 from e3_layers_amd.run.sde_utils import VPSDE, sde_loss
 from e3_layers_amd.utils import build
 
@@ -53,7 +53,7 @@ else:
 torch.manual_seed(100 + rank)               # different initial weights per rank ...
 model = build(tree).to(dev)
 broadcast_parameters(model)                 # ... made identical, as DDP does at construction
-opt = FusedAdamEMA(model.parameters(), lr=1e-2, ema_decay=0.99)
+opt = FusedAdamEMA(flat_param_order(model), lr=1e-2, ema_decay=0.99)
 flat = opt.grads
 flat.enable_direct_accumulation()
 if mode in ("overlap", "uneven"):

@@ -144,7 +144,18 @@ def _worker_schedule(rank, world, port, ret):
             flat._on_ready(list(model.layers[k].parameters()))
         flat.all_reduce_mean()
         grads.append(flat.gather().clone())
-    ret[rank] = (grads, sched, flat.overlapped_slices)
+    # a report that covers only part of a slice (a layer whose radial MLP runs in the batched stack reports its node-side
+    # weights alone) must not start that slice: the rest of its gradients may not have been written yet
+    early = flat.overlapped_slices
+    flat.zero()
+    _loss_sum(model, mine).backward()
+    flat._on_ready(list(model.layers[2].parameters())[:1])
+    assert flat.overlapped_slices == early and flat._issued == 0
+    flat._on_ready(list(model.layers[2].parameters()) + [model.head.weight])      # (a remainder parameter rides along: ignored)
+    assert flat.overlapped_slices == early + 1
+    flat.all_reduce_mean()
+    grads.append(flat.gather().clone())
+    ret[rank] = (grads, sched, early)
     dist.destroy_process_group()
 
 
