@@ -99,6 +99,8 @@ namespace {
 // 1: keyed-weight kernels (fwd + bwd), 2: weight-gradient GEMMs, 4: gate fwd + bwd, 8: table interpolation fwd + bwd,
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
 static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
+// the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
+static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
 
 enum SetId { LIN1_FWD, LIN1_DGRAD, LIN1_DGRAD_ACC, LIN1_WGRAD, POST_FWD, POST_DGRAD, POST_WGRAD, SC_FWD, SC_DGRAD, SC_WGRAD,
              LAST_FWD, LAST_DGRAD, LAST_WGRAD, N_SETS };
@@ -162,7 +164,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   const e3k_layer_desc& d = L->d;
   if (r.R == 0 || r.E == 0) return E3K_OK;
   if (r.have_rows) {      // the stack computed T (table) or w (per edge) already
-    if (r.use_table && !(ABLATE & 8)) {
+    if (r.use_table && !(ABLATE & 8) && !in_kernel_table(d, r)) {
       Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
       E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
     }
@@ -177,7 +179,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
     g.add(L, LAST_FWD, r.h, r.w_last, r.use_table ? r.T : r.w, r.R);
     E3K_TRY(g.run(0, st));
   }
-  if (r.use_table && !(ABLATE & 8)) {
+  if (r.use_table && !(ABLATE & 8) && !in_kernel_table(d, r)) {
     Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
     E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
   }
@@ -278,7 +280,8 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   void* side = a->fork ? a->side : main;
   void* side2 = a->fork ? a->side2 : main;
   if (a->N == 0) return E3K_OK;
-  if (!a->x || !a->sh || !a->x1 || !a->mid || !a->conv || !a->y || !a->rad.w) return E3K_ERR_INVALID;
+  if (!a->x || !a->sh || !a->x1 || !a->mid || !a->conv || !a->y) return E3K_ERR_INVALID;
+  if (in_kernel_table(d, a->rad) ? (!a->rad.T || !e3k_tp_table_supported(d.tp)) : !a->rad.w) return E3K_ERR_INVALID;
   // --- radial branch (unless the previous layer's look-ahead already issued it)
   if (!a->has_w && !(a->rad.have_rows && !a->rad.use_table)) {
     E3K_TRY(edge(L, 0, main, side));
@@ -319,7 +322,11 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   E3K_TRY(edge(L, 2, side, main));           // the per-edge weights
   {
     Timed t(L, E3K_PROF_TP_FWD, main, a->N, a->E);
-    E3K_TRY(e3k_tp_fwd(d.tp, a->x1, a->sh, a->rad.w, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->mid, main));
+    if (in_kernel_table(d, a->rad))
+      E3K_TRY(e3k_tp_fwd_table(d.tp, a->x1, a->sh, a->rad.T, a->rad.bin, a->rad.bin_t, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
+                               a->mid, main));
+    else
+      E3K_TRY(e3k_tp_fwd(d.tp, a->x1, a->sh, a->rad.w, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->mid, main));
   }
   if (a->next && a->next_rad && side != main) {
     E3K_TRY(edge(L, 3, main, side));         // behind this layer's tensor product: both are HBM streams
@@ -410,7 +417,12 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (!d.tp_bwd_x_overwrites && e3k::zero_fill(a->g_x1, sizeof(float) * a->N * d.d_x1, (hipStream_t)main))
       return E3K_ERR_LAUNCH;
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
-    if (!(ABLATE & 32)) E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+    if (ABLATE & 32) {
+    } else if (in_kernel_table(d, r)) {
+      E3K_TRY(e3k_tp_bwd_x_table(d.tp, a->sh, r.T, r.bin, r.bin_t, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+    } else {
+      E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+    }
   }
   if (need_radial_side && a->E > 0) {
     if (!a->g_w) return E3K_ERR_INVALID;

@@ -69,7 +69,31 @@ __device__ __forceinline__ void load_y_full(YRegs& y, const float* __restrict__ 
   for (int j = 0; j < 5; ++j) y.y2[j] = yr[4 + j];
 }
 
-template <int L1, int L3MAX, int PART>
+// TABLE: the edge's path weights are not read from w[e] but interpolated here from the three rows of the radial knot
+// table around the edge's radius (same weights, same order of operations as rtable_interp_fwd_kernel): w[E, W] is never
+// written or read; the table (11-19 MB a layer) is served by L2 / the Infinity Cache.
+struct KnotRows {
+  __amdgpu_buffer_rsrc_t ra, rb, rc;
+  float cm, c0, cp;
+};
+__device__ __forceinline__ KnotRows knot_rows(const TpArgs& a, int e, int row_w) {
+  const int i = uniform(a.bin[e]);
+  const float t = __uint_as_float(uniform((int)__float_as_uint(a.tt[e])));
+  const float* __restrict__ base = a.w + (int64_t)(i - 1) * a.W;
+  KnotRows k;
+  k.ra = row_rsrc(base, row_w);
+  k.rb = row_rsrc(base + a.W, row_w);
+  k.rc = row_rsrc(base + 2 * a.W, row_w);
+  k.cm = 0.5f * t * (t - 1.f);
+  k.c0 = 1.f - t * t;
+  k.cp = 0.5f * t * (t + 1.f);
+  return k;
+}
+__device__ __forceinline__ float knot_mix(const KnotRows& k, float va, float vb, float vc) {
+  return fmaf(k.cp, vc, fmaf(k.c0, vb, k.cm * va));
+}
+
+template <int L1, int L3MAX, bool TABLE, int PART>
 __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -93,14 +117,29 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
     YRegs yc;
     load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
-    const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
     float xc[D1], wc[S::NQ];
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
-    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      wc[Q] = buf_ld_stream(rw, u4, woff4[Q]);
-    });
+    if constexpr (TABLE) {
+      const KnotRows kr = knot_rows(a, e, row_w);
+      float wa[S::NQ], wb[S::NQ], wcc[S::NQ];
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wa[Q] = buf_ld(kr.ra, u4, woff4[Q]);
+        wb[Q] = buf_ld(kr.rb, u4, woff4[Q]);
+        wcc[Q] = buf_ld(kr.rc, u4, woff4[Q]);
+      });
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wc[Q] = knot_mix(kr, wa[Q], wb[Q], wcc[Q]);
+      });
+    } else {
+      const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wc[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+      });
+    }
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
@@ -120,10 +159,11 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
   });
 }
 
-template <int L1, int L3MAX, int PART, bool FULL>
+template <int L1, int L3MAX, bool TABLE, int PART, bool FULL>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  static_assert(FULL || !TABLE, "the table form exists for FULL plans only");
   if constexpr (FULL) {
-    tp_fwd_body_full<L1, L3MAX, PART>(a, g, node, u);
+    tp_fwd_body_full<L1, L3MAX, TABLE, PART>(a, g, node, u);
     return;
   }
   using S = Slots<L1>;
@@ -307,7 +347,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX, int PART>
+template <int L1, int L3MAX, bool TABLE, int PART>
 __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -332,18 +372,38 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     const int d = uniform(a.nbr[e]);
     YRegs yc;
     load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
-    const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
     float gn[S::TOTAL], wn[S::NQ];
-    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+    if constexpr (TABLE) {
+      const KnotRows kr = knot_rows(a, e, row_w);
+      float wa[S::NQ], wb[S::NQ], wcc[S::NQ];
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
 #pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k)
-        gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
-      wn[Q] = buf_ld_stream(rw, u4, woff4[Q]);
-    });
-    __builtin_amdgcn_sched_barrier(0);
+        for (int k = 0; k < 2 * L3 + 1; ++k)
+          gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+        wa[Q] = buf_ld(kr.ra, u4, woff4[Q]);
+        wb[Q] = buf_ld(kr.rb, u4, woff4[Q]);
+        wcc[Q] = buf_ld(kr.rc, u4, woff4[Q]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wn[Q] = knot_mix(kr, wa[Q], wb[Q], wcc[Q]);
+      });
+    } else {
+      const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k)
+          gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+        wn[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+    }
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
@@ -361,10 +421,11 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   }
 }
 
-template <int L1, int L3MAX, int PART, bool FULL>
+template <int L1, int L3MAX, bool TABLE, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  static_assert(FULL || !TABLE, "the table form exists for FULL plans only");
   if constexpr (FULL) {
-    tp_bwd_x_body_full<L1, L3MAX, PART>(a, g, node, u);
+    tp_bwd_x_body_full<L1, L3MAX, TABLE, PART>(a, g, node, u);
     return;
   }
   using S = Slots<L1>;
@@ -456,11 +517,11 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   E3K_TP_CASE(2, BODY, __VA_ARGS__)                                                                  \
   E3K_TP_CASE(3, BODY, __VA_ARGS__)
 
-template <int MAXL, int L3MAX, bool SPLIT, bool FULL>
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL, bool TABLE = false>
 __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_fwd_body, L3MAX)
+  E3K_TP_DISPATCH(tp_fwd_body, L3MAX, TABLE)
 }
 
 template <bool WITH_SH, int MAXL, int L3MAX, bool SPLIT, bool FULL>
@@ -470,11 +531,11 @@ __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_DISPATCH(tp_bwd_w_body, WITH_SH, L3MAX)
 }
 
-template <int MAXL, int L3MAX, bool SPLIT, bool FULL>
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL, bool TABLE = false>
 __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX)
+  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, TABLE)
 }
 #undef E3K_TP_DISPATCH
 #undef E3K_TP_CASE
@@ -653,7 +714,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 }
 
 namespace {
-enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X };
+enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -664,6 +725,21 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
+  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE) {      // FULL, un-split plans with l <= 2 (the l_max 2 models)
+    if (!p->full64 || p->split || p->max_l1 > 2) return E3K_ERR_UNSUPPORTED;
+    const bool lo = p->max_l3 <= p->max_l1;
+#define E3K_TP_LAUNCH_T(ML, L3)                                                                                                         \
+  if (kind == TP_FWD_TABLE)                                                                                                             \
+    hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);          \
+  else                                                                                                                                  \
+    hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
+    if (p->max_l1 == 2 && lo) { E3K_TP_LAUNCH_T(2, 2) }
+    else if (p->max_l1 == 0 && !lo) { E3K_TP_LAUNCH_T(0, 3) }
+    else return E3K_ERR_UNSUPPORTED;
+#undef E3K_TP_LAUNCH_T
+    E3K_CHECK_LAUNCH();
+    return E3K_OK;
+  }
 #define E3K_TP_LAUNCH_F(ML, L3, SP, FU)                                                                                      \
   switch (kind) {                                                                                                   \
     case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
@@ -674,6 +750,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
       hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<true, ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
       break;                                                                                                        \
     case TP_BWD_X: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    default: break;                                                                                                 \
   }
 #define E3K_TP_LAUNCH(ML, L3, SP)                  \
   if (p->full64) { E3K_TP_LAUNCH_F(ML, L3, SP, true) } \
@@ -732,4 +809,38 @@ extern "C" int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const floa
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X, a, plan, N, (hipStream_t)stream);
+}
+
+// ---- the same two passes with the path weights interpolated from the radial knot table inside the kernel ---------------
+// T [K + 1, W]: the radial MLP on the knots; bin / t [E]: every edge's centre knot (1 .. K - 1) and offset (e3k_rtable_bin).
+// E3K_ERR_UNSUPPORTED for plans the table form is not instantiated for (the caller then materialises w: e3k_rtable_interp_fwd).
+extern "C" int e3k_tp_table_supported(const e3k_tp_plan* p) {
+  if (!p || !p->full64 || p->split) return 0;
+  const bool lo = p->max_l3 <= p->max_l1;
+  return (p->max_l1 == 2 && lo) || (p->max_l1 == 0 && !lo);
+}
+
+extern "C" int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,
+                                const float* t, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
+                                int64_t E, float* out, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !T || !bin || !t || !src || !dst_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = T; a.bin = bin; a.tt = t; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_FWD_TABLE, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* t,
+                                  const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm,
+                                  int64_t N, int64_t E, float* g_x, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !T || !bin || !t || !dst || !src_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.sh = sh; a.w = T; a.bin = bin; a.tt = t; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_X_TABLE, a, plan, N, (hipStream_t)stream);
 }

@@ -43,6 +43,8 @@ struct TpArgs {
   const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
   const int32_t* ptr;  // CSR row pointers [N+1]
   const int32_t* perm; // CSR edge ids [E]
+  const int32_t* bin;  // TABLE kernels: centre knot of every edge [E]; w is then the knot table [K + 1, W]
+  const float* tt;     // TABLE kernels: offset of every edge from its centre knot, in knot spacings [E]
   int32_t d_in, d_sh, W, d_mid;
   int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
   int64_t n_items;

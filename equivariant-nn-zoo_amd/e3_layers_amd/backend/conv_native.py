@@ -188,6 +188,21 @@ class _Carve:
         return torch.empty(max(self.total, 64), device=dev, dtype=torch.float32)
 
 
+# 1: layers on the knot table whose tensor-product plan has the in-kernel form (e3k_tp_table_supported: the l_max 2 models)
+# interpolate their path weights inside tp_fwd / tp_bwd_x: no interpolation pass, no w[E, W] (0.2-0.3 GB a layer at 256
+# molecules) written, read twice and kept for the backward
+TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
+
+
+def in_kernel_table(plan, table, dev) -> bool:
+    if not TP_TABLE or table is None:
+        return False
+    hit = plan.__dict__.get("_tp_table_ok")
+    if hit is None:
+        hit = plan.__dict__["_tp_table_ok"] = bool(L.load().e3k_tp_table_supported(plan.tp_plan.handle(dev)))
+    return hit
+
+
 def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, keep: bool, w_last, w_hidden, buf, carve, w, t_tab):
     r = edge_radial.shape[0]
     rad.R, rad.E, rad.keep = r, n_edges, int(keep)
@@ -205,7 +220,8 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
     if keep:
         for i in range(len(w_hidden)):
             rad.z[i] = _ptr(buf, carve.off[f"z{i}"])
-    rad.w = w.data_ptr()
+    rad.w = _ptr(w)
+    rad.in_kernel = int(w is None)
 
 
 def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
@@ -218,7 +234,8 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
         rad.knots = radial_table.KNOTS
         rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
         rad.T = pre.data_ptr()
-        rad.w = w.data_ptr()
+        rad.w = _ptr(w)
+        rad.in_kernel = int(w is None)
     else:
         rad.w = pre.data_ptr()
 
@@ -346,7 +363,7 @@ def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
         for i in range(len(plan.mlp_alphas)):
             carve.add(f"z{i}", r * hdim)
     buf = carve.alloc(dev)
-    w = torch.empty(n_edges, width, device=dev, dtype=torch.float32)
+    w = None if in_kernel_table(plan, table, dev) else torch.empty(n_edges, width, device=dev, dtype=torch.float32)
     t_tab = torch.empty(r, width, device=dev, dtype=torch.float32) if table is not None else None
     return buf, carve, w, t_tab
 
@@ -386,8 +403,12 @@ class NativeConvBlockFn(torch.autograd.Function):
         # --- radial branch: this layer's (or the look-ahead's result), and the next layer's look-ahead
         pref, plan.prefetched = plan.prefetched, None
         mode = "stack" if stack else "native"
-        own_table = rbuf = rcarve = None
-        if stack and table is None:
+        own_table = rbuf = rcarve = t_tab = None
+        inker = in_kernel_table(plan, table, dev)
+        if stack and inker:
+            w = None                                 # the tensor-product kernels read the table rows themselves
+            _stack_radial_struct(a.rad, plan, pre, table, e, None)
+        elif stack and table is None:
             w = pre                                  # per-edge weights straight from the stack
             _stack_radial_struct(a.rad, plan, pre, None, e, None)
         elif pref is not None and pref[0][0] is edge_radial and pref[0][1] is table and pref[0][2:] == (keep, fork, mode):
@@ -408,7 +429,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         if not stack:
             _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab)
         nxt_keep = None
-        if stack and nxt is not None and fork and conv_block.LOOK_AHEAD and table is not None:
+        if stack and nxt is not None and fork and conv_block.LOOK_AHEAD and table is not None and not inker:
             plan_n, pre_n = nxt
             nl_n = native_layer(plan_n)
             if nl_n is not None:
@@ -462,7 +483,9 @@ class NativeConvBlockFn(torch.autograd.Function):
                 buf.record_stream(side2)
                 x.record_stream(side2)
                 _record_once(node_attrs, side2)
-            if w is not pre:
+            if w is None:
+                (pre if stack else t_tab).record_stream(main)      # (the table: allocated on the radial stream, read by the tensor product)
+            elif w is not pre:
                 w.record_stream(main)
             else:
                 pre.record_stream(main)        # (allocated by the stack on the radial stream, read by the tensor product here)
@@ -481,7 +504,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))
         if keep:
             ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
-                                  w_last, *w_hidden)
+                                  w_last, t_tab if (w is None and not stack) else None, *w_hidden)
             ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
             ctx.stack = stack
             ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
@@ -493,8 +516,8 @@ class NativeConvBlockFn(torch.autograd.Function):
 
         plan, topo, groups, in_cf, out_cf, fork, n_hidden, table, carve, rcarve, need_relayout = ctx.cfg
         saved = ctx.saved_tensors
-        x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last = saved[:10]
-        w_hidden = saved[10:10 + n_hidden]
+        x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last, t_keep = saved[:11]
+        w_hidden = saved[11:11 + n_hidden]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
         stack, need_pre = ctx.stack, need[12]
@@ -537,8 +560,10 @@ class NativeConvBlockFn(torch.autograd.Function):
         if stack:
             _stack_radial_struct(a.rad, plan, edge_radial, table, e, w)      # (edge_radial: the layer's pre-computed rows)
         else:
-            _radial_struct(a.rad, plan, edge_radial, table, e, True, w_last, w_hidden, rbuf, rcarve, w, None if table is None else w)
-            a.rad.T = None
+            _radial_struct(a.rad, plan, edge_radial, table, e, True, w_last, w_hidden, rbuf, rcarve, w,
+                           None if table is None else (w if w is not None else t_keep))
+            if w is not None:
+                a.rad.T = None
         a.gy = gy.data_ptr()
         # ---- gradient buffers: the flat gradient buffer (sink) or zero-filled temporaries handed back to autograd
         rets = {}

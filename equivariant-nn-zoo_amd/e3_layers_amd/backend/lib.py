@@ -86,7 +86,7 @@ class LayerDesc(C.Structure):
 
 class LayerRadial(C.Structure):
     _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
-                ("have_rows", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
+                ("have_rows", C.c_int32), ("in_kernel", C.c_int32), ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
                 ("bin_t", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
                 ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p)]
 
@@ -168,6 +168,9 @@ SIGNATURES = {
     "e3k_tp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "e3k_tp_bwd_x_overwrites": (C.c_int, [_P]),
+    "e3k_tp_table_supported": (C.c_int, [_P]),
+    "e3k_tp_fwd_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_x_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_csr_workspace_ints": (C.c_int64, [_I64, _I64]),
     "e3k_csr_build": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -218,6 +218,20 @@ int e3k_tp_bwd_w(const e3k_tp_plan* plan, const float* x, const float* sh, const
  * CSR by source (src_ptr, src_perm), dst [E]. */
 /* 1 when e3k_tp_bwd_x stores every element of g_x (no zero-fill needed): single-wave groups that tile [0, d_in). */
 int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* plan);
+
+/* The forward and the node-feature backward with the per-edge path weights interpolated INSIDE the kernel from the radial
+ * knot table (the weights `self.fc(edge_radial)` of nn/message_passing.py:93, never materialised as [E, W]):
+ * T [K + 1, W] = the radial MLP on the knots, bin / t [E] = each edge's centre knot and offset (e3k_rtable_bin).
+ * Same results as e3k_rtable_interp_fwd followed by e3k_tp_fwd / e3k_tp_bwd_x (same interpolation arithmetic).
+ * e3k_tp_table_supported: 1 when the plan has this form (channel-complete, un-split plans of the l_max 2 models), else the
+ * two entry points return E3K_ERR_UNSUPPORTED. */
+int e3k_tp_table_supported(const e3k_tp_plan* plan);
+int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,
+                     const float* t, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                     float* out, void* stream);
+int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* t,
+                       const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N,
+                       int64_t E, float* g_x, void* stream);
 int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
@@ -474,6 +488,10 @@ typedef struct {
   int32_t have_rows;         /* the MLP's output rows (T with the table, else w) were computed by e3k_radial_stack_fwd:
                                 the layer only interpolates (table) / uses w as it is; its backward stops at the gradient
                                 of those rows (g_T resp. g_w), which e3k_radial_stack_bwd takes from there */
+  int32_t in_kernel;         /* table only, plans with e3k_tp_table_supported: the tensor-product kernels interpolate the
+                                path weights from T themselves (e3k_tp_fwd_table / e3k_tp_bwd_x_table): no interpolation
+                                pass, w unused (may be null); the backward needs T */
+  int32_t _pad;
   const float* radial;       /* [R, k0] */
   const int32_t* bin;        /* table: centre knot per edge, */
   const int32_t* bin_ptr;    /*        CSR by knot (backward), */

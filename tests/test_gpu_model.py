@@ -345,12 +345,12 @@ def test_conv_block_equals_composed_layers(dev, monkeypatch, fork):
     assert prod.layer1._forward_block.__self__ is prod.layer1 and prod.layer0._block_plan() is not None
 
 
-@pytest.mark.parametrize("table", [1, 0])
-def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
+@pytest.mark.parametrize("form", ["stack", "in_kernel", "materialised", "per_edge"])
+def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, form):
     """The fused layer issues the NEXT layer's radial branch behind its own tensor product (conv_block.LOOK_AHEAD): same
     energies and parameter gradients as the in-order schedule; the results are consumed by the next layer of the same
     forward only (one issued under no_grad is not picked up by a training forward on the same tensors' addresses)."""
-    from e3_layers_amd.backend import conv_block, ops, radial_table
+    from e3_layers_amd.backend import conv_block, conv_native, ops, radial_table
     from e3_layers_amd.data.synthetic import synth_qm9
     from e3_layers_amd.nn import message_passing as mp
     from e3_layers_amd.utils import build
@@ -358,16 +358,19 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
     torch.manual_seed(0)
     model = build(_energy_tree(2, 64, 4)).to(dev).train()
     batch = synth_qm9(9, 24).to(dev)
+    table = int(form != "per_edge")
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
     monkeypatch.setattr(mp, "FWD_FORK", 1)                 # (the modes this test is about, whatever the environment says)
     monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(radial_table, "ENABLED", table)
+    # what is issued ahead -- stack: the MLPs ran as one batch on the knots, the next layer's INTERPOLATION; in_kernel: the
+    # tensor product interpolates itself, the next layer's MLP on the knots; materialised: MLP on the knots + interpolation;
+    # per_edge: the next layer's per-edge MLP (stacked per-edge MLPs leave nothing to issue ahead)
+    monkeypatch.setattr(mp, "RADIAL_STACK", int(form == "stack"))
+    monkeypatch.setattr(conv_native, "TP_TABLE", int(form == "in_kernel"))
     monkeypatch.setattr(radial_table, "KNOTS", 512)        # so that this small batch has enough edges per knot
     monkeypatch.setattr(radial_table, "GUARD_TOL", 1.0)    # (512 knots: bound 4e-6 -- this test is about launch order, not accuracy)
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
-    # table: the MLPs ran as one stack on the knots, the look-ahead is the next layer's interpolation; per edge: the stacked
-    # MLPs leave nothing to issue ahead, so the look-ahead is exercised with every layer running its own
-    monkeypatch.setattr(mp, "RADIAL_STACK", table)
 
     def run(ahead, grad=True):
         monkeypatch.setattr(conv_block, "LOOK_AHEAD", ahead)
@@ -395,7 +398,7 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, table):
         assert plan is not None and plan.prefetched is None                 # nothing left behind
 
 
-@pytest.mark.parametrize("table", [1, 0])
+@pytest.mark.parametrize("table", [2, 1, 0])
 @pytest.mark.parametrize("fork", [True, False])
 def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table):
     """The radial MLPs of all layers evaluated as one batch on the knot table (MessagePassing._stack_rows ->
@@ -416,13 +419,17 @@ def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table
     monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(conv_native, "ENABLED", 1)
     monkeypatch.setattr(mp, "STACK_MAX_EDGES", 10 ** 9)
-    monkeypatch.setattr(radial_table, "ENABLED", table)      # (0: the per-edge MLPs, stacked the same way)
+    monkeypatch.setattr(radial_table, "ENABLED", int(table > 0))      # (0: the per-edge MLPs, stacked the same way)
+    # 2: the tensor-product kernels interpolate from the table themselves (e3k_tp_fwd_table / e3k_tp_bwd_x_table) in the
+    # stacked runs, against layers that materialise w[E, W] (the reference run below switches it off)
+    monkeypatch.setattr(conv_native, "TP_TABLE", 0)
     monkeypatch.setattr(radial_table, "KNOTS", 512)
     monkeypatch.setattr(radial_table, "GUARD_TOL", 1.0)
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
 
     def run(stack, sink):
         monkeypatch.setattr(mp, "RADIAL_STACK", stack)
+        monkeypatch.setattr(conv_native, "TP_TABLE", int(stack and table == 2))
         model.zero_grad(set_to_none=True)
         flat = None
         if sink:
@@ -517,7 +524,9 @@ def test_bench_path_against_the_float64_oracle(dev, monkeypatch):
     flat = FlatGradients(prod.parameters())
     flat.enable_direct_accumulation()
     try:
-        ahead0 = conv_block.AHEAD_STATS[0]
+        from e3_layers_amd.backend import conv_native
+
+        ahead0, stack0 = conv_block.AHEAD_STATS[0], conv_native.STACK_STATS[0]
         dbatch = batch.clone().to(dev)
         target = dbatch["total_energy"]
         out = prod(dbatch)
@@ -535,7 +544,8 @@ def test_bench_path_against_the_float64_oracle(dev, monkeypatch):
         ops.join_side_streams()
         torch.cuda.synchronize()
         fork_on = prod.layer3.conv._fork_pays(n_edges)
-        assert fork_on and conv_block.AHEAD_STATS[0] - ahead0 >= 3           # ... and the look-ahead fed the inner layers
+        # ... and the radial MLPs ran as one stack ahead of the layers (this size) or the look-ahead fed the inner layers
+        assert fork_on and (conv_native.STACK_STATS[0] - stack0 == 1 or conv_block.AHEAD_STATS[0] - ahead0 >= 3)
         grads = {name: p.grad.detach().clone() for name, p in prod.named_parameters()}
     finally:
         flat.disable_direct_accumulation()

@@ -448,6 +448,64 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
     assert rel_err(y_edges, yr_edges) < TOL
 
 
+@pytest.mark.parametrize("left,out", [
+    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
+    ("64x0e", "64x0e+64x1o+64x2e"),
+])
+def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
+    """e3k_tp_fwd_table / e3k_tp_bwd_x_table (the path weights interpolated from the radial knot table inside the kernel) ==
+    e3k_rtable_interp_fwd into w[E, W] followed by e3k_tp_fwd / e3k_tp_bwd_x, bit for bit (same interpolation arithmetic, same
+    order of accumulation); plans without the form say so."""
+    import ctypes as C
+
+    from e3_layers_amd.backend import lib as L
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(21)
+    n, knots = 300, 256
+    ei = _random_graph(n, 9, 14)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, ("1x0e+1x1o+1x2e", "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    plan = mod.tp.plan
+    lib = L.load()
+    assert lib.e3k_tp_table_supported(plan.handle(dev)) == 1
+    topo = build_topology(ei.to(dev), n)
+    x = torch.randn(n, plan.d_in, device=dev)
+    sh = torch.randn(e, 9, device=dev)
+    g_out = torch.randn(n, plan.d_mid, device=dev)
+    table = torch.randn(knots + 1, plan.w_numel, device=dev)
+    bins = torch.randint(1, knots, (e,), device=dev, dtype=torch.int32)
+    bins[:4] = torch.tensor([1, knots - 1, 1, knots - 1], dtype=torch.int32)      # the ends of the table
+    t = torch.rand(e, device=dev) - 0.5
+    perm = torch.argsort(bins.long(), stable=True).int()
+    w = torch.empty(e, plan.w_numel, device=dev)
+    L.check(lib.e3k_rtable_interp_fwd(L.ptr(table), L.ptr(perm), L.ptr(bins), L.ptr(t), e, knots, plan.w_numel, L.ptr(w),
+                                      L.stream_ptr()), "interp")
+    ref_out = ops._tp_fwd_raw(x, sh, w, topo, plan)
+    ref_gx = ops._tp_bwd_x_raw(sh, w, g_out, topo, plan)
+    out_t = torch.empty_like(ref_out)
+    gx_t = (torch.empty if plan.bwd_x_overwrites(dev) else torch.zeros)(n, plan.d_in, device=dev)
+    L.check(lib.e3k_tp_fwd_table(plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(topo.src),
+                                 L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(out_t), L.stream_ptr()), "e3k_tp_fwd_table")
+    L.check(lib.e3k_tp_bwd_x_table(plan.handle(dev), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(g_out), L.ptr(topo.dst),
+                                   L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx_t), L.stream_ptr()), "e3k_tp_bwd_x_table")
+    torch.cuda.synchronize()
+    assert torch.equal(out_t, ref_out)
+    if plan.bwd_x_overwrites(dev):
+        assert torch.equal(gx_t, ref_gx)
+    else:                                   # (atomic accumulation across groups: the order is not fixed)
+        assert rel_err(gx_t, ref_gx) < 1e-6
+    # a plan without the in-kernel form (odd channel count): refused, not silently wrong
+    odd = TensorProductExpansion("24x0e+24x1o", ("1x0e+1x1o+1x2e", "edge_spherical"), ("24x0e+24x1o+24x2e", "edge_features"), "uvu",
+                                 internal_weight=False).to(dev)
+    assert lib.e3k_tp_table_supported(odd.tp.plan.handle(dev)) == 0
+    rc = lib.e3k_tp_fwd_table(odd.tp.plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(topo.src),
+                              L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(out_t), L.stream_ptr())
+    assert rc < 0
+
+
 def test_tp_repeated_sh_degree_shares_an_input_block(dev):
     """An edge_spherical with a degree that repeats ('1x1o+1x1e') opens a second group on the same input block: the
     backward w.r.t. x must ADD the groups' contributions (it stored, so the last group won: ADVICE r1)."""
