@@ -1166,8 +1166,10 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C)) f |= 8;
       const int wn = 64 * tn;
       const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + wn - 1) / wn);
-      int64_t splits = (1024 + tiles - 1) / tiles;
-      const int64_t max_splits = (M + 4 * e3k::WR - 1) / (4 * e3k::WR);
+      static const int kTarget = getenv("E3K_WGRAD_TARGET") ? atoi(getenv("E3K_WGRAD_TARGET")) : 1024;
+      static const int kChunks = getenv("E3K_WGRAD_CHUNKS") ? atoi(getenv("E3K_WGRAD_CHUNKS")) : 4;
+      int64_t splits = (kTarget + tiles - 1) / tiles;
+      const int64_t max_splits = (M + kChunks * e3k::WR - 1) / (kChunks * e3k::WR);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
       e3k::GemmBatch& gb = b.gb;

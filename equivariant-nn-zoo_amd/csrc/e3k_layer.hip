@@ -99,6 +99,7 @@ namespace {
 // 1: keyed-weight kernels (fwd + bwd), 2: weight-gradient GEMMs, 4: gate fwd + bwd, 8: table interpolation fwd + bwd,
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
 static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
+static const int BWDW_SIDE = getenv("E3K_BWDW_SIDE") ? atoi(getenv("E3K_BWDW_SIDE")) : 0;
 // the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
 static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
 
@@ -426,11 +427,16 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   }
   if (need_radial_side && a->E > 0) {
     if (!a->g_w) return E3K_ERR_INVALID;
+    // the weight-gradient pass: on the radial stream BEHIND tp_bwd_x (both are memory streams: side by side they only
+    // stretch each other), where it runs beside the GEMMs that follow on the main stream (this layer's linear_1 dgrad, the
+    // previous layer's gate' and post-TP dgrad) -- nothing on the main stream waits for it
+    void* wst = (BWDW_SIDE && side != main) ? side : main;
+    if (wst != main) E3K_TRY(edge(L, 2, main, side));
     {
-      Timed t(L, E3K_PROF_TP_BWD_W, main, a->N, a->E);
-      E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, main));
+      Timed t(L, E3K_PROF_TP_BWD_W, wst, a->N, a->E);
+      E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, wst));
     }
-    E3K_TRY(edge(L, 2, main, side));
+    if (wst == main) E3K_TRY(edge(L, 2, main, side));
     const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
     if (r.use_table) {
       Timed t(L, E3K_PROF_RTABLE_BWD, side, r.R, r.E);

@@ -659,6 +659,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             for st in (side, side2, side3):
                 if st is not main:
                     work.record_stream(st)
+            buf.record_stream(side)               # x1: operand of tp_bwd_w when it runs on the radial stream
             if side3 is not main:
                 buf.record_stream(side3)          # mid, x_cf: operands of the weight gradients
                 if x_in is not None:

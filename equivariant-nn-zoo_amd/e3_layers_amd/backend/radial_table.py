@@ -6,7 +6,10 @@ edge.  Instead of pushing every edge through the MLP (the largest block of matri
 dgrad and wgrad GEMMs of ``[E, 64] x [64, weight_numel]``), the MLP is evaluated on ``KNOTS + 1`` equidistant radii and
 every edge interpolates quadratically between the three knots around it; the backward transposes the interpolation
 (an ordered sum per knot over edges sorted by knot, no atomics) and then differentiates the MLP on the knots only.
-Interpolation error: ~5e-9 relative at 4096 knots, below the rounding error of evaluating the MLP in fp32 per edge.
+Interpolation error (h^3): ~4e-8 relative at the default 2048 knots for the shipped models (bound and measurements per knot
+count: tools/knot_error.py), below the ~1e-7 rounding error of evaluating the MLP in fp32 per edge.  The knot
+count also sets how much of the table the 4 MB L2 of an XCD holds when the tensor-product kernels gather its rows
+(e3k_tp_fwd_table): 2048 knots measured 0.23 ms / step faster than 4096 at 256 molecules.
 
 Applies when ``edge_radial`` still carries the tag ``RadialBasisEncoding.forward`` puts on its output (so nothing was
 concatenated to it: the diffusion configs mix bond types / residue offsets into the edge embedding and take the
@@ -27,8 +30,8 @@ from . import ops
 from .graph import build_topology      # (conv_block imports this module: keep it free of conv_block)
 
 ENABLED = int(os.environ.get("E3K_RADIAL_TABLE", "1"))
-KNOTS = int(os.environ.get("E3K_RADIAL_KNOTS", "4096"))          # intervals; KNOTS + 1 table rows
-MIN_EDGES_PER_KNOT = 4                                            # below this the per-edge MLP is the cheaper one
+KNOTS = int(os.environ.get("E3K_RADIAL_KNOTS", "2048"))          # intervals; KNOTS + 1 table rows
+MIN_EDGES_PER_KNOT = float(os.environ.get("E3K_RADIAL_MIN_EDGES_PER_KNOT", "4"))      # below this the per-edge MLP is the cheaper one
 
 
 class RadialSource:
@@ -106,7 +109,7 @@ def applicable(edge_radial, w_last=None) -> bool:
 # Quadratic Lagrange interpolation on knots h apart is off by at most h^3 max|f(3)| / (9 sqrt 3) (f(3): third derivative);
 # on the table itself h^3 f(3) is the third finite difference, so
 #     err <= max|T[i+3] - 3 T[i+2] + 3 T[i+1] - T[i]| / (9 sqrt 3)
-# -- read off the 4 097 rows the forward has just computed, relative to max|T|.  5e-9 for the shipped models at random
+# -- read off the table rows the forward has just computed, relative to max|T|.  4e-8 for the shipped models at random
 # init (8 Bessel functions through a smooth MLP); it grows like (frequency x weight scale)^3, so a 32-function basis, grown
 # Bessel frequencies or large trained weights can push it towards the 1e-5 parity budget.  The bound is evaluated on the
 # device the first time an MLP's table is built and every GUARD_EVERY-th time after (a few elementwise passes over 31 MB

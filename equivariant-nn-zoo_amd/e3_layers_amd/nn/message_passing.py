@@ -44,7 +44,11 @@ FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connec
 # step): the yardstick is the size of the per-edge weight tensor, edges x weight_numel, counted in edges of a
 # 1920-weight layer (n_dim 64, l_max 2).  Measured: config_energy 256 molecules (69 k x 1920) +12 %, protein
 # (29 k x 1920) +10 %, config_diffusion (42 k x 960) -15 %, config_energy_force 64 molecules (20 k x 1920) -10 %.
+# Round 3, with the radial MLP on the knot table (its branch is then a few launches over 2 049 rows, not per-edge GEMMs):
+# config_energy 96 / 128 / 160 molecules run 17 / 6 / 1 % FASTER on one stream, 192 / 256 molecules 8 % faster forked --
+# layers on the table use the larger yardstick.
 FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
+FORK_MIN_EDGES_TABLE = int(os.environ.get("E3K_FORK_MIN_EDGES_TABLE", "40000"))
 _FORK_REF_WIDTH = 1920
 # 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
 # as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next.
@@ -130,9 +134,10 @@ class FactorizedConvolution(Module):
             ev_next.record(side)
         nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
 
-    def _fork_pays(self, n_edges: int) -> bool:
+    def _fork_pays(self, n_edges: int, table: bool = False) -> bool:
         # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
-        return (n_edges * self._weight_numel >= FORK_MIN_EDGES * _FORK_REF_WIDTH) or n_edges >= 2 * FORK_MIN_EDGES
+        ref = FORK_MIN_EDGES_TABLE if table else FORK_MIN_EDGES
+        return (n_edges * self._weight_numel >= ref * _FORK_REF_WIDTH) or n_edges >= 2 * ref
 
     def forward_cf(self, data: Dict[str, Tensor]) -> Tensor:
         """Convolution output [N, out.dim] in the channel-fastest layout (reduce=True path)."""
@@ -144,7 +149,7 @@ class FactorizedConvolution(Module):
             src = radial_table.source_of(data["edge_radial"])
             src.bins()
             src.knot_basis()
-        if (FWD_FORK and x.is_cuda and self._fork_pays(data["edge_radial"].shape[0])
+        if (FWD_FORK and x.is_cuda and self._fork_pays(data["edge_radial"].shape[0], bool(table))
                 and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing())):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
@@ -164,7 +169,7 @@ class FactorizedConvolution(Module):
                         ready = torch.cuda.Event()
                         ready.record(side)
                 nxt = self._next_conv if RADIAL_AHEAD else None
-                if nxt is not None and not nxt._fork_pays(radial.shape[0]):
+                if nxt is not None and not nxt._fork_pays(radial.shape[0], bool(table)):
                     nxt = None
                 if nxt is not None:
                     self._issue_ahead(nxt, radial, side, main)
@@ -317,7 +322,8 @@ class MessagePassing(Module):
             if (pl.mlp_k0, pl.last_spec.d_in, tuple(pl.mlp_alphas), pl.mlp_act, pl.mlp_cst) != sig:
                 break
             if m is not self and (radial_table.applicable(edge_radial, fc[-1].weight) != use_table
-                                  or bool(FWD_FORK and m.conv._fork_pays(n_edges)) != bool(FWD_FORK and self.conv._fork_pays(n_edges))):
+                                  or bool(FWD_FORK and m.conv._fork_pays(n_edges, use_table))
+                                  != bool(FWD_FORK and self.conv._fork_pays(n_edges, use_table))):
                 break
             chain.append((m, pl, fc))
             m = m.__dict__.get("_next_mp")
@@ -357,14 +363,15 @@ class MessagePassing(Module):
                 return None                            # general (un-keyed) attributes: outer-product GEMMs, composed path
             groups = row_groups(key[0], key[1])
         topo = get_topology(data, x.shape[0])
-        fork = bool(FWD_FORK and conv._fork_pays(radial.shape[0])
-                    and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         table = None
         fc = list(conv.fc.children())
+        n_edges = radial.shape[0]
         if radial_table.applicable(radial, fc[-1].weight):      # the radial MLP on a knot table; every edge interpolates (backend/radial_table.py)
             src = radial_table.source_of(radial)
             table = src.bins()
             radial = src.knot_basis()            # [knots + 1, n_basis]: the block's MLP runs on these rows
+        fork = bool(FWD_FORK and conv._fork_pays(n_edges, table is not None)
+                    and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         if fork:      # gradient contributions of the shared inputs are summed on the streams that produce them
             main = torch.cuda.current_stream(x.device)
             side = ops.side_stream(x.device)
@@ -393,7 +400,7 @@ class MessagePassing(Module):
             return conv_block.conv_block(x, attrs, None, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                          conv.linear_1.weight, conv.tp.linear.weight,
                                          conv.sc.weight if conv.sc is not None else None, None, (), table=table, nxt=nxt, pre=pre)
-        if nmp is not None and fork and nmp.conv._fork_pays(data["edge_radial"].shape[0]):
+        if nmp is not None and fork and nmp.conv._fork_pays(n_edges, table is not None):
             plan_n = nmp._block_plan()
             if plan_n is not None and (nmp.conv.sc is None) == (conv.sc is None):
                 fc_n = list(nmp.conv.fc.children())

@@ -304,6 +304,7 @@ def test_conv_block_equals_composed_layers(dev, monkeypatch, fork):
     prod, orc = _build_pair(tree, dev)
     batch = synth_qm9(31, 24)                      # > 256 nodes: the keyed self-connection path
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0 if fork else 10 ** 9)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0 if fork else 10 ** 9)
     target = batch["total_energy"].to(dev)
 
     def run(enabled, sink):
@@ -360,6 +361,7 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, form):
     batch = synth_qm9(9, 24).to(dev)
     table = int(form != "per_edge")
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     monkeypatch.setattr(mp, "FWD_FORK", 1)                 # (the modes this test is about, whatever the environment says)
     monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(radial_table, "ENABLED", table)
@@ -415,6 +417,7 @@ def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table
     model = build(_energy_tree(2, 64, 4)).to(dev).train()
     batch = synth_qm9(13, 24).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0 if fork else 10 ** 9)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0 if fork else 10 ** 9)
     monkeypatch.setattr(mp, "FWD_FORK", 1)
     monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(conv_native, "ENABLED", 1)
@@ -521,6 +524,7 @@ def test_bench_path_against_the_float64_oracle(dev, monkeypatch):
     assert n_edges >= radial_table.MIN_EDGES_PER_KNOT * (radial_table.KNOTS + 1), n_edges
     assert conv_block.ENABLED and radial_table.ENABLED and conv_block.LOOK_AHEAD and mp.FWD_FORK
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)      # the multi-stream layout of the 256-molecule bench batch at this size
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     flat = FlatGradients(prod.parameters())
     flat.enable_direct_accumulation()
     try:
@@ -543,7 +547,7 @@ def test_bench_path_against_the_float64_oracle(dev, monkeypatch):
 
         ops.join_side_streams()
         torch.cuda.synchronize()
-        fork_on = prod.layer3.conv._fork_pays(n_edges)
+        fork_on = prod.layer3.conv._fork_pays(n_edges, True)
         # ... and the radial MLPs ran as one stack ahead of the layers (this size) or the look-ahead fed the inner layers
         assert fork_on and (conv_native.STACK_STATS[0] - stack0 == 1 or conv_block.AHEAD_STATS[0] - ahead0 >= 3)
         grads = {name: p.grad.detach().clone() for name, p in prod.named_parameters()}
@@ -842,6 +846,7 @@ def test_three_stream_convolution_equals_single_stream(dev, monkeypatch, forces)
     model = build(cfg).to(dev).train()
     batch = synth_qm9(9, 24).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
 
     def run(fork):
         monkeypatch.setattr(mp, "FWD_FORK", fork)
@@ -876,6 +881,7 @@ def test_sunk_weight_gradients_on_side_stream(dev, monkeypatch):
     flat = FlatGradients(model.parameters())
     flat.enable_direct_accumulation()
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
     try:
         res = []
@@ -1020,6 +1026,7 @@ def test_radial_look_ahead_equals_in_order(dev, monkeypatch):
     model = build(_energy_tree(2, 16, 3)).to(dev).train()
     batch = synth_qm9(4, 12).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     monkeypatch.setattr(mp, "FWD_FORK", 1)          # (the modes this test is about, whatever the environment says)
 
     def run(ahead):
@@ -1077,6 +1084,7 @@ def test_training_steps_do_not_accumulate_device_memory(dev, monkeypatch):
     model = build(_energy_tree(2, 16, 3)).to(dev).train()
     batch = synth_qm9(2, 16).to(dev)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     opt = FusedAdamEMA(model.parameters(), lr=1e-3)
     opt.grads.enable_direct_accumulation()
 
@@ -1145,6 +1153,7 @@ def test_forked_convolution_with_unkeyed_attributes(dev, monkeypatch):
     flat = FlatGradients(model.parameters())
     flat.enable_direct_accumulation()
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
 
     def run(fork, ahead):

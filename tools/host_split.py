@@ -51,3 +51,18 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"B={B} {'same batch' if same else 'fresh batch'}: prep {1e3*acc[0]/n:.2f} ms, forward {1e3*acc[1]/n:.2f} ms, backward {1e3*acc[2]/n:.2f} ms, "
       f"optimizer {1e3*acc[3]/n:.2f} ms host per step; enqueue {1e3*(t1-t0)/n:.2f}, wall {1e3*(t2-t0)/n:.2f} ms/step")
+if "--profile" in sys.argv:      # where the host time goes: cProfile over 30 steps (adds ~2x overhead; read the ranking, not the totals)
+    import cProfile, pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(30): step(False)
+    pr.disable()
+    torch.cuda.synchronize()
+    st = pstats.Stats(pr)
+    st.sort_stats("tottime").print_stats(45)
+if "--torch-profile" in sys.argv:      # host time per op / autograd node (forward and backward threads): torch.profiler, CPU side only
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU]) as prof:
+        for _ in range(20): step(False)
+    torch.cuda.synchronize()
+    print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
