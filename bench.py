@@ -324,15 +324,20 @@ def main():
             nl.profile(0)
         return recs
 
+    host_enqueue = [0.0]
+
     def timed_region():
         ops.PROFILE = {} if graph is None else None
         if graph is None:
             for nl in conv_native._LAYERS:
                 nl.profile(args.steps + 8)
         fence()
+        waited0 = opt.waited_seconds
         t0 = time.perf_counter()
         for _ in range(args.steps):
             out = run()
+        # the host's share: everything enqueued, minus what it spent waiting for the GPU to come within two steps
+        host_enqueue[0] = (time.perf_counter() - t0) - (opt.waited_seconds - waited0)
         fence()
         seconds = time.perf_counter() - t0
         recs, ops.PROFILE = ops.PROFILE, None
@@ -384,14 +389,25 @@ def main():
         loader.close()
 
     # ---- roofline blocks (rank 0's launches in the timed region) ---------------------------------------------------
-    def tp_bytes(kind, n, e, plan):
-        """Algorithmic bytes of one launch (SURVEY.md 8d variant A)."""
-        if kind == "tp_fwd":        # x[src] gather + sh + w stream + out rows
-            return e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
+    def in_kernel(e, plan):
+        """This launch interpolated its path weights from the knot table inside the kernel (csrc/e3k_tp.hip TABLE forms)."""
+        return bool(conv_native.TP_TABLE and radial_table.ENABLED and getattr(plan, "_e3k_table_form", False)
+                    and e >= radial_table.MIN_EDGES_PER_KNOT * (radial_table.KNOTS + 1))
+
+    def tp_bytes(kind, n, e, plan, variant="A"):
+        """Algorithmic bytes of one launch.  Variant A = the module-API operation
+        tp(x[src], sh, w) + scatter with the per-edge weights supplied (E x W streamed); variant B = the radial-fused
+        operation (weights produced in the kernel: here interpolated from the (K + 1) x W knot table, counted once)."""
+        w_term = 4 * plan.w_numel
+        extra = 0
+        if variant == "B" and kind != "tp_bwd_w":
+            w_term, extra = 8, 4 * (radial_table.KNOTS + 1) * plan.w_numel      # bin + offset per edge; the table once
+        if kind == "tp_fwd":        # x[src] gather + sh + w + out rows
+            return e * (4 * plan.d_in + 4 * plan.d_sh + w_term + 16) + n * 4 * plan.d_mid + extra
         if kind == "tp_bwd_w":      # x[src] gather + sh + g_w stream + g_mid rows
             return e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
-        if kind == "tp_bwd_x":      # compulsory: w stream + sh + g_mid once + g_x rows (the g_mid[dst] gather is not counted)
-            return e * (4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * (plan.d_mid + plan.d_in)
+        if kind == "tp_bwd_x":      # compulsory: w + sh + g_mid once + g_x rows (the g_mid[dst] gather is not counted)
+            return e * (4 * plan.d_sh + w_term + 16) + n * 4 * (plan.d_mid + plan.d_in) + extra
         raise KeyError(kind)
 
     def summarise(kind):
@@ -400,9 +416,24 @@ def main():
         tot_ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
         n = max(len(recs), 1)
         ach = tot_b / (tot_ms * 1e-3) / 1e9 if tot_ms > 0 else 0.0
-        return {"kernel": f"e3k::{kind}_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(ach / HBM_PEAK_GBS, 4), "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / n, 2),
-                "avg_launch_algorithmic_MB": round(tot_b / n / 1e6, 2)}
+        out = {"kernel": f"e3k::{kind}_kernel", "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "frac": round(ach / HBM_PEAK_GBS, 4), "launches": len(recs), "avg_launch_us": round(1e3 * tot_ms / n, 2),
+               "avg_launch_algorithmic_MB": round(tot_b / n / 1e6, 2)}
+        n_tab = sum(1 for _, _, (nn, e, plan) in recs if in_kernel(e, plan))
+        if n_tab and kind != "tp_bwd_w" and tot_ms > 0:
+            # These launches never read w[E, W] from HBM: they gather three rows of the cache-resident knot table per edge.
+            # `achieved` above keeps SURVEY 8d's variant A (the module-API operation's bytes: comparable with the earlier
+            # rounds and with the materialised form, whose interpolation pass is a separate kernel); variant B counts what
+            # this form has to move.
+            tot_bb = sum(tp_bytes(kind, *meta, variant="B" if in_kernel(meta[1], meta[2]) else "A") for _, _, meta in recs)
+            out.update({"launches_with_in_kernel_table": n_tab,
+                        "variant_B_avg_launch_algorithmic_MB": round(tot_bb / n / 1e6, 2),
+                        "variant_B_frac": round(tot_bb / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                        "note": "in-kernel knot-table form: E x W is not streamed from HBM (L2 / Infinity-Cache gathers of a "
+                                f"<= {4 * (radial_table.KNOTS + 1) * max(m[2].w_numel for _, _, m in recs) / 1e6:.0f} MB table per layer); frac = SURVEY 8d variant A "
+                                "bytes / time, variant_B_frac = the bytes this form must move / time -- the kernel is bound by "
+                                "cache-gather bandwidth, not by HBM"})
+        return out
 
     traffic = {}
     TRAFFIC_FILE = TRAFFIC_FILES.get(args.lmax, "")
@@ -420,7 +451,7 @@ def main():
                                   "NOT this run)") if t_fwd else None
     if t_fwd and main_k["avg_launch_us"] > 0:   # DRAM-side rate: counter bytes / this run's launch time / peak
         roofline["dram_frac"] = round(t_fwd / (main_k["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-    roofline.update({k: main_k[k] for k in ("kernel", "launches", "avg_launch_us", "avg_launch_algorithmic_MB")})
+    roofline.update({k: main_k[k] for k in main_k if k not in roofline})
     kernels = []
     for kind in ("tp_bwd_x", "tp_bwd_w"):
         k = summarise(kind)
@@ -470,6 +501,7 @@ def main():
             "unit": f"{unit}/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "host_busy_ms_per_step": round(1e3 * host_enqueue[0] / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {

@@ -200,6 +200,7 @@ def in_kernel_table(plan, table, dev) -> bool:
     hit = plan.__dict__.get("_tp_table_ok")
     if hit is None:
         hit = plan.__dict__["_tp_table_ok"] = bool(L.load().e3k_tp_table_supported(plan.tp_plan.handle(dev)))
+        plan.tp_plan._e3k_table_form = hit      # (bench.py: which byte model describes this plan's launches)
     return hit
 
 
@@ -241,6 +242,9 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
 
 
 STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
+# E3K_HOST_TIMING=1: host seconds inside the layer functions, split into the C call and the Python around it
+# (tools/host_split.py --layer-timing prints them): [fwd total, fwd C call, bwd total, bwd C call, calls]
+HOST_TIMING = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("E3K_HOST_TIMING") == "1" else None
 
 
 class RadialStackFn(torch.autograd.Function):
@@ -471,7 +475,14 @@ class NativeConvBlockFn(torch.autograd.Function):
             a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
             a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
         a.conv, a.x1, a.mid, a.y = _ptr(buf, off["conv"]), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
-        L.check(L.load().e3k_layer_fwd(layer, C.byref(a)), "e3k_layer_fwd")
+        if HOST_TIMING is not None:
+            import time
+
+            t_c = time.perf_counter()
+            L.check(L.load().e3k_layer_fwd(layer, C.byref(a)), "e3k_layer_fwd")
+            HOST_TIMING[1] += time.perf_counter() - t_c
+        else:
+            L.check(L.load().e3k_layer_fwd(layer, C.byref(a)), "e3k_layer_fwd")
         if own_table is not None:      # the a-posteriori error guard of the table just built (radial stream)
             with conv_block._on(side, main):
                 radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, own_table)
@@ -654,7 +665,14 @@ class NativeConvBlockFn(torch.autograd.Function):
             with conv_block._on(side, main):
                 g_radial = torch.empty_like(edge_radial)
             a.g_radial = g_radial.data_ptr()
-        L.check(L.load().e3k_layer_bwd(layer, C.byref(a)), "e3k_layer_bwd")
+        if HOST_TIMING is not None:
+            import time
+
+            t_c = time.perf_counter()
+            L.check(L.load().e3k_layer_bwd(layer, C.byref(a)), "e3k_layer_bwd")
+            HOST_TIMING[3] += time.perf_counter() - t_c
+        else:
+            L.check(L.load().e3k_layer_bwd(layer, C.byref(a)), "e3k_layer_bwd")
         if fork:      # (see the forward: only the stream / tensor pairs that need it)
             for st in (side, side2, side3):
                 if st is not main:

@@ -58,6 +58,7 @@ class FusedAdamEMA:
         # ``max_steps_ahead`` steps ago (0 = unbounded).
         self.max_steps_ahead = int(max_steps_ahead)
         self._step_events = []
+        self.waited_seconds = 0.0      # host time spent in that wait since construction
 
     # ------------------------------------------------------------------ step
     def zero_grad(self) -> None:
@@ -82,7 +83,13 @@ class FusedAdamEMA:
             done.record()
             self._step_events.append(done)
             if len(self._step_events) > self.max_steps_ahead:
-                self._step_events.pop(0).synchronize()
+                ev = self._step_events.pop(0)
+                if not ev.query():          # the host is ahead of the GPU: wait, and account for it (bench.py: host busy time)
+                    import time
+
+                    t0 = time.perf_counter()
+                    ev.synchronize()
+                    self.waited_seconds += time.perf_counter() - t0
 
     # ------------------------------------------------------------------ introspection (each is a device->host sync)
     @property

@@ -24,6 +24,14 @@ opt.grads.enable_direct_accumulation()
 resident = [synth_qm9(1000 + k, B, config_energy.QM9_SHIFTS).to(dev) for k in range(4)]
 if same:
     resident[0].update(build_topology(resident[0]["edge_index"], resident[0]["pos"].shape[0]).as_dict())
+if "--layer-timing" in sys.argv:     # (run with E3K_HOST_TIMING=1) host time inside the layer functions: total vs the C call
+    from e3_layers_amd.backend import conv_native as _cn
+    _f, _b = _cn.NativeConvBlockFn.forward, _cn.NativeConvBlockFn.backward
+    def _fw(ctx, *a):
+        t = time.perf_counter(); r = _f(ctx, *a); _cn.HOST_TIMING[0] += time.perf_counter() - t; _cn.HOST_TIMING[4] += 1; return r
+    def _bw(ctx, *a):
+        t = time.perf_counter(); r = _b(ctx, *a); _cn.HOST_TIMING[2] += time.perf_counter() - t; return r
+    _cn.NativeConvBlockFn.forward, _cn.NativeConvBlockFn.backward = staticmethod(_fw), staticmethod(_bw)
 acc = [0.0, 0.0, 0.0, 0.0]
 count = [0]
 def step(rec):
@@ -43,6 +51,8 @@ def step(rec):
         acc[0] += ta - t0; acc[1] += t1 - ta; acc[2] += t2 - t1; acc[3] += t3 - t2
 for _ in range(5): step(False)
 torch.cuda.synchronize()
+if "--layer-timing" in sys.argv:
+    _cn.HOST_TIMING[:] = [0.0, 0.0, 0.0, 0.0, 0]
 n = 20
 t0 = time.perf_counter()
 for _ in range(n): step(True)
@@ -66,3 +76,10 @@ if "--torch-profile" in sys.argv:      # host time per op / autograd node (forwa
         for _ in range(20): step(False)
     torch.cuda.synchronize()
     print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
+
+if "--layer-timing" in sys.argv:
+    from e3_layers_amd.backend import conv_native as _cn
+    ht = _cn.HOST_TIMING
+    c = max(ht[4], 1)
+    print(f"layer functions, host us per call over {ht[4]} calls: forward {1e6*ht[0]/c:.1f} (C call {1e6*ht[1]/c:.1f}), "
+          f"backward {1e6*ht[2]/c:.1f} (C call {1e6*ht[3]/c:.1f})")
