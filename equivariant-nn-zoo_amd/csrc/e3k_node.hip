@@ -128,13 +128,23 @@ __global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__
       break;
     }
   }
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+  auto eval = [&](int64_t r) -> float {
     const float* xr = x + r * in_dim;
     float v = 0.f;
     if (mode == 0) v = cst * act_f(act, xr[xi]);
     else if (mode > 0) v = xr[xi] * (cst * act_f(act, xr[gi]));
-    y[r * out_dim + c] = v;
+    return v;
+  };
+  int64_t r = blockIdx.y;
+  const int64_t step = gridDim.y;
+  for (; r + 3 * step < rows; r += 4 * step) {      // four rows in flight per trip
+    const float v0 = eval(r), v1 = eval(r + step), v2 = eval(r + 2 * step), v3 = eval(r + 3 * step);
+    y[r * out_dim + c] = v0;
+    y[(r + step) * out_dim + c] = v1;
+    y[(r + 2 * step) * out_dim + c] = v2;
+    y[(r + 3 * step) * out_dim + c] = v3;
   }
+  for (; r < rows; r += step) y[r * out_dim + c] = eval(r);
 }
 
 __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
@@ -168,7 +178,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       }
     }
   }
-  for (int64_t r = blockIdx.y; r < rows; r += gridDim.y) {
+  auto eval = [&](int64_t r) -> float {
     const float* xr = x + r * in_dim;
     const float* gr = gy + r * out_dim;
     const float* gr2 = gy2 ? gy2 + r * out_dim : nullptr;      // second addend of the incoming gradient (same layout)
@@ -184,8 +194,20 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__
       v = G(go) * (cst * act_f(act, xr[xi]));
     }
 #undef G
-    gx[r * in_dim + c] = v;
+    return v;
+  };
+  // four rows per trip: the loads of the four are in flight together (a one-row loop is a chain of load latencies: measured
+  // 60-88 us per layer at 256 molecules for 73 MB of traffic)
+  int64_t r = blockIdx.y;
+  const int64_t step = gridDim.y;
+  for (; r + 3 * step < rows; r += 4 * step) {
+    const float v0 = eval(r), v1 = eval(r + step), v2 = eval(r + 2 * step), v3 = eval(r + 3 * step);
+    gx[r * in_dim + c] = v0;
+    gx[(r + step) * in_dim + c] = v1;
+    gx[(r + 2 * step) * in_dim + c] = v2;
+    gx[(r + 3 * step) * in_dim + c] = v3;
   }
+  for (; r < rows; r += step) gx[r * in_dim + c] = eval(r);
 }
 
 // backward of gate_bwd (cotangent gh on gx): g_gy = (d y / d x) gh  — one thread per OUTPUT element
@@ -621,6 +643,16 @@ inline dim3 grid_cols(int cols, int64_t rows) {
   return dim3((unsigned)gx, (unsigned)gy);
 }
 
+// the same with fewer workgroups: threads that walk several rows, four at a time (gate kernels; measured at 4 608 rows:
+// forward 18.7 / 17.0 / 13.6 / 15.8 us with 8 k / 4 k / 2 k / 1 k workgroups, backward 31.3 / 31.0 / 36.0 / 58.0 us)
+inline dim3 grid_cols_deep(int cols, int64_t rows, int target) {
+  const int gx = (cols + 255) / 256;
+  int64_t gy = target / (gx > 0 ? gx : 1);
+  if (gy > rows) gy = rows;
+  if (gy < 1) gy = 1;
+  return dim3((unsigned)gx, (unsigned)gy);
+}
+
 inline unsigned grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   if (g > 8192) g = 8192;
@@ -731,7 +763,7 @@ extern "C" int e3k_gate_fwd(const float* x, int64_t rows, int32_t in_dim, int32_
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !y) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::gate_fwd_kernel, e3k::grid_cols(out_dim, rows), dim3(256), 0, (hipStream_t)stream, x,
+  hipLaunchKernelGGL(e3k::gate_fwd_kernel, e3k::grid_cols_deep(out_dim, rows, 2048), dim3(256), 0, (hipStream_t)stream, x,
                      rows, in_dim, out_dim, ga, y);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -747,7 +779,7 @@ extern "C" int e3k_gate_bwd(const float* x, const float* g_y, const float* g_y2,
   if (rows < 0 || in_dim <= 0 || out_dim <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::gate_bwd_kernel, e3k::grid_cols(in_dim, rows), dim3(256), 0, (hipStream_t)stream, x, g_y,
+  hipLaunchKernelGGL(e3k::gate_bwd_kernel, e3k::grid_cols_deep(in_dim, rows, 4096), dim3(256), 0, (hipStream_t)stream, x, g_y,
                      g_y2, rows, in_dim, out_dim, ga, g_x);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
