@@ -448,7 +448,9 @@ def main():
     t_fwd = traffic.get("tp_fwd", {}).get("traffic_bytes_per_launch")
     roofline["traffic"] = round(t_fwd) if t_fwd else None
     roofline["traffic_source"] = (f"{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over this command, "
-                                  "NOT this run)") if t_fwd else None
+                                  "NOT this run; the counters sit on the L2's fabric side: Infinity-Cache hits -- the knot-table "
+                                  "rows and the gathered node rows that miss an XCD's L2 -- are counted with the HBM bytes, so this "
+                                  "is an upper bound on DRAM traffic)") if t_fwd else None
     if t_fwd and main_k["avg_launch_us"] > 0:   # DRAM-side rate: counter bytes / this run's launch time / peak
         roofline["dram_frac"] = round(t_fwd / (main_k["avg_launch_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
     roofline.update({k: main_k[k] for k in main_k if k not in roofline})
