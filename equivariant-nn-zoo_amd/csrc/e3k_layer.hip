@@ -66,6 +66,7 @@ struct e3k_layer {
   std::vector<e3k_gate_seg> gate;
   std::vector<e3k_block> in_blocks;
   std::vector<e3k_kw_instr> kw;
+  e3k_kw_args* kwa = nullptr;      // the same table in device memory (the multi-layer keyed-weight launches)
   hipEvent_t ev[8];
   int n_ev;
   mutable ProfRing prof[PROF_KINDS];
@@ -215,6 +216,10 @@ extern "C" int e3k_layer_create(const e3k_layer_desc* desc, e3k_layer** out) {
   if (desc->in_blocks) L->in_blocks.assign(desc->in_blocks, desc->in_blocks + desc->n_in_blocks);
   if (desc->kw) L->kw.assign(desc->kw, desc->kw + desc->n_kw);
   L->n_ev = 0;
+  if (!L->kw.empty() && e3k_kw_args_create(L->kw.data(), (int32_t)L->kw.size(), desc->V, desc->ld_m, &L->kwa) != E3K_OK) {
+    delete L;
+    return E3K_ERR_INVALID;
+  }
   for (int i = 0; i < 8; ++i) {
     if (hipEventCreateWithFlags(&L->ev[i], hipEventDisableTiming) != hipSuccess) {
       e3k_layer_destroy(L);
@@ -239,6 +244,7 @@ extern "C" void e3k_layer_destroy(e3k_layer* L) {
   if (!L) return;
   prof_free(L);
   for (int i = 0; i < L->n_ev; ++i) (void)hipEventDestroy(L->ev[i]);
+  e3k_kw_args_destroy(L->kwa);
   delete L;
 }
 
@@ -295,13 +301,16 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
     x_cf = a->x_cf;
   }
   if (has_sc) {
-    if (!a->node_attrs || !a->a_rep || !a->m || !a->reps || !a->perm || !a->bounds || a->n_keys <= 0) return E3K_ERR_INVALID;
+    if (!a->m || !a->perm || !a->bounds || a->n_keys <= 0) return E3K_ERR_INVALID;
+    if (!a->have_m && (!a->node_attrs || !a->a_rep || !a->reps || !a->w_sc)) return E3K_ERR_INVALID;
     E3K_TRY(edge(L, 1, main, side2));        // x_cf (and the attributes) are ready
-    const int tot = a->n_keys * d.V;
-    hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->node_attrs, a->reps,
-                       a->n_keys, d.V, a->a_rep);
-    if (!(ABLATE & 1))
-      E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
+    if (!a->have_m) {      // (have_m: the per-key weights M came from e3k_kw_stack_fwd, issued on this stream before)
+      const int tot = a->n_keys * d.V;
+      hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)side2, a->node_attrs, a->reps,
+                         a->n_keys, d.V, a->a_rep);
+      if (!(ABLATE & 1))
+        E3K_TRY(e3k_keyed_weights_fwd(a->a_rep, a->w_sc, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m, a->m, side2));
+    }
     if (!d.sc_out_covered && e3k::zero_fill(a->conv, sizeof(float) * a->N * d.d_conv, (hipStream_t)side2))
       return E3K_ERR_LAUNCH;
     Seg g;
@@ -360,7 +369,9 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   for (int i = 0; i < d.n_hidden; ++i) need_hidden = need_hidden || a->gb_hidden[i];
   const bool need_radial_side = need_last || need_hidden || a->need_radial || (r.have_rows && a->g_w);
   const bool need_post = a->gb_post != nullptr, need_lin1 = a->gb_lin1 != nullptr;
-  const bool want_sc = has_sc && (a->gb_sc || a->need_attrs);
+  // have_m: the gradient of the per-key weights, gm, is this layer's OUTPUT (e3k_kw_stack_bwd turns the gm of all the
+  // layers into weight and attribute gradients in one pass, on the self-connection stream)
+  const bool want_sc = has_sc && (a->have_m ? a->gm != nullptr : (a->gb_sc || a->need_attrs));
   const bool need_x1 = a->need_x || need_lin1;
   if (!a->gy || !a->g_conv || !a->g_mid || !a->conv) return E3K_ERR_INVALID;
 
@@ -384,6 +395,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // weight gradients that only need g_conv: off the critical path (forked) or together with linear_1's below
   auto keyed_weight_grads = [&]() -> int {
     E3K_TRY(edge(L, 1, side3, side2));
+    if (a->have_m) return E3K_OK;
     if (a->need_attrs && e3k::zero_fill(a->ga, sizeof(float) * a->n_keys * d.V, (hipStream_t)side2)) return E3K_ERR_LAUNCH;
     if (!(ABLATE & 1))
       E3K_TRY(e3k_keyed_weights_bwd(a->a_rep, a->w_sc, a->gm, L->kw.data(), (int32_t)L->kw.size(), a->n_keys, d.V, d.ld_m,
@@ -556,6 +568,60 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
   }
   if (n_nets)
     E3K_TRY(e3k_mlp_hidden_bwd_multi(nets, n_nets, items[0].rad.radial, R, d0.k0, d0.h, d0.n_hidden, d0.alphas, d0.act, d0.cst, stream));
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+// ---- the per-key self-connection weights of several layers, batched ---------------------------------------------------
+extern "C" int e3k_kw_stack_fwd(const e3k_layer* const* layers, const e3k_kw_stack_item* items, int32_t n, const float* node_attrs,
+                                const int64_t* reps, int32_t n_keys, float* a_rep, void* stream) {
+  if (!layers || !items || n <= 0 || n > 8 || !node_attrs || !reps || !a_rep || n_keys <= 0) return E3K_ERR_INVALID;
+  const int V = layers[0]->d.V;
+  e3k_kw_multi_item mi[8];
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i]->kwa || layers[i]->d.V != V) return E3K_ERR_UNSUPPORTED;
+    mi[i] = e3k_kw_multi_item{layers[i]->kwa, items[i].w_sc, items[i].m, nullptr, 0, 0};
+  }
+  const int tot = n_keys * V;
+  hipLaunchKernelGGL(e3k::gather_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, (hipStream_t)stream, node_attrs, reps, n_keys, V,
+                     a_rep);
+  if (!(ABLATE & 1)) E3K_TRY(e3k_keyed_weights_fwd_multi(mi, n, a_rep, n_keys, stream));
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+extern "C" int64_t e3k_kw_stack_bwd_workspace(const e3k_layer* const* layers, int32_t n, int32_t n_keys) {
+  if (!layers || n <= 0 || n > 8) return 0;
+  e3k_kw_multi_item mi[8];
+  float dummy = 0.f;
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i]->kwa) return 0;
+    mi[i] = e3k_kw_multi_item{layers[i]->kwa, &dummy, &dummy, nullptr, 0, 0};
+  }
+  return e3k_keyed_weights_bwd_multi_workspace(mi, n, n_keys);
+}
+
+/* items[i].m = g_M of layer i (written by e3k_layer_bwd with have_m), items[i].gb_sc / acc_sc = its weight-gradient buffer;
+ * ga [n_keys, V] scratch, g_attrs [N, V] out (both NULL: the attributes need no gradient). */
+extern "C" int e3k_kw_stack_bwd(const e3k_layer* const* layers, const e3k_kw_stack_item* items, int32_t n, const float* a_rep,
+                                const int64_t* reps, const int32_t* bounds, int64_t N, int32_t n_keys, float* ga, float* g_attrs,
+                                float* workspace, void* stream) {
+  if (!layers || !items || n <= 0 || n > 8 || !a_rep || n_keys <= 0 || N < 0) return E3K_ERR_INVALID;
+  if ((ga != nullptr) != (g_attrs != nullptr) || (g_attrs && (!reps || !bounds))) return E3K_ERR_INVALID;
+  const int V = layers[0]->d.V;
+  e3k_kw_multi_item mi[8];
+  for (int i = 0; i < n; ++i) {
+    if (!layers[i]->kwa || layers[i]->d.V != V) return E3K_ERR_UNSUPPORTED;
+    mi[i] = e3k_kw_multi_item{layers[i]->kwa, items[i].w_sc, items[i].m, items[i].gb_sc, items[i].acc_sc, 0};
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (ga && e3k::zero_fill(ga, sizeof(float) * n_keys * V, st)) return E3K_ERR_LAUNCH;
+  if (!(ABLATE & 1)) E3K_TRY(e3k_keyed_weights_bwd_multi(mi, n, a_rep, n_keys, ga, workspace, stream));
+  if (g_attrs) {
+    if (e3k::zero_fill(g_attrs, sizeof(float) * N * V, st)) return E3K_ERR_LAUNCH;
+    const int tot = n_keys * V;
+    hipLaunchKernelGGL(e3k::scatter_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ga, reps, bounds, n_keys, V, g_attrs);
+  }
   if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
   return E3K_OK;
 }

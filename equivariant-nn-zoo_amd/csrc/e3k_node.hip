@@ -311,12 +311,10 @@ __device__ __forceinline__ const float* kw_locate(const KwArgs& ka, int64_t c, c
 // uses the same kernels with one key per node (thousands of keys)
 constexpr int KW_KT = 64;
 template <int MODE>   // 0: M = a . W    1: gW (+)= a^T . gM    (MODE 1: `M` is gM, `Wout_` is gW)
-__global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restrict__ a, const float* __restrict__ W,
-                                                             KwArgs ka, float* __restrict__ M, float* __restrict__ Wout_,
-                                                             int accumulate) {
-  __shared__ float as[KW_KT * KW_MAXV];
+__device__ __forceinline__ void kw_body(const float* __restrict__ a, const float* __restrict__ W, const KwArgs& ka, const int K,
+                                        float* __restrict__ M, float* __restrict__ Wout_, int accumulate, float* as) {
   const int t0 = blockIdx.y * KW_KT;
-  const int kt = (ka.K - t0 < KW_KT) ? ka.K - t0 : KW_KT;
+  const int kt = (K - t0 < KW_KT) ? K - t0 : KW_KT;
   for (int i = threadIdx.x; i < kt * ka.V; i += 256) as[i] = a[(int64_t)t0 * ka.V + i];
   __syncthreads();
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -357,21 +355,48 @@ __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restr
   }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restrict__ a, const float* __restrict__ W,
+                                                             KwArgs ka, float* __restrict__ M, float* __restrict__ Wout_,
+                                                             int accumulate) {
+  __shared__ float as[KW_KT * KW_MAXV];
+  kw_body<MODE>(a, W, ka, ka.K, M, Wout_, accumulate, as);
+}
+
+// the same for the self-connections of SEVERAL layers that share the attribute rows `a` (grid.z = layer): their instruction
+// tables live in device memory (e3k_kw_args_create, once per layer), the per-call pointers in the kernel arguments
+constexpr int KW_MAXL = 8;
+struct KwMulti {
+  int n, K;
+  const KwArgs* ka[KW_MAXL];
+  const float* W[KW_MAXL];
+  float* M[KW_MAXL];       // MODE 0: out; MODE 1 / bwd_a: gM
+  float* gW[KW_MAXL];
+  int acc[KW_MAXL];
+  int64_t ws_off[KW_MAXL]; // bwd_a: first workspace row of the layer
+};
+template <int MODE>
+__global__ __launch_bounds__(256) void keyed_weights_multi_kernel(const float* __restrict__ a, KwMulti m) {
+  __shared__ float as[KW_KT * KW_MAXV];
+  const int z = blockIdx.z;
+  if (MODE == 1 && !m.gW[z]) return;
+  kw_body<MODE>(a, m.W[z], *m.ka[z], m.K, m.M[z], m.gW[z], m.acc[z], as);
+}
+
 // ga[t,v] += sum_c gM[t,c] W[c,v]  (c over all ~1e5 columns): a [K x C] x [C x V] product with a tiny output.
 // Stage 1: a block stages 256 columns of gM ([K][256]) and of W ([V][256]) in LDS with coalesced loads; thread
 // (t, v) then owns one output and walks the 256 columns with 16-byte LDS reads; the block's K*V partials go to a
 // workspace row.  Stage 2: one block sums the workspace rows into ga (no same-address atomics: they serialised).
 constexpr int KWA_COLS = 256, KWA_KT = 16, KWA_RANGE = 128;
-__global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* __restrict__ gM, const float* __restrict__ W,
-                                                                   KwArgs ka, float* __restrict__ ws) {
-  __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
-  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+__device__ __forceinline__ void kw_bwd_a_body(const float* __restrict__ gM, const float* __restrict__ W, const KwArgs& ka_,
+                                              const int K, float* __restrict__ ws, float (*gs)[256], float (*wsm)[256]) {
+  struct { int K, V; int64_t ld_m, total; } ka{K, ka_.V, ka_.ld_m, ka_.total};
   const int t_id = threadIdx.x;
   const int64_t c = (int64_t)blockIdx.x * KWA_COLS + t_id;
   const bool ok = c < ka.total;
   {
     int wout = 1;
-    const float* base = ok ? kw_locate(ka, c, W, wout) : W;
+    const float* base = ok ? kw_locate(ka_, c, W, wout) : W;
     for (int v = 0; v < ka.V; ++v) wsm[v][t_id] = ok ? base[(int64_t)v * wout] : 0.f;
   }
   float* out = ws + (int64_t)blockIdx.x * ka.K * ka.V;
@@ -399,6 +424,22 @@ __global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* _
       out[(t0 + t) * ka.V + v] = acc;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* __restrict__ gM, const float* __restrict__ W,
+                                                                   KwArgs ka, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
+  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+  kw_bwd_a_body(gM, W, ka, ka.K, ws, gs, wsm);
+}
+
+__global__ __launch_bounds__(256) void keyed_weights_bwd_a_multi_kernel(KwMulti m, float* __restrict__ ws) {
+  __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
+  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+  const int z = blockIdx.z;
+  const KwArgs& ka = *m.ka[z];
+  if ((int64_t)blockIdx.x * KWA_COLS >= ka.total) return;      // (block-uniform: this layer has fewer column blocks)
+  kw_bwd_a_body(m.M[z], m.W[z], ka, m.K, ws + m.ws_off[z] * m.K * ka.V, gs, wsm);
 }
 
 // one block per 4 outputs: each wave sums its output's column of the workspace with 64 rows in flight
@@ -877,6 +918,125 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
     const int n = n_keys * V;
     hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0,
                        (hipStream_t)stream, workspace, (int)blocks, n, g_a);
+    E3K_CHECK_LAUNCH();
+  }
+  return E3K_OK;
+}
+
+// ---- the keyed weights of several layers that share the attribute rows, one launch per pass ----------------------------
+struct e3k_kw_args {
+  e3k::KwArgs host;
+  e3k::KwArgs* dev;
+};
+
+extern "C" int e3k_kw_args_create(const e3k_kw_instr* instr, int32_t n_instr, int32_t V, int64_t ld_m, e3k_kw_args** out) {
+  if (!out) return E3K_ERR_INVALID;
+  e3k_kw_args* o = new (std::nothrow) e3k_kw_args();
+  if (!o) return E3K_ERR_LAUNCH;
+  const int rc = make_kw(instr, n_instr, 1, V, ld_m, o->host);
+  if (rc != E3K_OK) {
+    delete o;
+    return rc;
+  }
+  o->host.K = 0;      // (the number of keys is a per-call argument)
+  if (hipMalloc(&o->dev, sizeof(e3k::KwArgs)) != hipSuccess ||
+      hipMemcpy(o->dev, &o->host, sizeof(e3k::KwArgs), hipMemcpyHostToDevice) != hipSuccess) {
+    if (o->dev) (void)hipFree(o->dev);
+    delete o;
+    return E3K_ERR_LAUNCH;
+  }
+  *out = o;
+  return E3K_OK;
+}
+
+extern "C" void e3k_kw_args_destroy(e3k_kw_args* o) {
+  if (!o) return;
+  if (o->dev) (void)hipFree(o->dev);
+  delete o;
+}
+
+namespace {
+int fill_multi(const e3k_kw_multi_item* items, int32_t n, int32_t n_keys, e3k::KwMulti& m, int64_t& max_total, int64_t& ws_rows) {
+  if (!items || n <= 0 || n > e3k::KW_MAXL || n_keys <= 0 || n_keys > e3k::KW_MAXK) return E3K_ERR_INVALID;
+  m.n = n;
+  m.K = n_keys;
+  max_total = 0;
+  ws_rows = 0;
+  for (int i = 0; i < n; ++i) {
+    const e3k_kw_multi_item& it = items[i];
+    if (!it.args || !it.W || !it.M) return E3K_ERR_INVALID;
+    if (it.args->host.V != items[0].args->host.V) return E3K_ERR_UNSUPPORTED;      // one attribute width for all
+    m.ka[i] = it.args->dev;
+    m.W[i] = it.W;
+    m.M[i] = it.M;
+    m.gW[i] = it.g_W;
+    m.acc[i] = it.accumulate_w;
+    m.ws_off[i] = ws_rows;
+    const int64_t total = it.args->host.total;
+    if (total > max_total) max_total = total;
+    ws_rows += (total + e3k::KWA_COLS - 1) / e3k::KWA_COLS;
+  }
+  return E3K_OK;
+}
+}  // namespace
+
+extern "C" int e3k_keyed_weights_fwd_multi(const e3k_kw_multi_item* items, int32_t n, const float* a, int32_t n_keys, void* stream) {
+  e3k::KwMulti m{};
+  int64_t max_total, ws_rows;
+  const int rc = fill_multi(items, n, n_keys, m, max_total, ws_rows);
+  if (rc != E3K_OK) return rc;
+  if (!a) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::keyed_weights_multi_kernel<0>,
+                     dim3((unsigned)((max_total + 255) / 256), (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT), (unsigned)n),
+                     dim3(256), 0, (hipStream_t)stream, a, m);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int64_t e3k_keyed_weights_bwd_multi_workspace(const e3k_kw_multi_item* items, int32_t n, int32_t n_keys) {
+  e3k::KwMulti m{};
+  int64_t max_total, ws_rows;
+  if (fill_multi(items, n, n_keys, m, max_total, ws_rows) != E3K_OK) return 0;
+  return ws_rows * n_keys * items[0].args->host.V;
+}
+
+/* items[i].M = g_M of layer i; g_W written / accumulated per item (NULL: skipped); g_a [n_keys, V] ACCUMULATED over all the
+ * layers (NULL: skipped; needs `workspace`). */
+extern "C" int e3k_keyed_weights_bwd_multi(const e3k_kw_multi_item* items, int32_t n, const float* a, int32_t n_keys, float* g_a,
+                                           float* workspace, void* stream) {
+  e3k::KwMulti m{};
+  int64_t max_total, ws_rows;
+  const int rc = fill_multi(items, n, n_keys, m, max_total, ws_rows);
+  if (rc != E3K_OK) return rc;
+  if (!a) return E3K_ERR_INVALID;
+  const int V = items[0].args->host.V;
+  const unsigned tiles = (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT);
+  bool any_w = false;
+  for (int i = 0; i < n; ++i) {
+    if (!items[i].g_W) continue;
+    any_w = true;
+    if (tiles > 1 && !items[i].accumulate_w) {   // the key tiles add with atomics: start from zero
+      const e3k::KwArgs& ka = items[i].args->host;
+      for (int j = 0; j < ka.n; ++j)
+        if (e3k::zero_fill(items[i].g_W + ka.ins[j].w_off, sizeof(float) * (size_t)ka.ins[j].u * V * ka.ins[j].w_out, (hipStream_t)stream))
+          return E3K_ERR_LAUNCH;
+    }
+  }
+  if (any_w) {
+    hipLaunchKernelGGL(e3k::keyed_weights_multi_kernel<1>, dim3((unsigned)((max_total + 255) / 256), tiles, (unsigned)n), dim3(256), 0,
+                       (hipStream_t)stream, a, m);
+    E3K_CHECK_LAUNCH();
+  }
+  if (g_a) {
+    if (!workspace) return E3K_ERR_INVALID;
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_multi_kernel,
+                       dim3((unsigned)((max_total + e3k::KWA_COLS - 1) / e3k::KWA_COLS),
+                            (unsigned)((n_keys + e3k::KWA_RANGE - 1) / e3k::KWA_RANGE), (unsigned)n),
+                       dim3(256), 0, (hipStream_t)stream, m, workspace);
+    E3K_CHECK_LAUNCH();
+    const int nn = n_keys * V;
+    hipLaunchKernelGGL(e3k::keyed_weights_bwd_a_reduce_kernel, dim3((unsigned)((nn + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                       workspace, (int)ws_rows, nn, g_a);
     E3K_CHECK_LAUNCH();
   }
   return E3K_OK;

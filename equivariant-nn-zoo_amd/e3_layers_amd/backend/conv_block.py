@@ -351,14 +351,16 @@ class ConvBlockFn(torch.autograd.Function):
 
 
 def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups, in_cf: bool, out_cf: bool, fork: bool,
-               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None, nxt=None, pre=None):
+               w_lin1, w_post, w_sc, w_last, w_hidden: Sequence[torch.Tensor], table=None, nxt=None, pre=None, m_pre=None):
     from . import conv_native
 
+    if m_pre is not None:    # the per-key self-connection weights of this layer come from conv_native.KwStackFn
+        node_attrs = w_sc = None
     if pre is not None:      # stack mode: the radial MLP's rows of this layer come from conv_native.RadialStackFn
         return conv_native.NativeConvBlockFn.apply(x, node_attrs, None, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
-                                                   pre, w_lin1, w_post, w_sc, None)
+                                                   pre, m_pre, w_lin1, w_post, w_sc, None)
     if conv_native.ENABLED and conv_native.native_layer(plan) is not None:      # the same sequence issued by csrc/e3k_layer.hip
         return conv_native.NativeConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
-                                                   nxt, None, w_lin1, w_post, w_sc, w_last, *w_hidden)
+                                                   nxt, None, m_pre, w_lin1, w_post, w_sc, w_last, *w_hidden)
     return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
                              w_lin1, w_post, w_sc, w_last, *w_hidden)

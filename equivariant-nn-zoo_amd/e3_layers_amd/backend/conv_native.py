@@ -358,6 +358,77 @@ class RadialStackFn(torch.autograd.Function):
         return (g_in, None, None, *rets)
 
 
+KW_STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
+
+
+class KwStackFn(torch.autograd.Function):
+    """The per-key contracted self-connection weights M_l[t] = sum_v a_t[v] W_l[:, v, :] of ALL the layers that read one
+    ``node_attrs`` tensor (``self.sc(x, node_attrs)`` of ``nn/message_passing.py:81-87,100``, keyed form), in one op:
+    forward = one gather of the keys' representative attribute rows + ONE launch for all layers; backward (behind the first
+    layer's backward, with the gM every layer handed back) = ONE launch for the weight gradients, one + a reduction for the
+    attribute gradient summed over the layers, one scatter to the representatives.  Per layer that was 2 launches forward
+    and 6 backward, plus an autograd add of the attribute gradients."""
+
+    @staticmethod
+    def forward(ctx, node_attrs, groups, plans, *w_sc):
+        L.require_cuda(node_attrs)
+        node_attrs = L.f32c(node_attrs)
+        dev = node_attrs.device
+        n, n_keys, v = len(plans), groups.n_keys, plans[0].sc_spec.v
+        a_rep = torch.empty(n_keys, v, device=dev, dtype=torch.float32)
+        ms = [torch.empty(n_keys, p.sc_ld_m, device=dev, dtype=torch.float32) for p in plans]
+        handles = (C.c_void_p * n)(*[native_layer(p).handle(dev) for p in plans])
+        items = (L.KwStackItem * n)()
+        for it, w, m in zip(items, w_sc, ms):
+            it.w_sc, it.m = w.data_ptr(), m.data_ptr()
+        L.check(L.load().e3k_kw_stack_fwd(handles, items, n, node_attrs.data_ptr(), groups.reps.data_ptr(), n_keys, a_rep.data_ptr(),
+                                          L.stream_ptr()), "e3k_kw_stack_fwd")
+        KW_STACK_STATS[0] += 1
+        KW_STACK_STATS[1] = n
+        if any(ctx.needs_input_grad):
+            ctx.save_for_backward(a_rep, *w_sc)
+            ctx.cfg = (plans, groups, tuple(node_attrs.shape))
+        return tuple(ms)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, *g_ms):
+        plans, groups, attrs_shape = ctx.cfg
+        saved = ctx.saved_tensors
+        a_rep, w_sc = saved[0], saved[1:]
+        dev = a_rep.device
+        need = ctx.needs_input_grad
+        live = [i for i in range(len(plans)) if g_ms[i] is not None]
+        rets = [None] * len(plans)
+        g_attrs = None
+        if live:
+            n, n_keys, v = len(live), groups.n_keys, plans[0].sc_spec.v
+            handles = (C.c_void_p * n)(*[native_layer(plans[i]).handle(dev) for i in live])
+            items = (L.KwStackItem * n)()
+            keep = []
+            for it, i in zip(items, live):
+                g = L.f32c(g_ms[i])
+                keep.append(g)
+                it.w_sc, it.m = w_sc[i].data_ptr(), g.data_ptr()
+                if need[3 + i]:
+                    sink = ops._sink_for(w_sc[i])
+                    if sink is not None:
+                        it.gb_sc, it.acc_sc = sink.data_ptr(), 1
+                    else:
+                        rets[i] = ops._kw_weight_buffer(w_sc[i], plans[i].sc_spec)
+                        it.gb_sc, it.acc_sc = rets[i].data_ptr(), 0
+            ga = ws = None
+            if need[0]:
+                ga = torch.empty(n_keys, v, device=dev, dtype=torch.float32)
+                g_attrs = torch.empty(attrs_shape, device=dev, dtype=torch.float32)
+                ws = torch.empty(max(int(L.load().e3k_kw_stack_bwd_workspace(handles, n, n_keys)), 1), device=dev, dtype=torch.float32)
+            L.check(L.load().e3k_kw_stack_bwd(handles, items, n, a_rep.data_ptr(), groups.reps.data_ptr(), groups.bounds.data_ptr(),
+                                              attrs_shape[0], n_keys, _ptr(ga), _ptr(g_attrs), _ptr(ws), L.stream_ptr()),
+                    "e3k_kw_stack_bwd")
+            del keep
+        return (g_attrs, None, None, *rets)
+
+
 def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
     """Buffers of one radial branch: (activations buffer, its carve, w [E, W], table rows [R, W] or None)."""
     r, hdim, width = edge_radial.shape[0], plan.last_spec.d_in, plan.last_spec.d_out
@@ -375,11 +446,13 @@ def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
 class NativeConvBlockFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf: bool, out_cf: bool, fork: bool, table, nxt,
-                pre, w_lin1, w_post, w_sc, w_last, *w_hidden):
+                pre, m_pre, w_lin1, w_post, w_sc, w_last, *w_hidden):
         """``pre`` (stack mode, ``RadialStackFn``): the radial MLP's output rows of this layer, computed for all layers of
         the network at once -- the knot table [knots + 1, W] (``table`` given: the layer interpolates) or the per-edge
         weights [E, W] themselves; ``edge_radial`` / ``w_last`` / ``w_hidden`` are then unused (None) and ``nxt`` =
-        (next plan, next layer's ``pre``) lets this layer issue the next one's interpolation early."""
+        (next plan, next layer's ``pre``) lets this layer issue the next one's interpolation early.
+        ``m_pre`` (``KwStackFn``): the per-key contracted self-connection weights M [n_keys, ld_m] of this layer, computed
+        for all layers at once; ``node_attrs`` / ``w_sc`` are then unused (None) and the backward hands back gM."""
         from . import conv_block
 
         stack = pre is not None
@@ -458,7 +531,8 @@ class NativeConvBlockFn(torch.autograd.Function):
         need_relayout = (not in_cf) and bool(tuple(b for b in plan.in_blocks if b[1] > 1 and b[2] > 1))
         if need_relayout:
             carve.add("x_cf", n * plan.lin1_spec.d_in)
-        if has_sc:
+        have_m = m_pre is not None
+        if has_sc and not have_m:
             carve.add("a_rep", groups.n_keys * plan.sc_spec.v)
             carve.add("m", groups.n_keys * plan.sc_ld_m)
         carve.add("conv", n * plan.post_spec.d_out)
@@ -470,10 +544,14 @@ class NativeConvBlockFn(torch.autograd.Function):
         if need_relayout:
             a.x_cf = _ptr(buf, off["x_cf"])
         if has_sc:
-            node_attrs = L.f32c(node_attrs)
-            a.node_attrs, a.w_sc = node_attrs.data_ptr(), w_sc.data_ptr()
             a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
-            a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
+            if have_m:
+                m_pre = L.f32c(m_pre)
+                a.have_m, a.m = 1, m_pre.data_ptr()
+            else:
+                node_attrs = L.f32c(node_attrs)
+                a.node_attrs, a.w_sc = node_attrs.data_ptr(), w_sc.data_ptr()
+                a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
         a.conv, a.x1, a.mid, a.y = _ptr(buf, off["conv"]), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
         if HOST_TIMING is not None:
             import time
@@ -493,7 +571,8 @@ class NativeConvBlockFn(torch.autograd.Function):
             if has_sc:
                 buf.record_stream(side2)
                 x.record_stream(side2)
-                _record_once(node_attrs, side2)
+                if not have_m:
+                    _record_once(node_attrs, side2)
             if w is None:
                 (pre if stack else t_tab).record_stream(main)      # (the table: allocated on the radial stream, read by the tensor product)
             elif w is not pre:
@@ -515,10 +594,10 @@ class NativeConvBlockFn(torch.autograd.Function):
             plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))
         if keep:
             ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
-                                  w_last, t_tab if (w is None and not stack) else None, *w_hidden)
+                                  w_last, t_tab if (w is None and not stack) else None, m_pre, *w_hidden)
             ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
             ctx.stack = stack
-            ctx.attrs_shape = tuple(node_attrs.shape) if has_sc else None
+            ctx.attrs_shape = tuple(node_attrs.shape) if (has_sc and not have_m) else None
         return y
 
     @staticmethod
@@ -527,12 +606,13 @@ class NativeConvBlockFn(torch.autograd.Function):
 
         plan, topo, groups, in_cf, out_cf, fork, n_hidden, table, carve, rcarve, need_relayout = ctx.cfg
         saved = ctx.saved_tensors
-        x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last, t_keep = saved[:11]
-        w_hidden = saved[11:11 + n_hidden]
+        x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last, t_keep, m_pre = saved[:12]
+        w_hidden = saved[12:12 + n_hidden]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
         stack, need_pre = ctx.stack, need[12]
-        p0 = 13
+        have_m, need_m = m_pre is not None, need[13]
+        p0 = 14
         need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
         need_hidden = need[p0 + 4:]
         if stack:
@@ -566,7 +646,11 @@ class NativeConvBlockFn(torch.autograd.Function):
         a.src_ptr, a.src_perm = topo.src_ptr.data_ptr(), topo.src_perm.data_ptr()
         a.w_lin1, a.w_post = w_lin1.data_ptr(), w_post.data_ptr()
         if has_sc:
-            a.a_rep, a.m, a.w_sc = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"]), w_sc.data_ptr()
+            if have_m:
+                a.have_m, a.m = 1, m_pre.data_ptr()
+                need_sc = need_attrs = False      # (formed by KwStackFn's backward from the gm this pass hands back)
+            else:
+                a.a_rep, a.m, a.w_sc = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"]), w_sc.data_ptr()
             a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
         if stack:
             _stack_radial_struct(a.rad, plan, edge_radial, table, e, w)      # (edge_radial: the layer's pre-computed rows)
@@ -603,8 +687,13 @@ class NativeConvBlockFn(torch.autograd.Function):
         for i, g in enumerate(gb_hidden):
             a.gb_hidden[i] = _ptr(g)
         need_radial_side = need_last or need_radial or any(need_hidden) or (stack and need_pre)
-        want_sc = has_sc and (need_sc or need_attrs)
-        g_pre = None
+        want_sc = has_sc and (need_sc or need_attrs) and not have_m
+        g_pre = g_m = None
+        if has_sc and have_m and need_m:      # gM: written by the keyed weight-gradient GEMM (weight-gradient stream), read by
+            # KwStackFn's backward on the self-connection stream (the executor orders the two)
+            with conv_block._on(side3, main):
+                g_m = torch.empty(groups.n_keys, plan.sc_ld_m, device=dev, dtype=torch.float32)
+            a.gm = g_m.data_ptr()
         # ---- scratch: one allocation
         sc_ = _Carve()
         sc_.add("g_conv", n * post.d_out)
@@ -694,12 +783,14 @@ class NativeConvBlockFn(torch.autograd.Function):
             for t in rets.values():
                 t.record_stream(main)
         if ops.GRAD_READY is not None:
-            needs = (need_lin1, need_post, need_sc or not has_sc) + (() if stack else (need_last, *need_hidden))
+            needs = (need_lin1, need_post, need_sc or not has_sc or have_m) + (() if stack else (need_last, *need_hidden))
             if all(needs) and not rets:          # every weight gradient of the layer went to the sink
                 # (stack mode: the radial MLP's gradients arrive with RadialStackFn's backward, after the last layer -- the
                 #  layer's slice of the all-reduce schedule is then its node-side weights, see run/parallel.py)
-                ops.GRAD_READY([w_lin1, w_post] + ([] if stack else [w_last, *w_hidden]) + ([w_sc] if has_sc else []))
+                ops.GRAD_READY([w_lin1, w_post] + ([] if stack else [w_last, *w_hidden]) + ([w_sc] if (has_sc and not have_m) else []))
         if g_pre is not None and fork and table is None:
             g_pre.record_stream(side)          # (allocated here, consumed by the stack's backward on the radial stream)
-        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None, g_pre,
+        if g_m is not None and fork:
+            g_m.record_stream(side2)
+        return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None, g_pre, g_m,
                 rets.get("lin1"), rets.get("post"), rets.get("sc"), rets.get("last"), *[rets.get(f"h{i}") for i in range(n_hidden)])

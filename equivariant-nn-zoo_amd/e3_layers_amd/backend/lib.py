@@ -96,6 +96,15 @@ class RadialStackItem(C.Structure):
                 ("g_h", C.c_void_p), ("g_radial", C.c_void_p)]
 
 
+class KwMultiItem(C.Structure):
+    _fields_ = [("args", C.c_void_p), ("W", C.c_void_p), ("M", C.c_void_p), ("g_W", C.c_void_p), ("accumulate_w", C.c_int32),
+                ("_pad", C.c_int32)]
+
+
+class KwStackItem(C.Structure):
+    _fields_ = [("w_sc", C.c_void_p), ("m", C.c_void_p), ("gb_sc", C.c_void_p), ("acc_sc", C.c_int32), ("_pad", C.c_int32)]
+
+
 class MlpNet(C.Structure):
     _fields_ = [("weights", C.c_void_p * 4), ("z", C.c_void_p * 4), ("out", C.c_void_p), ("g_out", C.c_void_p),
                 ("g_weights", C.c_void_p * 4), ("g_x", C.c_void_p)]
@@ -103,7 +112,7 @@ class MlpNet(C.Structure):
 
 class LayerFwdArgs(C.Structure):
     _fields_ = ([("N", C.c_int64), ("E", C.c_int64)]
-                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "keep", "fork", "has_w", "n_keys")]
+                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "keep", "fork", "has_w", "n_keys", "have_m", "_pad")]
                 + [(k, C.c_void_p) for k in ("main", "side", "side2", "x", "node_attrs", "sh", "src", "dst_ptr", "dst_perm", "perm",
                                              "bounds", "reps", "w_lin1", "w_post", "w_sc")]
                 + [("rad", LayerRadial), ("next", C.c_void_p), ("next_rad", C.POINTER(LayerRadial))]
@@ -112,7 +121,8 @@ class LayerFwdArgs(C.Structure):
 
 class LayerBwdArgs(C.Structure):
     _fields_ = ([("N", C.c_int64), ("E", C.c_int64)]
-                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "fork", "n_keys", "need_x", "need_attrs", "need_radial", "acc_sc")]
+                + [(k, C.c_int32) for k in ("in_cf", "out_cf", "fork", "n_keys", "need_x", "need_attrs", "need_radial", "acc_sc",
+                                            "have_m", "_pad")]
                 + [(k, C.c_void_p) for k in ("main", "side", "side2", "side3", "x_cf", "sh", "x1", "mid", "conv", "a_rep", "m",
                                              "src", "dst", "dst_ptr", "dst_perm", "src_ptr", "src_perm", "perm", "bounds", "reps",
                                              "w_lin1", "w_post", "w_sc")]
@@ -143,6 +153,14 @@ SIGNATURES = {
     "e3k_radial_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(RadialStackItem), _I32, _P]),
     "e3k_mlp_hidden_fwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
     "e3k_mlp_hidden_bwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
+    "e3k_kw_args_create": (C.c_int, [_P, _I32, _I32, _I64, C.POINTER(C.c_void_p)]),
+    "e3k_kw_args_destroy": (None, [_P]),
+    "e3k_keyed_weights_fwd_multi": (C.c_int, [C.POINTER(KwMultiItem), _I32, _P, _I32, _P]),
+    "e3k_keyed_weights_bwd_multi_workspace": (C.c_int64, [C.POINTER(KwMultiItem), _I32, _I32]),
+    "e3k_keyed_weights_bwd_multi": (C.c_int, [C.POINTER(KwMultiItem), _I32, _P, _I32, _P, _P, _P]),
+    "e3k_kw_stack_fwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(KwStackItem), _I32, _P, _P, _I32, _P, _P]),
+    "e3k_kw_stack_bwd_workspace": (C.c_int64, [C.POINTER(C.c_void_p), _I32, _I32]),
+    "e3k_kw_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(KwStackItem), _I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "e3k_layer_profile": (C.c_int, [_P, _I32]),
     "e3k_layer_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),

@@ -65,6 +65,10 @@ RADIAL_STACK = int(os.environ.get("E3K_RADIAL_STACK", "1"))
 # ... while the step is launch-bound: with more edges than this every layer runs its own MLP (its backward then overlaps
 # the earlier layers' backward instead of forming one tail behind the first layer's; measured cross-over)
 STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
+# 1: likewise the per-key self-connection weights M_l of all the layers that read one node_attrs tensor
+# (MessagePassing._kw_stack_rows); not while the all-reduce is overlapped with the backward (run/parallel.py): the
+# self-connection weights are most of a layer's parameters and their gradients would then only exist at the very end
+KW_STACK = int(os.environ.get("E3K_KW_STACK", "1"))
 
 
 def _stream_alias(t: Tensor, stream) -> Tensor:
@@ -344,6 +348,46 @@ class MessagePassing(Module):
             cache[id(m)] = (out, (grad, fork))
         return outs[0]
 
+    def _kw_stack_rows(self, node_attrs, attrs, groups, plan, fork: bool, n_edges: int, use_table: bool):
+        """This layer's per-key self-connection weights M [n_keys, ld_m] from one batched evaluation for every layer of the
+        ``_next_mp`` chain that has a keyed self-connection on the same attributes (``conv_native.KwStackFn``), or None.
+        ``node_attrs``: the tensor the layers share (the rows of the others wait on it); ``attrs``: its alias on the
+        self-connection stream when forked."""
+        from ..backend import conv_native
+
+        if not conv_native.ENABLED or conv_native.native_layer(plan) is None:
+            return None
+        grad = torch.is_grad_enabled()
+        cache = getattr(node_attrs, "_e3k_kw_stack", None)
+        if cache is None:
+            cache = node_attrs._e3k_kw_stack = {}
+        hit = cache.pop(id(self), None)
+        if hit is not None and hit[1] == (grad, fork, id(groups)):
+            return hit[0]
+        chain, m = [], self
+        while m is not None and len(chain) < 8:
+            pl = m._block_plan() if m is not self else plan
+            if pl is None or pl.sc_spec is None or conv_native.native_layer(pl) is None or pl.sc_spec.v != plan.sc_spec.v:
+                break
+            if m is not self and (bool(FWD_FORK and m.conv._fork_pays(n_edges, use_table))
+                                  != bool(FWD_FORK and self.conv._fork_pays(n_edges, use_table))):
+                break
+            chain.append((m, pl))
+            m = m.__dict__.get("_next_mp")
+        plans = [pl for _, pl in chain]
+        weights = [m.conv.sc.weight for m, _ in chain]
+        if fork:
+            main = torch.cuda.current_stream(attrs.device)
+            side2 = ops.side_stream(attrs.device, 1)
+            side2.wait_stream(main)             # (the attributes were produced on this stream)
+            with ops.on_stream(side2, main):    # forward AND backward of the stack live on the self-connection stream
+                outs = conv_native.KwStackFn.apply(attrs, groups, plans, *weights)
+        else:
+            outs = conv_native.KwStackFn.apply(attrs, groups, plans, *weights)
+        for (m, _), out in zip(chain[1:], outs[1:]):
+            cache[id(m)] = (out, (grad, fork, id(groups)))
+        return outs[0]
+
     def _forward_block(self, data, out_cf: bool):
         """The layer through ``conv_block`` when it applies to this call, else None (composed path)."""
         if not conv_block.ENABLED:
@@ -381,6 +425,9 @@ class MessagePassing(Module):
                 side2 = ops.side_stream(x.device, 1)
                 with ops.on_stream(side2, main):
                     attrs = _stream_alias(attrs, side2)
+        m_pre = None
+        if KW_STACK and groups is not None and ops.GRAD_READY is None and n_edges <= STACK_MAX_EDGES:
+            m_pre = self._kw_stack_rows(data["node_attrs"], attrs, groups, plan, fork, n_edges, table is not None)
         nxt = None
         nmp = self.__dict__.get("_next_mp")          # set by SequentialGraphNetwork: the next layer reads the same edge embedding
         pre = None
@@ -399,7 +446,8 @@ class MessagePassing(Module):
                     nxt = (nmp._block_plan(), pre_n[0])
             return conv_block.conv_block(x, attrs, None, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                          conv.linear_1.weight, conv.tp.linear.weight,
-                                         conv.sc.weight if conv.sc is not None else None, None, (), table=table, nxt=nxt, pre=pre)
+                                         conv.sc.weight if conv.sc is not None else None, None, (), table=table, nxt=nxt, pre=pre,
+                                         m_pre=m_pre)
         if nmp is not None and fork and nmp.conv._fork_pays(n_edges, table is not None):
             plan_n = nmp._block_plan()
             if plan_n is not None and (nmp.conv.sc is None) == (conv.sc is None):
@@ -410,7 +458,7 @@ class MessagePassing(Module):
                     nxt = (plan_n, fc_n[-1].weight, [m.weight for m in fc_n[:-1]])
         y = conv_block.conv_block(x, attrs, radial, sh, plan, topo, groups, bool(getattr(x, "_e3k_cf", False)), out_cf, fork,
                                   conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,
-                                  fc[-1].weight, [m.weight for m in fc[:-1]], table=table, nxt=nxt)
+                                  fc[-1].weight, [m.weight for m in fc[:-1]], table=table, nxt=nxt, m_pre=m_pre)
         return y
 
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):

@@ -373,6 +373,25 @@ int e3k_keyed_weights_bwd(const float* a, const float* W, const float* g_M, cons
                           int32_t n_keys, int32_t V, int64_t ld_m, float* g_a, float* g_W, int32_t accumulate_w,
                           float* workspace, void* stream);
 
+/* The same for the self-connections of several layers that read the SAME attribute rows `a` (the convolutions of one network:
+ * nn/message_passing.py:81-87 x layers), one launch per pass instead of one per layer.  e3k_kw_args: a layer's instruction
+ * table in device memory, created once.  items[i].M: forward OUT [n_keys, ld_m_i]; backward IN (g_M of layer i).  g_W as in
+ * e3k_keyed_weights_bwd, per item; g_a [n_keys, V] ACCUMULATED over all the layers (caller zeroes).  At most 8 layers. */
+typedef struct e3k_kw_args e3k_kw_args;
+int e3k_kw_args_create(const e3k_kw_instr* instr, int32_t n_instr, int32_t V, int64_t ld_m, e3k_kw_args** out);
+void e3k_kw_args_destroy(e3k_kw_args* args);
+typedef struct {
+  const e3k_kw_args* args;
+  const float* W;
+  float* M;
+  float* g_W;
+  int32_t accumulate_w, _pad;
+} e3k_kw_multi_item;
+int e3k_keyed_weights_fwd_multi(const e3k_kw_multi_item* items, int32_t n, const float* a, int32_t n_keys, void* stream);
+int64_t e3k_keyed_weights_bwd_multi_workspace(const e3k_kw_multi_item* items, int32_t n, int32_t n_keys);
+int e3k_keyed_weights_bwd_multi(const e3k_kw_multi_item* items, int32_t n, const float* a, int32_t n_keys, float* g_a,
+                                float* workspace, void* stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused hidden chain of the radial MLP.
  * Replaces the hidden layers of e3nn.nn.FullyConnectedNet([n_radial, H, ..., H, weight_numel], act)
@@ -508,6 +527,7 @@ typedef struct {
 typedef struct {
   int64_t N, E;
   int32_t in_cf, out_cf, keep, fork, has_w, n_keys;
+  int32_t have_m, _pad;              /* have_m: the per-key self-connection weights `m` were computed by e3k_kw_stack_fwd */
   void *main, *side, *side2;
   const float *x, *node_attrs, *sh;
   const int32_t *src, *dst_ptr, *dst_perm;
@@ -524,6 +544,8 @@ int e3k_layer_fwd(const e3k_layer* layer, const e3k_layer_fwd_args* a);
 typedef struct {
   int64_t N, E;
   int32_t in_cf, out_cf, fork, n_keys, need_x, need_attrs, need_radial, acc_sc;
+  int32_t have_m, _pad;              /* have_m: `gm` (gradient of the per-key weights) is an OUTPUT handed to e3k_kw_stack_bwd;
+                                        no weight / attribute gradient of the self-connection is formed here */
   void *main, *side, *side2, *side3;
   /* saved by the forward */
   const float *x_cf, *sh, *x1, *mid, *conv, *a_rep, *m;
@@ -560,6 +582,24 @@ typedef struct {
 } e3k_radial_stack_item;
 int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, void* stream);
 int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, void* stream);
+
+/* The per-key self-connection weights M_l = sum_v a[key, v] W_l[:, v, :] of several layers that read the same node attributes
+ * (nn/message_passing.py:81-87, 100 x layers), batched: forward = one gather of the keys' representative rows + ONE launch for
+ * all layers; backward (behind the first layer's backward, with the gm each layer's e3k_layer_bwd wrote) = ONE launch for the
+ * weight gradients, one + a reduction for the attribute gradient summed over the layers, one scatter to the representatives.
+ * Per layer that was 2 launches forward and 6 backward + an autograd add. */
+typedef struct {
+  const float* w_sc;
+  float* m;                  /* forward: OUT [n_keys, ld_m]; backward: IN, the gradient gm of that block */
+  float* gb_sc;              /* backward: weight-gradient buffer (NULL = not needed) */
+  int32_t acc_sc, _pad;      /*           1 = accumulate into it (gradient sink), 0 = write */
+} e3k_kw_stack_item;
+int e3k_kw_stack_fwd(const e3k_layer* const* layers, const e3k_kw_stack_item* items, int32_t n, const float* node_attrs,
+                     const int64_t* reps, int32_t n_keys, float* a_rep, void* stream);
+int64_t e3k_kw_stack_bwd_workspace(const e3k_layer* const* layers, int32_t n, int32_t n_keys);
+int e3k_kw_stack_bwd(const e3k_layer* const* layers, const e3k_kw_stack_item* items, int32_t n, const float* a_rep,
+                     const int64_t* reps, const int32_t* bounds, int64_t N, int32_t n_keys, float* ga, float* g_attrs,
+                     float* workspace, void* stream);
 
 /* Per-kernel timing of a layer's edge kernels (bench.py's roofline block: HIP events on the stream that runs the kernel).
  * e3k_layer_profile(layer, capacity): capacity > 0 arms `capacity` event pairs per kind, 0 disarms.

@@ -48,6 +48,7 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
         'printf("%zu %zu %zu %zu %zu\\n", sizeof(e3k_gemm_segment), sizeof(e3k_layer_desc), sizeof(e3k_layer_radial), sizeof(e3k_layer_fwd_args), sizeof(e3k_layer_bwd_args));\n'
         'printf("%zu %zu %zu %zu %zu %zu\\n", offsetof(e3k_gemm_segment, M1), offsetof(e3k_layer_desc, gate), offsetof(e3k_layer_desc, alphas), offsetof(e3k_layer_desc, tp_bwd_x_overwrites), offsetof(e3k_layer_fwd_args, rad), offsetof(e3k_layer_bwd_args, gb_hidden));\n'
         'printf("%zu %zu %zu\\n", offsetof(e3k_layer_fwd_args, x_cf), offsetof(e3k_layer_bwd_args, kw_ws), offsetof(e3k_layer_radial, z));\n'
+        'printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(e3k_radial_stack_item), sizeof(e3k_mlp_net), sizeof(e3k_kw_multi_item), sizeof(e3k_kw_stack_item), offsetof(e3k_radial_stack_item, g_rows), offsetof(e3k_layer_bwd_args, have_m));\n'
         "return 0;}\n")
     exe = tmp_path / "sizes"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
@@ -61,6 +62,8 @@ def test_struct_layouts_match_the_c_compiler(tmp_path):
     assert sizes[15:21] == [L.GemmSegment.M1.offset, L.LayerDesc.gate.offset, L.LayerDesc.alphas.offset,
                             L.LayerDesc.tp_bwd_x_overwrites.offset, L.LayerFwdArgs.rad.offset, L.LayerBwdArgs.gb_hidden.offset]
     assert sizes[21:24] == [L.LayerFwdArgs.x_cf.offset, L.LayerBwdArgs.kw_ws.offset, L.LayerRadial.z.offset]
+    assert sizes[24:30] == [C.sizeof(L.RadialStackItem), C.sizeof(L.MlpNet), C.sizeof(L.KwMultiItem), C.sizeof(L.KwStackItem),
+                            L.RadialStackItem.g_rows.offset, L.LayerBwdArgs.have_m.offset]
 
 
 def test_limits_agree_with_generated_header():

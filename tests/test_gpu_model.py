@@ -472,6 +472,70 @@ def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table
     assert conv_native.STACK_STATS[0] == n0 and rel_err(e_big, e0) < 1e-6
 
 
+@pytest.mark.parametrize("fork", [True, False])
+def test_kw_stack_equals_per_layer_keyed_weights(dev, monkeypatch, fork):
+    """The per-key self-connection weights of all layers formed in one batch (MessagePassing._kw_stack_rows ->
+    conv_native.KwStackFn: one launch forward, the weight and attribute gradients of all layers in one pass behind the first
+    layer's backward) against each layer forming its own: energies and every parameter gradient -- the self-connection weights
+    and, through the attribute gradient summed over the layers, the species embedding --, with the gradient sink and without,
+    forked and on one stream, with the radial stack on and off."""
+    from e3_layers_amd.backend import conv_block, conv_native, ops, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients, flat_param_order
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(4)
+    model = build(_energy_tree(2, 64, 4)).to(dev).train()
+    batch = synth_qm9(17, 24).to(dev)                      # > 256 nodes: the keyed self-connection
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0 if fork else 10 ** 9)
+    monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0 if fork else 10 ** 9)
+    monkeypatch.setattr(mp, "FWD_FORK", 1)
+    monkeypatch.setattr(conv_block, "ENABLED", 1)
+    monkeypatch.setattr(conv_native, "ENABLED", 1)
+    monkeypatch.setattr(mp, "STACK_MAX_EDGES", 10 ** 9)
+
+    def run(kw_stack, radial_stack, sink):
+        monkeypatch.setattr(mp, "KW_STACK", kw_stack)
+        monkeypatch.setattr(mp, "RADIAL_STACK", radial_stack)
+        model.zero_grad(set_to_none=True)
+        flat = None
+        if sink:
+            flat = FlatGradients(flat_param_order(model))
+            flat.enable_direct_accumulation()
+            flat.zero()
+        try:
+            n0 = conv_native.KW_STACK_STATS[0]
+            out = model(batch.clone())["total_energy"]
+            (out * torch.linspace(0.5, 1.5, out.numel(), device=dev).view_as(out)).sum().backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            grads = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+            calls = conv_native.KW_STACK_STATS[0] - n0
+        finally:
+            if flat is not None:
+                flat.disable_direct_accumulation()
+                model.zero_grad(set_to_none=True)
+        return out.detach().clone(), grads, calls
+
+    e0, g0, c0 = run(0, 0, False)
+    assert c0 == 0
+    for radial_stack in (0, 1):
+        for sink in (False, True):
+            e1, g1, c1 = run(1, radial_stack, sink)
+            assert c1 == 1 and conv_native.KW_STACK_STATS[1] == 4      # ONE evaluation for the four layers
+            assert rel_err(e1, e0) < 1e-6
+            assert set(g1) == set(g0)
+            for k in g0:
+                assert rel_err(g1[k], g0[k]) < 1e-5, (k, radial_stack, sink)
+    with torch.no_grad():
+        assert rel_err(model(batch.clone())["total_energy"], e0) < 1e-6
+    monkeypatch.setattr(ops, "GRAD_READY", lambda ws: None)            # overlapped all-reduce on: every layer forms its own
+    n0 = conv_native.KW_STACK_STATS[0]
+    e_ar = model(batch.clone())["total_energy"]
+    assert conv_native.KW_STACK_STATS[0] == n0 and rel_err(e_ar, e0) < 1e-6
+
+
 @pytest.mark.parametrize("block", [1, 0])
 def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, block):
     """The energy model with the radial MLPs evaluated through the knot table (a batch with enough edges for it to apply)
