@@ -494,6 +494,7 @@ def test_kw_stack_equals_per_layer_keyed_weights(dev, monkeypatch, fork):
     monkeypatch.setattr(conv_block, "ENABLED", 1)
     monkeypatch.setattr(conv_native, "ENABLED", 1)
     monkeypatch.setattr(mp, "STACK_MAX_EDGES", 10 ** 9)
+    monkeypatch.setattr(mp, "KW_STACK_MAX_EDGES", 10 ** 9)
 
     def run(kw_stack, radial_stack, sink):
         monkeypatch.setattr(mp, "KW_STACK", kw_stack)
