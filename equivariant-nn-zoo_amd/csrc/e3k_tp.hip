@@ -725,17 +725,22 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE) {      // FULL, un-split plans with l <= 2 (the l_max 2 models)
-    if (!p->full64 || p->split || p->max_l1 > 2) return E3K_ERR_UNSUPPORTED;
-    const bool lo = p->max_l3 <= p->max_l1;
-#define E3K_TP_LAUNCH_T(ML, L3)                                                                                                         \
-  if (kind == TP_FWD_TABLE)                                                                                                             \
-    hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);          \
-  else                                                                                                                                  \
-    hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
-    if (p->max_l1 == 2 && lo) { E3K_TP_LAUNCH_T(2, 2) }
-    else if (p->max_l1 == 0 && !lo) { E3K_TP_LAUNCH_T(0, 3) }
-    else return E3K_ERR_UNSUPPORTED;
+  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE) {      // channel-complete (FULL) plans, split or not
+    if (!p->full64) return E3K_ERR_UNSUPPORTED;
+    const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
+#define E3K_TP_LAUNCH_T(ML, L3, SP)                                                                                                     \
+  {                                                                                                                                     \
+    if (kind == TP_FWD_TABLE)                                                                                                           \
+      hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);           \
+    else                                                                                                                                \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);         \
+  }
+    switch (p->max_l1) {
+      case 0: if (lo) E3K_TP_LAUNCH_T(0, 0, false) else E3K_TP_LAUNCH_T(0, 3, false) break;
+      case 1: if (lo && !spl) E3K_TP_LAUNCH_T(1, 1, false) else if (!spl) E3K_TP_LAUNCH_T(1, 3, false) else E3K_TP_LAUNCH_T(1, 3, true) break;
+      case 2: if (lo && !spl) E3K_TP_LAUNCH_T(2, 2, false) else if (!spl) E3K_TP_LAUNCH_T(2, 3, false) else E3K_TP_LAUNCH_T(2, 3, true) break;
+      default: if (!spl) E3K_TP_LAUNCH_T(3, 3, false) else E3K_TP_LAUNCH_T(3, 3, true) break;
+    }
 #undef E3K_TP_LAUNCH_T
     E3K_CHECK_LAUNCH();
     return E3K_OK;
@@ -813,11 +818,9 @@ extern "C" int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const floa
 
 // ---- the same two passes with the path weights interpolated from the radial knot table inside the kernel ---------------
 // T [K + 1, W]: the radial MLP on the knots; bin / t [E]: every edge's centre knot (1 .. K - 1) and offset (e3k_rtable_bin).
-// E3K_ERR_UNSUPPORTED for plans the table form is not instantiated for (the caller then materialises w: e3k_rtable_interp_fwd).
+// E3K_ERR_UNSUPPORTED for plans that are not channel-complete (the caller then materialises w: e3k_rtable_interp_fwd).
 extern "C" int e3k_tp_table_supported(const e3k_tp_plan* p) {
-  if (!p || !p->full64 || p->split) return 0;
-  const bool lo = p->max_l3 <= p->max_l1;
-  return (p->max_l1 == 2 && lo) || (p->max_l1 == 0 && !lo);
+  return (p && p->full64) ? 1 : 0;
 }
 
 extern "C" int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,

@@ -223,8 +223,9 @@ int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* plan);
  * knot table (the weights `self.fc(edge_radial)` of nn/message_passing.py:93, never materialised as [E, W]):
  * T [K + 1, W] = the radial MLP on the knots, bin / t [E] = each edge's centre knot and offset (e3k_rtable_bin).
  * Same results as e3k_rtable_interp_fwd followed by e3k_tp_fwd / e3k_tp_bwd_x (same interpolation arithmetic).
- * e3k_tp_table_supported: 1 when the plan has this form (channel-complete, un-split plans of the l_max 2 models), else the
- * two entry points return E3K_ERR_UNSUPPORTED. */
+ * e3k_tp_table_supported: 1 when the plan has this form (channel-complete plans: every group a multiple of 64 channels with
+ * all its degree slots present -- the inner layers of every shipped model), else the two entry points return
+ * E3K_ERR_UNSUPPORTED. */
 int e3k_tp_table_supported(const e3k_tp_plan* plan);
 int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,
                      const float* t, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,

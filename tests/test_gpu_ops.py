@@ -451,6 +451,8 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
 @pytest.mark.parametrize("left,out", [
     ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
     ("64x0e", "64x0e+64x1o+64x2e"),
+    # l_max 3: the split (two waves per group) kernels
+    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o"),
 ])
 def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
     """e3k_tp_fwd_table / e3k_tp_bwd_x_table (the path weights interpolated from the radial knot table inside the kernel) ==
