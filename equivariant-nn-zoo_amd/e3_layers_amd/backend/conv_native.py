@@ -192,6 +192,8 @@ class _Carve:
 # interpolate their path weights inside tp_fwd / tp_bwd_x: no interpolation pass, no w[E, W] (0.2-0.3 GB a layer at 256
 # molecules) written, read twice and kept for the backward
 TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
+# 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
+FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
 
 
 def in_kernel_table(plan, table, dev) -> bool:
@@ -241,6 +243,16 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
         rad.w = pre.data_ptr()
 
 
+def _consumed_on(stream, *tensors):
+    """Gradients allocated on the side stream a stack's backward runs on are read on ``stream`` (AccumulateGrad, the next
+    node): the caching allocator must not hand their blocks back to the side stream before that reader is done."""
+    if stream is None:
+        return
+    for t in tensors:
+        if t is not None:
+            t.record_stream(stream)
+
+
 STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
 # E3K_HOST_TIMING=1: host seconds inside the layer functions, split into the C call and the Python around it
 # (tools/host_split.py --layer-timing prints them): [fwd total, fwd C call, bwd total, bwd C call, calls]
@@ -256,7 +268,9 @@ class RadialStackFn(torch.autograd.Function):
     and 4-5 backward over the same 4 097 knot rows: latency, not work."""
 
     @staticmethod
-    def forward(ctx, rows, plans, use_table: bool, *weights):
+    def forward(ctx, rows, plans, use_table: bool, main, *weights):
+        """``main``: the stream the rest of the network runs on when this op was put on the radial stream (else None):
+        gradients handed back to autograd are consumed there."""
         L.require_cuda(rows)
         rows = L.f32c(rows)
         dev = rows.device
@@ -302,6 +316,7 @@ class RadialStackFn(torch.autograd.Function):
         if keep:
             ctx.save_for_backward(rows, *bufs, *weights)
             ctx.cfg = (plans, use_table, carves, n_hidden)
+            ctx.main = main
         return tuple(outs)
 
     @staticmethod
@@ -337,7 +352,7 @@ class RadialStackFn(torch.autograd.Function):
                     rad.z[l] = _ptr(bufs[i], carves[i].off[f"z{l}"])
                 it.g_rows = g.data_ptr()
                 for l in range(per):
-                    if not need[3 + i * per + l]:
+                    if not need[4 + i * per + l]:
                         continue
                     w = weights[i * per + l]
                     sink = ops._sink_for(w)
@@ -355,7 +370,8 @@ class RadialStackFn(torch.autograd.Function):
             if g_rad is not None:
                 g_in = g_rad[0] if len(live) == 1 else g_rad.sum(0)
             del keepalive
-        return (g_in, None, None, *rets)
+        _consumed_on(ctx.main, g_in, *rets)
+        return (g_in, None, None, None, *rets)
 
 
 KW_STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
@@ -370,7 +386,7 @@ class KwStackFn(torch.autograd.Function):
     and 6 backward, plus an autograd add of the attribute gradients."""
 
     @staticmethod
-    def forward(ctx, node_attrs, groups, plans, *w_sc):
+    def forward(ctx, node_attrs, groups, plans, main, *w_sc):
         L.require_cuda(node_attrs)
         node_attrs = L.f32c(node_attrs)
         dev = node_attrs.device
@@ -388,6 +404,7 @@ class KwStackFn(torch.autograd.Function):
         if any(ctx.needs_input_grad):
             ctx.save_for_backward(a_rep, *w_sc)
             ctx.cfg = (plans, groups, tuple(node_attrs.shape))
+            ctx.main = main
         return tuple(ms)
 
     @staticmethod
@@ -410,7 +427,7 @@ class KwStackFn(torch.autograd.Function):
                 g = L.f32c(g_ms[i])
                 keep.append(g)
                 it.w_sc, it.m = w_sc[i].data_ptr(), g.data_ptr()
-                if need[3 + i]:
+                if need[4 + i]:
                     sink = ops._sink_for(w_sc[i])
                     if sink is not None:
                         it.gb_sc, it.acc_sc = sink.data_ptr(), 1
@@ -426,7 +443,8 @@ class KwStackFn(torch.autograd.Function):
                                               attrs_shape[0], n_keys, _ptr(ga), _ptr(g_attrs), _ptr(ws), L.stream_ptr()),
                     "e3k_kw_stack_bwd")
             del keep
-        return (g_attrs, None, None, *rets)
+        _consumed_on(ctx.main, g_attrs, *rets)
+        return (g_attrs, None, None, None, *rets)
 
 
 def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
@@ -466,7 +484,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         fork = bool(fork) and not torch.cuda.is_current_stream_capturing()
         side = ops.side_stream(dev, 0) if fork else main
-        side2 = ops.side_stream(dev, 1) if fork else main
+        side2 = ops.side_stream(dev, 1) if (fork and not FWD_SC_MAIN) else main
         keep = any(ctx.needs_input_grad)
         has_sc = plan.sc_spec is not None
         n, e = x.shape[0], sh.shape[0]
@@ -573,6 +591,9 @@ class NativeConvBlockFn(torch.autograd.Function):
                 x.record_stream(side2)
                 if not have_m:
                     _record_once(node_attrs, side2)
+                else:
+                    m_pre.record_stream(main)      # (allocated by KwStackFn on the self-connection stream; the backward's
+                                                   #  input-gradient GEMM reads it on this one)
             if w is None:
                 (pre if stack else t_tab).record_stream(main)      # (the table: allocated on the radial stream, read by the tensor product)
             elif w is not pre:

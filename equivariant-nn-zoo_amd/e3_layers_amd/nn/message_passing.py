@@ -342,9 +342,9 @@ class MessagePassing(Module):
             side = ops.side_stream(rows.device)
             side.wait_stream(main)              # (the knot basis was evaluated on this stream)
             with ops.on_stream(side, main):     # forward AND backward of the stack live on the radial stream
-                outs = conv_native.RadialStackFn.apply(rows, plans, use_table, *weights)
+                outs = conv_native.RadialStackFn.apply(rows, plans, use_table, main, *weights)
         else:
-            outs = conv_native.RadialStackFn.apply(rows, plans, use_table, *weights)
+            outs = conv_native.RadialStackFn.apply(rows, plans, use_table, None, *weights)
         for (m, _, _), out in zip(chain[1:], outs[1:]):
             cache[id(m)] = (out, (grad, fork))
         return outs[0]
@@ -382,9 +382,9 @@ class MessagePassing(Module):
             side2 = ops.side_stream(attrs.device, 1)
             side2.wait_stream(main)             # (the attributes were produced on this stream)
             with ops.on_stream(side2, main):    # forward AND backward of the stack live on the self-connection stream
-                outs = conv_native.KwStackFn.apply(attrs, groups, plans, *weights)
+                outs = conv_native.KwStackFn.apply(attrs, groups, plans, main, *weights)
         else:
-            outs = conv_native.KwStackFn.apply(attrs, groups, plans, *weights)
+            outs = conv_native.KwStackFn.apply(attrs, groups, plans, None, *weights)
         for (m, _), out in zip(chain[1:], outs[1:]):
             cache[id(m)] = (out, (grad, fork, id(groups)))
         return outs[0]
