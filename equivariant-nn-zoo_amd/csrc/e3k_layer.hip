@@ -101,6 +101,9 @@ namespace {
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
 static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
 static const int BWDW_SIDE = getenv("E3K_BWDW_SIDE") ? atoi(getenv("E3K_BWDW_SIDE")) : 0;
+// 1: e3k_tp_bwd_table_partial instead of tp_bwd_w + transposed interpolation (no g_w[E, W]); measured slower -- the gather in
+// knot order has no molecule locality: 256 molecules 5.33 -> 5.75 ms, 128: 3.49 -> 3.68 -- and therefore off
+static const int BWD_T = getenv("E3K_BWD_T") ? atoi(getenv("E3K_BWD_T")) : 0;
 static const int WGRAD_LATE = getenv("E3K_WGRAD_LATE") ? atoi(getenv("E3K_WGRAD_LATE")) : 1;
 // the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
 static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
@@ -368,7 +371,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   const bool need_last = a->gb_last != nullptr;
   bool need_hidden = false;
   for (int i = 0; i < d.n_hidden; ++i) need_hidden = need_hidden || a->gb_hidden[i];
-  const bool need_radial_side = need_last || need_hidden || a->need_radial || (r.have_rows && a->g_w);
+  const bool need_radial_side = need_last || need_hidden || a->need_radial || (r.have_rows && (a->g_w || a->g_T));
   const bool need_post = a->gb_post != nullptr, need_lin1 = a->gb_lin1 != nullptr;
   // have_m: the gradient of the per-key weights, gm, is this layer's OUTPUT (e3k_kw_stack_bwd turns the gm of all the
   // layers into weight and attribute gradients in one pass, on the self-connection stream)
@@ -447,8 +450,24 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     E3K_TRY(weight_grads(true, true, side3));
     if (want_sc) E3K_TRY(keyed_weight_grads());
   }
+  // in-kernel table: the weight-gradient pass and the transposed interpolation are ONE kernel in knot order
+  // (e3k_tp_bwd_table_partial), on the radial stream; g_w[E, W] is neither written nor read
+  const bool fused_t = BWD_T && need_radial_side && a->E > 0 && in_kernel_table(d, r) && a->table_ws && a->g_T;
+  if (fused_t) {
+    E3K_TRY(edge(L, 2, main, side));            // g_mid is complete (and, BWD_T = 1, tp_bwd_x has been issued)
+    {
+      Timed t(L, E3K_PROF_TP_BWD_W, side, a->N, a->E);
+      E3K_TRY(e3k_tp_bwd_table_partial(d.tp, a->x1, a->sh, a->g_mid, a->src, a->dst, r.bin_ptr, r.bin_perm, r.bin_t, a->N, a->E, r.knots,
+                                       a->table_ws, side));
+    }
+    E3K_TRY(e3k_rtable_bwd_combine(a->table_ws, r.knots, d.W, a->g_T, side));
+  }
   if (need_radial_side && a->E > 0) {
-    if (!a->g_w) return E3K_ERR_INVALID;
+    if (!a->g_w && !fused_t) return E3K_ERR_INVALID;
+    const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
+    if (fused_t) {
+      g_rows = a->g_T;
+    } else {
     // the weight-gradient pass: on the radial stream BEHIND tp_bwd_x (both are memory streams: side by side they only
     // stretch each other), where it runs beside the GEMMs that follow on the main stream (this layer's linear_1 dgrad, the
     // previous layer's gate' and post-TP dgrad) -- nothing on the main stream waits for it
@@ -459,11 +478,11 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
       E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, wst));
     }
     if (wst == main) E3K_TRY(edge(L, 2, main, side));
-    const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
     if (r.use_table) {
       Timed t(L, E3K_PROF_RTABLE_BWD, side, r.R, r.E);
       if (!(ABLATE & 8)) E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
       g_rows = a->g_T;
+    }
     }
     if (need_last && !(ABLATE & 16) && !r.have_rows) {
       Seg g;

@@ -145,6 +145,16 @@ extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, co
 
 extern "C" int64_t e3k_rtable_bwd_workspace_floats(int32_t K, int32_t W) { return (int64_t)(K + 1) * 3 * W; }
 
+// second pass alone (the first one done elsewhere: e3k_tp_bwd_table_partial)
+extern "C" int e3k_rtable_bwd_combine(const float* P, int32_t K, int32_t W, float* g_T, void* stream) {
+  if (K < 4 || W <= 0 || !P || !g_T) return E3K_ERR_INVALID;
+  if (W % 4) return E3K_ERR_UNSUPPORTED;
+  const int64_t q = (int64_t)(K + 1) * (W / 4);
+  hipLaunchKernelGGL(e3k::rtable_bwd_combine_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, W, g_T);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
 extern "C" int e3k_rtable_interp_bwd(const float* g_w, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t,
                                      int64_t E, int32_t K, int32_t W, float* workspace, float* g_T, void* stream) {
   if (E < 0 || K < 4 || W <= 0) return E3K_ERR_INVALID;

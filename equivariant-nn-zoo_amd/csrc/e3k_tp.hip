@@ -345,6 +345,79 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 }
 
 // ------------------------------------------------------------------------------------------
+// backward wrt the radial knot table, with NO per-edge weight gradient in memory: a wave = (knot bin, group, chunk) walks
+// the bin's edges (CSR by knot, ascending edge id), forms every edge's weight gradient g_w[e] in registers exactly as
+// tp_bwd_w does (x[src] and g_mid[dst] gathered per edge: there is no destination locality in knot order) and accumulates
+// the bin's three interpolation-weighted sums -- what rtable_bwd_partial_kernel computes from g_w[E, W] after tp_bwd_w
+// wrote it.  Same products, same order: P (and g_T after the combine pass) are bit-identical to that pair.
+// ------------------------------------------------------------------------------------------
+template <int L1, int L3MAX, int PART>
+__device__ __forceinline__ void tp_bwd_t_body_full(const TpArgs& a, const e3k_tp_group& g, const int bin, const int u) {
+  using S = Slots<L1>;
+  constexpr int D1 = 2 * L1 + 1;
+  const int u4 = u * 4;
+  const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
+  int goff4[S::NQ], gstr4[S::NQ];
+  float cf[S::NQ], am[S::NQ], a0[S::NQ], ap[S::NQ];
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    goff4[Q] = uniform(g.out_off[Q] * 4);
+    gstr4[Q] = uniform(g.out_stride[Q] * 4);
+    cf[Q] = g.coeff[Q];
+    am[Q] = a0[Q] = ap[Q] = 0.0f;
+  });
+  const int row_x = a.d_in * 4, row_g = a.d_mid * 4;
+  const int beg = uniform(a.ptr[bin]), end = uniform(a.ptr[bin + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]), d = uniform(a.nbr2[e]);
+    YRegs yc;
+    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    const float tv = __uint_as_float(uniform((int)__float_as_uint(a.tt[e])));
+    const float cm = 0.5f * tv * (tv - 1.f), c0 = 1.f - tv * tv, cp = 0.5f * tv * (tv + 1.f);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
+    const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
+    float xc[D1], gn[S::TOTAL];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
+      float tt[2 * L3 + 1];
+      CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+      float dot = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 2 * L3 + 1; ++k) dot = fmaf(gn[OFF + k], tt[k], dot);
+      const float gw = dot * cf[Q];
+      am[Q] = fmaf(cm, gw, am[Q]);
+      a0[Q] = fmaf(c0, gw, a0[Q]);
+      ap[Q] = fmaf(cp, gw, ap[Q]);
+    });
+  }
+  float* __restrict__ prow = a.g_w + (int64_t)bin * 3 * a.W;
+  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+    constexpr int Q = decltype(qc)::value;
+    float* __restrict__ c = prow + g.w_off[Q];
+    c[u] = am[Q];
+    (c + a.W)[u] = a0[Q];
+    (c + 2 * a.W)[u] = ap[Q];
+  });
+}
+
+template <int L1, int L3MAX, int PART, bool FULL>
+__device__ __forceinline__ void tp_bwd_t_body(const TpArgs& a, const e3k_tp_group& g, const int bin, const int u) {
+  static_assert(FULL, "the knot-order backward exists for channel-complete plans only");
+  tp_bwd_t_body_full<L1, L3MAX, PART>(a, g, bin, u);
+}
+
+// ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
 template <int L1, int L3MAX, bool TABLE, int PART>
@@ -537,6 +610,13 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, TABLE)
 }
+template <int MAXL, int L3MAX, bool SPLIT>
+__global__ __launch_bounds__(256) void tp_bwd_t_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                       const int2* __restrict__ gc, int n_gc) {
+  constexpr bool FULL = true;
+  E3K_TP_PROLOGUE
+  E3K_TP_DISPATCH(tp_bwd_t_body, L3MAX)
+}
 #undef E3K_TP_DISPATCH
 #undef E3K_TP_CASE
 
@@ -714,7 +794,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 }
 
 namespace {
-enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE };
+enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_BWD_T };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -725,6 +805,21 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
+  if (kind == TP_BWD_T) {
+    if (!p->full64) return E3K_ERR_UNSUPPORTED;
+    const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
+#define E3K_TP_LAUNCH_B(ML, L3, SP) \
+  hipLaunchKernelGGL((e3k::tp_bwd_t_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
+    switch (p->max_l1) {
+      case 0: if (lo) { E3K_TP_LAUNCH_B(0, 0, false) } else { E3K_TP_LAUNCH_B(0, 3, false) } break;
+      case 1: if (lo && !spl) { E3K_TP_LAUNCH_B(1, 1, false) } else if (!spl) { E3K_TP_LAUNCH_B(1, 3, false) } else { E3K_TP_LAUNCH_B(1, 3, true) } break;
+      case 2: if (lo && !spl) { E3K_TP_LAUNCH_B(2, 2, false) } else if (!spl) { E3K_TP_LAUNCH_B(2, 3, false) } else { E3K_TP_LAUNCH_B(2, 3, true) } break;
+      default: if (!spl) { E3K_TP_LAUNCH_B(3, 3, false) } else { E3K_TP_LAUNCH_B(3, 3, true) } break;
+    }
+#undef E3K_TP_LAUNCH_B
+    E3K_CHECK_LAUNCH();
+    return E3K_OK;
+  }
   if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE) {      // channel-complete (FULL) plans, split or not
     if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
@@ -846,4 +941,19 @@ extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, cons
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_TABLE, a, plan, N, (hipStream_t)stream);
+}
+
+// The weight-gradient pass and the transposed interpolation in one: P [K + 1, 3, W] (the per-knot partial sums that
+// e3k_rtable_interp_bwd's first pass forms from g_w[E, W]) straight from x, sh, g_out -- g_w never exists.  Follow with
+// e3k_rtable_bwd_combine.  bin_ptr [K + 2] / bin_perm [E]: CSR by knot (ascending edge id inside a knot); t [E]: offsets.
+extern "C" int e3k_tp_bwd_table_partial(const e3k_tp_plan* plan, const float* x, const float* sh, const float* g_out,
+                                        const int32_t* src, const int32_t* dst, const int32_t* bin_ptr, const int32_t* bin_perm,
+                                        const float* t, int64_t N, int64_t E, int32_t K, float* P, void* stream) {
+  if (!plan || N < 0 || E < 0 || K < 4) return E3K_ERR_INVALID;
+  if (!P || !bin_ptr) return E3K_ERR_INVALID;
+  if (E > 0 && (!x || !sh || !g_out || !src || !dst || !bin_perm || !t)) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.g_out = g_out; a.g_w = P; a.nbr = src; a.nbr2 = dst; a.ptr = bin_ptr; a.perm = bin_perm; a.tt = t;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_T, a, plan, (int64_t)K + 1, (hipStream_t)stream);
 }

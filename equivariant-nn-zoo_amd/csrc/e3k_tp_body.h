@@ -41,6 +41,7 @@ struct TpArgs {
   float* g_sh;         // [E, d_sh]
   float* g_x;          // [N, d_in]
   const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
+  const int32_t* nbr2; // bwd_t: dst[e] (nbr = src[e]; ptr / perm = the CSR by knot)
   const int32_t* ptr;  // CSR row pointers [N+1]
   const int32_t* perm; // CSR edge ids [E]
   const int32_t* bin;  // TABLE kernels: centre knot of every edge [E]; w is then the knot table [K + 1, W]

@@ -194,6 +194,10 @@ class _Carve:
 TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
 # 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
 FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
+# 1: with the in-kernel table the gradient of the table is formed by one kernel in knot order (e3k_tp_bwd_table_partial)
+# instead of tp_bwd_w -> g_w[E, W] -> transposed interpolation (csrc/e3k_layer.hip reads the same variable).  Correct
+# (bit-identical) and slower -- no molecule locality in knot order --, so off.
+BWD_T = int(os.environ.get("E3K_BWD_T", "0"))
 
 
 def in_kernel_table(plan, table, dev) -> bool:
@@ -731,7 +735,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         if need_radial_side:
             if stack and table is None:
                 g_pre = torch.empty(e, last.d_out, device=dev, dtype=torch.float32)      # g_w IS the gradient of the layer's rows
-            else:
+            elif not (w is None and BWD_T):      # (in-kernel table: the backward to the table keeps g_w[e] in registers)
                 sc_.add("g_w", e * last.d_out)
             if table is not None:
                 if stack:

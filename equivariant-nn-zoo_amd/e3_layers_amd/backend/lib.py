@@ -189,6 +189,8 @@ SIGNATURES = {
     "e3k_tp_table_supported": (C.c_int, [_P]),
     "e3k_tp_fwd_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_table_partial": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P]),
+    "e3k_rtable_bwd_combine": (C.c_int, [_P, _I32, _I32, _P, _P]),
     "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_csr_workspace_ints": (C.c_int64, [_I64, _I64]),
     "e3k_csr_build": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),

@@ -233,6 +233,14 @@ int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, c
 int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* t,
                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N,
                        int64_t E, float* g_x, void* stream);
+/* The gradient of the table: e3k_tp_bwd_w + the first pass of e3k_rtable_interp_bwd in one kernel that walks the edges in
+ * knot order (bin_ptr [K + 2] / bin_perm [E]: CSR by knot) and keeps every edge's weight gradient in registers:
+ * P [K + 1, 3, W] (e3k_rtable_bwd_workspace_floats) = the per-knot partial sums, bit-identical to that pair; then
+ * e3k_rtable_bwd_combine(P) -> g_T [K + 1, W].  g_w[E, W] never exists.  Plans with e3k_tp_table_supported. */
+int e3k_tp_bwd_table_partial(const e3k_tp_plan* plan, const float* x, const float* sh, const float* g_out, const int32_t* src,
+                             const int32_t* dst, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t, int64_t N,
+                             int64_t E, int32_t K, float* P, void* stream);
+int e3k_rtable_bwd_combine(const float* P, int32_t K, int32_t W, float* g_T, void* stream);
 int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 

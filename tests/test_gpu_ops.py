@@ -499,6 +499,23 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
         assert torch.equal(gx_t, ref_gx)
     else:                                   # (atomic accumulation across groups: the order is not fixed)
         assert rel_err(gx_t, ref_gx) < 1e-6
+    # the gradient of the table: tp_bwd_w -> g_w[E, W] -> transposed interpolation == one kernel in knot order, bit for bit
+    ptr = torch.zeros(knots + 2, dtype=torch.int32, device=dev)
+    ptr[1:] = torch.cumsum(torch.bincount(bins.long(), minlength=knots + 1), 0).int()
+    g_w = torch.empty(e, plan.w_numel, device=dev)
+    L.check(lib.e3k_tp_bwd_w(plan.handle(dev), L.ptr(x), L.ptr(sh), None, L.ptr(g_out), L.ptr(topo.src), L.ptr(topo.dst_ptr),
+                             L.ptr(topo.dst_perm), n, e, L.ptr(g_w), None, L.stream_ptr()), "e3k_tp_bwd_w")
+    n_ws = int(lib.e3k_rtable_bwd_workspace_floats(knots, plan.w_numel))
+    ws_ref, ws_new = torch.empty(n_ws, device=dev), torch.full((n_ws,), float("nan"), device=dev)
+    gt_ref, gt_new = torch.empty(knots + 1, plan.w_numel, device=dev), torch.empty(knots + 1, plan.w_numel, device=dev)
+    L.check(lib.e3k_rtable_interp_bwd(L.ptr(g_w), L.ptr(ptr), L.ptr(perm), L.ptr(t), e, knots, plan.w_numel, L.ptr(ws_ref), L.ptr(gt_ref),
+                                      L.stream_ptr()), "e3k_rtable_interp_bwd")
+    L.check(lib.e3k_tp_bwd_table_partial(plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(g_out), L.ptr(topo.src), L.ptr(topo.dst), L.ptr(ptr),
+                                         L.ptr(perm), L.ptr(t), n, e, knots, L.ptr(ws_new), L.stream_ptr()), "e3k_tp_bwd_table_partial")
+    L.check(lib.e3k_rtable_bwd_combine(L.ptr(ws_new), knots, plan.w_numel, L.ptr(gt_new), L.stream_ptr()), "e3k_rtable_bwd_combine")
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(gt_new).all())
+    assert torch.equal(gt_new, gt_ref)
     # a plan without the in-kernel form (odd channel count): refused, not silently wrong
     odd = TensorProductExpansion("24x0e+24x1o", ("1x0e+1x1o+1x2e", "edge_spherical"), ("24x0e+24x1o+24x2e", "edge_features"), "uvu",
                                  internal_weight=False).to(dev)
