@@ -101,9 +101,6 @@ namespace {
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
 static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
 static const int BWDW_SIDE = getenv("E3K_BWDW_SIDE") ? atoi(getenv("E3K_BWDW_SIDE")) : 0;
-// 1: e3k_tp_bwd_table_partial instead of tp_bwd_w + transposed interpolation (no g_w[E, W]); measured slower -- the gather in
-// knot order has no molecule locality: 256 molecules 5.33 -> 5.75 ms, 128: 3.49 -> 3.68 -- and therefore off
-static const int BWD_T = getenv("E3K_BWD_T") ? atoi(getenv("E3K_BWD_T")) : 0;
 static const int WGRAD_LATE = getenv("E3K_WGRAD_LATE") ? atoi(getenv("E3K_WGRAD_LATE")) : 1;
 // the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
 static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
@@ -452,9 +449,11 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   }
   // in-kernel table: the weight-gradient pass and the transposed interpolation are ONE kernel in knot order
   // (e3k_tp_bwd_table_partial), on the radial stream; g_w[E, W] is neither written nor read
-  const bool fused_t = BWD_T && need_radial_side && a->E > 0 && in_kernel_table(d, r) && a->table_ws && a->g_T;
+  // (rad.in_kernel = 2; measured slower -- the gather in knot order has no molecule locality: 256 molecules 5.33 -> 5.75 ms --
+  //  so the binding asks for it only under E3K_BWD_T=1)
+  const bool fused_t = r.in_kernel >= 2 && need_radial_side && a->E > 0 && in_kernel_table(d, r) && a->table_ws && a->g_T;
   if (fused_t) {
-    E3K_TRY(edge(L, 2, main, side));            // g_mid is complete (and, BWD_T = 1, tp_bwd_x has been issued)
+    E3K_TRY(edge(L, 2, main, side));            // g_mid is complete (and tp_bwd_x has been issued)
     {
       Timed t(L, E3K_PROF_TP_BWD_W, side, a->N, a->E);
       E3K_TRY(e3k_tp_bwd_table_partial(d.tp, a->x1, a->sh, a->g_mid, a->src, a->dst, r.bin_ptr, r.bin_perm, r.bin_t, a->N, a->E, r.knots,

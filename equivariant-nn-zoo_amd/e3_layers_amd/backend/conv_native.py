@@ -195,7 +195,7 @@ TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
 # 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
 FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
 # 1: with the in-kernel table the gradient of the table is formed by one kernel in knot order (e3k_tp_bwd_table_partial)
-# instead of tp_bwd_w -> g_w[E, W] -> transposed interpolation (csrc/e3k_layer.hip reads the same variable).  Correct
+# instead of tp_bwd_w -> g_w[E, W] -> transposed interpolation (asked for through rad.in_kernel = 2).  Correct
 # (bit-identical) and slower -- no molecule locality in knot order --, so off.
 BWD_T = int(os.environ.get("E3K_BWD_T", "0"))
 
@@ -228,7 +228,7 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
         for i in range(len(w_hidden)):
             rad.z[i] = _ptr(buf, carve.off[f"z{i}"])
     rad.w = _ptr(w)
-    rad.in_kernel = int(w is None)
+    rad.in_kernel = (2 if BWD_T else 1) if w is None else 0
 
 
 def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
@@ -242,7 +242,7 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
         rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
         rad.T = pre.data_ptr()
         rad.w = _ptr(w)
-        rad.in_kernel = int(w is None)
+        rad.in_kernel = (2 if BWD_T else 1) if w is None else 0
     else:
         rad.w = pre.data_ptr()
 

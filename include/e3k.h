@@ -518,7 +518,8 @@ typedef struct {
                                 of those rows (g_T resp. g_w), which e3k_radial_stack_bwd takes from there */
   int32_t in_kernel;         /* table only, plans with e3k_tp_table_supported: the tensor-product kernels interpolate the
                                 path weights from T themselves (e3k_tp_fwd_table / e3k_tp_bwd_x_table): no interpolation
-                                pass, w unused (may be null); the backward needs T */
+                                pass, w unused (may be null); the backward needs T.  2: the backward also forms the
+                                gradient of the table with e3k_tp_bwd_table_partial (no g_w; g_w may be null) */
   int32_t _pad;
   const float* radial;       /* [R, k0] */
   const int32_t* bin;        /* table: centre knot per edge, */

@@ -400,7 +400,7 @@ def test_conv_block_look_ahead_equals_in_order(dev, monkeypatch, form):
         assert plan is not None and plan.prefetched is None                 # nothing left behind
 
 
-@pytest.mark.parametrize("table", [2, 1, 0])
+@pytest.mark.parametrize("table", [3, 2, 1, 0])
 @pytest.mark.parametrize("fork", [True, False])
 def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table):
     """The radial MLPs of all layers evaluated as one batch on the knot table (MessagePassing._stack_rows ->
@@ -432,7 +432,8 @@ def test_radial_stack_equals_per_layer_radial_mlps(dev, monkeypatch, fork, table
 
     def run(stack, sink):
         monkeypatch.setattr(mp, "RADIAL_STACK", stack)
-        monkeypatch.setattr(conv_native, "TP_TABLE", int(stack and table == 2))
+        monkeypatch.setattr(conv_native, "TP_TABLE", int(stack and table >= 2))
+        monkeypatch.setattr(conv_native, "BWD_T", int(stack and table == 3))      # 3: also the table's gradient in knot order (no g_w)
         model.zero_grad(set_to_none=True)
         flat = None
         if sink:
