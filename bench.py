@@ -62,6 +62,9 @@ def parse():
                     help="feed the step from the prefetching loader (data/loader.py: collate of fresh samples on a worker thread, "
                          "pinned buffers, async H2D) instead of HBM-resident batches; reported beside the resident figure")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph-fresh", action="store_true",
+                    help="HIP-graph replay with a NEW batch every step: the resident batches are padded to one size bucket with a "
+                         "ghost graph (run/graph_step.py), each step copies the next one into the captured tensors and replays")
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) on ONE resident batch in a HIP graph and "
                          "replay it (no per-batch work in the replayed step: disclosed in config.launch)")
@@ -279,6 +282,34 @@ def main():
         captured = CapturedStep(lambda: step(fixed.view()), warmup=3)
         graph = captured.graph
         run = captured
+
+    bucket = None
+    if args.graph_fresh:
+        if cfg_kind != "energy" or args.loader or args.graph:
+            raise SystemExit("--graph-fresh replays the config_energy step on padded resident batches")
+        from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
+
+        # the bucket: here the capacity of the resident batches (a training run takes it from the dataset's statistics and
+        # steps a batch that does not fit eagerly)
+        n_cap, e_cap = bucket_capacity(list(zip(n_nodes, n_edges)))
+        padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host_batches]
+
+        def train_on(batch):
+            target, weight = batch["total_energy"], batch["_graph_weight"]      # weight: 1 / G for the real graphs, 0 for the ghost
+            loss = 1e3 * (((model(batch)["total_energy"] - target) ** 2) * weight).sum()
+            flat.zero()
+            loss.backward()
+            flat.all_reduce_mean()
+            opt.step()
+            return loss
+
+        bucket = BucketedStep(train_on, padded[0], warmup=3)
+        graph = bucket.captured.graph
+
+        def run():
+            b = padded[counter[0] % n_res]
+            counter[0] += 1
+            return bucket(b)
 
     def max_over_ranks(seconds: float) -> float:
         t = torch.tensor([seconds], device=dev, dtype=torch.float64)
@@ -513,7 +544,10 @@ def main():
                 "input": "prefetching loader (collate of fresh samples + pinned H2D inside the loop)" if args.loader else "HBM-resident batches",
                 "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
                 "ranks": dist.get_world_size() if world > 1 else 1,
-                "launch": "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager",
+                "launch": ((f"hip-graph replay, a NEW batch every step: padded to the bucket ({n_cap} nodes, {e_cap} edges) with a ghost "
+                            "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins inside the graph")
+                           if bucket is not None else
+                           "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager"),
                 "parameters": countParameters(model), "final_loss": round(float(loss.detach()), 4),
                 "retimed_after_stall": retimed,
             },

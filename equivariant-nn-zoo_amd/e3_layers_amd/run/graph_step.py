@@ -46,3 +46,128 @@ class CapturedStep:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Graph replay with a NEW batch every step: pad every batch to one size bucket with a ghost graph, copy it into the captured
+# tensors, replay.  
+#
+# A HIP graph freezes shapes and addresses.  The batches of a training run differ in N and E, so each is padded to the
+# bucket's (n_cap, e_cap) with ONE extra graph that holds the surplus nodes and edges: ghost nodes on a line 1.0-3.5 A apart
+# (valid geometry: finite spherical harmonics and radial basis), ghost edges between neighbouring ghost nodes (repeated as
+# often as needed: edges are independent), a valid species.  The ghost graph's energy is excluded from the loss (its weight in
+# the masked mean is 0), so the gradient that flows into the ghost's nodes and edges is exactly zero and every weight gradient
+# equals the un-padded batch's up to the order of the sums.  All host-side decisions of the model (knot table, stacks,
+# streams, keyed self-connection) depend on sizes only, which the bucket fixes.
+# ---------------------------------------------------------------------------------------------------------------------
+def ghost_sample(like, n_nodes: int, n_edges: int):
+    """A sample with ``n_nodes`` (>= 2 when it has edges) collinear nodes and ``n_edges`` nearest-neighbour edges, with the
+    keys of ``like`` (a ``Data`` sample on the host: ``pos``, ``species``, ``edge_index``, per-graph targets)."""
+    from ..data.data import Data
+
+    if n_nodes < (2 if n_edges else 1):
+        raise ValueError(f"a ghost graph with {n_edges} edges needs at least two nodes (got {n_nodes}): raise the node capacity")
+    # neighbour distances spread over [1.0, 3.5) A (golden-ratio sequence): ghost edges must not pile up in ONE knot bin of
+    # the radial table (a bin's edges are walked by one wave, its CSR row is ranked in O(len^2 / 64))
+    gaps = 1.0 + 2.5 * torch.frac(0.6180339887 * torch.arange(n_nodes, dtype=torch.float64))
+    pos = torch.zeros(n_nodes, 3, dtype=like["pos"].dtype)
+    pos[:, 0] = (torch.cumsum(gaps, 0) - gaps[0]).to(like["pos"].dtype)
+    k = torch.arange(n_edges, dtype=torch.int64)
+    a = k % max(n_nodes - 1, 1)
+    flip = (k // max(n_nodes - 1, 1)) % 2 == 1
+    src, dst = torch.where(flip, a + 1, a), torch.where(flip, a, a + 1)
+    tensors = {}
+    for key in like.keys():
+        v = like[key]
+        if key == "pos":
+            tensors[key] = pos
+        elif key == "edge_index":
+            tensors[key] = torch.stack([src, dst]).to(v.dtype)
+        elif key == "_n_nodes":
+            tensors[key] = torch.full_like(v, n_nodes)
+        elif key == "_n_edges":
+            tensors[key] = torch.full_like(v, n_edges)
+        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == like["pos"].shape[0] and key != "pos":
+            tensors[key] = v[:1].expand(n_nodes, *v.shape[1:]).clone()      # node-wise (species): the first node's value
+        elif torch.is_tensor(v):
+            tensors[key] = torch.zeros_like(v)                               # graph-wise targets
+        else:
+            tensors[key] = v
+    return Data(attrs=dict(like.attrs), **tensors)
+
+
+def pad_batch(batch, n_cap: int, e_cap: int):
+    """``batch`` (host or device) + one ghost graph so that it has exactly ``n_cap`` nodes and ``e_cap`` edges; returns the
+    padded Batch (on the batch's device) with ``_graph_weight`` [G + 1, 1] = 1 / G for the real graphs, 0 for the ghost."""
+    from ..data.data import Batch
+    from ..data.loader import samples_of
+
+    dev = batch["pos"].device
+    samples = samples_of(batch)
+    n, e = int(batch["pos"].shape[0]), int(batch["edge_index"].shape[1])
+    if n_cap < n + 2 or e_cap < e:
+        raise ValueError(f"batch with {n} nodes / {e} edges does not fit the bucket ({n_cap}, {e_cap}; two ghost nodes are the minimum)")
+    samples.append(ghost_sample(samples[0], n_cap - n, e_cap - e))
+    out = Batch.from_data_list(samples, attrs=dict(samples[0].attrs))
+    w = torch.full((len(samples), 1), 1.0 / (len(samples) - 1), dtype=torch.float32)
+    w[-1] = 0.0
+    out["_graph_weight"] = w
+    out.attrs["_graph_weight"] = ("graph", "1x0e")
+    return out.to(dev)
+
+
+GHOST_DEGREE = 16      # ghost edges per ghost node the capacities below aim for (the edge kernels walk a node's edges in one wave)
+
+
+def bucket_capacity(sizes, node_multiple: int = 32, edge_multiple: int = 1024):
+    """(n_cap, e_cap) for batches of ``sizes`` = [(n_nodes, n_edges), ...]: every batch fits with at least two ghost nodes, and
+    the ghost graph that absorbs a batch's missing edges has about ``GHOST_DEGREE`` edges per node -- a ghost node with
+    hundreds of edges is a wave that walks hundreds of edges on its own while the chip waits (measured: 40 ms instead of
+    3.5 ms per step at 128 molecules with 21 ghost nodes for 3 300 ghost edges)."""
+    e_cap = -(-max(e for _, e in sizes) // edge_multiple) * edge_multiple
+    n_cap = max(n + max(2, -(-(e_cap - e) // GHOST_DEGREE)) for n, e in sizes)
+    return -(-n_cap // node_multiple) * node_multiple, e_cap
+
+
+def forget_batch_memos(batch=None) -> None:
+    """Drops what the framework remembers about a batch by the identity of its tensors: CSR views (``backend/graph.py``),
+    species groups (``nn/core.py``) and the memos attached to the tensors themselves (``_e3k_*`` attributes: the flat species
+    index of ``OneHotEncoding``, stream aliases)."""
+    from ..backend import graph as _graph
+    from ..nn import core as _core
+
+    _graph._cache.clear()
+    _core._groups_cache.clear()
+    if batch is not None:
+        for k in batch.keys():
+            v = batch[k]
+            if torch.is_tensor(v):
+                for name in [a for a in vars(v) if a.startswith("_e3k_")] if hasattr(v, "__dict__") else []:
+                    delattr(v, name)
+
+
+class BucketedStep:
+    """``step = BucketedStep(train_on, example)``: ``train_on(batch)`` is captured once on a copy of the padded batch
+    ``example``; ``step(padded)`` copies the next padded batch of the same bucket into the captured tensors and replays."""
+
+    def __init__(self, fn: Callable[[Any], Any], example, warmup: int = 3):
+        self.static = example.clone()
+        self.keys = [k for k in self.static.keys() if torch.is_tensor(self.static[k])]
+
+        def captured_fn():
+            # The per-batch memos (CSR views keyed on the identity of ``edge_index``, species groups keyed on the key tensor, the
+            # flat species index OneHotEncoding keeps on its input tensor)
+            # would hit on the static tensors and leave the CSR build / grouping kernels OUT of the graph: the replay would then
+            # walk the warm-up batch's topology.  Forget them, so that these kernels are part of what is captured.
+            forget_batch_memos(self.static)
+            return fn(self.static.view())
+
+        self.captured = CapturedStep(captured_fn, warmup=warmup)
+
+    def __call__(self, padded):
+        for k in self.keys:
+            dst, src = self.static[k], padded[k]
+            if dst.shape != src.shape:
+                raise ValueError(f"{k}: {tuple(src.shape)} does not fit the captured {tuple(dst.shape)} (another bucket?)")
+            dst.copy_(src, non_blocking=True)
+        return self.captured()

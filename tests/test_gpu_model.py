@@ -538,6 +538,64 @@ def test_kw_stack_equals_per_layer_keyed_weights(dev, monkeypatch, fork):
     assert conv_native.KW_STACK_STATS[0] == n0 and rel_err(e_ar, e0) < 1e-6
 
 
+def test_bucketed_graph_replay_with_fresh_padded_batches_equals_eager(dev, monkeypatch):
+    """run/graph_step.py: batches of different sizes padded to one bucket with a ghost graph of zero loss weight, copied into
+    the captured tensors and replayed as ONE HIP graph (CSR build, species groups, knot bins, stacks, forward, loss, backward
+    inside the graph) -- against the eager step on the un-padded batch: the real graphs' energies, the loss and every
+    parameter gradient, for two different batches through the same captured graph."""
+    from e3_layers_amd.backend import ops, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
+    from e3_layers_amd.run.parallel import FlatGradients, flat_param_order
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(11)
+    model = build(_energy_tree(2, 64, 3)).to(dev).train()
+    monkeypatch.setattr(radial_table, "KNOTS", 512)        # so that these small batches take the knot-table path
+    monkeypatch.setattr(radial_table, "GUARD_TOL", 1.0)
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+    host = [synth_qm9(21, 24), synth_qm9(22, 24), synth_qm9(23, 24)]      # (one bucket = one graph count: the batch size)
+    n_cap, e_cap = bucket_capacity([(b["pos"].shape[0], b["edge_index"].shape[1]) for b in host])
+    padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host]
+    assert all(p["pos"].shape[0] == n_cap and p["edge_index"].shape[1] == e_cap for p in padded)
+    flat = FlatGradients(flat_param_order(model))
+    flat.enable_direct_accumulation()
+    energies = []
+    try:
+        def train_on(batch):
+            target = batch["total_energy"]           # (the model writes its prediction under the same key)
+            out = model(batch)["total_energy"]
+            energies.append(out)
+            loss = 1e3 * (((out - target) ** 2) * batch["_graph_weight"]).sum()
+            flat.zero()
+            loss.backward()
+            return loss
+
+        step = BucketedStep(train_on, padded[0], warmup=2)
+        e_static = energies[-1]                                  # the captured output tensor
+        replayed = []
+        for p in (padded[1], padded[2], padded[0]):
+            loss = step(p)
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            replayed.append((float(loss), e_static.detach().clone(), flat.gather().clone()))
+        for (loss_g, e_g, g_g), b in zip(replayed, (host[1], host[2], host[0])):
+            db = b.clone().to(dev)
+            target = db["total_energy"]
+            out = model(db)["total_energy"]
+            loss = 1e3 * torch.nn.functional.mse_loss(out, target)
+            flat.zero()
+            loss.backward()
+            ops.join_side_streams()
+            torch.cuda.synchronize()
+            assert rel_err(e_g[:-1], out) < 1e-6                      # the real graphs (the ghost graph is the last row)
+            assert bool(torch.isfinite(e_g).all())
+            assert abs(loss_g - float(loss)) <= 1e-5 * abs(float(loss))
+            assert rel_err(g_g, flat.gather()) < 1e-5
+    finally:
+        flat.disable_direct_accumulation()
+
+
 @pytest.mark.parametrize("block", [1, 0])
 def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, block):
     """The energy model with the radial MLPs evaluated through the knot table (a batch with enough edges for it to apply)

@@ -69,7 +69,8 @@ if "--profile" in sys.argv:      # where the host time goes: cProfile over 30 st
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("tottime").print_stats(40)
+    st.sort_stats("cumtime").print_stats(45)
 if "--torch-profile" in sys.argv:      # host time per op / autograd node (forward and backward threads): torch.profiler, CPU side only
     from torch.profiler import ProfilerActivity, profile
     with profile(activities=[ProfilerActivity.CPU]) as prof:
