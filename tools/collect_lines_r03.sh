@@ -11,9 +11,10 @@ $B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
 for b in 32 64 128 512; do $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done
 $B --loader > $OUT/bench_loader.json 2>/dev/null
 $B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
+for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done
 for c in energy_force diffusion diffusion_CA; do $B --config $c > $OUT/bench_$c.json 2>/dev/null; done
 uptime >> $OUT/lines_uptime.txt
-for f in default lmax3 b32 b64 b128 b512 loader graph_b32 energy_force diffusion diffusion_CA; do python3 -c "
+for f in default lmax3 b32 b64 b128 b512 loader graph_b32 graphfresh_b32 graphfresh_b64 graphfresh_b128 energy_force diffusion diffusion_CA; do python3 -c "
 import json,sys
 d=json.loads([l for l in open('$OUT/bench_$f.json') if l.startswith('{')][-1]); print('$f', d['ms_per_step'], d.get('host_busy_ms_per_step'))"; done
 cat $OUT/lines_uptime.txt

@@ -30,5 +30,6 @@ $B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
 for b in 32 64 128 512; do $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done
 $B --loader > $OUT/bench_loader.json 2>/dev/null
 $B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
+for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done
 for c in energy_force diffusion diffusion_CA; do $B --config $c > $OUT/bench_$c.json 2>/dev/null; done
 ls $OUT; tail -c 600 $OUT/bench_default.json
