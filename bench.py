@@ -285,20 +285,32 @@ def main():
 
     bucket = None
     if args.graph_fresh:
-        if cfg_kind != "energy" or args.loader or args.graph:
-            raise SystemExit("--graph-fresh replays the config_energy step on padded resident batches")
+        if cfg_kind not in ("energy", "energy_force") or args.loader or args.graph:
+            raise SystemExit("--graph-fresh replays the config_energy / config_energy_force step on padded resident batches")
         from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
 
         # the bucket: here the capacity of the resident batches (a training run takes it from the dataset's statistics and
         # steps a batch that does not fit eagerly)
         n_cap, e_cap = bucket_capacity(list(zip(n_nodes, n_edges)))
         padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host_batches]
+        if cfg_kind == "energy_force":
+            for p in padded:
+                p["forces_target"] = torch.randn(p["pos"].shape, device=dev, generator=gen)
+                p.attrs["forces_target"] = ("node", "1x1o")
 
         def train_on(batch):
             target, weight = batch["total_energy"], batch["_graph_weight"]      # weight: 1 / G for the real graphs, 0 for the ghost
-            loss = 1e3 * (((model(batch)["total_energy"] - target) ** 2) * weight).sum()
-            flat.zero()
-            loss.backward()
+            if cfg_kind == "energy":
+                loss = 1e3 * (((model(batch)["total_energy"] - target) ** 2) * weight).sum()
+                flat.zero()
+                loss.backward()
+            else:      # config_energy_force.py:18 loss_coeffs; the force term is a mean over the REAL nodes' components
+                f_t, wn = batch["forces_target"], batch["_node_weight"]
+                out = model(batch)
+                loss = (1e3 * (((out["total_energy"] - target) ** 2) * weight).sum()
+                        + 3e4 * (((out["forces"] - f_t) ** 2) * (wn / 3.0)).sum())
+                flat.zero()
+                backward_parameters(loss, opt.params)
             flat.all_reduce_mean()
             opt.step()
             return loss

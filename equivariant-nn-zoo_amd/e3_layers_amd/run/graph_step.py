@@ -98,7 +98,8 @@ def ghost_sample(like, n_nodes: int, n_edges: int):
 
 def pad_batch(batch, n_cap: int, e_cap: int):
     """``batch`` (host or device) + one ghost graph so that it has exactly ``n_cap`` nodes and ``e_cap`` edges; returns the
-    padded Batch (on the batch's device) with ``_graph_weight`` [G + 1, 1] = 1 / G for the real graphs, 0 for the ghost."""
+    padded Batch (on the batch's device) with ``_graph_weight`` [G + 1, 1] = 1 / G for the real graphs, 0 for the ghost, and
+    ``_node_weight`` [n_cap, 1] = 1 / N for the real nodes, 0 for the ghost's."""
     from ..data.data import Batch
     from ..data.loader import samples_of
 
@@ -113,6 +114,10 @@ def pad_batch(batch, n_cap: int, e_cap: int):
     w[-1] = 0.0
     out["_graph_weight"] = w
     out.attrs["_graph_weight"] = ("graph", "1x0e")
+    wn = torch.zeros(n_cap, 1, dtype=torch.float32)      # node-wise losses (forces): 1 / N_real on the real nodes
+    wn[:n] = 1.0 / n
+    out["_node_weight"] = wn
+    out.attrs["_node_weight"] = ("node", "1x0e")
     return out.to(dev)
 
 
