@@ -32,4 +32,7 @@ $B --loader > $OUT/bench_loader.json 2>/dev/null
 $B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
 for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done
 for c in energy_force diffusion diffusion_CA; do $B --config $c > $OUT/bench_$c.json 2>/dev/null; done
+# 6. measured errors of the model-level parity tests (tests/util.py: record_measured)
+rm -f $OUT/parity_measured.jsonl
+E3K_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl python3 -m pytest tests/test_gpu_model.py -q -m gpu -k "protein or diffusion or bench_path or guard or backbone" > $OUT/parity_tests.log 2>&1
 ls $OUT; tail -c 600 $OUT/bench_default.json

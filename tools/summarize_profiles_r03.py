@@ -113,3 +113,7 @@ for key in ("tp_fwd", "tp_bwd_x", "tp_bwd_w"):
             print(f"{tag} {key}: traffic {k['traffic_bytes_per_launch'] / 1e6:.0f} MB vs algorithmic {k['algorithmic_bytes_per_launch'] / 1e6:.0f} MB, "
                   f"rocprof {k['rocprof_avg_launch_us']:.1f} us, bench events {k['bench_event_avg_launch_us']} us")
 print(json.dumps(mfma["kernels"], indent=1)[:1500])
+
+pm = os.path.join(SRC, "parity_measured.jsonl")
+if os.path.exists(pm) and sum(1 for _ in open(pm)) > 1:
+    shutil.copy(pm, os.path.join(DST, "r03_parity_measured.jsonl"))
