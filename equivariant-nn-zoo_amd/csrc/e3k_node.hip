@@ -506,6 +506,70 @@ __global__ __launch_bounds__(256) void normact_fwd_kernel(const float* __restric
   }
 }
 
+// s, D = (d s / d x_m) / x_m and D2 = (d D / d x_m) / x_m of the channel's scaling (second derivatives: force training through a
+// 'norm' nonlinearity): with q = sum_m x_m^2,  y_m = x_m s,  g_x_m = g_y_m s + x_m D (g_y . x)
+__device__ __forceinline__ void normact_scale2(int act, float eps2, int normalize, float n2, float& s, float& d, float& d2) {
+  if (eps2 > 0.f) {
+    const bool clamped = n2 < eps2;
+    const float n = sqrtf(clamped ? eps2 : n2);
+    const float a = act_f(act, n), a1 = act_df(act, n), a2 = act_d2f(act, n);
+    float s1, s2;
+    if (normalize) {
+      s = a / n;
+      s1 = (a1 * n - a) / (n * n);
+      s2 = (a2 * n * n - 2.0f * a1 * n + 2.0f * a) / (n * n * n);
+    } else {
+      s = a;
+      s1 = a1;
+      s2 = a2;
+    }
+    d = clamped ? 0.f : s1 / n;
+    d2 = clamped ? 0.f : (s2 * n - s1) / (n * n * n);
+  } else {   // no epsilon: the argument of the nonlinearity is the squared norm
+    s = act_f(act, n2);
+    d = 2.0f * act_df(act, n2);
+    d2 = 4.0f * act_d2f(act, n2);
+  }
+}
+
+// backward of normact_bwd (cotangent h on g_x, cf layout like x):  F = sum_m h_m g_x_m = s (h . g_y) + D (h . x)(g_y . x)
+//   g_gy_m = s h_m + D (h . x) x_m                                                        (e3nn layout, like g_y)
+//   g_x_m  = D x_m (h . g_y) + D2 x_m (h . x)(g_y . x) + D (h_m (g_y . x) + (h . x) g_y_m)      (cf layout)
+__global__ __launch_bounds__(256) void normact_bwd2_kernel(const float* __restrict__ x, const float* __restrict__ gy,
+                                                            const float* __restrict__ h, int64_t rows, int row_dim, BlockArgs ba,
+                                                            int act, float eps2, int normalize, float* __restrict__ g_gy,
+                                                            float* __restrict__ g_x) {
+  const int64_t total = rows * row_dim;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / row_dim;
+    const int c = (int)(i - r * row_dim);
+    const float* xr = x + r * row_dim;
+    const float* gr = gy + r * row_dim;
+    const float* hr = h + r * row_dim;
+    for (int k = 0; k < ba.n; ++k) {
+      const e3k_block& b = ba.b[k];
+      const int rel = c - b.off;
+      if (rel >= 0 && rel < b.mul * b.dim) {
+        const int m = rel / b.mul, u = rel - m * b.mul;   // input element (m, u), channel-fastest
+        float n2 = 0.f, gx_ = 0.f, hx = 0.f, hg = 0.f;
+        for (int q = 0; q < b.dim; ++q) {
+          const float t = xr[b.off + q * b.mul + u], g = gr[b.off + u * b.dim + q], hh = hr[b.off + q * b.mul + u];
+          n2 = fmaf(t, t, n2);
+          gx_ = fmaf(g, t, gx_);
+          hx = fmaf(hh, t, hx);
+          hg = fmaf(hh, g, hg);
+        }
+        float s, d, d2;
+        normact_scale2(act, eps2, normalize, n2, s, d, d2);
+        const float xm = xr[c], hm = hr[c], gm = gr[b.off + u * b.dim + m];
+        if (g_gy) g_gy[r * row_dim + b.off + u * b.dim + m] = fmaf(s, hm, d * hx * xm);
+        if (g_x) g_x[i] = d * xm * hg + d2 * xm * hx * gx_ + d * (hm * gx_ + hx * gm);
+        break;
+      }
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void normact_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy,
                                                            int64_t rows, int row_dim, BlockArgs ba, int act, float eps2,
                                                            int normalize, float* __restrict__ gx) {
@@ -1067,6 +1131,21 @@ extern "C" int e3k_norm_act_bwd(const float* x, const float* g_y, int64_t rows, 
   if (!x || !g_y || !g_x) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::normact_bwd_kernel, dim3(e3k::grid_for(rows * row_dim)), dim3(256), 0, (hipStream_t)stream, x,
                      g_y, rows, row_dim, ba, act, epsilon * epsilon, normalize, g_x);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_norm_act_bwd2(const float* x, const float* g_y, const float* h, int64_t rows, int32_t row_dim,
+                                 const e3k_block* blocks, int32_t n_blocks, int32_t act, float epsilon, int32_t normalize,
+                                 float* g_gy, float* g_x, void* stream) {
+  e3k::BlockArgs ba{};
+  const int rc = make_blocks(blocks, n_blocks, row_dim, ba);
+  if (rc != E3K_OK) return rc;
+  if (rows < 0 || n_blocks == 0 || act < 0 || act > 5 || epsilon < 0.f) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!x || !g_y || !h || (!g_gy && !g_x)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::normact_bwd2_kernel, dim3(e3k::grid_for(rows * row_dim)), dim3(256), 0, (hipStream_t)stream, x, g_y, h,
+                     rows, row_dim, ba, act, epsilon * epsilon, normalize, g_gy, g_x);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

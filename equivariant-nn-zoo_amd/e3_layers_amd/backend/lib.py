@@ -209,6 +209,7 @@ SIGNATURES = {
     "e3k_gate_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, C.POINTER(GateSeg), _I32, _I32, _P, _P, _P]),
     "e3k_norm_act_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _I32, _F, _I32, _P, _P]),
     "e3k_norm_act_bwd": (C.c_int, [_P, _P, _I64, _I32, C.POINTER(Block), _I32, _I32, _F, _I32, _P, _P]),
+    "e3k_norm_act_bwd2": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(Block), _I32, _I32, _F, _I32, _P, _P, _P]),
     "e3k_layernorm_fwd": (C.c_int, [_P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
     "e3k_layernorm_bwd": (C.c_int, [_P, _P, _P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P]),
     "e3k_layernorm_bwd2": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, C.POINTER(Block), _I32, _P, _P, _P, _P, _P]),

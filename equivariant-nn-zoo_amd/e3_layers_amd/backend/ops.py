@@ -1687,37 +1687,42 @@ class NormActFn(torch.autograd.Function):
     def backward(ctx, gy):
         (x,) = ctx.saved_tensors
         blocks, act_id, eps, normalize = ctx.cfg
-        if torch.is_grad_enabled():   # double backward: torch restatement on the device
-            with torch.enable_grad():
-                (gx,) = torch.autograd.grad(_norm_act_composed(x, blocks, act_id, eps, normalize), x, gy, create_graph=True)
-            return gx, None, None, None, None
-        gy = L.f32c(gy)
-        gx = torch.empty_like(x)
-        L.check(L.load().e3k_norm_act_bwd(L.ptr(x), L.ptr(gy), x.shape[0], x.shape[1], _blocks(blocks), len(blocks), act_id,
-                                          eps, int(normalize), L.ptr(gx), L.stream_ptr()), "e3k_norm_act_bwd")
-        return gx, None, None, None, None
+        if torch.is_grad_enabled():   # double backward (force training): e3k_norm_act_bwd2
+            return NormActBwdFn.apply(x, gy, blocks, act_id, eps, normalize), None, None, None, None
+        return _norm_act_bwd_raw(x, gy, blocks, act_id, eps, normalize), None, None, None, None
 
 
-_TORCH_ACTS = {1: lambda t: torch.nn.functional.softplus(t) - math.log(2.0), 2: torch.nn.functional.silu,
-               3: lambda t: torch.tanh(t) * t.abs(), 4: torch.tanh, 5: torch.abs, 0: lambda t: t}
+def _norm_act_bwd_raw(x, gy, blocks, act_id, eps, normalize):
+    gy = L.f32c(gy)
+    gx = torch.empty_like(x)
+    L.check(L.load().e3k_norm_act_bwd(L.ptr(x), L.ptr(gy), x.shape[0], x.shape[1], _blocks(blocks), len(blocks), act_id,
+                                      eps, int(normalize), L.ptr(gx), L.stream_ptr()), "e3k_norm_act_bwd")
+    return gx
 
 
-def _norm_act_composed(x, blocks, act_id, eps, normalize):
-    rows, cols, pos = x.shape[0], [], 0
-    for off, mul, dim in blocks:
-        assert off == pos, "NormActivation blocks must tile the row"
-        blk = x[:, off:off + mul * dim].reshape(rows, dim, mul)
-        n2 = blk.pow(2).sum(1)
-        if eps > 0:
-            n = torch.where(n2 < eps * eps, torch.full_like(n2, eps * eps), n2).sqrt()
-        else:
-            n = n2
-        sc = _TORCH_ACTS[act_id](n)
-        if normalize:
-            sc = sc / n
-        cols.append((blk * sc.unsqueeze(1)).transpose(1, 2).reshape(rows, mul * dim))
-        pos += mul * dim
-    return torch.cat(cols, 1)
+class NormActBwdFn(torch.autograd.Function):
+    """The first backward of NormActivation as a differentiable op (round 2 differentiated a torch restatement here)."""
+
+    @staticmethod
+    def forward(ctx, x, gy, blocks, act_id: int, eps: float, normalize: bool):
+        x, gy = L.f32c(x), L.f32c(gy)
+        ctx.save_for_backward(x, gy)
+        ctx.cfg = (blocks, act_id, eps, normalize)
+        return _norm_act_bwd_raw(x, gy, blocks, act_id, eps, normalize)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, h):
+        x, gy = ctx.saved_tensors
+        blocks, act_id, eps, normalize = ctx.cfg
+        h = L.f32c(h)
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_gy = torch.empty_like(gy) if ctx.needs_input_grad[1] else None
+        if g_x is not None or g_gy is not None:
+            L.check(L.load().e3k_norm_act_bwd2(L.ptr(x), L.ptr(gy), L.ptr(h), x.shape[0], x.shape[1], _blocks(blocks), len(blocks),
+                                               act_id, eps, int(normalize), L.ptr(g_gy), L.ptr(g_x), L.stream_ptr()),
+                    "e3k_norm_act_bwd2")
+        return g_x, g_gy, None, None, None, None
 
 
 def norm_activation(x, blocks, act: str, eps: float, normalize: bool):

@@ -343,6 +343,10 @@ int e3k_norm_act_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_bl
                      float epsilon, int32_t normalize, float* y, void* stream);
 int e3k_norm_act_bwd(const float* x, const float* g_y, int64_t rows, int32_t row_dim, const e3k_block* blocks,
                      int32_t n_blocks, int32_t act, float epsilon, int32_t normalize, float* g_x, void* stream);
+/* backward of e3k_norm_act_bwd (force training through a 'norm' nonlinearity: GradientOutput, create_graph=True): with the
+ * cotangent h on g_x (layout of x), g_gy (layout of g_y) and g_x; either may be NULL. */
+int e3k_norm_act_bwd2(const float* x, const float* g_y, const float* h, int64_t rows, int32_t row_dim, const e3k_block* blocks,
+                      int32_t n_blocks, int32_t act, float epsilon, int32_t normalize, float* g_gy, float* g_x, void* stream);
 
 /* per-irreps-block RMS normalisation (LayerNormalization, nn/pointwise.py:32-51), e3nn layout */
 int e3k_layernorm_fwd(const float* x, int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks,

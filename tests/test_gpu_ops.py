@@ -853,6 +853,16 @@ def test_norm_activation(dev, act):
     (gg,) = torch.autograd.grad((g * c.float().to(dev)).sum(), xin)
     (rr,) = torch.autograd.grad((r * c).sum(), xr)
     assert rel_err(gg, rr) < 1e-4
+    # the second backward with respect to BOTH inputs of the first (e3k_norm_act_bwd2: x and the incoming gradient)
+    sd, sr = seed.float().to(dev).requires_grad_(True), seed.clone().requires_grad_(True)
+    (g2,) = torch.autograd.grad(mod(to_cf(xin, ir)), xin, sd, create_graph=True)
+    (r2,) = torch.autograd.grad(ref(xr), xr, sr, create_graph=True)
+    gg_x, gg_s = torch.autograd.grad((g2 * c.float().to(dev)).sum(), [xin, sd])
+    rr_x, rr_s = torch.autograd.grad((r2 * c).sum(), [xr, sr])
+    keep = torch.ones_like(rr_s, dtype=torch.bool)
+    keep[3, 16:28] = False                              # (the clamped channels: slope act(eps) / eps, see above)
+    assert rel_err(gg_x, rr_x) < 1e-4
+    assert rel_err(gg_s.cpu()[keep], rr_s[keep]) < 1e-4
 
 
 @pytest.mark.parametrize("in1,v,out,rows", [
