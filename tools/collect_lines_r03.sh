@@ -8,7 +8,7 @@ B="python3 bench.py --no-cpu-baseline"
 uptime > $OUT/lines_uptime.txt
 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 $B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
-for b in 32 64 128 512; do $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done
+for b in 32 64 128 512; do E3K_BENCH_AUTO=0 $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done      # (eager; the default picks the faster of eager / graph-fresh)
 $B --loader > $OUT/bench_loader.json 2>/dev/null
 $B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
 for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done
