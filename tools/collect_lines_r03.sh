@@ -5,11 +5,11 @@ cd "$GRAFT_REPO_ROOT" || exit 1
 OUT=gpurun_out/r03
 mkdir -p $OUT
 B="python3 bench.py --no-cpu-baseline"
-export E3K_BENCH_AUTO=0      # every line below is the mode its name says; only the default line chooses
 uptime > $OUT/lines_uptime.txt
-E3K_BENCH_AUTO=1 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
+python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
 $B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
-for b in 32 64 128 512; do E3K_BENCH_AUTO=0 $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done      # (eager; the default picks the faster of eager / graph-fresh)
+for b in 32 64 128; do E3K_BENCH_AUTO=0 $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done      # (pinned eager; the default picks the faster of eager / graph-fresh)
+$B --batch 512 > $OUT/bench_b512.json 2>/dev/null
 $B --loader > $OUT/bench_loader.json 2>/dev/null
 $B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
 for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done

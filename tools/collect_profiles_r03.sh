@@ -26,14 +26,9 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --kernel
 for c in energy_force diffusion diffusion_CA; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/cfg_$c -o s -- $B --config $c --steps 10 --warmup 3 > $OUT/cfg_$c.json 2> $OUT/cfg_$c.err
 done
-# 5. the lines themselves (no profiler)
-E3K_BENCH_AUTO=1 python3 bench.py --steps 20 --warmup 5 > $OUT/bench_default.json 2> $OUT/bench_default.err
-$B --lmax 3 > $OUT/bench_lmax3.json 2>/dev/null
-for b in 32 64 128 512; do E3K_BENCH_AUTO=0 $B --batch $b > $OUT/bench_b$b.json 2>/dev/null; done      # (eager; the default picks the faster of eager / graph-fresh)
-$B --loader > $OUT/bench_loader.json 2>/dev/null
-$B --graph --batch 32 > $OUT/bench_graph_b32.json 2>/dev/null
-for b in 32 64 128; do $B --graph-fresh --batch $b > $OUT/bench_graphfresh_b$b.json 2>/dev/null; done
-for c in energy_force diffusion diffusion_CA; do $B --config $c > $OUT/bench_$c.json 2>/dev/null; done
+# 5. the lines themselves (no profiler; launch mode chosen by the bench unless the line's name says otherwise)
+unset E3K_BENCH_AUTO
+bash tools/collect_lines_r03.sh > $OUT/lines.log 2>&1
 # 6. measured errors of the model-level parity tests (tests/util.py: record_measured)
 rm -f $OUT/parity_measured.jsonl
 E3K_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl python3 -m pytest tests/test_gpu_model.py -q -m gpu -k "protein or diffusion or bench_path or guard or backbone" > $OUT/parity_tests.log 2>&1
