@@ -596,6 +596,84 @@ def test_bucketed_graph_replay_with_fresh_padded_batches_equals_eager(dev, monke
         flat.disable_direct_accumulation()
 
 
+def test_bucketed_graph_training_follows_the_eager_trajectory(dev):
+    """What bench.py reports when its host is too loaded for the eager step: six optimizer steps (loss, backward, clip-free
+    Adam + EMA in the fused optimizer) replayed as ONE HIP graph on padded batches, a different batch every step, against the
+    same six steps taken eagerly on the un-padded batches from the same initial weights: per-step losses and the final
+    parameters / EMA."""
+    import copy
+
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
+    from e3_layers_amd.run.optim import FusedAdamEMA
+    from e3_layers_amd.run.parallel import flat_param_order
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(12)
+    base = build(_energy_tree(2, 64, 3)).to(dev).train()
+    host = [synth_qm9(31 + k, 24) for k in range(3)]
+    order = [0, 1, 2, 1, 0, 2]
+
+    def make():
+        model = copy.deepcopy(base)
+        opt = FusedAdamEMA(flat_param_order(model), lr=1e-3, ema_decay=0.99)
+        opt.grads.enable_direct_accumulation()
+        return model, opt
+
+    # eager, un-padded
+    model_e, opt_e = make()
+    losses_e = []
+    try:
+        for k in order:
+            b = host[k].clone().to(dev)
+            target = b["total_energy"]
+            loss = 1e3 * torch.nn.functional.mse_loss(model_e(b)["total_energy"], target)
+            opt_e.zero_grad()
+            loss.backward()
+            opt_e.step()
+            losses_e.append(float(loss))
+        torch.cuda.synchronize()
+        flat_e, ema_e = opt_e.flat.detach().clone(), opt_e.ema.detach().clone()
+    finally:
+        opt_e.grads.disable_direct_accumulation()
+
+    # graph replay, padded
+    model_g, opt_g = make()
+    try:
+        n_cap, e_cap = bucket_capacity([(b["pos"].shape[0], b["edge_index"].shape[1]) for b in host])
+        padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host]
+        start = opt_g.flat.detach().clone()
+        state0 = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in vars(opt_g).items()
+                  if k in ("exp_avg", "exp_avg_sq", "ema", "state")}
+
+        def train_on(batch):
+            target = batch["total_energy"]
+            loss = 1e3 * (((model_g(batch)["total_energy"] - target) ** 2) * batch["_graph_weight"]).sum()
+            opt_g.zero_grad()
+            loss.backward()
+            opt_g.step()
+            return loss
+
+        step = BucketedStep(train_on, padded[0], warmup=2)      # (the warm-up and the capture run took optimizer steps: rewind)
+        with torch.no_grad():
+            opt_g.flat.copy_(start)
+            for k, v in state0.items():
+                getattr(opt_g, k).copy_(v)
+        losses_g = []
+        for k in order:
+            losses_g.append(float(step(padded[k])))
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        for a, b in zip(losses_g, losses_e):
+            assert abs(a - b) <= 2e-4 * abs(b), (losses_g, losses_e)
+        # Adam divides by sqrt(v): parameters whose gradient is tiny amplify rounding differences; compare the updates' bulk
+        assert rel_err(opt_g.flat - start, flat_e - start) < 2e-3
+        assert rel_err(opt_g.ema, ema_e) < 1e-5
+    finally:
+        opt_g.grads.disable_direct_accumulation()
+
+
 @pytest.mark.parametrize("block", [1, 0])
 def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, block):
     """The energy model with the radial MLPs evaluated through the knot table (a batch with enough edges for it to apply)
