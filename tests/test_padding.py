@@ -61,3 +61,25 @@ def test_padding_refuses_what_does_not_fit():
         pad_batch(b, n + 64, e - 1)           # not enough edge capacity
     with pytest.raises(ValueError):
         ghost_sample(samples_of(b)[0], 1, 5)  # edges need two nodes
+
+
+def test_flat_param_order_puts_the_radial_mlps_behind_the_layer_slices():
+    """run/parallel.flat_param_order: every MessagePassing layer's node-side weights stay one contiguous run (its early
+    all-reduce slice), the radial MLPs of all layers follow at the tail (their gradients arrive together when the MLPs run as
+    one stack)."""
+    from e3_layers_amd.configs import config_energy
+    from e3_layers_amd.nn.message_passing import MessagePassing
+    from e3_layers_amd.run.parallel import flat_param_order
+    from e3_layers_amd.utils import build
+
+    model = build(config_energy.get_config(l_max=2, num_layers=3).model_config)
+    order = flat_param_order(model)
+    assert len(order) == len(list(model.parameters())) and {id(p) for p in order} == {id(p) for p in model.parameters()}
+    pos = {id(p): i for i, p in enumerate(order)}
+    radial = [p for m in model.modules() if isinstance(m, MessagePassing) for p in m.conv.fc.parameters()]
+    assert radial and sorted(pos[id(p)] for p in radial) == list(range(len(order) - len(radial), len(order)))
+    for m in model.modules():
+        if isinstance(m, MessagePassing):
+            fc = {id(p) for p in m.conv.fc.parameters()}
+            idx = sorted(pos[id(p)] for p in m.parameters() if id(p) not in fc)
+            assert idx == list(range(idx[0], idx[0] + len(idx)))
