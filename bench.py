@@ -300,6 +300,13 @@ def main():
                 p.attrs["forces_target"] = ("node", "1x1o")
 
         def train_on(batch):
+            if cfg_kind == "diffusion":       # VP-SDE denoising loss: a mean over the REAL nodes
+                loss = sde_loss(sde, model, batch, generator=gen, node_weight=batch["_node_weight"])[0]
+                flat.zero()
+                backward_parameters(loss, opt.params)
+                flat.all_reduce_mean()
+                opt.step()
+                return loss
             target, weight = batch["total_energy"], batch["_graph_weight"]      # weight: 1 / G for the real graphs, 0 for the ghost
             if cfg_kind == "energy":
                 loss = 1e3 * (((model(batch)["total_energy"] - target) ** 2) * weight).sum()
@@ -316,7 +323,7 @@ def main():
             opt.step()
             return loss
 
-        bucket_ = BucketedStep(train_on, padded[0], warmup=3)
+        bucket_ = BucketedStep(train_on, padded[0], warmup=3, generators=(gen,) if cfg_kind == "diffusion" else ())
 
         def run_():
             b = padded[counter[0] % n_res]
@@ -326,8 +333,9 @@ def main():
         return bucket_, run_, n_cap, e_cap
 
     if args.graph_fresh:
-        if cfg_kind not in ("energy", "energy_force") or args.loader or args.graph:
-            raise SystemExit("--graph-fresh replays the config_energy / config_energy_force step on padded resident batches")
+        if cfg_kind not in ("energy", "energy_force", "diffusion") or args.loader or args.graph:
+            raise SystemExit("--graph-fresh replays the config_energy / config_energy_force / config_diffusion step on padded resident "
+                             "batches (the protein net rebuilds its edge list inside the model: data-dependent sizes)")
         bucket, run, n_cap, e_cap = make_bucket()
         graph = bucket.captured.graph
 

@@ -22,7 +22,9 @@ import torch
 
 
 class CapturedStep:
-    def __init__(self, fn: Callable[[], Any], warmup: int = 3, device=None):
+    def __init__(self, fn: Callable[[], Any], warmup: int = 3, device=None, generators=()):
+        """``generators``: device ``torch.Generator`` objects ``fn`` draws from (other than the default one): they are registered
+        with the graph, so that every replay advances them."""
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep needs a HIP device: there is no CPU fallback for graph replay")
         self.fn = fn
@@ -40,6 +42,8 @@ class CapturedStep:
 
         check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
         self.graph = torch.cuda.CUDAGraph()
+        for g in generators:
+            self.graph.register_generator_state(g)
         with torch.cuda.graph(self.graph):
             self.out = fn()
 
@@ -87,8 +91,11 @@ def ghost_sample(like, n_nodes: int, n_edges: int):
             tensors[key] = torch.full_like(v, n_nodes)
         elif key == "_n_edges":
             tensors[key] = torch.full_like(v, n_edges)
-        elif torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == like["pos"].shape[0] and key != "pos":
+        elif torch.is_tensor(v) and (like.attrs.get(key, ("",))[0] == "node"
+                                     or (key not in like.attrs and v.dim() >= 1 and v.shape[0] == like["pos"].shape[0])):
             tensors[key] = v[:1].expand(n_nodes, *v.shape[1:]).clone()      # node-wise (species): the first node's value
+        elif torch.is_tensor(v) and like.attrs.get(key, ("",))[0] == "edge":
+            tensors[key] = (v[:1].expand(n_edges, *v.shape[1:]).clone() if v.shape[0] else v.new_zeros((n_edges,) + tuple(v.shape[1:])))
         elif torch.is_tensor(v):
             tensors[key] = torch.zeros_like(v)                               # graph-wise targets
         else:
@@ -155,7 +162,7 @@ class BucketedStep:
     """``step = BucketedStep(train_on, example)``: ``train_on(batch)`` is captured once on a copy of the padded batch
     ``example``; ``step(padded)`` copies the next padded batch of the same bucket into the captured tensors and replays."""
 
-    def __init__(self, fn: Callable[[Any], Any], example, warmup: int = 3):
+    def __init__(self, fn: Callable[[Any], Any], example, warmup: int = 3, generators=()):
         self.static = example.clone()
         self.keys = [k for k in self.static.keys() if torch.is_tensor(self.static[k])]
 
@@ -167,7 +174,7 @@ class BucketedStep:
             forget_batch_memos(self.static)
             return fn(self.static.view())
 
-        self.captured = CapturedStep(captured_fn, warmup=warmup)
+        self.captured = CapturedStep(captured_fn, warmup=warmup, generators=generators)
 
     def __call__(self, padded):
         for k in self.keys:

@@ -106,8 +106,10 @@ def get_score_fn(sde: VPSDE, model, train: bool = False):
     return score_fn
 
 
-def sde_loss(sde: VPSDE, model, batch, eps: float = 1e-5, train: bool = True, generator=None) -> Tuple[torch.Tensor, dict]:
-    """mean over graphs/nodes of (score * std + z)^2, t ~ U(eps, 1) per graph."""
+def sde_loss(sde: VPSDE, model, batch, eps: float = 1e-5, train: bool = True, generator=None,
+             node_weight=None) -> Tuple[torch.Tensor, dict]:
+    """mean over graphs/nodes of (score * std + z)^2, t ~ U(eps, 1) per graph.  ``node_weight`` [N, 1] (sums to 1 over the
+    nodes that count): a weighted mean instead -- a batch padded with a ghost graph (run/graph_step.py) gives it weight 0."""
     dev = batch["_n_nodes"].device
     t = torch.rand(len(batch), device=dev, generator=generator) * (sde.T - eps) + eps
     pert = batch.clone()
@@ -118,7 +120,8 @@ def sde_loss(sde: VPSDE, model, batch, eps: float = 1e-5, train: bool = True, ge
     losses = {}
     for key in sde.irreps:
         err = torch.square(scores[f"score_{key}"] * misc["std"] + misc["zs"][key])
-        losses[key] = err.reshape(err.shape[0], -1).mean(dim=-1).mean()
+        per_node = err.reshape(err.shape[0], -1).mean(dim=-1)
+        losses[key] = per_node.mean() if node_weight is None else (per_node * node_weight.reshape(-1)).sum()
     total = sum(losses.values())
     losses["total"] = total
     return total, losses

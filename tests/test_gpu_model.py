@@ -164,6 +164,14 @@ def test_config_diffusion_score_network(dev):
         assert rel_err(p.grad, r.grad) < GTOL, name
     # the harness helper runs end to end on the device
     total, parts = sde_loss(sde, prod, batch.clone().to(dev))
+    # node weights (a batch padded with a ghost graph gives the ghost weight 0): uniform weights reproduce the plain mean
+    # (same draws: the device generator is re-seeded)
+    dbatch = batch.clone().to(dev)
+    n = dbatch["pos"].shape[0]
+    g1, g2 = torch.Generator(device=dev).manual_seed(5), torch.Generator(device=dev).manual_seed(5)
+    plain = sde_loss(sde, prod, dbatch.clone(), generator=g1)[0]
+    weighted = sde_loss(sde, prod, dbatch.clone(), generator=g2, node_weight=torch.full((n, 1), 1.0 / n, device=dev))[0]
+    assert abs(float(plain) - float(weighted)) <= 1e-5 * abs(float(plain))
     assert torch.isfinite(total) and "pos" in parts
 
 
