@@ -369,6 +369,29 @@ def main():
             and os.environ.get("E3K_BENCH_AUTO", "1") != "0"):
         auto = {"eager_ms_per_step": round(1e3 * ref_step, 3), "eager_host_busy_ms_per_step": round(1e3 * host_ref / n_ref, 3),
                 "chosen": "eager"}
+        # the eager step on ONE stream: as fast as the four-stream layout when the host has no slack (256 molecules: 5.24 vs
+        # 5.23 ms on a loaded host, 5.26 vs 5.00 on an idle one) with a third less host work
+        from e3_layers_amd.nn import message_passing as _mp
+
+        forked = (_mp.FORK_MIN_EDGES, _mp.FORK_MIN_EDGES_TABLE)
+        _mp.FORK_MIN_EDGES = _mp.FORK_MIN_EDGES_TABLE = 10 ** 12
+        for _ in range(2):
+            run()
+        fence()
+        waited_ref = opt.waited_seconds
+        t0 = time.perf_counter()
+        for _ in range(n_ref):
+            run()
+        host_one = (time.perf_counter() - t0) - (opt.waited_seconds - waited_ref)
+        fence()
+        one_step = (time.perf_counter() - t0) / n_ref
+        auto["eager_one_stream_ms_per_step"] = round(1e3 * one_step, 3)
+        auto["eager_one_stream_host_busy_ms_per_step"] = round(1e3 * host_one / n_ref, 3)
+        if one_step < 0.98 * ref_step:
+            ref_step, host_ref = one_step, host_one
+            auto["chosen"] = "eager, one stream"
+        else:
+            _mp.FORK_MIN_EDGES, _mp.FORK_MIN_EDGES_TABLE = forked
         if host_ref / n_ref >= 0.85 * ref_step or os.environ.get("E3K_BENCH_AUTO") == "try-graph":
             try:
                 bucket_c, run_c, n_cap_c, e_cap_c = make_bucket()
@@ -603,6 +626,8 @@ def main():
                 "input": "prefetching loader (collate of fresh samples + pinned H2D inside the loop)" if args.loader else "HBM-resident batches",
                 "global_batch": world * args.batch, "parallelism": f"graph-parallel dp{world}",
                 "ranks": dist.get_world_size() if world > 1 else 1,
+                "streams": ("one (captured)" if graph is not None else
+                            "one" if (auto or {}).get("chosen") == "eager, one stream" else "per size: four from 60 000 edges (table layers)"),
                 "launch": ((f"hip-graph replay, a NEW batch every step: padded to the bucket ({n_cap} nodes, {e_cap} edges) with a ghost "
                             "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins inside the graph")
                            if bucket is not None else

@@ -48,7 +48,11 @@ FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connec
 # config_energy 96 / 128 / 160 molecules run 17 / 6 / 1 % FASTER on one stream, 192 / 256 molecules 8 % faster forked --
 # layers on the table use the larger yardstick.
 FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
-FORK_MIN_EDGES_TABLE = int(os.environ.get("E3K_FORK_MIN_EDGES_TABLE", "40000"))
+# Last third of round 3, with the stacks on one stream at every size: 192 molecules run faster on ONE stream (4.38 vs 4.52 ms),
+# 384 / 512 molecules 4-5 % faster forked (6.73 vs 7.03, 8.25 vs 8.68); 256 molecules depend on the HOST: forked 5.00 vs 5.26 ms
+# on an idle one, 5.23 vs 5.24 on a loaded one, where the fork's extra host work (4.0 instead of 2.6 ms per step) leaves no
+# slack.  Layers on the table fork from 60 000 edges; bench.py times both layouts and keeps the faster (E3K_FORK_MIN_EDGES_TABLE).
+FORK_MIN_EDGES_TABLE = int(os.environ.get("E3K_FORK_MIN_EDGES_TABLE", "60000"))
 _FORK_REF_WIDTH = 1920
 # 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
 # as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next.
@@ -141,7 +145,9 @@ class FactorizedConvolution(Module):
 
     def _fork_pays(self, n_edges: int, table: bool = False) -> bool:
         # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
-        ref = FORK_MIN_EDGES_TABLE if table else FORK_MIN_EDGES
+        if table:       # (every layer of the network the same way: a mix of forked and one-stream layers was the slowest)
+            return n_edges >= FORK_MIN_EDGES_TABLE
+        ref = FORK_MIN_EDGES
         return (n_edges * self._weight_numel >= ref * _FORK_REF_WIDTH) or n_edges >= 2 * ref
 
     def forward_cf(self, data: Dict[str, Tensor]) -> Tensor:
@@ -432,7 +438,9 @@ class MessagePassing(Module):
         nxt = None
         nmp = self.__dict__.get("_next_mp")          # set by SequentialGraphNetwork: the next layer reads the same edge embedding
         pre = None
-        if RADIAL_STACK and data["edge_radial"].shape[0] <= STACK_MAX_EDGES:
+        # (on ONE stream -- small batches, a captured step -- there is no backward overlap to lose: the stack at every size;
+        #  graph-replayed 256 / 512 molecules 5.57 -> 5.33 / 9.14 -> 8.83 ms)
+        if RADIAL_STACK and (n_edges <= STACK_MAX_EDGES or not fork):
             if table is not None:
                 cache = src._stack
             else:      # per-edge MLPs: the rows of the layers wait on the edge embedding of this forward pass
