@@ -365,8 +365,10 @@ def main():
     # (run/graph_step.py) does not depend on the host at all and costs 5.5 ms there.  So: when the reference steps were bound
     # by the host, capture the bucketed step, time it, and keep whichever is faster for the timed region.  One rank, default
     # workload only; E3K_BENCH_AUTO=0 pins the eager step.
-    if (world == 1 and cfg_kind == "energy" and not (args.loader or args.graph or args.graph_fresh) and n_ref
+    if (cfg_kind == "energy" and not (args.loader or args.graph or args.graph_fresh) and n_ref
             and os.environ.get("E3K_BENCH_AUTO", "1") != "0"):
+        # (several ranks: only the choice between the two eager layouts -- they issue the same collectives, so the ranks cannot
+        #  diverge; the times compared are the maxima over the ranks, so every rank takes the same decision)
         auto = {"eager_ms_per_step": round(1e3 * ref_step, 3), "eager_host_busy_ms_per_step": round(1e3 * host_ref / n_ref, 3),
                 "chosen": "eager"}
         # the eager step on ONE stream: as fast as the four-stream layout when the host has no slack (256 molecules: 5.24 vs
@@ -384,7 +386,7 @@ def main():
             run()
         host_one = (time.perf_counter() - t0) - (opt.waited_seconds - waited_ref)
         fence()
-        one_step = (time.perf_counter() - t0) / n_ref
+        one_step = max_over_ranks(time.perf_counter() - t0) / n_ref
         auto["eager_one_stream_ms_per_step"] = round(1e3 * one_step, 3)
         auto["eager_one_stream_host_busy_ms_per_step"] = round(1e3 * host_one / n_ref, 3)
         if one_step < 0.98 * ref_step:
@@ -392,7 +394,7 @@ def main():
             auto["chosen"] = "eager, one stream"
         else:
             _mp.FORK_MIN_EDGES, _mp.FORK_MIN_EDGES_TABLE = forked
-        if host_ref / n_ref >= 0.85 * ref_step or os.environ.get("E3K_BENCH_AUTO") == "try-graph":
+        if world == 1 and (host_ref / n_ref >= 0.85 * ref_step or os.environ.get("E3K_BENCH_AUTO") == "try-graph"):
             try:
                 bucket_c, run_c, n_cap_c, e_cap_c = make_bucket()
                 for _ in range(2):
