@@ -299,13 +299,15 @@ def main():
                 p["forces_target"] = torch.randn(p["pos"].shape, device=dev, generator=gen)
                 p.attrs["forces_target"] = ("node", "1x1o")
 
-        def train_on(batch):
+        def finish():
+            flat.all_reduce_mean()
+            opt.step()
+
+        def gradients_of(batch):
             if cfg_kind == "diffusion":       # VP-SDE denoising loss: a mean over the REAL nodes
                 loss = sde_loss(sde, model, batch, generator=gen, node_weight=batch["_node_weight"])[0]
                 flat.zero()
                 backward_parameters(loss, opt.params)
-                flat.all_reduce_mean()
-                opt.step()
                 return loss
             target, weight = batch["total_energy"], batch["_graph_weight"]      # weight: 1 / G for the real graphs, 0 for the ghost
             if cfg_kind == "energy":
@@ -319,11 +321,27 @@ def main():
                         + 3e4 * (((out["forces"] - f_t) ** 2) * (wn / 3.0)).sum())
                 flat.zero()
                 backward_parameters(loss, opt.params)
-            flat.all_reduce_mean()
-            opt.step()
             return loss
 
-        bucket_ = BucketedStep(train_on, padded[0], warmup=3, generators=(gen,) if cfg_kind == "diffusion" else ())
+        gens = (gen,) if cfg_kind == "diffusion" else ()
+        if world == 1:      # the whole step is the graph
+
+            def train_on(batch):
+                loss = gradients_of(batch)
+                finish()
+                return loss
+
+            bucket_ = BucketedStep(train_on, padded[0], warmup=3, generators=gens)
+        else:
+            # several ranks: forward + backward are the graph, the flat all-reduce (the same fixed sequence of slices as in the
+            # eager step, issued in one go) and the fused optimizer launch follow it eagerly -- RCCL stays outside the capture
+            def backward_on(batch):
+                loss = gradients_of(batch)
+                ops.join_side_streams()      # the sunk weight gradients land inside the capture
+                return loss
+
+            flat.early_start = False
+            bucket_ = BucketedStep(backward_on, padded[0], warmup=3, generators=gens, tail=finish)
 
         def run_():
             b = padded[counter[0] % n_res]
@@ -394,24 +412,39 @@ def main():
             auto["chosen"] = "eager, one stream"
         else:
             _mp.FORK_MIN_EDGES, _mp.FORK_MIN_EDGES_TABLE = forked
-        if world == 1 and (host_ref / n_ref >= 0.85 * ref_step or os.environ.get("E3K_BENCH_AUTO") == "try-graph"):
+        # (several ranks: every quantity a rank decides on is a maximum over the ranks, the capture itself issues no collective,
+        #  and the ranks agree on its outcome before the first replayed step: they cannot take different branches)
+        if max_over_ranks(host_ref / n_ref / ref_step) >= 0.85 or os.environ.get("E3K_BENCH_AUTO") == "try-graph":
+            made = None
             try:
-                bucket_c, run_c, n_cap_c, e_cap_c = make_bucket()
-                for _ in range(2):
-                    run_c()
-                fence()
-                t0 = time.perf_counter()
-                for _ in range(5):
-                    run_c()
-                fence()
-                graph_step = (time.perf_counter() - t0) / 5
-                auto["graph_fresh_ms_per_step"] = round(1e3 * graph_step, 3)
-                if graph_step < 0.95 * ref_step:
-                    bucket, run, graph, ref_step = bucket_c, run_c, bucket_c.captured.graph, graph_step
-                    n_cap, e_cap = n_cap_c, e_cap_c
-                    auto["chosen"] = "graph-fresh"
+                made = make_bucket()
             except Exception as ex:      # (the eager step stays: the capture is an optimisation of the measurement, not part of it)
                 auto["graph_fresh_error"] = f"{type(ex).__name__}: {ex}"[:200]
+            if max_over_ranks(0.0 if made is not None else 1.0) > 0.0:
+                made = None
+                auto.setdefault("graph_fresh_error", "another rank could not capture")
+            if made is not None:
+                bucket_c, run_c, n_cap_c, e_cap_c = made
+                try:
+                    for _ in range(2):
+                        run_c()
+                    fence()
+                    t0 = time.perf_counter()
+                    for _ in range(5):
+                        run_c()
+                    fence()
+                    graph_step = max_over_ranks(time.perf_counter() - t0) / 5
+                    auto["graph_fresh_ms_per_step"] = round(1e3 * graph_step, 3)
+                    if graph_step < 0.95 * ref_step:
+                        bucket, run, graph, ref_step = bucket_c, run_c, bucket_c.captured.graph, graph_step
+                        n_cap, e_cap = n_cap_c, e_cap_c
+                        auto["chosen"] = "graph-fresh"
+                except Exception as ex:
+                    if world > 1:
+                        raise      # the ranks are past the point where they could agree to go back
+                    auto["graph_fresh_error"] = f"{type(ex).__name__}: {ex}"[:200]
+            if bucket is None:
+                flat.early_start = True
 
     from e3_layers_amd.backend import conv_native, radial_table
 
@@ -631,7 +664,8 @@ def main():
                 "streams": ("one (captured)" if graph is not None else
                             "one" if (auto or {}).get("chosen") == "eager, one stream" else "per size: four from 60 000 edges (table layers)"),
                 "launch": ((f"hip-graph replay, a NEW batch every step: padded to the bucket ({n_cap} nodes, {e_cap} edges) with a ghost "
-                            "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins inside the graph")
+                            "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins inside the graph"
+                            + ("; forward + backward replayed, the flat all-reduce and the optimizer launch follow eagerly" if world > 1 else ""))
                            if bucket is not None else
                            "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager"),
                 "launch_auto": auto,

@@ -160,9 +160,16 @@ def forget_batch_memos(batch=None) -> None:
 
 class BucketedStep:
     """``step = BucketedStep(train_on, example)``: ``train_on(batch)`` is captured once on a copy of the padded batch
-    ``example``; ``step(padded)`` copies the next padded batch of the same bucket into the captured tensors and replays."""
+    ``example``; ``step(padded)`` copies the next padded batch of the same bucket into the captured tensors and replays.
 
-    def __init__(self, fn: Callable[[Any], Any], example, warmup: int = 3, generators=()):
+    ``tail``: what follows every replay eagerly, on the current stream.  Several ranks: ``fn`` = forward + loss + backward into
+    the flat gradient buffer (it must end with ``ops.join_side_streams()``), ``tail`` = the flat all-reduce and the optimizer
+    step -- three launches and the collectives behind one graph launch, so the step needs no host time to speak of and the
+    RCCL calls stay outside the capture.  The warm-up and the capture run ``fn`` alone (no collective is issued while a rank
+    may still fail to capture; the caller agrees on the outcome over the ranks before the first ``step()``)."""
+
+    def __init__(self, fn: Callable[[Any], Any], example, warmup: int = 3, generators=(), tail: Callable[[], Any] = None):
+        self.tail = tail
         self.static = example.clone()
         self.keys = [k for k in self.static.keys() if torch.is_tensor(self.static[k])]
 
@@ -182,4 +189,7 @@ class BucketedStep:
             if dst.shape != src.shape:
                 raise ValueError(f"{k}: {tuple(src.shape)} does not fit the captured {tuple(dst.shape)} (another bucket?)")
             dst.copy_(src, non_blocking=True)
-        return self.captured()
+        out = self.captured()
+        if self.tail is not None:
+            self.tail()
+        return out

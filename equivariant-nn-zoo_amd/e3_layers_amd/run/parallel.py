@@ -154,6 +154,9 @@ class FlatGradients:
     _issued = 0            # schedule entries issued this step
     _ready = None          # schedule positions whose layer has reported this step
     _works = ()
+    early_start = True     # False: layers' reports are ignored, the whole sequence is issued by all_reduce_mean() (a step whose
+                           # backward is a graph replay reports nothing anyway; this also keeps the capture's eager warm-up steps
+                           # free of collectives, so a rank whose capture fails cannot leave the others inside one)
     overlapped_slices = 0  # slices whose collective started ahead of all_reduce_mean() since construction (tests / logs)
 
     def enable_overlapped_all_reduce(self, model: "torch.nn.Module" = None, layer_params=None) -> None:
@@ -244,7 +247,7 @@ class FlatGradients:
         self._issued = upto
 
     def _on_ready(self, weights) -> None:
-        if self._layer_of is None or (self.buffer.is_cuda and torch.cuda.is_current_stream_capturing()):
+        if self._layer_of is None or not self.early_start or (self.buffer.is_cuda and torch.cuda.is_current_stream_capturing()):
             return
         pos, seen = None, set()
         for w in weights:

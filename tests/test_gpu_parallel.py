@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 rank, world, out = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"]), sys.argv[2]
-mode = sys.argv[3] if len(sys.argv) > 3 else "plain"          # plain | overlap | uneven
+mode = sys.argv[3] if len(sys.argv) > 3 else "plain"          # plain | overlap | uneven | replay
 model_kind = sys.argv[4] if len(sys.argv) > 4 else "energy"   # energy | force | protein
 torch.cuda.set_device(0)
 dev = torch.device("cuda", 0)
@@ -56,7 +56,7 @@ broadcast_parameters(model)                 # ... made identical, as DDP does at
 opt = FusedAdamEMA(flat_param_order(model), lr=1e-2, ema_decay=0.99)
 flat = opt.grads
 flat.enable_direct_accumulation()
-if mode in ("overlap", "uneven"):
+if mode in ("overlap", "uneven", "replay"):
     flat.enable_overlapped_all_reduce(model)
 start = opt.flat.clone()
 if mode == "uneven" and world > 1:
@@ -69,6 +69,45 @@ else:
     mine = shard_batch(batch, rank, world).to(dev)
 n_mine = len(mine)
 flat.zero()
+after2 = None
+if mode == "replay":
+    # forward + backward as a HIP-graph replay on the rank's shard padded to a bucket, the flat all-reduce (the static schedule,
+    # issued in one go) and the optimizer launch eagerly behind it: run/graph_step.BucketedStep(tail=...), what bench.py does
+    # with several ranks when the host cannot keep up
+    from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
+    host = mine.to("cpu")
+    n_cap, e_cap = bucket_capacity([(host["pos"].shape[0], host["edge_index"].shape[1])])
+    padded = pad_batch(host, n_cap, e_cap).to(dev)
+    snap = {}
+
+    def backward_on(b):
+        target, weight = b["total_energy"], b["_graph_weight"]
+        loss = ((model(b)["total_energy"] - target).square() * weight).sum() * (n_mine * world / len(batch))
+        flat.zero()
+        loss.backward()
+        ops.join_side_streams()
+        return loss
+
+    def finish():
+        flat.all_reduce_mean()
+        snap.setdefault("grad", flat.gather().clone())
+        opt.step()
+
+    flat.early_start = False
+    step = BucketedStep(backward_on, padded, warmup=2, tail=finish)
+    assert torch.equal(opt.flat, start)          # warm-up and capture ran no optimizer step
+    step(padded)
+    grad = snap["grad"]
+    after1 = opt.flat.detach().clone()
+    step(padded)
+    torch.cuda.synchronize()
+    after2 = opt.flat.detach().cpu().clone()
+    torch.save({"overlapped": flat.overlapped_slices, "schedule": list(flat._schedule), "grad": grad.cpu(), "start": start.cpu(),
+                "after": after1.cpu(), "after2": after2, "n": n_mine, "n_nodes": int(mine["_n_nodes"].sum()),
+                "sink_entries": len(ops.GRAD_SINK)}, out)
+    dist.barrier()
+    dist.destroy_process_group()
+    sys.exit(0)
 if model_kind == "energy":
     target = mine["total_energy"]
     res = model(mine)
@@ -157,6 +196,21 @@ def test_two_ranks_on_one_gpu_match_the_single_process_step(dev, tmp_path, mode)
     assert denom > 0
     assert float((r0["grad"] - one["grad"]).norm()) / denom < 2e-5
     assert float((r0["after"] - one["after"]).norm()) / float(one["after"].norm()) < 1e-6
+
+
+def test_two_ranks_graph_replay_with_eager_all_reduce_matches_the_single_process_step(dev, tmp_path):
+    """Several ranks, host-independent: each rank replays forward + backward of its padded shard as one HIP graph, the static
+    all-reduce sequence and the optimizer launch follow eagerly (BucketedStep(tail=...)).  One such step equals the
+    single-process eager step on the union batch; a second replay keeps the ranks identical."""
+    r0, r1 = _launch(2, tmp_path, "replay")
+    one = _launch(1, tmp_path)[0]
+    assert r0["n"] + r1["n"] == 40 and r0["overlapped"] == r1["overlapped"] == 0 and len(r0["schedule"]) >= 4
+    assert torch.equal(r0["start"], one["start"])
+    assert torch.equal(r0["grad"], r1["grad"]) and torch.equal(r0["after"], r1["after"]) and torch.equal(r0["after2"], r1["after2"])
+    denom = float(one["grad"].norm())
+    assert denom > 0 and float((r0["grad"] - one["grad"]).norm()) / denom < 2e-5
+    assert float((r0["after"] - one["after"]).norm()) / float(one["after"].norm()) < 1e-6
+    assert not torch.equal(r0["after2"], r0["after"])
 
 
 def test_uneven_shards_on_either_side_of_the_fused_path_threshold_do_not_diverge(dev, tmp_path):
