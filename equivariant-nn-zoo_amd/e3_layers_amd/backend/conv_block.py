@@ -41,8 +41,12 @@ class ConvBlockPlan:
     """Static description of one layer (specs own their cached launch descriptors)."""
 
     def __init__(self, *, in_blocks, lin1_spec, mlp_alphas, mlp_act, mlp_cst, mlp_k0, last_spec, tp_plan, post_spec, scale,
-                 sc_spec, sc_m_off, sc_ld_m, gate_spec):
+                 sc_spec, sc_m_off, sc_ld_m, gate_spec, addend: bool = False):
         self.in_blocks, self.lin1_spec = in_blocks, lin1_spec
+        # addend: the self-connection is NOT part of the block (general, un-keyed node attributes: the outer-product form of
+        # ops.fctp); its output [N, d_conv] (cf) is handed in, the trailing Linear accumulates on top of it, and the backward
+        # hands the gradient of the convolution output back for it (native executor only; travels in the ``m_pre`` slot)
+        self.addend = bool(addend)
         self.mlp_alphas, self.mlp_act, self.mlp_cst, self.last_spec = tuple(mlp_alphas), mlp_act, float(mlp_cst), last_spec
         self.mlp_k0 = int(mlp_k0)
         self.tp_plan, self.post_spec, self.scale = tp_plan, post_spec, float(scale)

@@ -68,13 +68,16 @@ class NativeLayer:
         d = L.LayerDesc()
         lin1, post, last, sc = plan.lin1_spec, plan.post_spec, plan.last_spec, plan.sc_spec
         has_sc = sc is not None
+        if plan.addend and has_sc:
+            raise NotImplementedError("addend with a keyed self-connection in the block")
+        acc_post = has_sc or plan.addend      # the trailing Linear adds to what the self-connection left in the buffer
         T = ops._templates
         d.lin1_fwd = self._set(T(lin1, ("fwd", 1.0, False, 0, 1.0, False), lambda: ops._lin_fwd_templates(lin1, 1.0, False, 0, 1.0, False)).rounds)
         d.lin1_dgrad = self._set(T(lin1, ("dgrad", 1.0, False), lambda: ops._lin_dgrad_templates(lin1, 1.0, False)).rounds)
         d.lin1_dgrad_acc = self._set(T(lin1, ("dgrad", 1.0, True), lambda: ops._lin_dgrad_templates(lin1, 1.0, True)).rounds)
         d.lin1_wgrad = self._set(T(lin1, ("wgrad", 1.0), lambda: ops._lin_wgrad_templates(lin1, 1.0)).rounds)
         sc_ = plan.scale
-        d.post_fwd = self._set(T(post, ("fwd", sc_, has_sc, 0, 1.0, False), lambda: ops._lin_fwd_templates(post, sc_, has_sc, 0, 1.0, False)).rounds)
+        d.post_fwd = self._set(T(post, ("fwd", sc_, acc_post, 0, 1.0, False), lambda: ops._lin_fwd_templates(post, sc_, acc_post, 0, 1.0, False)).rounds)
         d.post_dgrad = self._set(T(post, ("dgrad", sc_, False), lambda: ops._lin_dgrad_templates(post, sc_, False)).rounds)
         d.post_wgrad = self._set(T(post, ("wgrad", sc_), lambda: ops._lin_wgrad_templates(post, sc_)).rounds)
         if has_sc:
@@ -103,6 +106,8 @@ class NativeLayer:
             d.alphas[i] = al
         d.d_in, d.d_x1, d.d_mid, d.d_conv, d.d_out, d.W = lin1.d_in, lin1.d_out, post.d_in, post.d_out, plan.gate_spec.out_dim, last.d_out
         d.post_in_covered, d.lin1_in_covered, d.post_out_covered = int(post.in_covered), int(lin1.in_covered), int(post.out_covered)
+        if plan.addend:
+            d.post_out_covered = 1      # (no zero fill: the buffer holds the addend)
         d.sc_in_covered = int(sc.in_covered) if has_sc else 1
         d.sc_out_covered = int(sc.out_covered) if has_sc else 1
         if plan.gate_spec.in_dim != post.d_out or (has_sc and (sc.d_out != post.d_out or sc.d_in != lin1.d_in)):
@@ -491,7 +496,13 @@ class NativeConvBlockFn(torch.autograd.Function):
         side2 = ops.side_stream(dev, 1) if (fork and not FWD_SC_MAIN) else main
         keep = any(ctx.needs_input_grad)
         has_sc = plan.sc_spec is not None
+        addend = None
+        if plan.addend:      # the self-connection's output, computed outside the block (travels in the m_pre slot)
+            addend, m_pre = L.f32c(m_pre), None
+            L.require_cuda(addend)
         n, e = x.shape[0], sh.shape[0]
+        if addend is not None and tuple(addend.shape) != (n, plan.post_spec.d_out):
+            raise ValueError(f"addend {tuple(addend.shape)} is not [N, d_conv] = ({n}, {plan.post_spec.d_out})")
         a = L.LayerFwdArgs()
         a.N, a.E = n, e
         a.in_cf, a.out_cf, a.keep, a.fork = int(in_cf), int(out_cf), int(keep), int(fork)
@@ -575,6 +586,8 @@ class NativeConvBlockFn(torch.autograd.Function):
                 a.node_attrs, a.w_sc = node_attrs.data_ptr(), w_sc.data_ptr()
                 a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
         a.conv, a.x1, a.mid, a.y = _ptr(buf, off["conv"]), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
+        if addend is not None:
+            buf[off["conv"]:off["conv"] + n * plan.post_spec.d_out].view(n, plan.post_spec.d_out).copy_(addend)
         if HOST_TIMING is not None:
             import time
 
@@ -637,6 +650,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
         stack, need_pre = ctx.stack, need[12]
         have_m, need_m = m_pre is not None, need[13]
+        need_addend = bool(plan.addend and need[13])
         p0 = 14
         need_lin1, need_post, need_sc, need_last = need[p0], need[p0 + 1], need[p0 + 2], need[p0 + 3]
         need_hidden = need[p0 + 4:]
@@ -755,6 +769,9 @@ class NativeConvBlockFn(torch.autograd.Function):
         work = sc_.alloc(dev)
         so = sc_.off
         a.g_conv, a.g_mid = _ptr(work, so["g_conv"]), _ptr(work, so["g_mid"])
+        if need_addend:      # d(gate)/d(conv) is the addend's gradient: its own tensor instead of the scratch slot
+            g_m = torch.empty(n, post.d_out, device=dev, dtype=torch.float32)
+            a.g_conv = g_m.data_ptr()
         if "g_x1" in so:
             a.g_x1 = _ptr(work, so["g_x1"])
         if need_x:
@@ -816,6 +833,6 @@ class NativeConvBlockFn(torch.autograd.Function):
         if g_pre is not None and fork and table is None:
             g_pre.record_stream(side)          # (allocated here, consumed by the stack's backward on the radial stream)
         if g_m is not None and fork:
-            g_m.record_stream(side2)
+            g_m.record_stream(side3 if need_addend else side2)      # (addend: read by the weight-gradient GEMMs there)
         return (g_x, g_attrs, g_radial, None, None, None, None, None, None, None, None, None, g_pre, g_m,
                 rets.get("lin1"), rets.get("post"), rets.get("sc"), rets.get("last"), *[rets.get(f"h{i}") for i in range(n_hidden)])

@@ -72,6 +72,9 @@ STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
 # 1: likewise the per-key self-connection weights M_l of all the layers that read one node_attrs tensor
 # (MessagePassing._kw_stack_rows); not while the all-reduce is overlapped with the backward (run/parallel.py): the
 # self-connection weights are most of a layer's parameters and their gradients would then only exist at the very end
+# 1: a layer whose self-connection has general (un-keyed) node attributes still runs as a fused block: the self-connection is
+# computed by ops.fctp outside and handed in as an addend (MessagePassing._forward_block_addend)
+BLOCK_ADDEND = int(os.environ.get("E3K_BLOCK_ADDEND", "1"))
 KW_STACK = int(os.environ.get("E3K_KW_STACK", "1"))
 KW_STACK_MAX_EDGES = int(os.environ.get("E3K_KW_STACK_MAX_EDGES", "1000000000"))      # (192 / 256 molecules: -0.10 / -0.03 ms: no limit)
 
@@ -277,9 +280,11 @@ class MessagePassing(Module):
                 and tuple(irreps_blocks(self.equivariant_nonlin.irreps_out)) == nxt.conv._in_blocks)
 
     # ---- the layer as one autograd node (backend/conv_block.py) --------------------------------------------------
-    def _block_plan(self):
-        """Static part of the fused block, or None when this layer's structure is not served by it."""
-        plan = self.__dict__.get("_cb_plan", False)
+    def _block_plan(self, addend: bool = False):
+        """Static part of the fused block, or None when this layer's structure is not served by it.  ``addend``: the variant
+        whose self-connection is computed OUTSIDE the block and handed in (general node attributes, ``ConvBlockPlan.addend``)."""
+        slot = "_cb_plan_add" if addend else "_cb_plan"
+        plan = self.__dict__.get(slot, False)
         if plan is not False:
             return plan
         plan = None
@@ -291,7 +296,7 @@ class MessagePassing(Module):
             fc = list(conv.fc.children())
             hidden, last = fc[:-1], fc[-1]
             sc_spec = sc_m_off = sc_ld = None
-            if conv.sc is not None:
+            if conv.sc is not None and not addend:
                 sc_spec = conv.sc._spec
                 sc_m_off, pos = [], 0
                 for ins in sc_spec.instr:
@@ -304,9 +309,10 @@ class MessagePassing(Module):
                 mlp_k0=hidden[0].h_in,
                 last_spec=last._spec, tp_plan=conv.tp.tp.plan, post_spec=conv.tp.linear.spec("cf", "cf"),
                 scale=1.0 if conv.avg_num_neighbors is None else float(conv.avg_num_neighbors) ** -0.5,
-                sc_spec=sc_spec, sc_m_off=sc_m_off, sc_ld_m=sc_ld, gate_spec=self.equivariant_nonlin._spec)
+                sc_spec=sc_spec, sc_m_off=sc_m_off, sc_ld_m=sc_ld, gate_spec=self.equivariant_nonlin._spec,
+                addend=bool(addend and conv.sc is not None))
             plan.guard_key = last.weight
-        self.__dict__["_cb_plan"] = plan
+        self.__dict__[slot] = plan
         return plan
 
     def _stack_rows(self, cache: dict, rows, edge_radial, plan, fork: bool, use_table: bool):
@@ -411,7 +417,10 @@ class MessagePassing(Module):
             attrs = data["node_attrs"]
             key = get_row_key(attrs)
             if not conv.sc.keyed_pays(key, x.shape[0]):
-                return None                            # general (un-keyed) attributes: outer-product GEMMs, composed path
+                # general (un-keyed) attributes: the self-connection is the outer-product form (ops.fctp) -- computed here, its
+                # output handed to the block, which adds the convolution to it in front of the gate (config_diffusion: atom
+                # type x the molecule's time embedding, 2 304 distinct rows over 2 335 nodes)
+                return self._forward_block_addend(data, x, sh, radial, out_cf)
             groups = row_groups(key[0], key[1])
         topo = get_topology(data, x.shape[0])
         table = None
@@ -469,6 +478,27 @@ class MessagePassing(Module):
                                   conv.linear_1.weight, conv.tp.linear.weight, conv.sc.weight if conv.sc is not None else None,
                                   fc[-1].weight, [m.weight for m in fc[:-1]], table=table, nxt=nxt, m_pre=m_pre)
         return y
+
+    def _forward_block_addend(self, data, x, sh, radial, out_cf: bool):
+        from ..backend import conv_native
+
+        plan = self._block_plan(addend=True) if BLOCK_ADDEND else None
+        if plan is None or not conv_native.ENABLED or conv_native.native_layer(plan) is None:
+            return None
+        conv = self.conv
+        x_cf = x if getattr(x, "_e3k_cf", False) else ops.relayout(x, conv._in_blocks, True)
+        sc_out = conv.sc(x_cf, data["node_attrs"])           # [N, d_conv], cf
+        topo = get_topology(data, x.shape[0])
+        fc = list(conv.fc.children())
+        table = None
+        if radial_table.applicable(radial, fc[-1].weight):
+            src = radial_table.source_of(radial)
+            table = src.bins()
+            radial = src.knot_basis()
+        # one stream, no stacks, no look-ahead: the shapes that reach this are small (the score nets)
+        return conv_block.conv_block(x_cf, None, radial, sh, plan, topo, None, True, out_cf, False,
+                                     conv.linear_1.weight, conv.tp.linear.weight, None,
+                                     fc[-1].weight, [m.weight for m in fc[:-1]], table=table, m_pre=sc_out)
 
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
         old_x = data["input_features"]

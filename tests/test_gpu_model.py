@@ -1365,6 +1365,7 @@ def test_forked_convolution_with_unkeyed_attributes(dev, monkeypatch):
     monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
     monkeypatch.setattr(mp, "FORK_MIN_EDGES_TABLE", 0)
     monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
+    monkeypatch.setattr(mp, "BLOCK_ADDEND", 0)      # (the composed, forked path is what this test exercises)
 
     def run(fork, ahead):
         monkeypatch.setattr(mp, "FWD_FORK", fork)
@@ -1385,6 +1386,58 @@ def test_forked_convolution_with_unkeyed_attributes(dev, monkeypatch):
     assert float(g0.norm()) > 0
     assert rel_err(s1, s0) < 1e-6 and rel_err(g1, g0) < 1e-5
     assert rel_err(s2, s0) < 1e-6 and rel_err(g2, g0) < 1e-5
+
+
+@pytest.mark.parametrize("sink", [False, True])
+def test_block_with_the_self_connection_as_addend_equals_composed_layers(dev, monkeypatch, sink):
+    """config_diffusion's score net: general node attributes (atom type x time embedding), so the self-connection is the
+    un-keyed outer-product form.  The layers still run as fused blocks on the native executor -- the self-connection is
+    computed outside and handed in, the trailing Linear accumulates on it in front of the gate, the block's backward hands
+    back the gradient of the convolution output (``ConvBlockPlan.addend``).  Same score and parameter gradients as the
+    composed per-op path, with and without the gradient sink."""
+    from e3_layers_amd.backend import conv_native, ops
+    from e3_layers_amd.configs import config_diffusion
+    from e3_layers_amd.data.synthetic import synth_qm9_diffusion
+    from e3_layers_amd.nn import message_passing as mp
+    from e3_layers_amd.run.parallel import FlatGradients
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    model = build(config_diffusion.get_config().model_config).to(dev).train()
+    batch = synth_qm9_diffusion(5, 24).to(dev)
+    batch["t"] = torch.rand(len(batch), 1, device=dev)
+    flat = FlatGradients(model.parameters())
+    if sink:
+        flat.enable_direct_accumulation()
+    calls = [0]
+    orig = conv_native.NativeConvBlockFn.forward
+
+    def counted(ctx, *a):
+        calls[0] += 1
+        return orig(ctx, *a)
+
+    monkeypatch.setattr(conv_native.NativeConvBlockFn, "forward", staticmethod(counted))
+
+    def run(addend):
+        monkeypatch.setattr(mp, "BLOCK_ADDEND", addend)
+        calls[0] = 0
+        flat.zero()
+        score = model(batch.clone())["score"]
+        score.square().mean().backward()
+        ops.join_side_streams()
+        torch.cuda.synchronize()
+        return score.detach().clone(), flat.gather().clone(), calls[0]
+
+    try:
+        s0, g0, n0 = run(0)
+        s1, g1, n1 = run(1)
+        s2, g2, _ = run(1)
+    finally:
+        flat.disable_direct_accumulation()
+    assert n0 == 0 and n1 == 4                      # all four convolutions of the score net ran as blocks
+    assert float(g0.norm()) > 0 and bool((g0 != 0).float().mean() > 0.5)
+    assert rel_err(s1, s0) < 1e-6 and rel_err(g1, g0) < 1e-5
+    assert torch.equal(s1, s2) and rel_err(g2, g1) < 1e-6   # run to run (the weight-gradient reductions are split over workgroups)
 
 
 def test_radial_table_guard_vetoes_a_table_that_would_miss_the_parity_budget(dev, monkeypatch):
