@@ -388,8 +388,11 @@ __global__ __launch_bounds__(256) void keyed_weights_multi_kernel(const float* _
 // (t, v) then owns one output and walks the 256 columns with 16-byte LDS reads; the block's K*V partials go to a
 // workspace row.  Stage 2: one block sums the workspace rows into ga (no same-address atomics: they serialised).
 constexpr int KWA_COLS = 256, KWA_KT = 16, KWA_RANGE = 128;
+// rows of the staged W tile are padded by one 16-byte slot: the lanes of a ds_read_b128 group read the same columns of 16
+// different rows (v), and with a 1 024-byte row stride all of them would sit on the same four banks (16-way conflict)
+constexpr int KWA_WLD = KWA_COLS + 4;
 __device__ __forceinline__ void kw_bwd_a_body(const float* __restrict__ gM, const float* __restrict__ W, const KwArgs& ka_,
-                                              const int K, float* __restrict__ ws, float (*gs)[256], float (*wsm)[256]) {
+                                              const int K, float* __restrict__ ws, float (*gs)[KWA_COLS], float (*wsm)[KWA_WLD]) {
   struct { int K, V; int64_t ld_m, total; } ka{K, ka_.V, ka_.ld_m, ka_.total};
   const int t_id = threadIdx.x;
   const int64_t c = (int64_t)blockIdx.x * KWA_COLS + t_id;
@@ -429,13 +432,13 @@ __device__ __forceinline__ void kw_bwd_a_body(const float* __restrict__ gM, cons
 __global__ __launch_bounds__(256) void keyed_weights_bwd_a_kernel(const float* __restrict__ gM, const float* __restrict__ W,
                                                                    KwArgs ka, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
-  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_WLD];
   kw_bwd_a_body(gM, W, ka, ka.K, ws, gs, wsm);
 }
 
 __global__ __launch_bounds__(256) void keyed_weights_bwd_a_multi_kernel(KwMulti m, float* __restrict__ ws) {
   __shared__ __attribute__((aligned(16))) float gs[KWA_KT][KWA_COLS];
-  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_COLS];
+  __shared__ __attribute__((aligned(16))) float wsm[KW_MAXV][KWA_WLD];
   const int z = blockIdx.z;
   const KwArgs& ka = *m.ka[z];
   if ((int64_t)blockIdx.x * KWA_COLS >= ka.total) return;      // (block-uniform: this layer has fewer column blocks)
