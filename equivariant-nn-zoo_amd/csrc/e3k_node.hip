@@ -307,16 +307,26 @@ __device__ __forceinline__ const float* kw_locate(const KwArgs& ka, int64_t c, c
   return W + in.w_off + (int64_t)u * ka.V * in.w_out + w;
 }
 
-// grid.y tiles the keys (KW_KT per workgroup): a handful of species keys is one tile; the un-keyed self-connection
-// uses the same kernels with one key per node (thousands of keys)
-constexpr int KW_KT = 64;
+// grid.y tiles the keys: a handful of species keys is one tile; the un-keyed self-connection uses the same kernels with
+// one key per node (thousands of keys).  The tile is a loop bound only (the attribute rows come through the scalar cache),
+// so the launcher picks it: 64 keys, or 512 when the columns alone fill the chip -- the protein net's 80 keys are then ONE
+// tile and MODE 1 stores its sums instead of adding two tiles' with 77 M atomics.
+constexpr int KW_KT = 64, KW_KT_WIDE = 512;
+static inline unsigned kw_tiles(int n_keys, int64_t col_blocks) {
+  const int kt = col_blocks >= 1024 ? KW_KT_WIDE : KW_KT;
+  return (unsigned)((n_keys + kt - 1) / kt);
+}
 template <int MODE>   // 0: M = a . W    1: gW (+)= a^T . gM    (MODE 1: `M` is gM, `Wout_` is gW)
 __device__ __forceinline__ void kw_body(const float* __restrict__ a, const float* __restrict__ W, const KwArgs& ka, const int K,
-                                        float* __restrict__ M, float* __restrict__ Wout_, int accumulate, float* as) {
-  const int t0 = blockIdx.y * KW_KT;
-  const int kt = (K - t0 < KW_KT) ? K - t0 : KW_KT;
-  for (int i = threadIdx.x; i < kt * ka.V; i += 256) as[i] = a[(int64_t)t0 * ka.V + i];
-  __syncthreads();
+                                        float* __restrict__ M, float* __restrict__ Wout_, int accumulate) {
+  // The attribute rows a[t, :] are the same for every lane: they are read through the scalar cache (uniform address, s_load)
+  // and enter the FMAs as SGPR operands.  (Staged in LDS before: 32 broadcast ds_read_b32 per key and thread made both
+  // modes LDS-bound -- 198 us per launch for the 8 layers of the protein net, 80 keys x 32 attributes.)
+  const int tile = uniform((K + (int)gridDim.y - 1) / (int)gridDim.y);
+  const int t0 = uniform((int)blockIdx.y * tile);
+  const int kt = (K - t0 < tile) ? K - t0 : tile;
+  if (kt <= 0) return;
+  const int V = uniform(ka.V);
   const int64_t c = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (c >= ka.total) return;
   int wout;
@@ -324,12 +334,13 @@ __device__ __forceinline__ void kw_body(const float* __restrict__ a, const float
   if constexpr (MODE == 0) {
     float wv[KW_MAXV];
 #pragma unroll
-    for (int v = 0; v < KW_MAXV; ++v) wv[v] = v < ka.V ? base[(int64_t)v * wout] : 0.f;
+    for (int v = 0; v < KW_MAXV; ++v) wv[v] = v < V ? base[(int64_t)v * wout] : 0.f;
     for (int t = 0; t < kt; ++t) {
+      const float* __restrict__ ar = a + (int64_t)(t0 + t) * V;
       float acc = 0.f;
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
-        if (v < ka.V) acc = fmaf(as[t * ka.V + v], wv[v], acc);
+        if (v < V) acc = fmaf(ar[v], wv[v], acc);
       M[(int64_t)(t0 + t) * ka.ld_m + c] = acc;
     }
   } else {
@@ -337,20 +348,21 @@ __device__ __forceinline__ void kw_body(const float* __restrict__ a, const float
 #pragma unroll
     for (int v = 0; v < KW_MAXV; ++v) gv[v] = 0.f;
     for (int t = 0; t < kt; ++t) {
+      const float* __restrict__ ar = a + (int64_t)(t0 + t) * V;
       const float g = M[(int64_t)(t0 + t) * ka.ld_m + c];
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
-        if (v < ka.V) gv[v] = fmaf(as[t * ka.V + v], g, gv[v]);
+        if (v < V) gv[v] = fmaf(ar[v], g, gv[v]);
     }
     float* dst = Wout_ + (base - W);
     if (gridDim.y == 1) {
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
-        if (v < ka.V) dst[(int64_t)v * wout] = accumulate ? dst[(int64_t)v * wout] + gv[v] : gv[v];
+        if (v < V) dst[(int64_t)v * wout] = accumulate ? dst[(int64_t)v * wout] + gv[v] : gv[v];
     } else {   // several key tiles add into the same element (the launcher zero-fills when not accumulating)
 #pragma unroll
       for (int v = 0; v < KW_MAXV; ++v)
-        if (v < ka.V) atomicAdd(dst + (int64_t)v * wout, gv[v]);
+        if (v < V) atomicAdd(dst + (int64_t)v * wout, gv[v]);
     }
   }
 }
@@ -359,8 +371,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void keyed_weights_kernel(const float* __restrict__ a, const float* __restrict__ W,
                                                              KwArgs ka, float* __restrict__ M, float* __restrict__ Wout_,
                                                              int accumulate) {
-  __shared__ float as[KW_KT * KW_MAXV];
-  kw_body<MODE>(a, W, ka, ka.K, M, Wout_, accumulate, as);
+  kw_body<MODE>(a, W, ka, ka.K, M, Wout_, accumulate);
 }
 
 // the same for the self-connections of SEVERAL layers that share the attribute rows `a` (grid.z = layer): their instruction
@@ -377,10 +388,9 @@ struct KwMulti {
 };
 template <int MODE>
 __global__ __launch_bounds__(256) void keyed_weights_multi_kernel(const float* __restrict__ a, KwMulti m) {
-  __shared__ float as[KW_KT * KW_MAXV];
   const int z = blockIdx.z;
   if (MODE == 1 && !m.gW[z]) return;
-  kw_body<MODE>(a, m.W[z], *m.ka[z], m.K, m.M[z], m.gW[z], m.acc[z], as);
+  kw_body<MODE>(a, m.W[z], *m.ka[z], m.K, m.M[z], m.gW[z], m.acc[z]);
 }
 
 // ga[t,v] += sum_c gM[t,c] W[c,v]  (c over all ~1e5 columns): a [K x C] x [C x V] product with a tiny output.
@@ -944,7 +954,7 @@ extern "C" int e3k_keyed_weights_fwd(const float* a, const float* W, const e3k_k
   if (rc != E3K_OK) return rc;
   if (!a || !W || !M) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::keyed_weights_kernel<0>,
-                     dim3((unsigned)((ka.total + 255) / 256), (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT)), dim3(256), 0,
+                     dim3((unsigned)((ka.total + 255) / 256), e3k::kw_tiles(n_keys, (ka.total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, a, W, ka, M, (float*)nullptr, 0);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -965,7 +975,7 @@ extern "C" int e3k_keyed_weights_bwd(const float* a, const float* W, const float
   if (rc != E3K_OK) return rc;
   if (!a || !W || !g_M || (!g_a && !g_W)) return E3K_ERR_INVALID;
   if (g_W) {
-    const unsigned tiles = (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT);
+    const unsigned tiles = e3k::kw_tiles(n_keys, (ka.total + 255) / 256);
     if (tiles > 1 && !accumulate_w) {   // the key tiles add with atomics: start from zero
       for (int i = 0; i < n_instr; ++i)
         if (e3k::zero_fill(g_W + instr[i].w_off, sizeof(float) * (size_t)instr[i].u * V * instr[i].w_out, (hipStream_t)stream))
@@ -1054,7 +1064,7 @@ extern "C" int e3k_keyed_weights_fwd_multi(const e3k_kw_multi_item* items, int32
   if (rc != E3K_OK) return rc;
   if (!a) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::keyed_weights_multi_kernel<0>,
-                     dim3((unsigned)((max_total + 255) / 256), (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT), (unsigned)n),
+                     dim3((unsigned)((max_total + 255) / 256), e3k::kw_tiles(n_keys, (max_total + 255) / 256 * n), (unsigned)n),
                      dim3(256), 0, (hipStream_t)stream, a, m);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
@@ -1077,7 +1087,7 @@ extern "C" int e3k_keyed_weights_bwd_multi(const e3k_kw_multi_item* items, int32
   if (rc != E3K_OK) return rc;
   if (!a) return E3K_ERR_INVALID;
   const int V = items[0].args->host.V;
-  const unsigned tiles = (unsigned)((n_keys + e3k::KW_KT - 1) / e3k::KW_KT);
+  const unsigned tiles = e3k::kw_tiles(n_keys, (max_total + 255) / 256 * n);
   bool any_w = false;
   for (int i = 0; i < n; ++i) {
     if (!items[i].g_W) continue;
