@@ -155,6 +155,18 @@ def _worker_schedule(rank, world, port, ret):
     assert flat.overlapped_slices == early + 1
     flat.all_reduce_mean()
     grads.append(flat.gather().clone())
+    # early_start = False (a rank whose backward is a graph replay, or the capture's eager warm-up steps): reports are ignored
+    # and the whole fixed sequence is issued by all_reduce_mean() -- also when the OTHER rank still starts its slices early
+    before = flat.overlapped_slices
+    flat.early_start = rank == 0
+    flat.zero()
+    _loss_sum(model, mine).backward()
+    for k in (2, 1, 0):
+        flat._on_ready(list(model.layers[k].parameters()))
+    assert flat.overlapped_slices == before + (3 if rank == 0 else 0)
+    flat.all_reduce_mean()
+    flat.early_start = True
+    grads.append(flat.gather().clone())
     ret[rank] = (grads, sched, early)
     dist.destroy_process_group()
 
