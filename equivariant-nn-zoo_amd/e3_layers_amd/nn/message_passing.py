@@ -75,6 +75,7 @@ STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
 # 1: a layer whose self-connection has general (un-keyed) node attributes still runs as a fused block: the self-connection is
 # computed by ops.fctp outside and handed in as an addend (MessagePassing._forward_block_addend)
 BLOCK_ADDEND = int(os.environ.get("E3K_BLOCK_ADDEND", "1"))
+ADDEND_FORK = int(os.environ.get("E3K_ADDEND_FORK", "1"))
 KW_STACK = int(os.environ.get("E3K_KW_STACK", "1"))
 KW_STACK_MAX_EDGES = int(os.environ.get("E3K_KW_STACK_MAX_EDGES", "1000000000"))      # (192 / 256 molecules: -0.10 / -0.03 ms: no limit)
 
@@ -495,8 +496,16 @@ class MessagePassing(Module):
             src = radial_table.source_of(radial)
             table = src.bins()
             radial = src.knot_basis()
-        # one stream, no stacks, no look-ahead: the shapes that reach this are small (the score nets)
-        return conv_block.conv_block(x_cf, None, radial, sh, plan, topo, None, True, out_cf, False,
+        # no stacks, no look-ahead (the shapes that reach this are the score nets); the radial branch and the weight
+        # gradients fork onto their streams under the same rule as the keyed block
+        fork = bool(ADDEND_FORK and FWD_FORK and conv._fork_pays(data["edge_radial"].shape[0], table is not None)
+                    and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
+        if fork:
+            main = torch.cuda.current_stream(x.device)
+            side = ops.side_stream(x.device)
+            with ops.on_stream(side, main):
+                radial = _stream_alias(radial, side)
+        return conv_block.conv_block(x_cf, None, radial, sh, plan, topo, None, True, out_cf, fork,
                                      conv.linear_1.weight, conv.tp.linear.weight, None,
                                      fc[-1].weight, [m.weight for m in fc[:-1]], table=table, m_pre=sc_out)
 

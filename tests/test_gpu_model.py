@@ -1388,13 +1388,13 @@ def test_forked_convolution_with_unkeyed_attributes(dev, monkeypatch):
     assert rel_err(s2, s0) < 1e-6 and rel_err(g2, g0) < 1e-5
 
 
-@pytest.mark.parametrize("sink", [False, True])
-def test_block_with_the_self_connection_as_addend_equals_composed_layers(dev, monkeypatch, sink):
+@pytest.mark.parametrize("sink,fork", [(False, False), (True, False), (True, True), (False, True)])
+def test_block_with_the_self_connection_as_addend_equals_composed_layers(dev, monkeypatch, sink, fork):
     """config_diffusion's score net: general node attributes (atom type x time embedding), so the self-connection is the
     un-keyed outer-product form.  The layers still run as fused blocks on the native executor -- the self-connection is
     computed outside and handed in, the trailing Linear accumulates on it in front of the gate, the block's backward hands
     back the gradient of the convolution output (``ConvBlockPlan.addend``).  Same score and parameter gradients as the
-    composed per-op path, with and without the gradient sink."""
+    composed per-op path, with and without the gradient sink, on one stream and forked."""
     from e3_layers_amd.backend import conv_native, ops
     from e3_layers_amd.configs import config_diffusion
     from e3_layers_amd.data.synthetic import synth_qm9_diffusion
@@ -1409,6 +1409,9 @@ def test_block_with_the_self_connection_as_addend_equals_composed_layers(dev, mo
     flat = FlatGradients(model.parameters())
     if sink:
         flat.enable_direct_accumulation()
+    if fork:      # radial branch and weight gradients of the block on their own streams
+        monkeypatch.setattr(mp, "FORK_MIN_EDGES", 0)
+        monkeypatch.setattr(ops, "WGRAD_SIDE_MIN_ROWS", 0)
     calls = [0]
     orig = conv_native.NativeConvBlockFn.forward
 
