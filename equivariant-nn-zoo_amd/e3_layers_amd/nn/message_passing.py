@@ -74,6 +74,7 @@ STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
 # self-connection weights are most of a layer's parameters and their gradients would then only exist at the very end
 # 1: a layer whose self-connection has general (un-keyed) node attributes still runs as a fused block: the self-connection is
 # computed by ops.fctp outside and handed in as an addend (MessagePassing._forward_block_addend)
+CF_CHAIN_NORM = int(os.environ.get("E3K_CF_CHAIN_NORM", "1"))      # cf hand-over through LayerNormalization
 BLOCK_ADDEND = int(os.environ.get("E3K_BLOCK_ADDEND", "1"))
 ADDEND_FORK = int(os.environ.get("E3K_ADDEND_FORK", "1"))
 KW_STACK = int(os.environ.get("E3K_KW_STACK", "1"))
@@ -275,8 +276,10 @@ class MessagePassing(Module):
 
     def cf_chain_ok(self, nxt) -> bool:
         """This layer may hand ``nxt`` its output in cf layout (see ``_emit_cf``)."""
+        # (LayerNormalization is a per-block reduction over ALL elements of an irrep block: the same numbers in either layout,
+        #  so a normalised layer hands over in cf too -- the protein score net's eight layers)
         return (CF_CHAIN and isinstance(nxt, MessagePassing) and isinstance(self.equivariant_nonlin, Gate)
-                and not self.resnet and not self.normalize and not nxt.resnet
+                and not self.resnet and (not self.normalize or CF_CHAIN_NORM) and not nxt.resnet
                 and isinstance(nxt.conv, FactorizedConvolution) and nxt.conv.reduce
                 and tuple(irreps_blocks(self.equivariant_nonlin.irreps_out)) == nxt.conv._in_blocks)
 
@@ -514,6 +517,8 @@ class MessagePassing(Module):
         blk = self._forward_block(data, bool(self._emit_cf))
         if blk is not None:
             if self._emit_cf:
+                if self.normalize:
+                    blk = self.norm({"input": blk}, attrs)[0]["output"]
                 blk._e3k_cf = True
                 return ({"output_features": blk},
                         {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
@@ -533,6 +538,8 @@ class MessagePassing(Module):
             conv_cf = ops.relayout(out["output_features"], tuple(irreps_blocks(self.equivariant_nonlin.irreps_in)), True)
         if self._emit_cf:
             output = self.equivariant_nonlin(conv_cf, out_cf=True)
+            if self.normalize:
+                output = self.norm({"input": output}, attrs)[0]["output"]
             output._e3k_cf = True
             return ({"output_features": output},
                     {"output_features": (attrs["input_features"][0], self.irreps_out["output_features"])})
