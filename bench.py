@@ -381,9 +381,10 @@ def main():
     # Python + launches per 5.0-5.4 ms step at 256 molecules on an idle host); on a loaded host -- the boxes of this pool are
     # shared -- it becomes host-bound (7 ms seen).  The HIP-graph replay with a new padded batch every step
     # (run/graph_step.py) does not depend on the host at all and costs 5.5 ms there.  So: when the reference steps were bound
-    # by the host, capture the bucketed step, time it, and keep whichever is faster for the timed region.  One rank, default
-    # workload only; E3K_BENCH_AUTO=0 pins the eager step.
-    if (cfg_kind == "energy" and not (args.loader or args.graph or args.graph_fresh) and n_ref
+    # by the host, capture the bucketed step, time it, and keep whichever is faster for the timed region.  One rank; the
+    # config_energy, config_energy_force and config_diffusion workloads (the ones the bucketed replay serves);
+    # E3K_BENCH_AUTO=0 pins the eager step.
+    if (cfg_kind in ("energy", "energy_force", "diffusion") and not (args.loader or args.graph or args.graph_fresh) and n_ref
             and os.environ.get("E3K_BENCH_AUTO", "1") != "0"):
         # (several ranks: only the choice between the two eager layouts -- they issue the same collectives, so the ranks cannot
         #  diverge; the times compared are the maxima over the ranks, so every rank takes the same decision)
