@@ -110,12 +110,23 @@ def sde_loss(sde: VPSDE, model, batch, eps: float = 1e-5, train: bool = True, ge
              node_weight=None) -> Tuple[torch.Tensor, dict]:
     """mean over graphs/nodes of (score * std + z)^2, t ~ U(eps, 1) per graph.  ``node_weight`` [N, 1] (sums to 1 over the
     nodes that count): a weighted mean instead -- a batch padded with a ghost graph (run/graph_step.py) gives it weight 0."""
+    pert, misc = sde_perturb(sde, batch, eps, generator)
+    return sde_loss_of(sde, model, pert, misc, train, node_weight)
+
+
+def sde_perturb(sde: VPSDE, batch, eps: float = 1e-5, generator=None):
+    """First half of ``sde_loss``: t ~ U(eps, 1) per graph and the noised copy of the batch (no model involved) -> (pert, misc).
+    A loop that wants the next batch's data-only layers early calls ``model.prepare(pert)`` on the result."""
     dev = batch["_n_nodes"].device
     t = torch.rand(len(batch), device=dev, generator=generator) * (sde.T - eps) + eps
     pert = batch.clone()
     pert.attrs["t"] = ("graph", "1x0e")
     pert["t"] = t
-    pert, misc = sde.marginal(pert, generator=generator)
+    return sde.marginal(pert, generator=generator)
+
+
+def sde_loss_of(sde: VPSDE, model, pert, misc, train: bool = True, node_weight=None) -> Tuple[torch.Tensor, dict]:
+    """Second half of ``sde_loss``: the score network on the noised batch and the denoising loss."""
     scores = get_score_fn(sde, model, train)(pert)
     losses = {}
     for key in sde.irreps:

@@ -220,6 +220,40 @@ def test_config_diffusion_CA_protein_network(dev):
     assert res["score_CA"].shape == (80, 3) and int(res["_n_edges"].sum()) == res["edge_index"].shape[1]
 
 
+def test_prepare_runs_the_data_only_layers_ahead_of_the_forward(dev):
+    """``SequentialGraphNetwork.prepare`` (the protein nets' edge list, which reads a count back) + ``forward`` on the marked
+    batch = ``forward`` alone; ``sde_perturb`` + ``prepare`` + ``sde_loss_of`` = ``sde_loss`` (the software-pipelined loop of
+    ``bench.py --config diffusion_CA``)."""
+    from e3_layers_amd.configs import config_diffusion_CA
+    from e3_layers_amd.data.synthetic import synth_protein
+    from e3_layers_amd.run.sde_utils import VPSDE, sde_loss, sde_loss_of, sde_perturb
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(0)
+    full = build(config_diffusion_CA.get_config(num_layers=3).model_config).to(dev)
+    b = synth_protein(2, 2, n_res=40).to(dev)
+    torch.manual_seed(11)                      # (the random-edge criterion draws from the default generator)
+    ref = full(b.clone())
+    torch.manual_seed(11)
+    p = b.clone()
+    assert "edge_index" not in p or p["edge_index"].shape[1] != ref["edge_index"].shape[1]
+    assert full.prepare(p) == 1 and p._e3k_prepared == 1 and p["edge_index"].shape[1] == ref["edge_index"].shape[1]
+    assert full.prepare(p) == 1                # nothing left to run ahead
+    out = full(p)
+    assert torch.equal(out["edge_index"], ref["edge_index"]) and torch.equal(out["score_CA"], ref["score_CA"])
+    sde = VPSDE({"CA": 3})
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(3)
+    torch.manual_seed(12)
+    l0 = sde_loss(sde, full, b.clone(), generator=gen)[0]
+    gen.manual_seed(3)
+    torch.manual_seed(12)
+    pert, misc = sde_perturb(sde, b.clone(), generator=gen)
+    full.prepare(pert)
+    l1 = sde_loss_of(sde, full, pert, misc)[0]
+    assert torch.equal(l0, l1) and bool(torch.isfinite(l1))
+
+
 def _protein_parity(dev, module, n_layers, l_max, n_res, backbone, heads, tol, gtol):
     """Product vs float64 oracle on the protein score net with a CPU-built, seeded edge set fed to both sides."""
     from e3_layers_amd.data.synthetic import synth_protein
