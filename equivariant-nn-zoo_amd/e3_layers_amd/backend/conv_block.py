@@ -364,7 +364,8 @@ def conv_block(x, node_attrs, edge_radial, sh, plan: ConvBlockPlan, topo, groups
         return conv_native.NativeConvBlockFn.apply(x, node_attrs, None, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
                                                    pre, m_pre, w_lin1, w_post, w_sc, None)
     if conv_native.ENABLED and conv_native.native_layer(plan) is not None:      # the same sequence issued by csrc/e3k_layer.hip
-        return conv_native.NativeConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
-                                                   nxt, None, m_pre, w_lin1, w_post, w_sc, w_last, *w_hidden)
+        out = conv_native.NativeConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table,
+                                                  nxt, None, m_pre, w_lin1, w_post, w_sc, w_last, *w_hidden)
+        return out[0] if isinstance(out, tuple) else out      # (addend form: the dirtied addend rides along as a second output)
     return ConvBlockFn.apply(x, node_attrs, edge_radial, sh, plan, topo, groups, in_cf, out_cf, fork, table, nxt,
                              w_lin1, w_post, w_sc, w_last, *w_hidden)

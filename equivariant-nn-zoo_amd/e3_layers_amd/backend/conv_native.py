@@ -203,6 +203,8 @@ FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
 # instead of tp_bwd_w -> g_w[E, W] -> transposed interpolation (asked for through rad.in_kernel = 2).  Correct
 # (bit-identical) and slower -- no molecule locality in knot order --, so off.
 BWD_T = int(os.environ.get("E3K_BWD_T", "0"))
+# 1: the addend of an addend-form layer (ConvBlockPlan.addend) is accumulated on in place instead of being copied into the block's buffer
+ADDEND_INPLACE = int(os.environ.get("E3K_ADDEND_INPLACE", "1"))
 
 
 def in_kernel_table(plan, table, dev) -> bool:
@@ -497,9 +499,14 @@ class NativeConvBlockFn(torch.autograd.Function):
         keep = any(ctx.needs_input_grad)
         has_sc = plan.sc_spec is not None
         addend = None
+        addend_inplace = False
         if plan.addend:      # the self-connection's output, computed outside the block (travels in the m_pre slot)
+            given = m_pre
             addend, m_pre = L.f32c(m_pre), None
             L.require_cuda(addend)
+            # the tensor itself becomes the block's pre-gate buffer (as Linear(base=...) does): the trailing Linear accumulates into
+            # it, the gate's backward reads it -- no copy.  (A caller that handed in something that had to be converted gets the copy.)
+            addend_inplace = ADDEND_INPLACE and addend is given and addend.requires_grad == given.requires_grad
         n, e = x.shape[0], sh.shape[0]
         if addend is not None and tuple(addend.shape) != (n, plan.post_spec.d_out):
             raise ValueError(f"addend {tuple(addend.shape)} is not [N, d_conv] = ({n}, {plan.post_spec.d_out})")
@@ -568,7 +575,8 @@ class NativeConvBlockFn(torch.autograd.Function):
         if has_sc and not have_m:
             carve.add("a_rep", groups.n_keys * plan.sc_spec.v)
             carve.add("m", groups.n_keys * plan.sc_ld_m)
-        carve.add("conv", n * plan.post_spec.d_out)
+        if not addend_inplace:
+            carve.add("conv", n * plan.post_spec.d_out)
         carve.add("x1", n * plan.lin1_spec.d_out)
         carve.add("mid", n * plan.post_spec.d_in)
         buf = carve.alloc(dev)
@@ -585,9 +593,15 @@ class NativeConvBlockFn(torch.autograd.Function):
                 node_attrs = L.f32c(node_attrs)
                 a.node_attrs, a.w_sc = node_attrs.data_ptr(), w_sc.data_ptr()
                 a.a_rep, a.m = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"])
-        a.conv, a.x1, a.mid, a.y = _ptr(buf, off["conv"]), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
-        if addend is not None:
-            buf[off["conv"]:off["conv"] + n * plan.post_spec.d_out].view(n, plan.post_spec.d_out).copy_(addend)
+        a.x1, a.mid, a.y = _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), y.data_ptr()
+        if addend_inplace:
+            ctx.mark_dirty(addend)
+            ctx.set_materialize_grads(False)
+            a.conv = addend.data_ptr()
+        else:
+            a.conv = _ptr(buf, off["conv"])
+            if addend is not None:
+                buf[off["conv"]:off["conv"] + n * plan.post_spec.d_out].view(n, plan.post_spec.d_out).copy_(addend)
         if HOST_TIMING is not None:
             import time
 
@@ -632,19 +646,27 @@ class NativeConvBlockFn(torch.autograd.Function):
             plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))
         if keep:
             ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
-                                  w_last, t_tab if (w is None and not stack) else None, m_pre, *w_hidden)
+                                  w_last, t_tab if (w is None and not stack) else None, addend if addend_inplace else m_pre, *w_hidden)
             ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
             ctx.stack = stack
             ctx.attrs_shape = tuple(node_attrs.shape) if (has_sc and not have_m) else None
+        ctx.addend_inplace = addend_inplace
+        if addend_inplace:      # (a dirty input has to be an output; nothing reads it downstream)
+            return y, addend
         return y
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, *unused):
         from . import conv_block
 
         plan, topo, groups, in_cf, out_cf, fork, n_hidden, table, carve, rcarve, need_relayout = ctx.cfg
         saved = ctx.saved_tensors
         x_in, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc, w_last, t_keep, m_pre = saved[:12]
+        conv_ext = None
+        if ctx.addend_inplace:      # slot 11 holds the pre-gate buffer (the addend, accumulated on in place)
+            conv_ext, m_pre = m_pre, None
+            if gy is None:
+                gy = torch.zeros(conv_ext.shape[0], plan.gate_spec.out_dim, device=conv_ext.device, dtype=torch.float32)
         w_hidden = saved[12:12 + n_hidden]
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
@@ -680,7 +702,8 @@ class NativeConvBlockFn(torch.autograd.Function):
         a.need_x, a.need_attrs, a.need_radial = int(need_x), int(bool(need_attrs and has_sc)), int(need_radial)
         a.main, a.side, a.side2, a.side3 = main.cuda_stream, side.cuda_stream, side2.cuda_stream, side3.cuda_stream
         a.x_cf = _ptr(buf, off["x_cf"]) if need_relayout else x_in.data_ptr()
-        a.sh, a.x1, a.mid, a.conv = sh.data_ptr(), _ptr(buf, off["x1"]), _ptr(buf, off["mid"]), _ptr(buf, off["conv"])
+        a.sh, a.x1, a.mid = sh.data_ptr(), _ptr(buf, off["x1"]), _ptr(buf, off["mid"])
+        a.conv = conv_ext.data_ptr() if conv_ext is not None else _ptr(buf, off["conv"])
         a.src, a.dst, a.dst_ptr, a.dst_perm = topo.src.data_ptr(), topo.dst.data_ptr(), topo.dst_ptr.data_ptr(), topo.dst_perm.data_ptr()
         a.src_ptr, a.src_perm = topo.src_ptr.data_ptr(), topo.src_perm.data_ptr()
         a.w_lin1, a.w_post = w_lin1.data_ptr(), w_post.data_ptr()
