@@ -506,7 +506,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             L.require_cuda(addend)
             # the tensor itself becomes the block's pre-gate buffer (as Linear(base=...) does): the trailing Linear accumulates into
             # it, the gate's backward reads it -- no copy.  (A caller that handed in something that had to be converted gets the copy.)
-            addend_inplace = ADDEND_INPLACE and addend is given and addend.requires_grad == given.requires_grad
+            addend_inplace = bool(ADDEND_INPLACE) and addend is given and not (addend.is_leaf and addend.requires_grad)
         n, e = x.shape[0], sh.shape[0]
         if addend is not None and tuple(addend.shape) != (n, plan.post_spec.d_out):
             raise ValueError(f"addend {tuple(addend.shape)} is not [N, d_conv] = ({n}, {plan.post_spec.d_out})")
