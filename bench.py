@@ -164,7 +164,7 @@ def main():
     from e3_layers_amd.configs import config_diffusion, config_diffusion_CA, config_energy, config_energy_force
     from e3_layers_amd.data.synthetic import synth_protein, synth_qm9, synth_qm9_diffusion
     from e3_layers_amd.run.optim import FusedAdamEMA
-    from e3_layers_amd.run.parallel import backward_parameters, broadcast_parameters, flat_param_order
+    from e3_layers_amd.run.parallel import backward_parameters, broadcast_parameters, flat_param_order, param_names
     from e3_layers_amd.run.sde_utils import VPSDE, sde_loss, sde_loss_of, sde_perturb
     from e3_layers_amd.utils import build, countParameters
 
@@ -195,7 +195,8 @@ def main():
     model = build(tree).to(dev)
     broadcast_parameters(model)
     # parameters, gradients, Adam moments and the EMA shadow as flat vectors: one all-reduce, one fused optimizer launch
-    opt = FusedAdamEMA(flat_param_order(model), lr=cfg.learning_rate, **opt_kw)
+    order = flat_param_order(model)
+    opt = FusedAdamEMA(order, lr=cfg.learning_rate, names=param_names(model, order), **opt_kw)
     flat = opt.grads
     flat.enable_direct_accumulation()
     if world > 1 and os.environ.get("E3K_OVERLAP_ALLREDUCE", "1") != "0":

@@ -91,10 +91,40 @@ def check_indices() -> None:
     _check_pending_flags()
 
 
+_capture_flags: dict = {}      # device index -> persistent int32 [1] flag that captured builds OR their own flags into
+
+
+def capture_flag(device) -> torch.Tensor:
+    """The persistent error flag of ``device`` for builds recorded into a HIP graph (allocated OUTSIDE any capture: call this
+    before recording starts -- ``run/graph_step.CapturedStep`` does).  A flag made inside the graph lives in the graph's private
+    pool and is overwritten by every replay; this one survives, ``poll_capture_flags()`` reads it back after a replay."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    f = _capture_flags.get(idx)
+    if f is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("capture_flag() must be called before the capture starts (CapturedStep does)")
+        f = _capture_flags[idx] = torch.zeros(1, dtype=torch.int32, device=torch.device("cuda", idx))
+    return f
+
+
+def poll_capture_flags() -> None:
+    """After a graph replay: send the persistent flags to the host (no sync; they are looked at with the other deferred flags)."""
+    for f in _capture_flags.values():
+        defer_flag(f, "a batch fed through a captured (graph-replayed) step held node ids outside [0, num_nodes) in its edge_index "
+                      "(such edges were attached to node 0) or row keys outside [0, n_keys) (such rows were dropped from the keyed "
+                      "self-connection)")
+
+
 def defer_flag(flag: torch.Tensor, message: str) -> None:
     """Registers a device int32 [1] error flag (non-zero = bad input) to be read back without a sync."""
     global _flag_ring, _flag_next
     if torch.cuda.is_current_stream_capturing():
+        # recorded into the graph: every replay folds this build's flag into the device's persistent one (sticky: a bad batch
+        # stays flagged until somebody reads it -- CapturedStep polls after each replay)
+        idx = flag.device.index if flag.device.index is not None else torch.cuda.current_device()
+        keep = _capture_flags.get(idx)
+        if keep is not None:
+            keep.bitwise_or_(flag.reshape(1).to(torch.int32))
         return
     _check_pending_flags()
     if len(_pending_flags) >= _FLAG_RING - 1:

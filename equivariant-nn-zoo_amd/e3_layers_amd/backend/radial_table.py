@@ -144,6 +144,9 @@ def _guard_of(w_last, create: bool = False):
 
 
 def _poll(g: _Guard) -> None:
+    if torch.cuda.is_current_stream_capturing():
+        return                             # Event.query() is not allowed while a stream captures (it would invalidate the capture);
+                                           # ``drain_guards()`` empties the lists before CapturedStep starts recording
     while g.pending and g.pending[0][0].query():
         _, host = g.pending.pop(0)
         g.last = float(host[0])
@@ -155,6 +158,17 @@ def _poll(g: _Guard) -> None:
                               f"({KNOTS} knots): this radial MLP is evaluated per edge from now on "
                               "(E3K_RADIAL_KNOTS raises the resolution)")
             g.ok = False
+
+
+def drain_guards() -> None:
+    """Read back every pending guard estimate (call after a device synchronisation, before a graph capture: no event may be
+    queried while the stream records -- ``run/graph_step.CapturedStep`` does)."""
+    for ref, g in list(_GUARDS.values()):
+        if ref() is None:
+            continue
+        for ev, _ in g.pending:
+            ev.synchronize()
+        _poll(g)
 
 
 def guard_ok(w_last) -> bool:

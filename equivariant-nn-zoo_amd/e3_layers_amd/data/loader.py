@@ -19,12 +19,14 @@ importable and fail loudly when it is not.
 """
 from __future__ import annotations
 
+import atexit
 import json
 import math
 import os
 import queue
 import re
 import threading
+import weakref
 from inspect import signature
 from typing import Iterator, List, Optional, Sequence
 
@@ -218,8 +220,7 @@ class PrefetchLoader:
         self.device = torch.device(device) if device is not None else None
         self.shuffle, self.seed, self.drop_last, self.epochs, self.depth = bool(shuffle), int(seed), bool(drop_last), epochs, int(depth)
         self.n = len(store)
-        if self.n < self.batch_size and drop_last:
-            raise ValueError(f"{self.n} graphs cannot fill a batch of {self.batch_size}")
+        # (a split that cannot fill one batch -- n_val = 0 -- fails when it is iterated, as the reference's DataLoader does, not here)
 
     def __len__(self) -> int:
         per = self.n // self.batch_size if self.drop_last else -(-self.n // self.batch_size)
@@ -245,15 +246,41 @@ class PrefetchLoader:
         return _PrefetchIter(self)
 
 
+_LIVE_ITERS: "weakref.WeakSet" = weakref.WeakSet()      # iterators whose worker thread has been started
+
+
+def _close_live_iters() -> None:
+    for it in list(_LIVE_ITERS):
+        try:
+            it.close()
+        except Exception:
+            pass
+
+
+atexit.register(_close_live_iters)      # a worker that still holds a HIP stream at interpreter shutdown aborts the process
+
+
 class _PrefetchIter:
+    """The worker thread (and its HIP copy stream) start with the first ``next()``: an iterator that is created and never
+    used -- ``getDataIters`` hands out the eval iterator eagerly -- costs nothing and needs no ``close()``; live ones are closed
+    at interpreter exit (``atexit``) if the caller did not."""
+
     def __init__(self, loader: PrefetchLoader):
         self.loader = loader
         self.q: "queue.Queue" = queue.Queue(maxsize=max(loader.depth, 1))
         self.stop = threading.Event()
         dev = loader.device
         self.cuda = dev is not None and dev.type == "cuda"
-        self.copy_stream = torch.cuda.Stream(device=dev) if self.cuda else None
+        self.copy_stream = None
+        self.thread = None
+
+    def _start(self) -> None:
+        loader = self.loader
+        if loader.n < loader.batch_size and loader.drop_last:
+            raise ValueError(f"{loader.n} graphs cannot fill a batch of {loader.batch_size}")
+        self.copy_stream = torch.cuda.Stream(device=loader.device) if self.cuda else None
         self.thread = threading.Thread(target=self._work, name="e3k-prefetch", daemon=True)
+        _LIVE_ITERS.add(self)
         self.thread.start()
 
     def _stage(self, slot: dict, key: str, t: torch.Tensor) -> torch.Tensor:
@@ -308,6 +335,10 @@ class _PrefetchIter:
         return self
 
     def __next__(self) -> Batch:
+        if self.thread is None:
+            if self.stop.is_set():
+                raise StopIteration
+            self._start()
         batch, ready = self.q.get()
         if batch is None:
             raise StopIteration
@@ -329,8 +360,9 @@ class _PrefetchIter:
                 self.q.get_nowait()
         except queue.Empty:
             pass
-        if self.thread.is_alive() and threading.current_thread() is not self.thread:
+        if self.thread is not None and self.thread.is_alive() and threading.current_thread() is not self.thread:
             self.thread.join(timeout=10)
+        _LIVE_ITERS.discard(self)
 
     def __del__(self):
         try:

@@ -96,7 +96,7 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         loop calls this for the NEXT batch before it enqueues the current batch's backward: the read-back then waits for the
         forward alone instead of for a whole step queued in front of it.  Same stream, same kernels, only earlier."""
         data, attrs = batch.data, batch.attrs
-        done = int(getattr(batch, "_e3k_prepared", 0))
+        done = 0       # (a second prepare() on the same object starts over: whatever the first one derived may be stale by now)
         for _, layer in self.layers[done:]:
             if isinstance(layer, torch.nn.Module):
                 break
@@ -110,7 +110,11 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         # layer names appear in a torch profile when one is running; otherwise the 2 x 14 record_function ops per forward
         # are 0.3 ms of pure host time
         profiling = torch.autograd._profiler_enabled()
+        # the mark applies to exactly ONE forward: a sampler / reverse-SDE loop that updates ``pos`` in place and calls the model
+        # again on the same Batch object must get its edge list rebuilt, not the stale one
         start = int(getattr(batch, "_e3k_prepared", 0))
+        if start:
+            batch._e3k_prepared = 0
         for key, layer in (self.layers[start:] if start else self.layers):
             if profiling:
                 with record_function(key):

@@ -41,6 +41,13 @@ class CapturedStep:
         from ..backend.graph import check_indices
 
         check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
+        from ..backend import radial_table
+
+        radial_table.drain_guards()      # ... and the knot-table guards' pending read-backs (no Event.query() inside a capture)
+        from ..backend.graph import capture_flag
+
+        capture_flag(dev)                # the persistent flag the captured index checks fold into (a bad batch fed
+                                         # through a replay must raise, as it does on the eager path)
         self.graph = torch.cuda.CUDAGraph()
         for g in generators:
             self.graph.register_generator_state(g)
@@ -49,6 +56,9 @@ class CapturedStep:
 
     def __call__(self):
         self.graph.replay()
+        from ..backend.graph import poll_capture_flags
+
+        poll_capture_flags()             # (one 4-byte async copy: read by the next build / optimizer step / check_indices())
         return self.out
 
 

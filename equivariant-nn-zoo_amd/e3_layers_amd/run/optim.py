@@ -23,12 +23,49 @@ from ..backend import lib as L
 from .parallel import FlatGradients, flat_layout
 
 
+def layout_moves(mine, theirs):
+    """How to copy a checkpoint's flat vectors (layout ``theirs``) into an optimizer's (layout ``mine``): None = identical
+    layouts (plain copies), else [(dst offset, src offset, numel)] matched by name; raises when the two cannot be matched."""
+    if theirs is None:
+        raise ValueError("checkpoint without a parameter layout (written before round 4): it cannot be told whether its "
+                         "flat vectors follow this optimizer's parameter order -- re-save it with the current code")
+    mine = [(int(o), int(n), tuple(sh), nm) for o, n, sh, nm in mine]
+    theirs = [(int(o), int(n), tuple(sh), nm) for o, n, sh, nm in theirs]
+    same_shapes = [(o, n, sh) for o, n, sh, _ in mine] == [(o, n, sh) for o, n, sh, _ in theirs]
+    named_m, named_t = all(nm is not None for *_, nm in mine), all(nm is not None for *_, nm in theirs)
+    if same_shapes and (not (named_m and named_t) or [nm for *_, nm in mine] == [nm for *_, nm in theirs]):
+        return None
+    if named_m and named_t:
+        src = {nm: (o, n, sh) for o, n, sh, nm in theirs}
+        if set(src) != {nm for *_, nm in mine}:
+            raise ValueError("checkpoint and optimizer hold different parameter names: "
+                             f"{sorted(set(src) ^ {nm for *_, nm in mine})[:6]} ...")
+        moves = []
+        for o, n, sh, nm in mine:
+            so, sn, ssh = src[nm]
+            if (sn, ssh) != (n, sh):
+                raise ValueError(f"parameter {nm}: checkpoint shape {ssh} != {sh}")
+            moves.append((o, so, n))
+        return moves
+    raise ValueError("the checkpoint's parameter layout differs from this optimizer's and names are missing on one side: "
+                     "build both FusedAdamEMA objects with names= (or with the same parameter order)")
+
+
 class FusedAdamEMA:
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas: Tuple[float, float] = (0.9, 0.999),
                  eps: float = 1e-8, weight_decay: float = 0.0, ema_decay: Optional[float] = None,
                  ema_use_num_updates: bool = True, max_grad_norm: Optional[float] = None, skip_nonfinite: bool = False,
-                 max_steps_ahead: int = 2):
+                 max_steps_ahead: int = 2, names: Optional[Iterable[str]] = None):
+        """``names``: one name per entry of ``params`` (e.g. from ``model.named_parameters()``; ``named(model, order)`` builds
+        them): stored with ``state_dict()`` so that a checkpoint written under another parameter ORDER (``flat_param_order``
+        moves the radial MLPs to the tail) is re-mapped by name instead of silently permuting weights and moments."""
+        params = list(params)
+        if names is not None:
+            names = [n for n, p in zip(list(names), params) if p.requires_grad]
         self.params = [p for p in params if p.requires_grad]
+        self.names = names
+        if names is not None and (len(names) != len(self.params) or len(set(names)) != len(names)):
+            raise ValueError("names must be unique and match params one to one")
         if not self.params:
             raise ValueError("no trainable parameters")
         L.require_cuda(*self.params)
@@ -119,20 +156,38 @@ class FusedAdamEMA:
         finally:
             self.flat.copy_(saved)
 
+    def layout(self) -> list:
+        """[(offset, numel, shape, name or None)] of every parameter in the flat vectors -- the meaning of ``state_dict()``'s tensors."""
+        names = self.names if self.names is not None else [None] * len(self.params)
+        return [(int(o), int(p.numel()), tuple(p.shape), n) for p, o, n in zip(self.params, self.offsets, names)]
+
     def state_dict(self) -> dict:
-        return {"flat": self.flat.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
+        return {"layout": self.layout(), "flat": self.flat.clone(), "exp_avg": self.exp_avg.clone(), "exp_avg_sq": self.exp_avg_sq.clone(),
                 "ema": None if self.ema is None else self.ema.clone(), "state": self.state.clone(),
                 "hyper": dict(lr=self.lr, betas=self.betas, eps=self.eps, weight_decay=self.weight_decay,
                               ema_decay=self.ema_decay, ema_use_num_updates=self.ema_use_num_updates,
                               max_grad_norm=self.max_grad_norm, skip_nonfinite=self.skip_nonfinite)}
 
     def load_state_dict(self, sd: dict) -> None:
+        """The flat vectors carry no structure of their own: the checkpoint's ``layout`` must be this optimizer's (same
+        parameters in the same order), or both sides must carry names, in which case every slice is copied to where its
+        parameter lives here.  Anything else raises -- equal lengths do not make two layouts the same
+        (``flat_param_order(model)`` and ``model.parameters()`` hold the same tensors in different orders)."""
+        moves = layout_moves(self.layout(), sd.get("layout"))
+
+        def put(dst, src_t):
+            if moves is None:
+                dst.copy_(src_t)
+            else:
+                for o, so, n in moves:
+                    dst[o:o + n].copy_(src_t[so:so + n])
+
         with torch.no_grad():
-            self.flat.copy_(sd["flat"])
-            self.exp_avg.copy_(sd["exp_avg"])
-            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            put(self.flat, sd["flat"])
+            put(self.exp_avg, sd["exp_avg"])
+            put(self.exp_avg_sq, sd["exp_avg_sq"])
             if self.ema is not None and sd.get("ema") is not None:
-                self.ema.copy_(sd["ema"])
+                put(self.ema, sd["ema"])
             self.state.copy_(sd["state"])
         for k, v in sd.get("hyper", {}).items():
             setattr(self, k, v)

@@ -97,6 +97,13 @@ def flat_param_order(model: torch.nn.Module) -> list:
     return [p for p in model.parameters() if id(p) not in tail_ids] + tail
 
 
+def param_names(model: torch.nn.Module, params: Sequence[torch.nn.Parameter]) -> List[str]:
+    """``model.named_parameters()``'s name of every entry of ``params`` (``FusedAdamEMA(params, names=...)``: a checkpoint then
+    survives a change of the flat parameter order)."""
+    by_id = {id(p): n for n, p in model.named_parameters()}
+    return [by_id[id(p)] for p in params]
+
+
 class FlatGradients:
     """Points every ``p.grad`` at a slice of one contiguous buffer."""
 

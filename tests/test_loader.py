@@ -45,8 +45,12 @@ def test_prefetch_from_a_sample_list_and_without_drop_last():
     got = list(loader)
     assert [len(b) for b in got] == [4, 4, 2]
     _same(got[2], Batch.from_data_list([s.data for s in samples[8:]], dict(samples[0].attrs)))
+    # a split that cannot fill one batch fails when it is USED (as the reference's DataLoader does), not when it is built:
+    # getDataIters hands out an eval iterator for n_val = 0 that nobody may ever touch
+    short = iter(PrefetchLoader(samples, batch_size=16))
+    assert short.thread is None                    # no worker thread, no HIP stream before the first next()
     with pytest.raises(ValueError):
-        PrefetchLoader(samples, batch_size=16)
+        next(short)
 
 
 def test_endless_loader_resets_and_reshuffles():
