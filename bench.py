@@ -130,19 +130,89 @@ def cpu_baseline(budget_s):
     }
 
 
+def launch_ranks(args) -> int:
+    """``python bench.py --gpus N`` as given (no torchrun around it): this process touches no GPU -- it starts N FRESH rank
+    processes through ``python -m torch.distributed.run`` (one per GPU, rendezvous on 127.0.0.1, the reference's
+    ``torch.multiprocessing.spawn`` of ``train.py:272,280-304``), relays their output, and prints rank 0's JSON line ONCE, with
+    the CPU baseline of the same run (measured here, after the ranks have finished, so that it does not disturb their hosts'
+    launch rates) added to it.  A rank that fails makes the elastic agent end its siblings; the agent's exit code is ours."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["E3K_BENCH_CHILD"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
+    line = None
+    try:
+        for out in proc.stdout:
+            text = out.rstrip("\n")
+            if text.startswith("{") and '"metric"' in text:
+                line = text                      # rank 0's result: held back until the baseline has been added
+            else:
+                print(text, flush=True)
+        rc = proc.wait()
+    except BaseException:
+        proc.kill()                              # (exactly the process started here; the agent takes its ranks with it)
+        proc.wait()
+        raise
+    if rc != 0 or line is None:
+        if line is not None:
+            print(line, flush=True)
+        print(f"bench.py: the {args.gpus}-rank run failed (exit code {rc}" + ("" if line is not None else ", no result line") + ")",
+              file=sys.stderr, flush=True)
+        return rc if rc != 0 else 1
+    result = json.loads(line)
+    if not args.no_cpu_baseline and args.config == "energy" and os.environ.get("E3K_BENCH_DRY_RUN") is None:
+        result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
+    result.setdefault("config", {})["launcher"] = f"bench.py started {args.gpus} rank processes itself (torch.distributed.run, 127.0.0.1:{port})"
+    print(json.dumps(result), flush=True)
+    return 0
+
+
+def dry_run(args, world: int, rank: int) -> None:
+    """E3K_BENCH_DRY_RUN: the launcher's plumbing without a GPU (tests/test_parallel_gloo.py) -- the ranks rendezvous over gloo,
+    all-reduce one number and rank 0 prints a stub line; ``fail-rankK`` makes rank K exit with code 3 first."""
+    mode = os.environ["E3K_BENCH_DRY_RUN"]
+    if mode == f"fail-rank{rank}":
+        raise SystemExit(3)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        assert float(t) == world * (world + 1) / 2
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "dry-run", "value": 0.0, "unit": "molecules/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "config": {"workload": "launcher dry run (no GPU work)"}}), flush=True)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as `python bench.py --gpus N`: become the launcher BEFORE anything touches a GPU (fresh child processes only --
+        # a process that has initialised HIP must never be re-executed)
+        raise SystemExit(launch_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: start it as `python bench.py --gpus "
+                         f"{args.gpus}` (it launches its ranks itself) or under `python -m torch.distributed.run --nproc-per-node "
+                         f"{args.gpus} bench.py --gpus {args.gpus} ...`")
+    if os.environ.get("E3K_BENCH_DRY_RUN") is not None:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if args.gpus != world:
-        raise SystemExit(f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: start it as "
-                         f"`python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...`")
     # one process per GPU; E3K_DIST_BACKEND=gloo lets two ranks share one GPU to smoke-test the N>1 path
     backend = os.environ.get("E3K_DIST_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1)

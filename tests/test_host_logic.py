@@ -386,3 +386,30 @@ def test_batch_index_select_is_one_gather_per_tensor():
     first = b[1]["pos"].clone()
     sub = b[[1, 2]]
     assert torch.equal(sub[0]["pos"], first)
+
+
+def test_optimizer_checkpoint_layout_is_verified_or_remapped_by_name():
+    """``FusedAdamEMA.state_dict()`` used to hold bare flat vectors; a checkpoint written under
+    ``flat_param_order(model)`` loaded into an optimizer built from ``model.parameters()`` (same numel) silently permuted
+    weights and moments.  The layout now travels with the checkpoint: identical -> plain copy, named on both sides ->
+    re-mapped slice by slice, anything else raises."""
+    from e3_layers_amd.run.optim import layout_moves
+
+    a = [(0, 6, (2, 3), "w1"), (64, 4, (4,), "b"), (128, 6, (2, 3), "w2")]
+    assert layout_moves(a, list(a)) is None
+    # the same parameters in another order (what flat_param_order does to the radial MLPs)
+    b = [(0, 4, (4,), "b"), (64, 6, (2, 3), "w1"), (128, 6, (2, 3), "w2")]
+    assert layout_moves(a, b) == [(0, 64, 6), (64, 0, 4), (128, 128, 6)]
+    # same shapes at every position but the names say the order differs: re-mapped, not trusted
+    c = [(0, 6, (2, 3), "w2"), (64, 4, (4,), "b"), (128, 6, (2, 3), "w1")]
+    assert layout_moves(a, c) == [(0, 128, 6), (64, 64, 4), (128, 0, 6)]
+    unnamed = [(o, n, sh, None) for o, n, sh, _ in b]
+    with pytest.raises(ValueError):
+        layout_moves(a, unnamed)            # different layout, no names on one side
+    with pytest.raises(ValueError):
+        layout_moves(a, None)               # a pre-round-4 checkpoint
+    with pytest.raises(ValueError):
+        layout_moves(a, [(0, 6, (2, 3), "w1"), (64, 4, (4,), "b"), (128, 6, (2, 3), "other")])
+    with pytest.raises(ValueError):
+        layout_moves(a, [(0, 6, (3, 2), "w1"), (64, 4, (4,), "b"), (128, 6, (2, 3), "w2")][::-1])
+    assert layout_moves([(o, n, sh, None) for o, n, sh, _ in a], a) is None      # same order, names on one side only

@@ -194,3 +194,28 @@ def test_overlapped_all_reduce_sequence_does_not_depend_on_which_layers_report()
     for a, b in zip(g0, g1):
         assert torch.equal(a, b)
         assert torch.allclose(a * world, full, rtol=1e-5, atol=1e-6)
+
+
+def test_bench_launches_its_own_ranks():
+    """``python bench.py --gpus N`` must run as given.  Without WORLD_SIZE the script becomes a launcher
+    before anything touches a GPU: N fresh rank processes through torch.distributed.run, rank 0's JSON line relayed once, the
+    agent's exit code passed on.  Dry run (E3K_BENCH_DRY_RUN: gloo rendezvous + one all-reduce, no GPU work)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["E3K_BENCH_DRY_RUN"] = "1"
+    ok = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"], env=env,
+                        capture_output=True, text=True, timeout=240)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, ok.stdout                                   # ONE JSON line, printed by the launcher
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and "launcher" in res["config"]
+    env["E3K_BENCH_DRY_RUN"] = "fail-rank1"                              # a rank that dies: non-zero exit, no result line
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert bad.returncode != 0
+    assert not [l for l in bad.stdout.splitlines() if l.startswith("{")]
