@@ -639,10 +639,12 @@ def main():
         loader.close()
 
     # ---- roofline blocks (rank 0's launches in the timed region) ---------------------------------------------------
+    table_rows = radial_table.layout(float(getattr(tree, "r_max", 4.0)), radial_table.KNOTS)[0] + 1      # rows of a layer's knot table
+
     def in_kernel(e, plan):
         """This launch interpolated its path weights from the knot table inside the kernel (csrc/e3k_tp.hip TABLE forms)."""
         return bool(conv_native.TP_TABLE and radial_table.ENABLED and getattr(plan, "_e3k_table_form", False)
-                    and e >= radial_table.MIN_EDGES_PER_KNOT * (radial_table.KNOTS + 1))
+                    and e >= radial_table.MIN_EDGES_PER_KNOT * table_rows)
 
     def tp_bytes(kind, n, e, plan, variant="A"):
         """Algorithmic bytes of one launch.  Variant A = the module-API operation
@@ -651,7 +653,7 @@ def main():
         w_term = 4 * plan.w_numel
         extra = 0
         if variant == "B" and kind != "tp_bwd_w":
-            w_term, extra = 8, 4 * (radial_table.KNOTS + 1) * plan.w_numel      # bin + offset per edge; the table once
+            w_term, extra = 20, 4 * table_rows * plan.w_numel      # knot (4 B) + four interpolation weights (16 B) per edge; the table once
         if kind == "tp_fwd":        # x[src] gather + sh + w + out rows
             return e * (4 * plan.d_in + 4 * plan.d_sh + w_term + 16) + n * 4 * plan.d_mid + extra
         if kind == "tp_bwd_w":      # x[src] gather + sh + g_w stream + g_mid rows
@@ -680,7 +682,7 @@ def main():
                         "variant_B_avg_launch_algorithmic_MB": round(tot_bb / n / 1e6, 2),
                         "variant_B_frac": round(tot_bb / (tot_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                         "note": "in-kernel knot-table form: E x W is not streamed from HBM (L2 / Infinity-Cache gathers of a "
-                                f"<= {4 * (radial_table.KNOTS + 1) * max(m[2].w_numel for _, _, m in recs) / 1e6:.0f} MB table per layer); frac = SURVEY 8d variant A "
+                                f"<= {4 * table_rows * max(m[2].w_numel for _, _, m in recs) / 1e6:.1f} MB table per layer); frac = SURVEY 8d variant A "
                                 "bytes / time, variant_B_frac = the bytes this form must move / time -- the kernel is bound by "
                                 "cache-gather bandwidth, not by HBM"})
         return out

@@ -169,7 +169,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   if (r.have_rows) {      // the stack computed T (table) or w (per edge) already
     if (r.use_table && !(ABLATE & 8) && !in_kernel_table(d, r)) {
       Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
-      E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
+      E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_coef, r.E, r.knots, d.W, r.w, st));
     }
     return E3K_OK;
   }
@@ -184,7 +184,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   }
   if (r.use_table && !(ABLATE & 8) && !in_kernel_table(d, r)) {
     Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
-    E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_t, r.E, r.knots, d.W, r.w, st));
+    E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_coef, r.E, r.knots, d.W, r.w, st));
   }
   return E3K_OK;
 }
@@ -334,7 +334,7 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   {
     Timed t(L, E3K_PROF_TP_FWD, main, a->N, a->E);
     if (in_kernel_table(d, a->rad))
-      E3K_TRY(e3k_tp_fwd_table(d.tp, a->x1, a->sh, a->rad.T, a->rad.bin, a->rad.bin_t, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
+      E3K_TRY(e3k_tp_fwd_table(d.tp, a->x1, a->sh, a->rad.T, a->rad.bin, a->rad.bin_coef, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
                                a->mid, main));
     else
       E3K_TRY(e3k_tp_fwd(d.tp, a->x1, a->sh, a->rad.w, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->mid, main));
@@ -437,7 +437,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
     if (ABLATE & 32) {
     } else if (in_kernel_table(d, r)) {
-      E3K_TRY(e3k_tp_bwd_x_table(d.tp, a->sh, r.T, r.bin, r.bin_t, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+      E3K_TRY(e3k_tp_bwd_x_table(d.tp, a->sh, r.T, r.bin, r.bin_coef, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
     } else {
       E3K_TRY(e3k_tp_bwd_x(d.tp, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
     }
@@ -447,26 +447,10 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     E3K_TRY(weight_grads(true, true, side3));
     if (want_sc) E3K_TRY(keyed_weight_grads());
   }
-  // in-kernel table: the weight-gradient pass and the transposed interpolation are ONE kernel in knot order
-  // (e3k_tp_bwd_table_partial), on the radial stream; g_w[E, W] is neither written nor read
-  // (rad.in_kernel = 2; measured slower -- the gather in knot order has no molecule locality: 256 molecules 5.33 -> 5.75 ms --
-  //  so the binding asks for it only under E3K_BWD_T=1)
-  const bool fused_t = r.in_kernel >= 2 && need_radial_side && a->E > 0 && in_kernel_table(d, r) && a->table_ws && a->g_T;
-  if (fused_t) {
-    E3K_TRY(edge(L, 2, main, side));            // g_mid is complete (and tp_bwd_x has been issued)
-    {
-      Timed t(L, E3K_PROF_TP_BWD_W, side, a->N, a->E);
-      E3K_TRY(e3k_tp_bwd_table_partial(d.tp, a->x1, a->sh, a->g_mid, a->src, a->dst, r.bin_ptr, r.bin_perm, r.bin_t, a->N, a->E, r.knots,
-                                       a->table_ws, side));
-    }
-    E3K_TRY(e3k_rtable_bwd_combine(a->table_ws, r.knots, d.W, a->g_T, side));
-  }
   if (need_radial_side && a->E > 0) {
-    if (!a->g_w && !fused_t) return E3K_ERR_INVALID;
+    if (!a->g_w) return E3K_ERR_INVALID;
     const float* g_rows = a->g_w;                 // gradient of the MLP's output rows: per edge, or per knot behind the table
-    if (fused_t) {
-      g_rows = a->g_T;
-    } else {
+    {
     // the weight-gradient pass: on the radial stream BEHIND tp_bwd_x (both are memory streams: side by side they only
     // stretch each other), where it runs beside the GEMMs that follow on the main stream (this layer's linear_1 dgrad, the
     // previous layer's gate' and post-TP dgrad) -- nothing on the main stream waits for it
@@ -479,7 +463,9 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (wst == main) E3K_TRY(edge(L, 2, main, side));
     if (r.use_table) {
       Timed t(L, E3K_PROF_RTABLE_BWD, side, r.R, r.E);
-      if (!(ABLATE & 8)) E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_ptr, r.bin_perm, r.bin_t, r.E, r.knots, d.W, a->table_ws, a->g_T, side));
+      if (!(ABLATE & 8))
+        E3K_TRY(e3k_rtable_interp_bwd(a->g_w, r.bin_coef, nullptr, r.bin_ptr, r.bin_seg, r.bin_perm, r.E, r.knots, d.W, a->table_ws,
+                                      a->g_T, 0, side));
       g_rows = a->g_T;
     }
     }
@@ -559,7 +545,35 @@ extern "C" int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_la
   return E3K_OK;
 }
 
-extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, void* stream) {
+extern "C" int e3k_radial_slope_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, const e3k_slope_ctx* sl,
+                                    float* const* hp, float* const* D, void* stream) {
+  if (!layers || !rads || n <= 0 || n > 16 || !sl || !sl->knots || !sl->bessel_w || !hp || !D) return E3K_ERR_INVALID;
+  const e3k_layer_desc& d0 = layers[0]->d;
+  const int64_t R = rads[0].R;
+  if (R <= 0) return E3K_OK;
+  const float* wh[16 * 4] = {nullptr};
+  for (int i = 0; i < n; ++i) {
+    const e3k_layer_desc& d = layers[i]->d;
+    if (d.k0 != d0.k0 || d.h != d0.h || d.n_hidden != d0.n_hidden || d.act != d0.act || d.cst != d0.cst) return E3K_ERR_UNSUPPORTED;
+    for (int l = 0; l < d.n_hidden; ++l) {
+      if (d.alphas[l] != d0.alphas[l]) return E3K_ERR_UNSUPPORTED;
+      wh[i * 4 + l] = rads[i].w_hidden[l];
+    }
+    if (rads[i].R != R || !hp[i] || !D[i]) return E3K_ERR_INVALID;
+  }
+  E3K_TRY(e3k_slope_tangent_fwd(wh, n, d0.n_hidden, d0.alphas, sl->knots, R, sl->bessel_w, d0.k0, d0.h, sl->r_max, sl->r_min, sl->p,
+                                sl->one_over_r, sl->cutoff_kind, d0.act, d0.cst, hp, stream));
+  for (int base = 0; base < n; base += 4) {      // D_l = H'_l W_last_l: the layers' last-layer GEMMs, four per call
+    Seg g;
+    for (int i = base; i < n && i < base + 4; ++i) g.add(layers[i], LAST_FWD, hp[i], rads[i].w_last, D[i], R);
+    E3K_TRY(g.run(0, stream));
+  }
+  if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
+  return E3K_OK;
+}
+
+extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n,
+                                    const e3k_slope_ctx* sl, void* stream) {
   if (!layers || !items || n <= 0 || n > 16) return E3K_ERR_INVALID;
   const e3k_layer_desc& d0 = layers[0]->d;
   const int64_t R = items[0].rad.R;
@@ -573,9 +587,18 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
       if (items[i].gb_last && items[i].g_rows)
         g.add(layers[i], LAST_WGRAD, items[i].rad.h, items[i].gb_last, const_cast<float*>(items[i].g_rows), R);
     E3K_TRY(g.run(1, stream));
+    Seg gs;                                        // ... and through the slope table: gb_last += H'^T g_D
+    for (int i = base; i < n && i < base + 4; ++i)
+      if (items[i].gb_last && items[i].g_slope && items[i].hp)
+        gs.add(layers[i], LAST_WGRAD, items[i].hp, items[i].gb_last, const_cast<float*>(items[i].g_slope), R);
+    E3K_TRY(gs.run(1, stream));
   }
+  const float* sl_w[16 * 4] = {nullptr};      // the nets whose slope table received a gradient: the float64 reverse sweep
+  float* sl_g[16 * 4] = {nullptr};
+  const float* sl_ghp[16];
+  int n_adj = 0;
   for (int base = 0; base < n; base += 4) {        // their input gradients, then the hidden chains
-    Seg g;
+    Seg g, gsl;
     for (int i = base; i < n && i < base + 4; ++i) {
       const e3k_radial_stack_item& it = items[i];
       bool need_hidden = it.g_radial != nullptr;
@@ -583,6 +606,15 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
       if (!need_hidden || !it.g_rows) continue;
       if (!it.g_h) return E3K_ERR_INVALID;
       g.add(layers[i], LAST_DGRAD, it.g_rows, it.rad.w_last, it.g_h, R);
+      if (it.g_slope) {
+        if (!it.g_hp || !sl) return E3K_ERR_INVALID;
+        for (int l = 0; l < 4; ++l) {
+          sl_w[n_adj * 4 + l] = it.rad.w_hidden[l];
+          sl_g[n_adj * 4 + l] = it.gb_hidden[l];
+        }
+        sl_ghp[n_adj++] = it.g_hp;
+        gsl.add(layers[i], LAST_DGRAD, it.g_slope, it.rad.w_last, it.g_hp, R);
+      }
       e3k_mlp_net nt{};
       for (int l = 0; l < 4; ++l) {
         nt.weights[l] = it.rad.w_hidden[l];
@@ -594,6 +626,12 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
       nets[n_nets++] = nt;
     }
     E3K_TRY(g.run(0, stream));
+    E3K_TRY(gsl.run(0, stream));
+  }
+  if (n_adj) {    // the hidden weights' and Bessel frequencies' share of the slope tables' gradient (added into the same buffers)
+    if (!sl->acc || !sl->knots || !sl->bessel_w) return E3K_ERR_INVALID;
+    E3K_TRY(e3k_slope_tangent_bwd(sl_w, n_adj, d0.n_hidden, d0.alphas, sl->knots, R, sl->bessel_w, d0.k0, d0.h, sl->r_max, sl->r_min,
+                                  sl->p, sl->one_over_r, sl->cutoff_kind, d0.act, d0.cst, sl_ghp, sl->acc, sl_g, sl->g_bessel, stream));
   }
   if (n_nets)
     E3K_TRY(e3k_mlp_hidden_bwd_multi(nets, n_nets, items[0].rad.radial, R, d0.k0, d0.h, d0.n_hidden, d0.alphas, d0.act, d0.cst, stream));

@@ -5,17 +5,29 @@
 // when edge_radial is RadialBasisEncoding(edge_length) (e3_layers/nn/embedding.py:210-219): the per-edge path weights
 // are then a smooth function of ONE scalar, w[e, :] = f(r_e) with f = fc o basis o cutoff : [0, r_max] -> R^W.
 // The reference (and e3k_gemm) evaluates f per edge -- 2 * 64 * W flops per edge forward and twice that backward, the
-// largest block of matrix work of a training step.  Here f is evaluated on K + 1 equidistant knots (K = 4096: 17x fewer
-// rows than a 256-molecule batch has edges) by the same MLP kernels, and every edge interpolates the three knots around
-// it with the quadratic Lagrange weights
-//     i = round(r / h), t = r / h - i,   w[e] = t(t-1)/2 T[i-1] + (1 - t^2) T[i] + t(t+1)/2 T[i+1].
-// f is smooth (sines over r times a polynomial envelope through an MLP with ssp activations): the interpolation error is
-// ~h^3 f''' / 16 -- measured 5e-9 relative for K = 4096, below the 2.5e-8 rounding error of evaluating f in fp32
-// (tests/test_gpu_ops.py::test_radial_table_matches_the_per_edge_mlp).  r >= r_max maps to the last knot, where the
-// envelope (and every derivative up to the 5th) is zero: f is constant there, exactly.
-// The backward is the transpose: g_T[j] = sum over the edges whose stencil holds knot j of their weight times g_w[e] --
-// edges are sorted by centre knot once per batch (the CSR build of e3k_graph.hip with the knot as "node"), so row j is
-// a deterministic ordered sum over three consecutive bins; no atomics.  The MLP's own backward then runs on K + 1 rows.
+// largest block of matrix work of a training step.  Here f is evaluated on K + 1 equidistant knots by the same MLP kernels
+// and every edge interpolates the FOUR knots around it with the cubic Lagrange weights (round 4; rounds 2-3: three knots,
+// quadratic, on 2 048-4 096 knots)
+//     x = r / h, i = floor(x) clamped to [1, K - 2], t = x - i      (h = 2^-m: x and t are EXACT in fp32, and so are the knots k h),
+//     w[e] = c0(t) T[i-1] + c1(t) T[i] + c2(t) T[i+1] + c3(t) T[i+2],
+//     c0 = -t(t-1)(t-2)/6, c1 = (t+1)(t-1)(t-2)/2, c2 = -(t+1)t(t-2)/2, c3 = (t+1)t(t-1)/6.
+// Error 3/128 h^4 max|f''''| on values (h^3 max|f''''| / 12 on the slope dw/dr, which force training differentiates): the
+// same accuracy as the quadratic rule on 4x fewer knots, so the table the tensor-product kernels gather from
+// (e3k_tp_fwd_table: 4 rows per edge) is 4 MB instead of 14 and stays in an XCD's L2.  r >= r_max maps to x = K:
+// t = 2, weights (0, 0, 0, 1): the last knot, where the envelope and its first five derivatives vanish (f is constant).
+//
+// Every edge carries its four weights as data (coef [E, 4]): the kernels that consume a table -- interpolation, its
+// transpose, the tensor-product kernels -- are BILINEAR in (coef, T).  Force training needs dw/dr: differentiating the
+// weights (d coef / d r applied to T) amplifies the fp32 rounding of the table by 1 / h (measured: 7e-6 .. 4e-5 relative slope
+// error at any knot count), so the slope is its own table D = dT/dr on the knots (e3k_radial_slope_*: the hidden chain
+// re-evaluated in float64, differenced there, the last layer applied in fp32), interpolated with the SAME weights -- 5e-8.
+//
+// Edges are grouped by knot with a STABLE counting sort (ascending edge id inside a knot: the transposed interpolation
+// sums in a fixed order, no atomics, bit-identical run to run): one wave ranks a chunk of 1 024 edges against its own
+// histogram in LDS, one workgroup scans the (chunk x knot) counts, one thread per edge places it.  No per-row sort, so a
+// knot that holds thousands of edges (real molecules: C-H 1.09 A, C-C 1.52 A cluster in a handful of bins) costs what
+// any other edge costs; the transpose splits a knot's edges into segments of <= 64, one wave each, and combines the
+// segments' partial sums in order.
 #include "e3k_common.h"
 
 namespace e3k {
@@ -30,143 +42,273 @@ __device__ __forceinline__ float4 nt_load4(const float4* p) {
   return make_float4(t.x, t.y, t.z, t.w);
 }
 
-// centre knot and offset of every edge
-__global__ __launch_bounds__(256) void rtable_bin_kernel(const float* __restrict__ r, int64_t E, float h_inv, int32_t K,
-                                                         int64_t* __restrict__ bin2, float* __restrict__ t_out) {
-  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (e >= E) return;
-  float x = r[e] * h_inv;
-  x = x < 0.f ? 0.f : (x > (float)K ? (float)K : x);     // (NaN radii fall through to knot 1 with t = NaN: the weights are NaN)
-  int i = (int)(x + 0.5f);
-  i = i < 1 ? 1 : (i > K - 1 ? K - 1 : i);
-  bin2[e] = i;            // [2, E] int64 "edge_index" (both rows the knot): the CSR builder groups edges by centre knot
-  bin2[E + e] = i;
-  t_out[e] = x - (float)i;
+constexpr int RT_CHUNK = 1024;      // edges ranked by one wave
+constexpr int RT_SEG = 64;          // edges of one knot summed by one wave of the transpose
+
+// ---- pass 1: knot, weights, rank inside (chunk, knot), chunk histogram ------------------------------------------------
+// one wave per chunk of RT_CHUNK consecutive edges; LDS: one (K + 1)-entry histogram per wave
+__global__ __launch_bounds__(64) void rtable_bins_rank_kernel(const float* __restrict__ r, int64_t E, float h_inv, int32_t K,
+                                                              int32_t* __restrict__ bin, float* __restrict__ coef,
+                                                              int32_t* __restrict__ lrank,
+                                                              int32_t* __restrict__ chunk_hist) {
+  extern __shared__ int32_t hist[];
+  const int lane = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  for (int b = lane; b <= K; b += 64) hist[b] = 0;
+  __syncthreads();
+  const int64_t base = chunk * RT_CHUNK;
+  for (int it = 0; it < RT_CHUNK / 64; ++it) {
+    const int64_t e = base + it * 64 + lane;
+    const bool live = e < E;
+    int i = 1;
+    if (live) {
+      const float raw = r[e] * h_inv;
+      float x = raw < 0.f ? 0.f : (raw > (float)K ? (float)K : raw);      // (NaN radii stay NaN: NaN weights)
+      i = (int)x;
+      i = i < 1 ? 1 : (i > K - 2 ? K - 2 : i);
+      const float t = x - (float)i;
+      const float tm1 = t - 1.f, tm2 = t - 2.f, tp1 = t + 1.f;
+      float4 c;
+      c.x = -t * tm1 * tm2 * (1.f / 6.f);
+      c.y = tp1 * tm1 * tm2 * 0.5f;
+      c.z = -tp1 * t * tm2 * 0.5f;
+      c.w = tp1 * t * tm1 * (1.f / 6.f);
+      bin[e] = i;
+      *reinterpret_cast<float4*>(coef + 4 * e) = c;
+    }
+    // stable rank among the edges of the same knot seen so far in this chunk: the lanes of one knot are served together
+    unsigned long long todo = __ballot(live);
+    int rank = 0;
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int b = __shfl(i, leader, 64);
+      const unsigned long long same = __ballot(live && i == b) & todo;
+      const int seen = hist[b];                                // (uniform address: one LDS read, broadcast)
+      if (live && i == b) rank = seen + __popcll(same & ((1ull << lane) - 1ull));
+      if (lane == leader) hist[b] = seen + __popcll(same);
+      todo &= ~same;
+    }
+    if (live) lrank[e] = rank;
+  }
+  __syncthreads();
+  for (int b = lane; b <= K; b += 64) chunk_hist[chunk * (K + 1) + b] = hist[b];
 }
 
-// w[e, :] = c_-1 T[i-1, :] + c_0 T[i, :] + c_+1 T[i+1, :];  one wave per edge, 16-byte columns.  Edges are taken in
-// KNOT order (perm): the ~17 edges of a knot, handled by neighbouring waves, read the same three table rows, which
-// then come from L1/L2 instead of 23 KB per edge from the Infinity Cache (measured 255 -> see DESIGN.md us per layer).
+// ---- pass 2: one workgroup.  chunk_hist[c][b] -> number of edges of knot b in the chunks before c (in place);
+// ptr[b] = first position of knot b in knot order (ptr[K + 1] = E); seg[b] = first segment of knot b (RT_SEG edges each)
+__global__ __launch_bounds__(1024) void rtable_bins_scan_kernel(int32_t* __restrict__ chunk_hist, int32_t n_chunks, int32_t K,
+                                                                int32_t* __restrict__ ptr, int32_t* __restrict__ seg) {
+  __shared__ int32_t wave_tot[2][16];
+  __shared__ int32_t carry[2];
+  const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+  if (t < 2) carry[t] = 0;
+  __syncthreads();
+  for (int base = 0; base <= K; base += 1024) {
+    const int b = base + t;
+    int32_t cnt = 0;
+    if (b <= K) {
+      for (int c = 0; c < n_chunks; ++c) {
+        const int32_t v = chunk_hist[(int64_t)c * (K + 1) + b];
+        chunk_hist[(int64_t)c * (K + 1) + b] = cnt;
+        cnt += v;
+      }
+    }
+    const int32_t sg = (cnt + RT_SEG - 1) / RT_SEG;
+    int32_t x = cnt, y = sg;      // inclusive scans inside the wave
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int32_t xx = __shfl_up(x, off, 64), yy = __shfl_up(y, off, 64);
+      if (lane >= off) x += xx, y += yy;
+    }
+    if (lane == 63) wave_tot[0][w] = x, wave_tot[1][w] = y;
+    __syncthreads();
+    int32_t bx = carry[0], by = carry[1];
+    for (int k = 0; k < w; ++k) bx += wave_tot[0][k], by += wave_tot[1][k];
+    if (b <= K) {
+      ptr[b] = bx + x - cnt;
+      seg[b] = by + y - sg;
+      if (b == K) ptr[K + 1] = bx + x, seg[K + 1] = by + y;
+    }
+    __syncthreads();
+    if (t == 1023) carry[0] = bx + x, carry[1] = by + y;
+    __syncthreads();
+  }
+}
+
+// ---- pass 3: perm[position in knot order] = edge id
+__global__ __launch_bounds__(256) void rtable_bins_place_kernel(const int32_t* __restrict__ bin, const int32_t* __restrict__ lrank,
+                                                                const int32_t* __restrict__ chunk_off, const int32_t* __restrict__ ptr,
+                                                                int64_t E, int32_t K, int32_t* __restrict__ perm) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E) return;
+  const int b = bin[e];
+  perm[ptr[b] + chunk_off[(e / RT_CHUNK) * (K + 1) + b] + lrank[e]] = (int32_t)e;
+}
+
+// w[e, :] = sum_k coef[e, k] T[bin[e] - 1 + k, :];  one wave per edge, 16-byte columns.  Edges are taken in KNOT order
+// (perm): the edges of a knot, handled by neighbouring waves, read the same four table rows (L1 / L2 hits).
 __global__ __launch_bounds__(256) void rtable_interp_fwd_kernel(const float* __restrict__ T, const int32_t* __restrict__ perm,
-                                                                const int32_t* __restrict__ bin, const float* __restrict__ tt,
+                                                                const int32_t* __restrict__ bin, const float* __restrict__ coef,
                                                                 int64_t E, int32_t W, float* __restrict__ w) {
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= E) return;
   const int lane = threadIdx.x & 63;
   const int e = uniform(perm[p]);
   const int i = uniform(bin[e]);
-  const float t = __uint_as_float(uniform((int)__float_as_uint(tt[e])));
-  const float cm = 0.5f * t * (t - 1.f), c0 = 1.f - t * t, cp = 0.5f * t * (t + 1.f);
+  const float* __restrict__ cp = coef + 4 * (int64_t)e;
+  const float c0 = __uint_as_float(uniform((int)__float_as_uint(cp[0]))), c1 = __uint_as_float(uniform((int)__float_as_uint(cp[1])));
+  const float c2 = __uint_as_float(uniform((int)__float_as_uint(cp[2]))), c3 = __uint_as_float(uniform((int)__float_as_uint(cp[3])));
   const float4* __restrict__ a = reinterpret_cast<const float4*>(T + (int64_t)(i - 1) * W);
   const float4* __restrict__ b = reinterpret_cast<const float4*>(T + (int64_t)i * W);
   const float4* __restrict__ c = reinterpret_cast<const float4*>(T + (int64_t)(i + 1) * W);
+  const float4* __restrict__ d = reinterpret_cast<const float4*>(T + (int64_t)(i + 2) * W);
   float4* __restrict__ o = reinterpret_cast<float4*>(w + (int64_t)e * W);
   for (int q = lane; q < (W >> 2); q += 64) {
-    const float4 va = a[q], vb = b[q], vc = c[q];
-    float4 v;
-    v.x = fmaf(cp, vc.x, fmaf(c0, vb.x, cm * va.x));
-    v.y = fmaf(cp, vc.y, fmaf(c0, vb.y, cm * va.y));
-    v.z = fmaf(cp, vc.z, fmaf(c0, vb.z, cm * va.z));
-    v.w = fmaf(cp, vc.w, fmaf(c0, vb.w, cm * va.w));
+    const float4 va = a[q], vb = b[q], vc = c[q], vd = d[q];
+    float4 v;      // the order of e3k::knot_mix (csrc/e3k_tp.hip): the in-kernel form gives the same bits
+    v.x = fmaf(c3, vd.x, fmaf(c2, vc.x, fmaf(c1, vb.x, c0 * va.x)));
+    v.y = fmaf(c3, vd.y, fmaf(c2, vc.y, fmaf(c1, vb.y, c0 * va.y)));
+    v.z = fmaf(c3, vd.z, fmaf(c2, vc.z, fmaf(c1, vb.z, c0 * va.z)));
+    v.w = fmaf(c3, vd.w, fmaf(c2, vc.w, fmaf(c1, vb.w, c0 * va.w)));
     nt_store4(o + q, v);      // written once, read by the edge kernels later: streamed past the caches
   }
 }
 
-// backward, pass 1: one wave per (knot bin b, 256-column chunk) reads the g_w rows of the bin's edges ONCE (ascending edge
-// id) and forms their three weighted sums -- the contributions of bin b to the table rows b-1, b, b+1:  P[b][0..2][cols]
-__global__ __launch_bounds__(256) void rtable_bwd_partial_kernel(const float* __restrict__ gw, const int32_t* __restrict__ ptr,
-                                                                 const int32_t* __restrict__ perm, const float* __restrict__ tt,
-                                                                 int32_t K, int32_t W, int32_t n_chunks, float* __restrict__ P) {
+// backward, pass 1: one wave per (segment of <= RT_SEG edges of ONE knot b, 256-column chunk) reads the g_w rows of its edges
+// ONCE (ascending edge id) and forms their four weighted sums -- the segment's contributions to the table rows b-1 .. b+2:
+// P[segment][0..3][cols].  scale [E] (optional): every edge's weights are multiplied by scale[e] (force training: the slope
+// table's gradient is the transpose applied with the radius' cotangent as per-edge factor).
+__global__ __launch_bounds__(256) void rtable_bwd_partial_kernel(const float* __restrict__ gw, const float* __restrict__ coef,
+                                                                 const float* __restrict__ scale,
+                                                                 const int32_t* __restrict__ ptr, const int32_t* __restrict__ seg,
+                                                                 const int32_t* __restrict__ perm, int32_t K, int32_t W,
+                                                                 int32_t n_chunks, int64_t n_seg_cap, float* __restrict__ P) {
   const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (item >= (int64_t)(K + 1) * n_chunks) return;
-  const int b = (int)(item / n_chunks), chunk = (int)(item - (int64_t)b * n_chunks);
+  if (item >= n_seg_cap * n_chunks) return;
+  const int s = uniform((int)(item / n_chunks)), chunk = uniform((int)(item - (int64_t)s * n_chunks));
+  if (s >= uniform(seg[K + 1])) return;
+  int lo = 0, hi = K + 1;                     // the knot whose segment range holds s: seg[b] <= s < seg[b + 1]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (uniform(seg[mid]) <= s) lo = mid; else hi = mid;
+  }
+  const int b = lo;
   const int lane = threadIdx.x & 63;
   const int col = chunk * 256 + lane * 4;
   if (col >= W) return;
-  float4 am = make_float4(0.f, 0.f, 0.f, 0.f), a0 = am, ap = am;
-  const int beg = uniform(ptr[b]), end = uniform(ptr[b + 1]);
-  for (int p = beg; p < end; ++p) {
-    const int e = uniform(perm[p]);
-    const float t = __uint_as_float(uniform((int)__float_as_uint(tt[e])));
-    const float cm = 0.5f * t * (t - 1.f), c0 = 1.f - t * t, cp = 0.5f * t * (t + 1.f);
+  const int beg = uniform(ptr[b]) + (s - uniform(seg[b])) * RT_SEG;
+  const int end_b = uniform(ptr[b + 1]);
+  const int end = beg + RT_SEG < end_b ? beg + RT_SEG : end_b;
+  float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), a1 = a0, a2 = a0, a3 = a0;
+  auto add = [&](int e) {
+    const float* __restrict__ cp = coef + 4 * (int64_t)e;
+    float c0 = __uint_as_float(uniform((int)__float_as_uint(cp[0]))), c1 = __uint_as_float(uniform((int)__float_as_uint(cp[1])));
+    float c2 = __uint_as_float(uniform((int)__float_as_uint(cp[2]))), c3 = __uint_as_float(uniform((int)__float_as_uint(cp[3])));
+    if (scale) {
+      const float sc = __uint_as_float(uniform((int)__float_as_uint(scale[e])));
+      c0 *= sc; c1 *= sc; c2 *= sc; c3 *= sc;
+    }
     const float4 g = nt_load4(reinterpret_cast<const float4*>(gw + (int64_t)e * W + col));      // read once
-    am.x = fmaf(cm, g.x, am.x); am.y = fmaf(cm, g.y, am.y); am.z = fmaf(cm, g.z, am.z); am.w = fmaf(cm, g.w, am.w);
     a0.x = fmaf(c0, g.x, a0.x); a0.y = fmaf(c0, g.y, a0.y); a0.z = fmaf(c0, g.z, a0.z); a0.w = fmaf(c0, g.w, a0.w);
-    ap.x = fmaf(cp, g.x, ap.x); ap.y = fmaf(cp, g.y, ap.y); ap.z = fmaf(cp, g.z, ap.z); ap.w = fmaf(cp, g.w, ap.w);
+    a1.x = fmaf(c1, g.x, a1.x); a1.y = fmaf(c1, g.y, a1.y); a1.z = fmaf(c1, g.z, a1.z); a1.w = fmaf(c1, g.w, a1.w);
+    a2.x = fmaf(c2, g.x, a2.x); a2.y = fmaf(c2, g.y, a2.y); a2.z = fmaf(c2, g.z, a2.z); a2.w = fmaf(c2, g.w, a2.w);
+    a3.x = fmaf(c3, g.x, a3.x); a3.y = fmaf(c3, g.y, a3.y); a3.z = fmaf(c3, g.z, a3.z); a3.w = fmaf(c3, g.w, a3.w);
+  };
+  for (int p = beg; p < end; ++p) {
+    add(uniform(perm[p]));
   }
-  float* row = P + (int64_t)b * 3 * W + col;
-  *reinterpret_cast<float4*>(row) = am;
-  *reinterpret_cast<float4*>(row + W) = a0;
-  *reinterpret_cast<float4*>(row + 2 * W) = ap;
+  float* row = P + (int64_t)s * 4 * W + col;
+  *reinterpret_cast<float4*>(row) = a0;
+  *reinterpret_cast<float4*>(row + W) = a1;
+  *reinterpret_cast<float4*>(row + 2 * W) = a2;
+  *reinterpret_cast<float4*>(row + 3 * W) = a3;
 }
 
-// pass 2: g_T[j] = P[j+1][0] + P[j][1] + P[j-1][2]  (a fixed order: deterministic), one thread per 16 bytes
-__global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __restrict__ P, int32_t K, int32_t W,
-                                                                 float* __restrict__ gT) {
+// pass 2: g_T[j] (+)= sum_k sum over the segments of knot j + 1 - k of P[segment][k]  (a fixed order: deterministic),
+// one thread per 16 bytes
+__global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __restrict__ P, const int32_t* __restrict__ seg,
+                                                                 int32_t K, int32_t W, int32_t accumulate, float* __restrict__ gT) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int w4 = W >> 2;
   if (q >= (int64_t)(K + 1) * w4) return;
   const int j = (int)(q / w4), col = (int)(q - (int64_t)j * w4) * 4;
   float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto add = [&](int b, int slot) {
-    if (b < 1 || b > K - 1) return;       // only these bins hold edges
-    const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)b * 3 + slot) * W + col);
-    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-  };
-  add(j + 1, 0);
-  add(j, 1);
-  add(j - 1, 2);
-  *reinterpret_cast<float4*>(gT + (int64_t)j * W + col) = acc;
+  float4* out = reinterpret_cast<float4*>(gT + (int64_t)j * W + col);
+  if (accumulate) acc = *out;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int b = j + 1 - k;
+    if (b < 1 || b > K - 2) continue;       // only these knots hold edges
+    const int s0 = seg[b], s1 = seg[b + 1];
+    for (int s = s0; s < s1; ++s) {
+      const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)s * 4 + k) * W + col);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  *out = acc;
 }
 
 }  // namespace e3k
 
-extern "C" int e3k_rtable_bin(const float* r, int64_t E, float r_max, int32_t K, int64_t* bin2, float* t, void* stream) {
-  if (E < 0 || K < 4 || !(r_max > 0.f)) return E3K_ERR_INVALID;
-  if (E == 0) return E3K_OK;
-  if (!r || !bin2 || !t) return E3K_ERR_INVALID;
-  hipLaunchKernelGGL(e3k::rtable_bin_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, (hipStream_t)stream, r, E,
-                     (float)K / r_max, K, bin2, t);
+extern "C" int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K) {
+  const int64_t n_chunks = (E + e3k::RT_CHUNK - 1) / e3k::RT_CHUNK;
+  return E + n_chunks * ((int64_t)K + 1);      // [rank inside (chunk, knot) | chunk x knot counts -> offsets]
+}
+
+extern "C" int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
+                               int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
+  // h_inv = 1 / knot spacing; a power of two makes x = r * h_inv and the offset t = x - floor(x) exact (the caller's choice:
+  // backend/radial_table.py lays its tables out that way)
+  if (E < 0 || K < 4 || !(h_inv > 0.f)) return E3K_ERR_INVALID;
+  if (K > 16383 || E >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;      // (K + 1) int32 of LDS per wave
+  if (!bin_ptr || !bin_seg) return E3K_ERR_INVALID;
+  if (E > 0 && (!r || !bin || !coef || !bin_perm || !workspace)) return E3K_ERR_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t n_chunks = (E + e3k::RT_CHUNK - 1) / e3k::RT_CHUNK;
+  int32_t* lrank = workspace;
+  int32_t* chunk_hist = workspace + E;
+  if (E > 0)
+    hipLaunchKernelGGL(e3k::rtable_bins_rank_kernel, dim3((unsigned)n_chunks), dim3(64), sizeof(int32_t) * (K + 1), st, r, E,
+                       h_inv, K, bin, coef, lrank, chunk_hist);
+  hipLaunchKernelGGL(e3k::rtable_bins_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_hist, (int32_t)n_chunks, K, bin_ptr, bin_seg);
+  if (E > 0)
+    hipLaunchKernelGGL(e3k::rtable_bins_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, bin, lrank, chunk_hist,
+                       bin_ptr, E, K, bin_perm);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
 
-extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* t, int64_t E,
+extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E,
                                      int32_t K, int32_t W, float* w, void* stream) {
   if (E < 0 || K < 4 || W <= 0) return E3K_ERR_INVALID;
   if (W % 4) return E3K_ERR_UNSUPPORTED;
   if (E == 0) return E3K_OK;
-  if (!T || !bin_perm || !bin || !t || !w) return E3K_ERR_INVALID;
+  if (!T || !bin_perm || !bin || !coef || !w) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::rtable_interp_fwd_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T, bin_perm,
-                     bin, t, E, W, w);
+                     bin, coef, E, W, w);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }
 
-extern "C" int64_t e3k_rtable_bwd_workspace_floats(int32_t K, int32_t W) { return (int64_t)(K + 1) * 3 * W; }
+static inline int64_t rtable_seg_cap(int64_t E, int32_t K) { return E / e3k::RT_SEG + (int64_t)K + 2; }
 
-// second pass alone (the first one done elsewhere: e3k_tp_bwd_table_partial)
-extern "C" int e3k_rtable_bwd_combine(const float* P, int32_t K, int32_t W, float* g_T, void* stream) {
-  if (K < 4 || W <= 0 || !P || !g_T) return E3K_ERR_INVALID;
-  if (W % 4) return E3K_ERR_UNSUPPORTED;
-  const int64_t q = (int64_t)(K + 1) * (W / 4);
-  hipLaunchKernelGGL(e3k::rtable_bwd_combine_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, P, K, W, g_T);
-  E3K_CHECK_LAUNCH();
-  return E3K_OK;
-}
+extern "C" int64_t e3k_rtable_bwd_workspace_floats(int64_t E, int32_t K, int32_t W) { return rtable_seg_cap(E, K) * 4 * W; }
 
-extern "C" int e3k_rtable_interp_bwd(const float* g_w, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t,
-                                     int64_t E, int32_t K, int32_t W, float* workspace, float* g_T, void* stream) {
+extern "C" int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scale,
+                                     const int32_t* bin_ptr, const int32_t* bin_seg, const int32_t* bin_perm, int64_t E, int32_t K,
+                                     int32_t W, float* workspace, float* g_T, int32_t accumulate, void* stream) {
   if (E < 0 || K < 4 || W <= 0) return E3K_ERR_INVALID;
   if (W % 4) return E3K_ERR_UNSUPPORTED;
-  if (!g_T || !bin_ptr || !workspace || (E > 0 && (!g_w || !bin_perm || !t))) return E3K_ERR_INVALID;
+  if (!g_T || !bin_ptr || !bin_seg || !workspace || (E > 0 && (!g_w || !coef || !bin_perm))) return E3K_ERR_INVALID;
   const int n_chunks = (W + 255) / 256;
-  const int64_t items = (int64_t)(K + 1) * n_chunks;
+  const int64_t cap = rtable_seg_cap(E, K);
+  const int64_t items = cap * n_chunks;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(e3k::rtable_bwd_partial_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, g_w, bin_ptr, bin_perm,
-                     t, K, W, n_chunks, workspace);
+  hipLaunchKernelGGL(e3k::rtable_bwd_partial_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, st, g_w, coef, scale,
+                     bin_ptr, bin_seg, bin_perm, K, W, n_chunks, cap, workspace);
   const int64_t q = (int64_t)(K + 1) * (W / 4);
-  hipLaunchKernelGGL(e3k::rtable_bwd_combine_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, workspace, K, W, g_T);
+  hipLaunchKernelGGL(e3k::rtable_bwd_combine_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, st, workspace, bin_seg, K, W,
+                     accumulate, g_T);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

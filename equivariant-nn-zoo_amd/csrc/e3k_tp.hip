@@ -69,34 +69,52 @@ __device__ __forceinline__ void load_y_full(YRegs& y, const float* __restrict__ 
   for (int j = 0; j < 5; ++j) y.y2[j] = yr[4 + j];
 }
 
-// TABLE: the edge's path weights are not read from w[e] but interpolated here from the three rows of the radial knot
-// table around the edge's radius (same weights, same order of operations as rtable_interp_fwd_kernel): w[E, W] is never
-// written or read; the table (11-19 MB a layer) is served by L2 / the Infinity Cache.
+// MODE 1 (table): the edge's path weights are not read from w[e] but interpolated here from the four rows of the radial knot
+// table around the edge's radius with the edge's weights coef[e, 0..3] (same products, same order as
+// rtable_interp_fwd_kernel): w[E, W] is never written or read; the table (2-4 MB a layer) is served by L2.
+// MODE 2 (table, second-order forms of force training): a second operand set (x2, sh2, s2) rides along and the kernel forms
+// the sum of the three terms in which exactly one of (x, sh, w) is replaced by its partner -- x2, sh2, and s2[e] * dw/dr[e]
+// with dw/dr interpolated from the slope table D (a.w2) by the same four weights: the derivative of the trilinear product
+// along (x2, sh2, s2 in r) -- in one walk over the edges instead of three.
 struct KnotRows {
-  __amdgpu_buffer_rsrc_t ra, rb, rc;
-  float cm, c0, cp;
+  __amdgpu_buffer_rsrc_t ra, rb, rc, rd;
+  float c0, c1, c2, c3;
 };
-__device__ __forceinline__ KnotRows knot_rows(const TpArgs& a, int e, int row_w) {
+struct KnotRows2 {      // the same four rows of the slope table
+  __amdgpu_buffer_rsrc_t ra, rb, rc, rd;
+};
+__device__ __forceinline__ KnotRows2 knot_rows2(const TpArgs& a, int e, int row_w) {
   const int i = uniform(a.bin[e]);
-  const float t = __uint_as_float(uniform((int)__float_as_uint(a.tt[e])));
+  const float* __restrict__ base = a.w2 + (int64_t)(i - 1) * a.W;
+  KnotRows2 k;
+  k.ra = row_rsrc(base, row_w);
+  k.rb = row_rsrc(base + a.W, row_w);
+  k.rc = row_rsrc(base + 2 * a.W, row_w);
+  k.rd = row_rsrc(base + 3 * a.W, row_w);
+  return k;
+}
+__device__ __forceinline__ float sload(const float* __restrict__ p) { return __uint_as_float(uniform((int)__float_as_uint(*p))); }
+__device__ __forceinline__ KnotRows knot_rows(const TpArgs& a, const float* __restrict__ coef, int e, int row_w) {
+  const int i = uniform(a.bin[e]);
   const float* __restrict__ base = a.w + (int64_t)(i - 1) * a.W;
+  const float* __restrict__ cp = coef + 4 * (int64_t)e;
   KnotRows k;
   k.ra = row_rsrc(base, row_w);
   k.rb = row_rsrc(base + a.W, row_w);
   k.rc = row_rsrc(base + 2 * a.W, row_w);
-  k.cm = 0.5f * t * (t - 1.f);
-  k.c0 = 1.f - t * t;
-  k.cp = 0.5f * t * (t + 1.f);
+  k.rd = row_rsrc(base + 3 * a.W, row_w);
+  k.c0 = sload(cp); k.c1 = sload(cp + 1); k.c2 = sload(cp + 2); k.c3 = sload(cp + 3);
   return k;
 }
-__device__ __forceinline__ float knot_mix(const KnotRows& k, float va, float vb, float vc) {
-  return fmaf(k.cp, vc, fmaf(k.c0, vb, k.cm * va));
+__device__ __forceinline__ float knot_mix(float c0, float c1, float c2, float c3, float va, float vb, float vc, float vd) {
+  return fmaf(c3, vd, fmaf(c2, vc, fmaf(c1, vb, c0 * va)));
 }
 
-template <int L1, int L3MAX, bool TABLE, int PART>
+template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
+  constexpr bool TABLE = MODE >= 1, JVP = MODE == 2;
   const int u4 = u * 4;
   const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
   int woff4[S::NQ];
@@ -114,25 +132,41 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
   for (int t = beg; t < end; ++t) {
     const int e = uniform(a.perm[t]);
     const int s = uniform(a.nbr[e]);
-    YRegs yc;
+    YRegs yc, y2;
     load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    if constexpr (JVP) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
-    float xc[D1], wc[S::NQ];
+    float xc[D1], x2c[JVP ? D1 : 1], wc[S::NQ], w2[JVP ? S::NQ : 1];
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+    if constexpr (JVP) {
+      const __amdgpu_buffer_rsrc_t rx2 = row_rsrc(a.x2 + (int64_t)s * a.d_in, row_x);
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x2c[i] = buf_ld(rx2, u4, xoff4 + i * mul4);
+    }
     if constexpr (TABLE) {
-      const KnotRows kr = knot_rows(a, e, row_w);
-      float wa[S::NQ], wb[S::NQ], wcc[S::NQ];
+      const KnotRows kr = knot_rows(a, a.coef, e, row_w);
+      float wa[S::NQ], wb[S::NQ], wcc[S::NQ], wd[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         wa[Q] = buf_ld(kr.ra, u4, woff4[Q]);
         wb[Q] = buf_ld(kr.rb, u4, woff4[Q]);
         wcc[Q] = buf_ld(kr.rc, u4, woff4[Q]);
+        wd[Q] = buf_ld(kr.rd, u4, woff4[Q]);
       });
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        wc[Q] = knot_mix(kr, wa[Q], wb[Q], wcc[Q]);
+        wc[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, wa[Q], wb[Q], wcc[Q], wd[Q]);
       });
+      if constexpr (JVP) {
+        const KnotRows2 k2 = knot_rows2(a, e, row_w);
+        const float sc = sload(a.s2 + e);
+        slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          w2[Q] = sc * knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(k2.ra, u4, woff4[Q]), buf_ld(k2.rb, u4, woff4[Q]),
+                                buf_ld(k2.rc, u4, woff4[Q]), buf_ld(k2.rd, u4, woff4[Q]));
+        });
+      }
     } else {
       const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -146,8 +180,18 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
       const float wv = wc[Q] * cf[Q];
       float tt[2 * L3 + 1];
       CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+      if constexpr (JVP) {
+        // d/d(eps) [ w(r + eps s2) * xy(x + eps x2, y + eps y2) ] at eps = 0
+        const float wv2 = w2[Q] * cf[Q];
+        float ta[2 * L3 + 1], tb[2 * L3 + 1];
+        CG<L1, L2, L3>::xy(x2c, yref<L2>(yc), ta);
+        CG<L1, L2, L3>::xy(xc, yref<L2>(y2), tb);
 #pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
+        for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, ta[k] + tb[k], fmaf(wv2, tt[k], acc[OFF + k]));
+      } else {
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
+      }
     });
   }
   float* __restrict__ orow = a.out + (int64_t)node * a.d_mid;
@@ -159,11 +203,11 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
   });
 }
 
-template <int L1, int L3MAX, bool TABLE, int PART, bool FULL>
+template <int L1, int L3MAX, int MODE, int PART, bool FULL>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  static_assert(FULL || !TABLE, "the table form exists for FULL plans only");
+  static_assert(FULL || MODE == 0, "the table forms exist for FULL plans only");
   if constexpr (FULL) {
-    tp_fwd_body_full<L1, L3MAX, TABLE, PART>(a, g, node, u);
+    tp_fwd_body_full<L1, L3MAX, MODE, PART>(a, g, node, u);
     return;
   }
   using S = Slots<L1>;
@@ -219,10 +263,67 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 }
 
 // ------------------------------------------------------------------------------------------
+// nine (sh) or four (coef) per-lane partials -> wave totals added to a row of g_sh / g_coef by ONE wave instruction.
+// A butterfly that halves the value set at every level (each lane keeps the half its partner discards) needs
+// 5+3+2+1+1+1 = 13 cross-lane moves for nine values instead of 9 x 6, and leaves value `idx` on the lanes whose upper bits
+// spell idx.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void wave_add9(const float (&v9)[9], float* __restrict__ row, const int32_t* y_off) {
+  const int lane = threadIdx.x & 63;
+  int idx = 0;
+  const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
+  float l5[5], l3[3], l2[2];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    const float hi = i + 5 < 9 ? v9[i + 5] : 0.0f;
+    const float recv = __shfl_xor(b5 ? v9[i] : hi, 32, 64);
+    l5[i] = (b5 ? hi : v9[i]) + recv;
+  }
+  idx += b5 ? 5 : 0;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float hi = i + 3 < 5 ? l5[i + 3] : 0.0f;
+    const float recv = __shfl_xor(b4 ? l5[i] : hi, 16, 64);
+    l3[i] = (b4 ? hi : l5[i]) + recv;
+  }
+  idx += b4 ? 3 : 0;
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const float hi = i + 2 < 3 ? l3[i + 2] : 0.0f;
+    const float recv = __shfl_xor(b3 ? l3[i] : hi, 8, 64);
+    l2[i] = (b3 ? hi : l3[i]) + recv;
+  }
+  idx += b3 ? 2 : 0;
+  float tot = (b2 ? l2[1] : l2[0]) + __shfl_xor(b2 ? l2[0] : l2[1], 4, 64);
+  idx += b2 ? 1 : 0;
+  tot += __shfl_xor(tot, 2, 64);
+  tot += __shfl_xor(tot, 1, 64);
+  // which of the nine values this lane holds: the halving tree over (5|4) -> (3|2) -> (2|1) -> (1|1);
+  // paths that step into padding carry zeros and are skipped
+  // valid index sets: b5=0: counts 5 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
+  //                              b4=1: 2 -> b3=0: 2 -> b2: 1|1 ; b3=1: 0 (padding)
+  //                   b5=1: counts 4 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
+  //                              b4=1: 1 -> b3=0: 1 -> b2=0 only ; b3=1: padding
+  bool valid;
+  if (!b4) valid = !b3 || !b2;
+  else if (!b5) valid = !b3;
+  else valid = !b3 && !b2;
+  if (valid && (lane & 3) == 0) {
+    int off = -1;
+    if (idx == 0) off = y_off[0];
+    else if (idx < 4) off = y_off[1] >= 0 ? y_off[1] + (idx - 1) : -1;
+    else off = y_off[2] >= 0 ? y_off[2] + (idx - 4) : -1;
+    if (off >= 0) atomicAdd(row + off, tot);
+  }
+}
+// ------------------------------------------------------------------------------------------
 // backward wrt the per-edge weights (and optionally the spherical harmonics)
 // ------------------------------------------------------------------------------------------
-template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL>
+// DUAL (FULL plans, no g_sh): the weight gradient of the product's derivative along (x2, sh2) --
+//   g_w[e] = coeff * <g_mid[dst], xy(x2[src], sh) + xy(x[src], sh2)> -- one of the second-order terms of force training.
+template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL, bool DUAL = false>
 __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  static_assert(!DUAL || (FULL && !WITH_SH), "the dual form is built for channel-complete plans, weight gradient only");
   // (the buffer-addressed form of tp_fwd / tp_bwd_x was tried here too: 71 instead of 60 VGPRs, 7 instead of 8 waves per SIMD,
   //  the step 3-5 % slower -- this kernel keeps the flat row pointers; it has no scalar-register spills to begin with)
   using S = Slots<L1>;
@@ -247,12 +348,18 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
   for (int t = beg; t < end; ++t) {
     const int e = uniform(a.perm[t]);
     const int s = uniform(a.nbr[e]);
-    YRegs yc;
+    YRegs yc, y2;
     load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
     const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform
-    float xc[D1];
+    float xc[D1], x2c[DUAL ? D1 : 1];
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
+    if constexpr (DUAL) {
+      load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
+      const float* __restrict__ x2r = a.x2 + (int64_t)s * a.d_in + g.x_off;
+#pragma unroll
+      for (int i = 0; i < D1; ++i) x2c[i] = (x2r + i * mul)[u];
+    }
     float* __restrict__ gwr = a.g_w + (int64_t)e * a.W;
     const float* __restrict__ wr = a.w + (int64_t)e * a.W;
     YRegs gy;
@@ -268,7 +375,15 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
       if (FULL || (mask & (1u << Q))) {
         float tt[2 * L3 + 1], gk[2 * L3 + 1];
-        CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+        if constexpr (DUAL) {
+          float tb[2 * L3 + 1];
+          CG<L1, L2, L3>::xy(x2c, yref<L2>(yc), tt);
+          CG<L1, L2, L3>::xy(xc, yref<L2>(y2), tb);
+#pragma unroll
+          for (int k = 0; k < 2 * L3 + 1; ++k) tt[k] += tb[k];
+        } else {
+          CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
+        }
         float dot = 0.0f;
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) {
@@ -283,147 +398,124 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
       }
     });
     if constexpr (WITH_SH) {
-      // nine per-lane partials (l2 = 0, 1, 2 components) -> nine wave totals.  A butterfly that halves the value
-      // set at every level (each lane keeps the half its partner discards) needs 5+3+2+1+1+1 = 13 cross-lane
-      // moves instead of 9 x 6, and leaves value `idx` on the lanes whose upper bits spell idx: the nine sums are
-      // added to grad_sh by ONE wave instruction with nine active lanes.
-      float* __restrict__ gsr = a.g_sh + (int64_t)e * a.d_sh;
-      const int lane = threadIdx.x & 63;
       float v9[9];
       v9[0] = gy.y0[0];
 #pragma unroll
       for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
-      int idx = 0;
-      const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
-      float l5[5], l3[3], l2[2];
-#pragma unroll
-      for (int i = 0; i < 5; ++i) {
-        const float hi = i + 5 < 9 ? v9[i + 5] : 0.0f;
-        const float recv = __shfl_xor(b5 ? v9[i] : hi, 32, 64);
-        l5[i] = (b5 ? hi : v9[i]) + recv;
-      }
-      idx += b5 ? 5 : 0;
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const float hi = i + 3 < 5 ? l5[i + 3] : 0.0f;
-        const float recv = __shfl_xor(b4 ? l5[i] : hi, 16, 64);
-        l3[i] = (b4 ? hi : l5[i]) + recv;
-      }
-      idx += b4 ? 3 : 0;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const float hi = i + 2 < 3 ? l3[i + 2] : 0.0f;
-        const float recv = __shfl_xor(b3 ? l3[i] : hi, 8, 64);
-        l2[i] = (b3 ? hi : l3[i]) + recv;
-      }
-      idx += b3 ? 2 : 0;
-      float tot = (b2 ? l2[1] : l2[0]) + __shfl_xor(b2 ? l2[0] : l2[1], 4, 64);
-      idx += b2 ? 1 : 0;
-      tot += __shfl_xor(tot, 2, 64);
-      tot += __shfl_xor(tot, 1, 64);
-      // which of the nine values this lane holds: the halving tree over (5|4) -> (3|2) -> (2|1) -> (1|1);
-      // paths that step into padding carry zeros and are skipped
-      // valid index sets: b5=0: counts 5 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
-      //                              b4=1: 2 -> b3=0: 2 -> b2: 1|1 ; b3=1: 0 (padding)
-      //                   b5=1: counts 4 -> b4=0: 3 -> b3=0: 2 -> b2: 1|1 ; b3=1: 1 -> b2=0 only
-      //                              b4=1: 1 -> b3=0: 1 -> b2=0 only ; b3=1: padding
-      bool valid;
-      if (!b4) valid = !b3 || !b2;
-      else if (!b5) valid = !b3;
-      else valid = !b3 && !b2;
-      if (valid && (lane & 3) == 0) {
-        int off = -1;
-        if (idx == 0) off = g.y_off[0];
-        else if (idx < 4) off = g.y_off[1] >= 0 ? g.y_off[1] + (idx - 1) : -1;
-        else off = g.y_off[2] >= 0 ? g.y_off[2] + (idx - 4) : -1;
-        if (off >= 0) atomicAdd(gsr + off, tot);
-      }
+      wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, g.y_off);
     }
   }
 }
 
 // ------------------------------------------------------------------------------------------
-// backward wrt the radial knot table, with NO per-edge weight gradient in memory: a wave = (knot bin, group, chunk) walks
-// the bin's edges (CSR by knot, ascending edge id), forms every edge's weight gradient g_w[e] in registers exactly as
-// tp_bwd_w does (x[src] and g_mid[dst] gathered per edge: there is no destination locality in knot order) and accumulates
-// the bin's three interpolation-weighted sums -- what rtable_bwd_partial_kernel computes from g_w[E, W] after tp_bwd_w
-// wrote it.  Same products, same order: P (and g_T after the combine pass) are bit-identical to that pair.
+// backward wrt the edge quantities with the path weights on the knot table (the FIRST backward of a force evaluation:
+// d E / d pos flows through the spherical harmonics and through the radius, i.e. the interpolation weights):
+//   g_sh[e, :] += d/d sh <g_mid[dst], TP(x[src], sh, w[e])>                 (nine values per edge), w[e] = sum_k coef[e,k] T[..]
+//   g_r[e]     += sum_c g_w[e, c] dw/dr[e, c], dw/dr[e] = sum_k coef[e,k] D[..] (one value per edge; g_w stays in registers)
+// and, when asked (g_w != NULL), the per-edge weight gradient itself.  Same walk as tp_bwd_w (per destination node, the node's
+// gradient rows resident).  D is the slope of the table on the knots (the radial MLP's forward-mode derivative, evaluated
+// where rounding cannot hurt it: differentiating the fp32 table itself amplifies its rounding by 1 / knot spacing).
 // ------------------------------------------------------------------------------------------
 template <int L1, int L3MAX, int PART>
-__device__ __forceinline__ void tp_bwd_t_body_full(const TpArgs& a, const e3k_tp_group& g, const int bin, const int u) {
+__device__ __forceinline__ void tp_bwd_e_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int u4 = u * 4;
   const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
-  int goff4[S::NQ], gstr4[S::NQ];
-  float cf[S::NQ], am[S::NQ], a0[S::NQ], ap[S::NQ];
-  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-    constexpr int Q = decltype(qc)::value;
-    goff4[Q] = uniform(g.out_off[Q] * 4);
-    gstr4[Q] = uniform(g.out_stride[Q] * 4);
-    cf[Q] = g.coeff[Q];
-    am[Q] = a0[Q] = ap[Q] = 0.0f;
-  });
-  const int row_x = a.d_in * 4, row_g = a.d_mid * 4;
-  const int beg = uniform(a.ptr[bin]), end = uniform(a.ptr[bin + 1]);
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int s = uniform(a.nbr[e]), d = uniform(a.nbr2[e]);
-    YRegs yc;
-    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
-    const float tv = __uint_as_float(uniform((int)__float_as_uint(a.tt[e])));
-    const float cm = 0.5f * tv * (tv - 1.f), c0 = 1.f - tv * tv, cp = 0.5f * tv * (tv + 1.f);
-    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
-    const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
-    float xc[D1], gn[S::TOTAL];
-#pragma unroll
-    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+  int woff4[S::NQ];
+  float cf[S::NQ];
+  float go[S::TOTAL];
+  {
+    const float* __restrict__ grow = a.g_out + (int64_t)node * a.d_mid;      // wave-uniform
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+      woff4[Q] = uniform(g.w_off[Q] * 4);
+      cf[Q] = g.coeff[Q];
 #pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+      for (int k = 0; k < 2 * L3 + 1; ++k) go[OFF + k] = (grow + g.out_off[Q] + k * g.out_stride[Q])[u];
     });
-    __builtin_amdgcn_sched_barrier(0);
+  }
+  const int row_x = a.d_in * 4, row_w = a.W * 4;
+  const int y_off[3] = {0, 1, 4};
+  const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  for (int t = beg; t < end; ++t) {
+    const int e = uniform(a.perm[t]);
+    const int s = uniform(a.nbr[e]);
+    YRegs yc;
+    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
+    const KnotRows kr = knot_rows(a, a.coef, e, row_w);
+    float xc[D1];
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
+    const KnotRows2 k2 = knot_rows2(a, e, row_w);
+    float wv_[S::NQ], dv_[S::NQ];
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      wv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(kr.ra, u4, woff4[Q]), buf_ld(kr.rb, u4, woff4[Q]),
+                        buf_ld(kr.rc, u4, woff4[Q]), buf_ld(kr.rd, u4, woff4[Q]));
+      dv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(k2.ra, u4, woff4[Q]), buf_ld(k2.rb, u4, woff4[Q]),
+                        buf_ld(k2.rc, u4, woff4[Q]), buf_ld(k2.rd, u4, woff4[Q]));
+    });
+    YRegs gy;
+    gy.y0[0] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) gy.y1[j] = 0.0f;
+#pragma unroll
+    for (int j = 0; j < 5; ++j) gy.y2[j] = 0.0f;
+    float gr = 0.f;
+    float* __restrict__ gwr = a.g_w ? a.g_w + (int64_t)e * a.W : nullptr;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
-      float tt[2 * L3 + 1];
+      float tt[2 * L3 + 1], gk[2 * L3 + 1];
       CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
       float dot = 0.0f;
 #pragma unroll
-      for (int k = 0; k < 2 * L3 + 1; ++k) dot = fmaf(gn[OFF + k], tt[k], dot);
+      for (int k = 0; k < 2 * L3 + 1; ++k) {
+        gk[k] = go[OFF + k];
+        dot = fmaf(gk[k], tt[k], dot);
+      }
       const float gw = dot * cf[Q];
-      am[Q] = fmaf(cm, gw, am[Q]);
-      a0[Q] = fmaf(c0, gw, a0[Q]);
-      ap[Q] = fmaf(cp, gw, ap[Q]);
+      if (gwr) E3K_STREAM_STORE(gw, (gwr + g.w_off[Q]) + u);
+      gr = fmaf(gw, dv_[Q], gr);
+      CG<L1, L2, L3>::xg(xc, gk, wv_[Q] * cf[Q], yref<L2>(gy));
     });
+    if (a.g_sh) {
+      float v9[9];
+      v9[0] = gy.y0[0];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
+      wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off);
+    }
+    if (a.g_r) {
+      gr = wave_sum(gr);
+      if ((threadIdx.x & 63) == 0) atomicAdd(a.g_r + e, gr);
+    }
   }
-  float* __restrict__ prow = a.g_w + (int64_t)bin * 3 * a.W;
-  slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-    constexpr int Q = decltype(qc)::value;
-    float* __restrict__ c = prow + g.w_off[Q];
-    c[u] = am[Q];
-    (c + a.W)[u] = a0[Q];
-    (c + 2 * a.W)[u] = ap[Q];
-  });
 }
 
 template <int L1, int L3MAX, int PART, bool FULL>
-__device__ __forceinline__ void tp_bwd_t_body(const TpArgs& a, const e3k_tp_group& g, const int bin, const int u) {
-  static_assert(FULL, "the knot-order backward exists for channel-complete plans only");
-  tp_bwd_t_body_full<L1, L3MAX, PART>(a, g, bin, u);
+__device__ __forceinline__ void tp_bwd_e_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  static_assert(FULL, "the table-form edge backward exists for channel-complete plans only");
+  tp_bwd_e_body_full<L1, L3MAX, PART>(a, g, node, u);
 }
 
 // ------------------------------------------------------------------------------------------
 // backward wrt the node features: walk the out-edges of a source node
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX, bool TABLE, int PART>
+// MODE 0: w streamed; 1: w interpolated from the knot table; 2 (table, DUAL): g_x = yg(sh2, g, w) + yg(sh, g, s2 * dw/dr) --
+// the node-feature gradient of the product's derivative along (sh2, s2 in r) (second-order term of force training)
+template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
+  constexpr bool TABLE = MODE >= 1, DUAL = MODE == 2;
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -443,13 +535,14 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   for (int t = beg; t < end; ++t) {
     const int e = uniform(a.perm[t]);
     const int d = uniform(a.nbr[e]);
-    YRegs yc;
+    YRegs yc, y2;
     load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
-    float gn[S::TOTAL], wn[S::NQ];
+    float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
     if constexpr (TABLE) {
-      const KnotRows kr = knot_rows(a, e, row_w);
-      float wa[S::NQ], wb[S::NQ], wcc[S::NQ];
+      const KnotRows kr = knot_rows(a, a.coef, e, row_w);
+      float wa[S::NQ], wb[S::NQ], wcc[S::NQ], wd[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
         constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
@@ -459,12 +552,22 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
         wa[Q] = buf_ld(kr.ra, u4, woff4[Q]);
         wb[Q] = buf_ld(kr.rb, u4, woff4[Q]);
         wcc[Q] = buf_ld(kr.rc, u4, woff4[Q]);
+        wd[Q] = buf_ld(kr.rd, u4, woff4[Q]);
       });
       __builtin_amdgcn_sched_barrier(0);
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        wn[Q] = knot_mix(kr, wa[Q], wb[Q], wcc[Q]);
+        wn[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, wa[Q], wb[Q], wcc[Q], wd[Q]);
       });
+      if constexpr (DUAL) {
+        const KnotRows2 k2 = knot_rows2(a, e, row_w);
+        const float sc = sload(a.s2 + e);
+        slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          w2[Q] = sc * knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(k2.ra, u4, woff4[Q]), buf_ld(k2.rb, u4, woff4[Q]),
+                                buf_ld(k2.rc, u4, woff4[Q]), buf_ld(k2.rd, u4, woff4[Q]));
+        });
+      }
     } else {
       const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -483,7 +586,12 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
       float gk[2 * L3 + 1];
 #pragma unroll
       for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
-      CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
+      if constexpr (DUAL) {
+        CG<L1, L2, L3>::yg(yref<L2>(y2), gk, wn[Q] * cf[Q], gx);
+        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, w2[Q] * cf[Q], gx);
+      } else {
+        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
+      }
     });
   }
   float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
@@ -494,11 +602,11 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   }
 }
 
-template <int L1, int L3MAX, bool TABLE, int PART, bool FULL>
+template <int L1, int L3MAX, int MODE, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  static_assert(FULL || !TABLE, "the table form exists for FULL plans only");
+  static_assert(FULL || MODE == 0, "the table forms exist for FULL plans only");
   if constexpr (FULL) {
-    tp_bwd_x_body_full<L1, L3MAX, TABLE, PART>(a, g, node, u);
+    tp_bwd_x_body_full<L1, L3MAX, MODE, PART>(a, g, node, u);
     return;
   }
   using S = Slots<L1>;
@@ -590,11 +698,18 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   E3K_TP_CASE(2, BODY, __VA_ARGS__)                                                                  \
   E3K_TP_CASE(3, BODY, __VA_ARGS__)
 
-template <int MAXL, int L3MAX, bool SPLIT, bool FULL, bool TABLE = false>
+template <int L1, int L3MAX, int PART, bool FULL>
+__device__ __forceinline__ void tp_bwd_w_dual_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+  tp_bwd_w_body<L1, false, L3MAX, PART, FULL, true>(a, g, node, u);
+}
+
+// MODE: 0 = per-edge weights streamed from w[E, W]; 1 = interpolated from the knot table inside the kernel; 2 = the table
+// form's second-order (JVP / DUAL) variant -- FULL plans only for 1 and 2
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
 __global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_fwd_body, L3MAX, TABLE)
+  E3K_TP_DISPATCH(tp_fwd_body, L3MAX, MODE)
 }
 
 template <bool WITH_SH, int MAXL, int L3MAX, bool SPLIT, bool FULL>
@@ -604,18 +719,26 @@ __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_DISPATCH(tp_bwd_w_body, WITH_SH, L3MAX)
 }
 
-template <int MAXL, int L3MAX, bool SPLIT, bool FULL, bool TABLE = false>
+template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
 __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, TABLE)
+  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
 }
-template <int MAXL, int L3MAX, bool SPLIT>
-__global__ __launch_bounds__(256) void tp_bwd_t_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+// table-form edge backward (g_sh, g_coef, optionally g_w) and the dual weight gradient: channel-complete, un-split plans
+template <int MAXL, int L3MAX>
+__global__ __launch_bounds__(256) void tp_bwd_e_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
-  constexpr bool FULL = true;
+  constexpr bool FULL = true, SPLIT = false;
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_t_body, L3MAX)
+  E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX)
+}
+template <int MAXL, int L3MAX>
+__global__ __launch_bounds__(256) void tp_bwd_w_dual_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+                                                            const int2* __restrict__ gc, int n_gc) {
+  constexpr bool FULL = true, SPLIT = false;
+  E3K_TP_PROLOGUE
+  E3K_TP_DISPATCH(tp_bwd_w_dual_body, L3MAX)
 }
 #undef E3K_TP_DISPATCH
 #undef E3K_TP_CASE
@@ -794,7 +917,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 }
 
 namespace {
-enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_BWD_T };
+enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -805,18 +928,24 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   const int64_t blocks = (args.n_items + 3) / 4;
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-  if (kind == TP_BWD_T) {
-    if (!p->full64) return E3K_ERR_UNSUPPORTED;
-    const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
-#define E3K_TP_LAUNCH_B(ML, L3, SP) \
-  hipLaunchKernelGGL((e3k::tp_bwd_t_kernel<ML, L3, SP>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);
+  if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL) {
+    // second-order forms of force training: channel-complete plans walked by one wave per group (the l_max <= 2 models)
+    if (!p->full64 || p->split) return E3K_ERR_UNSUPPORTED;
+    const bool lo = p->max_l3 <= p->max_l1;
+#define E3K_TP_LAUNCH_2(ML, L3)                                                                                                         \
+  switch (kind) {                                                                                                                       \
+    case TP_FWD_JVP: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;     \
+    case TP_BWD_X_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_E: hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                      \
+    default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                       \
+  }
     switch (p->max_l1) {
-      case 0: if (lo) { E3K_TP_LAUNCH_B(0, 0, false) } else { E3K_TP_LAUNCH_B(0, 3, false) } break;
-      case 1: if (lo && !spl) { E3K_TP_LAUNCH_B(1, 1, false) } else if (!spl) { E3K_TP_LAUNCH_B(1, 3, false) } else { E3K_TP_LAUNCH_B(1, 3, true) } break;
-      case 2: if (lo && !spl) { E3K_TP_LAUNCH_B(2, 2, false) } else if (!spl) { E3K_TP_LAUNCH_B(2, 3, false) } else { E3K_TP_LAUNCH_B(2, 3, true) } break;
-      default: if (!spl) { E3K_TP_LAUNCH_B(3, 3, false) } else { E3K_TP_LAUNCH_B(3, 3, true) } break;
+      case 0: if (lo) { E3K_TP_LAUNCH_2(0, 0) } else { E3K_TP_LAUNCH_2(0, 3) } break;
+      case 1: if (lo) { E3K_TP_LAUNCH_2(1, 1) } else { E3K_TP_LAUNCH_2(1, 3) } break;
+      case 2: if (lo) { E3K_TP_LAUNCH_2(2, 2) } else { E3K_TP_LAUNCH_2(2, 3) } break;
+      default: E3K_TP_LAUNCH_2(3, 3) break;
     }
-#undef E3K_TP_LAUNCH_B
+#undef E3K_TP_LAUNCH_2
     E3K_CHECK_LAUNCH();
     return E3K_OK;
   }
@@ -826,9 +955,9 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
 #define E3K_TP_LAUNCH_T(ML, L3, SP)                                                                                                     \
   {                                                                                                                                     \
     if (kind == TP_FWD_TABLE)                                                                                                           \
-      hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);           \
+      hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, 1>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);              \
     else                                                                                                                                \
-      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);         \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 1>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
   }
     switch (p->max_l1) {
       case 0: if (lo) E3K_TP_LAUNCH_T(0, 0, false) else E3K_TP_LAUNCH_T(0, 3, false) break;
@@ -912,48 +1041,97 @@ extern "C" int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const floa
 }
 
 // ---- the same two passes with the path weights interpolated from the radial knot table inside the kernel ---------------
-// T [K + 1, W]: the radial MLP on the knots; bin / t [E]: every edge's centre knot (1 .. K - 1) and offset (e3k_rtable_bin).
-// E3K_ERR_UNSUPPORTED for plans that are not channel-complete (the caller then materialises w: e3k_rtable_interp_fwd).
+// T [K + 1, W]: the radial MLP on the knots; bin [E]: every edge's knot i (stencil rows i - 1 .. i + 2); coef [E, 4]: its four
+// interpolation weights (e3k_rtable_bins).  E3K_ERR_UNSUPPORTED for plans that are not channel-complete (the caller then
+// materialises w: e3k_rtable_interp_fwd).
 extern "C" int e3k_tp_table_supported(const e3k_tp_plan* p) {
   return (p && p->full64) ? 1 : 0;
 }
+extern "C" int e3k_tp_table2_supported(const e3k_tp_plan* p) {
+  return (p && p->full64 && !p->split) ? 1 : 0;
+}
 
 extern "C" int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,
-                                const float* t, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
+                                const float* coef, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
                                 int64_t E, float* out, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !T || !bin || !t || !src || !dst_perm))) return E3K_ERR_INVALID;
+  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !T || !bin || !coef || !src || !dst_perm))) return E3K_ERR_INVALID;
   e3k::TpArgs a{};
-  a.x = x; a.sh = sh; a.w = T; a.bin = bin; a.tt = t; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.x = x; a.sh = sh; a.w = T; a.bin = bin; a.coef = coef; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_FWD_TABLE, a, plan, N, (hipStream_t)stream);
 }
 
-extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* t,
+extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* coef,
                                   const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm,
                                   int64_t N, int64_t E, float* g_x, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !T || !bin || !t || !dst || !src_perm))) return E3K_ERR_INVALID;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !T || !bin || !coef || !dst || !src_perm))) return E3K_ERR_INVALID;
   e3k::TpArgs a{};
-  a.sh = sh; a.w = T; a.bin = bin; a.tt = t; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.sh = sh; a.w = T; a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_TABLE, a, plan, N, (hipStream_t)stream);
 }
 
-// The weight-gradient pass and the transposed interpolation in one: P [K + 1, 3, W] (the per-knot partial sums that
-// e3k_rtable_interp_bwd's first pass forms from g_w[E, W]) straight from x, sh, g_out -- g_w never exists.  Follow with
-// e3k_rtable_bwd_combine.  bin_ptr [K + 2] / bin_perm [E]: CSR by knot (ascending edge id inside a knot); t [E]: offsets.
-extern "C" int e3k_tp_bwd_table_partial(const e3k_tp_plan* plan, const float* x, const float* sh, const float* g_out,
-                                        const int32_t* src, const int32_t* dst, const int32_t* bin_ptr, const int32_t* bin_perm,
-                                        const float* t, int64_t N, int64_t E, int32_t K, float* P, void* stream) {
-  if (!plan || N < 0 || E < 0 || K < 4) return E3K_ERR_INVALID;
-  if (!P || !bin_ptr) return E3K_ERR_INVALID;
-  if (E > 0 && (!x || !sh || !g_out || !src || !dst || !bin_perm || !t)) return E3K_ERR_INVALID;
+// ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------
+// With F = <g, TP(x[src], sh, w(T, coef))> (linear in each of g, x, sh, T, coef):
+// (w[e] = sum_k coef[e,k] T[bin[e]-1+k], dw/dr[e] = sum_k coef[e,k] D[bin[e]-1+k] with D the slope table)
+//   e3k_tp_bwd_e_table   g_sh = dF/dsh, g_r = <dF/dw, dw/dr> (both ACCUMULATED with atomics: zero-fill them), optionally g_w
+//   e3k_tp_fwd_jvp_table out = TP(x2, sh, w) + TP(x, sh2, w) + TP(x, sh, s2 * dw/dr)
+//   e3k_tp_bwd_x_dual_table g_x = dF/dx at (sh2, w) + dF/dx at (sh, s2 * dw/dr)
+//   e3k_tp_bwd_w_dual    g_w[e] = dF/dw at (x2, sh) + dF/dw at (x, sh2)       (no table involved: w is the open slot)
+extern "C" int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
+                                  const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
+                                  const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0 || E == 0) return E3K_OK;
+  if (!x || !sh || !T || !D || !bin || !coef || !g_out || !src || !dst_ptr || !dst_perm || (!g_sh && !g_r && !g_w)) return E3K_ERR_INVALID;
   e3k::TpArgs a{};
-  a.x = x; a.sh = sh; a.g_out = g_out; a.g_w = P; a.nbr = src; a.nbr2 = dst; a.ptr = bin_ptr; a.perm = bin_perm; a.tt = t;
+  a.x = x; a.sh = sh; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_sh = g_sh; a.g_r = g_r; a.g_w = g_w;
+  a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
-  return launch_all(TP_BWD_T, a, plan, (int64_t)K + 1, (hipStream_t)stream);
+  return launch_all(TP_BWD_E, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
+                                    const float* T, const float* D, const int32_t* bin, const float* coef, const float* s2,
+                                    const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                                    float* out, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !x2 || !out || !dst_ptr || (E > 0 && (!sh || !sh2 || !T || !D || !bin || !coef || !s2 || !src || !dst_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.x2 = x2; a.sh = sh; a.sh2 = sh2; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.s2 = s2; a.out = out;
+  a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_FWD_JVP, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh, const float* sh2, const float* T, const float* D,
+                                       const int32_t* bin, const float* coef, const float* s2, const float* g_out, const int32_t* dst,
+                                       const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !sh2 || !T || !D || !bin || !coef || !s2 || !dst || !src_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.sh = sh; a.sh2 = sh2; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.s2 = s2; a.g_out = g_out; a.g_x = g_x;
+  a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_X_DUAL, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_w_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
+                                 const float* g_out, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
+                                 int64_t E, float* g_w, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0 || E == 0) return E3K_OK;
+  if (!x || !x2 || !sh || !sh2 || !g_out || !src || !dst_ptr || !dst_perm || !g_w) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.x2 = x2; a.sh = sh; a.sh2 = sh2; a.g_out = g_out; a.g_w = g_w; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_W_DUAL, a, plan, N, (hipStream_t)stream);
 }

@@ -41,11 +41,18 @@ struct TpArgs {
   float* g_sh;         // [E, d_sh]
   float* g_x;          // [N, d_in]
   const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)
-  const int32_t* nbr2; // bwd_t: dst[e] (nbr = src[e]; ptr / perm = the CSR by knot)
   const int32_t* ptr;  // CSR row pointers [N+1]
   const int32_t* perm; // CSR edge ids [E]
-  const int32_t* bin;  // TABLE kernels: centre knot of every edge [E]; w is then the knot table [K + 1, W]
-  const float* tt;     // TABLE kernels: offset of every edge from its centre knot, in knot spacings [E]
+  const int32_t* bin;  // TABLE kernels: knot i of every edge [E] (stencil rows i-1 .. i+2); w is then the knot table [K + 1, W]
+  const float* coef;   // TABLE kernels: the four interpolation weights of every edge [E, 4] (e3k_rtable_bins)
+  // force training on the table: the slope table D [K + 1, W] (d T / d r on the knots, interpolated with the SAME weights:
+  // dw/dr[e] = sum_k coef[e, k] D[bin[e] - 1 + k]) and the second operand set of the JVP / DUAL forms (the double backward:
+  // the product rule over (x, sh, r))
+  const float* w2;     // D
+  const float* x2;     // [N, d_in] cf
+  const float* sh2;    // [E, d_sh]
+  const float* s2;     // [E]: the radius' partner (a cotangent): the third term's weights are s2[e] * dw/dr[e]
+  float* g_r;          // [E]: gradient w.r.t. the radius (tp_bwd_e), accumulated with one atomic per wave and edge
   int32_t d_in, d_sh, W, d_mid;
   int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
   int64_t n_items;

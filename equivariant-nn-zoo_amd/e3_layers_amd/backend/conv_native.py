@@ -199,10 +199,6 @@ class _Carve:
 TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
 # 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
 FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
-# 1: with the in-kernel table the gradient of the table is formed by one kernel in knot order (e3k_tp_bwd_table_partial)
-# instead of tp_bwd_w -> g_w[E, W] -> transposed interpolation (asked for through rad.in_kernel = 2).  Correct
-# (bit-identical) and slower -- no molecule locality in knot order --, so off.
-BWD_T = int(os.environ.get("E3K_BWD_T", "0"))
 # 1: the addend of an addend-form layer (ConvBlockPlan.addend) is accumulated on in place instead of being copied into the block's buffer
 ADDEND_INPLACE = int(os.environ.get("E3K_ADDEND_INPLACE", "1"))
 
@@ -217,15 +213,20 @@ def in_kernel_table(plan, table, dev) -> bool:
     return hit
 
 
+def _table_fields(rad: L.LayerRadial, table) -> None:
+    """``table``: radial_table.KnotBins"""
+    rad.knots = table.knots
+    rad.bin, rad.bin_ptr, rad.bin_perm = table.bin.data_ptr(), table.ptr.data_ptr(), table.perm.data_ptr()
+    rad.bin_coef, rad.bin_seg = table.coef.data_ptr(), table.seg.data_ptr()
+
+
 def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, keep: bool, w_last, w_hidden, buf, carve, w, t_tab):
     r = edge_radial.shape[0]
     rad.R, rad.E, rad.keep = r, n_edges, int(keep)
     rad.use_table = int(table is not None)
     rad.radial = edge_radial.data_ptr()
     if table is not None:
-        bin32, t, ptr, perm = table
-        rad.knots = radial_table.KNOTS
-        rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
+        _table_fields(rad, table)
         rad.T = t_tab.data_ptr()
     rad.w_last = w_last.data_ptr()
     for i, wh in enumerate(w_hidden):
@@ -235,7 +236,7 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
         for i in range(len(w_hidden)):
             rad.z[i] = _ptr(buf, carve.off[f"z{i}"])
     rad.w = _ptr(w)
-    rad.in_kernel = (2 if BWD_T else 1) if w is None else 0
+    rad.in_kernel = 1 if w is None else 0
 
 
 def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
@@ -244,12 +245,10 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
     rad.R, rad.E, rad.keep, rad.have_rows = pre.shape[0], n_edges, 0, 1
     rad.use_table = int(table is not None)
     if table is not None:
-        bin32, t, ptr, perm = table
-        rad.knots = radial_table.KNOTS
-        rad.bin, rad.bin_ptr, rad.bin_perm, rad.bin_t = bin32.data_ptr(), ptr.data_ptr(), perm.data_ptr(), t.data_ptr()
+        _table_fields(rad, table)
         rad.T = pre.data_ptr()
         rad.w = _ptr(w)
-        rad.in_kernel = (2 if BWD_T else 1) if w is None else 0
+        rad.in_kernel = 1 if w is None else 0
     else:
         rad.w = pre.data_ptr()
 
@@ -262,6 +261,14 @@ def _consumed_on(stream, *tensors):
     for t in tensors:
         if t is not None:
             t.record_stream(stream)
+
+
+def _slope_ctx(slope, knots_r, bessel_w) -> L.SlopeCtx:
+    _, r_max, r_min, p, one_over_r, kind = slope
+    sl = L.SlopeCtx()
+    sl.knots, sl.bessel_w = knots_r.data_ptr(), bessel_w.data_ptr()
+    sl.r_max, sl.r_min, sl.p, sl.one_over_r, sl.cutoff_kind = float(r_max), float(r_min), float(p), int(one_over_r), int(kind)
+    return sl
 
 
 STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
@@ -279,9 +286,13 @@ class RadialStackFn(torch.autograd.Function):
     and 4-5 backward over the same 4 097 knot rows: latency, not work."""
 
     @staticmethod
-    def forward(ctx, rows, plans, use_table: bool, main, *weights):
+    def forward(ctx, rows, plans, use_table: bool, main, slope, bessel_w, *weights):
         """``main``: the stream the rest of the network runs on when this op was put on the radial stream (else None):
-        gradients handed back to autograd are consumed there."""
+        gradients handed back to autograd are consumed there.
+        ``slope`` (force training, table only): (knot radii [R], r_max, r_min, p, one_over_r, cutoff kind) and ``bessel_w`` (the
+        basis' frequencies: a differentiable input then, else None) -- the op returns the layers' SLOPE tables D_l = d T_l / d r
+        behind their tables T_l (``e3k_radial_slope_fwd``: forward-mode derivative of the hidden chains per knot in float64, last
+        layers in fp32)."""
         L.require_cuda(rows)
         rows = L.f32c(rows)
         dev = rows.device
@@ -290,6 +301,7 @@ class RadialStackFn(torch.autograd.Function):
         per = 1 + n_hidden
         assert len(weights) == n * per
         keep = any(ctx.needs_input_grad)
+        ctx.n_slope = 0
         r, hdim = rows.shape[0], plans[0].last_spec.d_in
         handles = (C.c_void_p * n)(*[native_layer(p).handle(dev) for p in plans])
         rads = (L.LayerRadial * n)()
@@ -324,26 +336,48 @@ class RadialStackFn(torch.autograd.Function):
         if use_table:
             for plan, out, i in zip(plans, outs, range(n)):
                 radial_table.guard(plan.guard_key if plan.guard_key is not None else weights[i * per], out)
+        hps, slopes = [], []
+        if slope is not None:
+            if not use_table:
+                raise ValueError("slope tables exist on the knot table only")
+            knots_r = L.f32c(slope[0])
+            bw = L.f32c(bessel_w.detach())
+            hps = [torch.empty(r, hdim, device=dev, dtype=torch.float32) for _ in plans]
+            slopes = [torch.empty(r, plan.last_spec.d_out, device=dev, dtype=torch.float32) for plan in plans]
+            sl = _slope_ctx(slope, knots_r, bw)
+            L.check(L.load().e3k_radial_slope_fwd(handles, rads, n, C.byref(sl), (C.c_void_p * n)(*[t.data_ptr() for t in hps]),
+                                                  (C.c_void_p * n)(*[t.data_ptr() for t in slopes]), L.stream_ptr()),
+                    "e3k_radial_slope_fwd")
+            ctx.n_slope = n
+            for plan, d_tab, i in zip(plans, slopes, range(n)):
+                radial_table.guard(plan.guard_key if plan.guard_key is not None else weights[i * per], d_tab, slope=True)
         if keep:
-            ctx.save_for_backward(rows, *bufs, *weights)
+            extra = (knots_r, bw) if slope is not None else ()
+            ctx.save_for_backward(rows, *bufs, *weights, *hps, *extra)
             ctx.cfg = (plans, use_table, carves, n_hidden)
             ctx.main = main
-        return tuple(outs)
+            ctx.slope = slope
+        return tuple(outs) + tuple(slopes)
 
     @staticmethod
     @once_differentiable
-    def backward(ctx, *g_rows):
+    def backward(ctx, *g_all):
         plans, use_table, carves, n_hidden = ctx.cfg
         n, per = len(plans), 1 + n_hidden
         saved = ctx.saved_tensors
-        rows, bufs, weights = saved[0], saved[1:1 + n], saved[1 + n:]
+        rows, bufs, weights = saved[0], saved[1:1 + n], saved[1 + n:1 + n + n * per]
+        tail = saved[1 + n + n * per:]                      # (slope mode: the layers' H' rows, the knot radii, the frequencies)
+        hps = tail[:n] if ctx.n_slope else ()
+        g_rows, g_slopes = g_all[:n], (g_all[n:] if hps else ())
         dev = rows.device
         r, hdim, k0 = rows.shape[0], plans[0].last_spec.d_in, rows.shape[1]
         need = ctx.needs_input_grad
         need_rows = need[0]
+        if hps:      # a layer whose slope table received a gradient takes part even when its table did not
+            g_rows = tuple(g if (g is not None or g_slopes[i] is None) else torch.zeros_like(g_slopes[i]) for i, g in enumerate(g_rows))
         live = [i for i in range(n) if g_rows[i] is not None]
         rets = [None] * (n * per)
-        g_in = None
+        g_in = g_bessel = None
         if live:
             handles = (C.c_void_p * len(live))(*[native_layer(plans[i]).handle(dev) for i in live])
             items = (L.RadialStackItem * len(live))()
@@ -363,7 +397,7 @@ class RadialStackFn(torch.autograd.Function):
                     rad.z[l] = _ptr(bufs[i], carves[i].off[f"z{l}"])
                 it.g_rows = g.data_ptr()
                 for l in range(per):
-                    if not need[4 + i * per + l]:
+                    if not need[6 + i * per + l]:
                         continue
                     w = weights[i * per + l]
                     sink = ops._sink_for(w)
@@ -377,12 +411,28 @@ class RadialStackFn(torch.autograd.Function):
                 it.g_h = g_h[j].data_ptr()
                 if g_rad is not None:
                     it.g_radial = g_rad[j].data_ptr()
-            L.check(L.load().e3k_radial_stack_bwd(handles, items, len(live), L.stream_ptr()), "e3k_radial_stack_bwd")
+                if hps and g_slopes[i] is not None:
+                    gs = L.f32c(g_slopes[i])
+                    g_hp = torch.empty(r, hdim, device=dev, dtype=torch.float32)
+                    keepalive += [gs, g_hp]
+                    it.g_slope, it.hp, it.g_hp = gs.data_ptr(), hps[i].data_ptr(), g_hp.data_ptr()
+            sl_ref = None
+            if hps and any(g_slopes[i] is not None for i in live):
+                knots_r, bw = tail[n], tail[n + 1]
+                sl = _slope_ctx(ctx.slope, knots_r, bw)
+                acc = torch.empty(int(L.load().e3k_slope_tangent_bwd_scratch(len(live), n_hidden, k0, hdim)), device=dev, dtype=torch.float64)
+                sl.acc = acc.data_ptr()
+                if need[5]:
+                    g_bessel = torch.zeros_like(bw)
+                    sl.g_bessel = g_bessel.data_ptr()
+                keepalive.append(acc)
+                sl_ref = C.byref(sl)
+            L.check(L.load().e3k_radial_stack_bwd(handles, items, len(live), sl_ref, L.stream_ptr()), "e3k_radial_stack_bwd")
             if g_rad is not None:
                 g_in = g_rad[0] if len(live) == 1 else g_rad.sum(0)
             del keepalive
-        _consumed_on(ctx.main, g_in, *rets)
-        return (g_in, None, None, None, *rets)
+        _consumed_on(ctx.main, g_in, g_bessel, *rets)
+        return (g_in, None, None, None, None, g_bessel, *rets)
 
 
 KW_STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
@@ -772,7 +822,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         if need_radial_side:
             if stack and table is None:
                 g_pre = torch.empty(e, last.d_out, device=dev, dtype=torch.float32)      # g_w IS the gradient of the layer's rows
-            elif not (w is None and BWD_T):      # (in-kernel table: the backward to the table keeps g_w[e] in registers)
+            else:
                 sc_.add("g_w", e * last.d_out)
             if table is not None:
                 if stack:
@@ -780,7 +830,7 @@ class NativeConvBlockFn(torch.autograd.Function):
                         g_pre = torch.empty(r, last.d_out, device=dev, dtype=torch.float32)
                 else:
                     sc_.add("g_T", r * last.d_out)
-                sc_.add("table_ws", int(L.load().e3k_rtable_bwd_workspace_floats(radial_table.KNOTS, last.d_out)))
+                sc_.add("table_ws", int(L.load().e3k_rtable_bwd_workspace_floats(e, table.knots, last.d_out)))
             if need_radial or any(need_hidden):
                 sc_.add("g_h", r * last.d_in)
         if want_sc:

@@ -87,13 +87,18 @@ class LayerDesc(C.Structure):
 class LayerRadial(C.Structure):
     _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
                 ("have_rows", C.c_int32), ("in_kernel", C.c_int32), ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
-                ("bin_t", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
+                ("bin_coef", C.c_void_p), ("bin_seg", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
                 ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p)]
 
 
 class RadialStackItem(C.Structure):
     _fields_ = [("rad", LayerRadial), ("g_rows", C.c_void_p), ("gb_last", C.c_void_p), ("gb_hidden", C.c_void_p * 4),
-                ("g_h", C.c_void_p), ("g_radial", C.c_void_p)]
+                ("g_h", C.c_void_p), ("g_radial", C.c_void_p), ("g_slope", C.c_void_p), ("hp", C.c_void_p), ("g_hp", C.c_void_p)]
+
+
+class SlopeCtx(C.Structure):
+    _fields_ = [("knots", C.c_void_p), ("bessel_w", C.c_void_p), ("r_max", C.c_float), ("r_min", C.c_float), ("p", C.c_float),
+                ("one_over_r", C.c_int32), ("cutoff_kind", C.c_int32), ("_pad", C.c_int32), ("acc", C.c_void_p), ("g_bessel", C.c_void_p)]
 
 
 class KwMultiItem(C.Structure):
@@ -150,7 +155,14 @@ SIGNATURES = {
     "e3k_layer_fwd": (C.c_int, [_P, C.POINTER(LayerFwdArgs)]),
     "e3k_layer_bwd": (C.c_int, [_P, C.POINTER(LayerBwdArgs)]),
     "e3k_radial_stack_fwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(LayerRadial), _I32, _P]),
-    "e3k_radial_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(RadialStackItem), _I32, _P]),
+    "e3k_radial_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(RadialStackItem), _I32, C.POINTER(SlopeCtx), _P]),
+    "e3k_radial_slope_fwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(LayerRadial), _I32, C.POINTER(SlopeCtx), C.POINTER(C.c_void_p),
+                                       C.POINTER(C.c_void_p), _P]),
+    "e3k_slope_tangent_fwd": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I32, C.POINTER(C.c_float), _P, _I64, _P, _I32, _I32, _F, _F, _F,
+                                        _I32, _I32, _I32, _F, C.POINTER(C.c_void_p), _P]),
+    "e3k_slope_tangent_bwd_scratch": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "e3k_slope_tangent_bwd": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I32, C.POINTER(C.c_float), _P, _I64, _P, _I32, _I32, _F, _F, _F,
+                                        _I32, _I32, _I32, _F, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_void_p), _P, _P]),
     "e3k_mlp_hidden_fwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
     "e3k_mlp_hidden_bwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),
     "e3k_kw_args_create": (C.c_int, [_P, _I32, _I32, _I64, C.POINTER(C.c_void_p)]),
@@ -189,16 +201,20 @@ SIGNATURES = {
     "e3k_tp_table_supported": (C.c_int, [_P]),
     "e3k_tp_fwd_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
-    "e3k_tp_bwd_table_partial": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _I32, _P, _P]),
-    "e3k_rtable_bwd_combine": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "e3k_tp_table2_supported": (C.c_int, [_P]),
+    "e3k_tp_bwd_e_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "e3k_tp_fwd_jvp_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_x_dual_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_w_dual": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_csr_workspace_ints": (C.c_int64, [_I64, _I64]),
     "e3k_csr_build": (C.c_int, [_P, _I64, _I64, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "e3k_group_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
-    "e3k_rtable_bin": (C.c_int, [_P, _I64, _F, _I32, _P, _P, _P]),
+    "e3k_rtable_bins_workspace_ints": (C.c_int64, [_I64, _I32]),
+    "e3k_rtable_bins": (C.c_int, [_P, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "e3k_rtable_interp_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
-    "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I32, _I32]),
-    "e3k_rtable_interp_bwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
+    "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),
+    "e3k_rtable_interp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P]),
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),

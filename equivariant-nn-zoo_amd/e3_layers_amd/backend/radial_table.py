@@ -1,21 +1,27 @@
-"""Per-edge radial weights through a knot table (``csrc/e3k_rtable.hip``).
+"""Per-edge radial weights through a knot table (``csrc/e3k_rtable.hip``, ``csrc/e3k_slope.hip``).
 
 ``weight = fc(edge_radial)`` (``e3_layers/nn/message_passing.py:74-79,93``) with ``edge_radial =
 RadialBasisEncoding(edge_length)`` (``e3_layers/nn/embedding.py:210-219``) is a smooth function of one scalar per
 edge.  Instead of pushing every edge through the MLP (the largest block of matrix work of a training step: forward,
-dgrad and wgrad GEMMs of ``[E, 64] x [64, weight_numel]``), the MLP is evaluated on ``KNOTS + 1`` equidistant radii and
-every edge interpolates quadratically between the three knots around it; the backward transposes the interpolation
-(an ordered sum per knot over edges sorted by knot, no atomics) and then differentiates the MLP on the knots only.
-Interpolation error (h^3): ~4e-8 relative at the default 2048 knots for the shipped models (bound and measurements per knot
-count: tools/knot_error.py), below the ~1e-7 rounding error of evaluating the MLP in fp32 per edge.  The knot
-count also sets how much of the table the 4 MB L2 of an XCD holds when the tensor-product kernels gather its rows
-(e3k_tp_fwd_table): 2048 knots measured 0.23 ms / step faster than 4096 at 256 molecules.
+dgrad and wgrad GEMMs of ``[E, 64] x [64, weight_numel]``), the MLP is evaluated on ``knots + 1`` equidistant radii and
+every edge interpolates between the FOUR knots around it with cubic Lagrange weights (round 4; rounds 2-3: quadratic on
+2 048 knots); the backward transposes the interpolation (an ordered sum per knot over edges sorted by knot, no atomics)
+and then differentiates the MLP on the knots only.
+
+Knot counts (``tools/knot_error.py``; float64 study in DESIGN.md section 4): cubic, 512 knots: 1.0e-7 relative -- the fp32
+rounding of the table itself -- where the quadratic rule needed 2 048; the table the tensor-product kernels gather from
+(``e3k_tp_fwd_table``: four rows per edge) is 3.9 MB per layer instead of 14 and fits an XCD's 4 MB L2.
+
+Force training (``GradientOutput``: the radii require grad) needs ``dw/dr`` as well.  Differentiating the interpolation
+weights amplifies the table's fp32 rounding by 1 / knot spacing (7e-6 .. 4e-5 relative at any knot count: beyond the
+force tolerance), so the slope is a table of its own, ``D = dT/dr`` on the knots (``conv_native.RadialStackFn`` with
+``slope`` -> ``e3k_radial_slope_fwd``: the hidden chain's forward-mode derivative per knot in float64, the last layer in fp32),
+interpolated with the same weights (2e-7 at 512 knots).
 
 Applies when ``edge_radial`` still carries the tag ``RadialBasisEncoding.forward`` puts on its output (so nothing was
 concatenated to it: the diffusion configs mix bond types / residue offsets into the edge embedding and take the
-per-edge path), the envelope is the polynomial cutoff (f is constant beyond ``r_max``), the radii need no gradient
-(no forces / double backward: the composed per-edge ops serve those), and the batch has several times more edges than
-the table has knots.  ``E3K_RADIAL_TABLE=0`` disables it.
+per-edge path), the envelope is the polynomial cutoff (f is constant beyond ``r_max``) and the batch has several times
+more edges than the table has knots.  ``E3K_RADIAL_TABLE=0`` disables it.
 """
 from __future__ import annotations
 
@@ -27,11 +33,59 @@ import torch
 
 from . import lib as L
 from . import ops
-from .graph import build_topology      # (conv_block imports this module: keep it free of conv_block)
 
 ENABLED = int(os.environ.get("E3K_RADIAL_TABLE", "1"))
-KNOTS = int(os.environ.get("E3K_RADIAL_KNOTS", "2048"))          # intervals; KNOTS + 1 table rows
+# Target knot counts over [0, r_max]; the spacing actually used is the power of two at or below r_max / target (``layout``):
+# r / h, the offset inside a knot interval and the knot radii k h are then EXACT in fp32 -- with an arbitrary spacing their
+# rounding (6e-8 relative, i.e. 3e-5 of an interval at knot 500) shows up as 1e-6 in the interpolated weights.
+KNOTS = int(os.environ.get("E3K_RADIAL_KNOTS", "512"))                  # r_max 4: 512 intervals of 2^-7 A; r_max 5: 640
+KNOTS_SLOPE = int(os.environ.get("E3K_RADIAL_KNOTS_SLOPE", "512"))       # ... when the radii require grad (value + slope tables)
 MIN_EDGES_PER_KNOT = float(os.environ.get("E3K_RADIAL_MIN_EDGES_PER_KNOT", "4"))      # below this the per-edge MLP is the cheaper one
+
+
+def layout(r_max: float, target: int):
+    """(intervals K, spacing h): h = 2^-m <= r_max / target, K h >= r_max (the table's last rows sit at or beyond r_max, where the
+    function is constant)."""
+    import math
+
+    m = math.ceil(math.log2(max(int(target), 4) / float(r_max)) - 1e-9)
+    h = 2.0 ** (-m)
+    return max(int(math.ceil(float(r_max) / h - 1e-9)), 4), h
+
+
+class KnotBins:
+    """What a batch's edges look like from the table's side (``e3k_rtable_bins``): ``bin`` int32 [E] (knot i: stencil rows
+    i - 1 .. i + 2), ``coef`` [E, 4] (the four weights), the edges grouped by knot -- ``ptr`` [K + 2], ``perm`` [E] (ascending
+    edge id inside a knot), ``seg`` [K + 2] (first <= 64-edge segment of every knot) -- and the knot count."""
+
+    __slots__ = ("bin", "coef", "ptr", "perm", "seg", "knots", "spacing", "_buf", "__weakref__")
+
+    def __init__(self, bin, coef, ptr, perm, seg, knots: int, spacing: float, buf=None):
+        self.bin, self.coef, self.ptr, self.perm, self.seg, self.knots, self.spacing = bin, coef, ptr, perm, seg, int(knots), float(spacing)
+        self._buf = buf
+
+    def tensors(self):
+        """The distinct allocations behind the views (what ``record_stream`` has to see)."""
+        return (self._buf, self.coef) if self._buf is not None else (self.bin, self.coef, self.ptr, self.perm, self.seg)
+
+    def __iter__(self):
+        return iter(self.tensors())
+
+
+def build_bins(r: torch.Tensor, r_max: float, target: int) -> KnotBins:
+    """``target``: the knot count asked for over [0, r_max] (``layout`` turns it into a power-of-two spacing)."""
+    knots, h = layout(r_max, target)
+    r = L.f32c(r.detach().reshape(-1))
+    L.require_cuda(r)
+    e, dev = r.numel(), r.device
+    lib = L.load()
+    sizes = [e, e, knots + 2, knots + 2, int(lib.e3k_rtable_bins_workspace_ints(e, knots))]
+    buf = torch.empty(sum(sizes), dtype=torch.int32, device=dev)      # one allocation: [bin | perm | ptr | seg | workspace]
+    bin32, perm, ptr, seg, work = torch.split(buf, sizes)
+    coef = torch.empty(e, 4, dtype=torch.float32, device=dev)
+    L.check(lib.e3k_rtable_bins(L.ptr(r), e, 1.0 / h, knots, L.ptr(bin32), L.ptr(coef), L.ptr(ptr), L.ptr(seg), L.ptr(perm),
+                                L.ptr(work), L.stream_ptr()), "e3k_rtable_bins")
+    return KnotBins(bin32, coef, ptr, perm, seg, knots, h, buf)
 
 
 class RadialSource:
@@ -43,46 +97,43 @@ class RadialSource:
 
     def __init__(self, module, r: torch.Tensor, version: int = 0):
         self.module, self.r, self.version = weakref.ref(module), r, int(version)
-        self._bins = None
-        self._knot_basis = None
+        self._bins = {}
+        self._knot_basis = {}
         self._stack = {}      # id(MessagePassing) -> (its radial MLP's rows on the knots, mode): nn/message_passing.py:_stack_rows
 
-    def bins(self):
-        """(centre knot int32 [E], offset t [E], CSR by knot) -- once per batch, shared by the layers."""
-        if self._bins is None:
-            r = L.f32c(self.r.detach().reshape(-1))
-            e = r.numel()
-            mod = self.module()
-            bin2 = torch.empty(2, e, dtype=torch.int64, device=r.device)
-            t = torch.empty(e, dtype=torch.float32, device=r.device)
-            L.check(L.load().e3k_rtable_bin(L.ptr(r), e, float(mod.basis.r_max), KNOTS, L.ptr(bin2), L.ptr(t), L.stream_ptr()),
-                    "e3k_rtable_bin")
-            topo = build_topology(bin2, KNOTS + 1)
-            self._bins = (topo.dst, t, topo.dst_ptr, topo.dst_perm)
-        return self._bins
+    def bins(self, knots: Optional[int] = None) -> KnotBins:
+        """Once per batch and (target) knot count, shared by the layers."""
+        knots = KNOTS if knots is None else int(knots)
+        hit = self._bins.get(knots)
+        if hit is None:
+            hit = self._bins[knots] = build_bins(self.r, float(self.module().basis.r_max), knots)
+        return hit
 
-    def knot_basis(self):
+    def knot_basis(self, knots: Optional[int] = None):
         """RadialBasisEncoding on the knots (differentiable w.r.t. the Bessel frequencies) -- once per forward."""
-        kb = self._knot_basis
+        knots = KNOTS if knots is None else int(knots)
+        kb = self._knot_basis.get(knots)
         if kb is None or kb[1] != torch.is_grad_enabled():
             mod = self.module()
             b, c = mod.basis, mod.cutoff
-            knots = _knots(float(b.r_max), self.r.device)
-            basis = ops.radial_basis(knots, b.bessel_weights, b.r_max, b.r_min, c.p, b.one_over_r, c.cutoff.kind)
-            kb = self._knot_basis = (basis, torch.is_grad_enabled())
+            basis = ops.radial_basis(knot_radii(float(b.r_max), knots, self.r.device), b.bessel_weights, b.r_max, b.r_min, c.p,
+                                     b.one_over_r, c.cutoff.kind)
+            kb = self._knot_basis[knots] = (basis, torch.is_grad_enabled())
         return kb[0]
 
 
 _KNOT_CACHE = {}
 
 
-def _knots(r_max: float, device) -> torch.Tensor:
-    key = (r_max, KNOTS, str(device))
+def knot_radii(r_max: float, target: int, device) -> torch.Tensor:
+    """The radii of the table's rows for a target knot count: k h, exact in fp32 (h a power of two)."""
+    key = (r_max, target, str(device))
     k = _KNOT_CACHE.get(key)
     if k is None:
-        k = torch.arange(KNOTS + 1, dtype=torch.float32) * (r_max / KNOTS)
-        k[0] = 1e-6 * r_max / KNOTS            # sin(w r) / r at r = 0: evaluate next to it (f is smooth there)
-        k = _KNOT_CACHE[key] = k.to(device)
+        knots, h = layout(r_max, target)
+        k = torch.arange(knots + 1, dtype=torch.float64) * h
+        k[0] = 1e-6 * h                        # sin(w r) / r at r = 0: evaluate next to it (f is smooth there)
+        k = _KNOT_CACHE[key] = k.float().to(device)
     return k
 
 
@@ -90,34 +141,47 @@ def source_of(edge_radial) -> Optional[RadialSource]:
     return getattr(edge_radial, "_e3k_radial_src", None)
 
 
-def applicable(edge_radial, w_last=None) -> bool:
-    """``w_last``: the last-layer weight of the radial MLP that would run on the table -- its a-posteriori error guard
-    (``guard`` below) can veto the table for that MLP."""
+def knots_for(edge_radial, w_last=None, allow_grad: bool = False) -> int:
+    """The (target) knot count of the table that serves this edge embedding, or 0 when the table does not apply.  ``w_last``: the
+    last-layer weight of the radial MLP that would run on the table -- its a-posteriori error guard (``guard`` below) can
+    veto the table for that MLP.  ``allow_grad``: the caller can differentiate w.r.t. the radii through the slope table
+    (the force block, ``backend/conv_force.py``); everyone else takes the per-edge path when the radii require grad."""
     if not ENABLED or not edge_radial.is_cuda:
-        return False
+        return 0
     src = source_of(edge_radial)
-    if src is None or src.module() is None or src.r.requires_grad:
-        return False
+    if src is None or src.module() is None:
+        return 0
+    grad = bool(src.r.requires_grad)
+    if grad and not allow_grad:
+        return 0
     if edge_radial._version != src.version:
-        return False                       # modified in place since RadialBasisEncoding produced it
-    if w_last is not None and not guard_ok(w_last):
-        return False
-    return edge_radial.shape[0] >= MIN_EDGES_PER_KNOT * (KNOTS + 1)
+        return 0                           # modified in place since RadialBasisEncoding produced it
+    if w_last is not None and not guard_ok(w_last, slope=grad):
+        return 0
+    knots = KNOTS_SLOPE if grad else KNOTS
+    rows = layout(float(src.module().basis.r_max), knots)[0] + 1
+    return knots if edge_radial.shape[0] >= MIN_EDGES_PER_KNOT * rows else 0
+
+
+def applicable(edge_radial, w_last=None) -> bool:
+    return knots_for(edge_radial, w_last) > 0
 
 
 # ---- a-posteriori guard of the interpolation error ---------------------------------------------------------------------
-# Quadratic Lagrange interpolation on knots h apart is off by at most h^3 max|f(3)| / (9 sqrt 3) (f(3): third derivative);
-# on the table itself h^3 f(3) is the third finite difference, so
-#     err <= max|T[i+3] - 3 T[i+2] + 3 T[i+1] - T[i]| / (9 sqrt 3)
-# -- read off the table rows the forward has just computed, relative to max|T|.  4e-8 for the shipped models at random
-# init (8 Bessel functions through a smooth MLP); it grows like (frequency x weight scale)^3, so a 32-function basis, grown
-# Bessel frequencies or large trained weights can push it towards the 1e-5 parity budget.  The bound is evaluated on the
-# device the first time an MLP's table is built and every GUARD_EVERY-th time after (a few elementwise passes over 31 MB
-# on the radial stream), copied to pinned memory without a sync and looked at on a later call: above GUARD_TOL the table
-# is switched off for that MLP (per-edge evaluation from then on) with a warning.
+# Cubic Lagrange interpolation on knots h apart, evaluated in the middle interval of its four knots, is off by at most
+# 3/128 h^4 max|f(4)|; on the table itself h^4 f(4) is the fourth finite difference, so
+#     err <= 3/128 max|T[i+4] - 4 T[i+3] + 6 T[i+2] - 4 T[i+1] + T[i]|
+# -- read off the table rows the forward has just computed, relative to max|T|.  ~1e-7 for the shipped models at random
+# init on 512 knots (8 Bessel functions through a smooth MLP: the fp32 rounding of the rows, whose fourth difference carries
+# 16 eps, is most of it); it grows like (frequency x weight scale)^4, so a 32-function basis, grown Bessel frequencies or
+# large trained weights can push it towards the 1e-5 parity budget.  The bound is evaluated on the device the first time an
+# MLP's table is built and every GUARD_EVERY-th time after (a few elementwise passes over 4 MB on the radial stream), copied
+# to pinned memory without a sync and looked at on a later call: above GUARD_TOL the table is switched off for that MLP
+# (per-edge evaluation from then on) with a warning.  The slope table of force training has a guard of its own (same rule on
+# D, relative to max|D|: what is interpolated there is the slope).
 GUARD_TOL = float(os.environ.get("E3K_RADIAL_TABLE_TOL", "1e-6"))
 GUARD_EVERY = int(os.environ.get("E3K_RADIAL_TABLE_CHECK_EVERY", "64"))
-_C3 = 1.0 / (9.0 * 3.0 ** 0.5)
+_C4 = 3.0 / 128.0
 
 
 class _Guard:
@@ -127,23 +191,23 @@ class _Guard:
         self.calls, self.pending, self.ok, self.last = 0, [], True, None
 
 
-_GUARDS: dict = {}      # id(weight) -> (weak reference to the weight, its guard): tensors compare elementwise, so they cannot
-                        # key a WeakKeyDictionary; the entry is dropped when the weight dies
+_GUARDS: dict = {}      # (id(weight), slope) -> (weak reference to the weight, its guard): tensors compare elementwise, so they
+                        # cannot key a WeakKeyDictionary; the entry is dropped when the weight dies
 
 
-def _guard_of(w_last, create: bool = False):
-    hit = _GUARDS.get(id(w_last))
+def _guard_of(w_last, slope: bool = False, create: bool = False):
+    key = (id(w_last), bool(slope))
+    hit = _GUARDS.get(key)
     if hit is not None and hit[0]() is w_last:
         return hit[1]
     if not create:
         return None
-    key = id(w_last)
     g = _Guard()
     _GUARDS[key] = (weakref.ref(w_last, lambda _r, key=key: _GUARDS.pop(key, None)), g)
     return g
 
 
-def _poll(g: _Guard) -> None:
+def _poll(g: _Guard, what: str = "value") -> None:
     if torch.cuda.is_current_stream_capturing():
         return                             # Event.query() is not allowed while a stream captures (it would invalidate the capture);
                                            # ``drain_guards()`` empties the lists before CapturedStep starts recording
@@ -154,51 +218,54 @@ def _poll(g: _Guard) -> None:
             if g.ok:
                 import warnings
 
-                warnings.warn(f"radial knot table: interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e} "
-                              f"({KNOTS} knots): this radial MLP is evaluated per edge from now on "
-                              "(E3K_RADIAL_KNOTS raises the resolution)")
+                warnings.warn(f"radial knot table ({what}): interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e}: this "
+                              "radial MLP is evaluated per edge from now on (E3K_RADIAL_KNOTS / E3K_RADIAL_KNOTS_SLOPE raise the "
+                              "resolution)")
             g.ok = False
 
 
 def drain_guards() -> None:
     """Read back every pending guard estimate (call after a device synchronisation, before a graph capture: no event may be
     queried while the stream records -- ``run/graph_step.CapturedStep`` does)."""
-    for ref, g in list(_GUARDS.values()):
+    for (_, slope), (ref, g) in list(_GUARDS.items()):
         if ref() is None:
             continue
         for ev, _ in g.pending:
             ev.synchronize()
-        _poll(g)
+        _poll(g, "slope" if slope else "value")
 
 
-def guard_ok(w_last) -> bool:
-    g = _guard_of(w_last)
-    if g is None:
-        return True
-    _poll(g)
-    return g.ok
+def guard_ok(w_last, slope: bool = False) -> bool:
+    """The value table's guard, and -- ``slope`` -- the slope table's too."""
+    ok = True
+    for kind in ((False, True) if slope else (False,)):
+        g = _guard_of(w_last, kind)
+        if g is not None:
+            _poll(g, "slope" if kind else "value")
+            ok = ok and g.ok
+    return ok
 
 
-def guard_error(w_last):
-    """Last error bound read back for this MLP (None before the first one arrived)."""
-    g = _guard_of(w_last)
+def guard_error(w_last, slope: bool = False):
+    """Last error bound read back for this MLP's value (or slope) table (None before the first one arrived)."""
+    g = _guard_of(w_last, slope)
     if g is None:
         return None
     _poll(g)
     return g.last
 
 
-def guard(w_last, table: torch.Tensor) -> None:
+def guard(w_last, table: torch.Tensor, slope: bool = False) -> None:
     """Call with the table just computed (on the stream that computed it)."""
-    g = _guard_of(w_last, create=True)
+    g = _guard_of(w_last, slope, create=True)
     g.calls += 1
-    _poll(g)
-    if (g.calls - 1) % max(GUARD_EVERY, 1) != 0 or torch.cuda.is_current_stream_capturing() or table.shape[0] < 4:
+    _poll(g, "slope" if slope else "value")
+    if (g.calls - 1) % max(GUARD_EVERY, 1) != 0 or torch.cuda.is_current_stream_capturing() or table.shape[0] < 5:
         return
     with torch.no_grad():
         t = table.detach()
-        d3 = t[3:] - 3.0 * t[2:-1] + 3.0 * t[1:-2] - t[:-3]
-        est = (d3.abs().amax() * _C3 / t.abs().amax().clamp_min(1e-30)).reshape(1)
+        d4 = t[4:] - 4.0 * t[3:-1] + 6.0 * t[2:-2] - 4.0 * t[1:-3] + t[:-4]
+        est = (d4.abs().amax() * _C4 / t.abs().amax().clamp_min(1e-30)).reshape(1)
         host = torch.empty(1, dtype=torch.float32).pin_memory()
         host.copy_(est, non_blocking=True)
         ev = torch.cuda.Event()
@@ -206,40 +273,42 @@ def guard(w_last, table: torch.Tensor) -> None:
     g.pending.append((ev, host))
 
 
-def interp_fwd_raw(table: torch.Tensor, bins) -> torch.Tensor:
-    bin32, t, ptr, perm = bins
-    e, width = bin32.numel(), table.shape[1]
+def interp_fwd_raw(table: torch.Tensor, bins: KnotBins) -> torch.Tensor:
+    e, width = bins.bin.numel(), table.shape[1]
     w = torch.empty(e, width, device=table.device, dtype=torch.float32)
-    with ops.timed_launch("rtable_fwd", (e, KNOTS, width)):
-        L.check(L.load().e3k_rtable_interp_fwd(L.ptr(table), L.ptr(perm), L.ptr(bin32), L.ptr(t), e, KNOTS, width, L.ptr(w),
-                                               L.stream_ptr()), "e3k_rtable_interp_fwd")
+    with ops.timed_launch("rtable_fwd", (e, bins.knots, width)):
+        L.check(L.load().e3k_rtable_interp_fwd(L.ptr(table), L.ptr(bins.perm), L.ptr(bins.bin), L.ptr(bins.coef), e, bins.knots, width,
+                                               L.ptr(w), L.stream_ptr()), "e3k_rtable_interp_fwd")
     return w
 
 
-def interp_bwd_raw(g_w: torch.Tensor, bins) -> torch.Tensor:
-    bin32, t, ptr, perm = bins
-    width = g_w.shape[1]
-    g_t = torch.empty(KNOTS + 1, width, device=g_w.device, dtype=torch.float32)
-    work = torch.empty(L.load().e3k_rtable_bwd_workspace_floats(KNOTS, width), device=g_w.device, dtype=torch.float32)
-    with ops.timed_launch("rtable_bwd", (bin32.numel(), KNOTS, width)):
-        L.check(L.load().e3k_rtable_interp_bwd(L.ptr(g_w), L.ptr(ptr), L.ptr(perm), L.ptr(t), bin32.numel(), KNOTS, width,
-                                               L.ptr(work), L.ptr(g_t), L.stream_ptr()), "e3k_rtable_interp_bwd")
+def interp_bwd_raw(g_w: torch.Tensor, bins: KnotBins, scale: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """g_T = (interpolation)^T g_w; ``scale`` [E]: every edge's weights times scale[e] (the slope table's gradient in the double
+    backward of force training)."""
+    e, width = bins.bin.numel(), g_w.shape[1]
+    lib = L.load()
+    g_t = torch.empty(bins.knots + 1, width, device=g_w.device, dtype=torch.float32)
+    work = torch.empty(lib.e3k_rtable_bwd_workspace_floats(e, bins.knots, width), device=g_w.device, dtype=torch.float32)
+    with ops.timed_launch("rtable_bwd", (e, bins.knots, width)):
+        L.check(lib.e3k_rtable_interp_bwd(L.ptr(g_w), L.ptr(bins.coef), L.ptr(scale), L.ptr(bins.ptr), L.ptr(bins.seg), L.ptr(bins.perm),
+                                          e, bins.knots, width, L.ptr(work), L.ptr(g_t), 0, L.stream_ptr()), "e3k_rtable_interp_bwd")
     return g_t
 
 
 class RadialTableFn(torch.autograd.Function):
-    """w [E, W] = interpolation of the table T [KNOTS + 1, W] at the edges' radii; backward: g_T (the radii are data)."""
+    """w [E, W] = interpolation of the table T [knots + 1, W] at the edges' radii; backward: g_T (the radii are data)."""
 
     @staticmethod
-    def forward(ctx, table, src: RadialSource):
-        ctx.src = src
-        return interp_fwd_raw(L.f32c(table), src.bins())
+    def forward(ctx, table, bins: KnotBins):
+        ctx.bins = bins
+        return interp_fwd_raw(L.f32c(table), bins)
 
     @staticmethod
     def backward(ctx, g_w):
         if torch.is_grad_enabled():
-            raise RuntimeError("double backward through the radial table is not built: set E3K_RADIAL_TABLE=0")
-        return interp_bwd_raw(L.f32c(g_w), ctx.src.bins()), None
+            raise RuntimeError("double backward through the materialised radial table is not built (force training runs the "
+                               "force block, backend/conv_force.py, or the per-edge path): set E3K_RADIAL_TABLE=0")
+        return interp_bwd_raw(L.f32c(g_w), ctx.bins), None
 
 
 def last_weight(fc):
@@ -252,4 +321,4 @@ def table_weights(fc, edge_radial) -> torch.Tensor:
     src = source_of(edge_radial)
     table = fc(src.knot_basis())            # the MLP on KNOTS + 1 rows: its forward AND backward shrink with it
     guard(last_weight(fc), table)
-    return RadialTableFn.apply(table, src)
+    return RadialTableFn.apply(table, src.bins())

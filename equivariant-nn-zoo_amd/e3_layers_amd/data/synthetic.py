@@ -37,14 +37,87 @@ def _grow_molecule(n: int, gen: torch.Generator) -> torch.Tensor:
     return pos
 
 
-def synth_qm9_list(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: Optional[float] = 4.0):
+# ---- bonds="clustered": chemistry-like geometry ---------------------------------------------------------------------------
+# Real QM9 does not spread its bond lengths over 1.0-1.55 A: C-H sits at 1.09, C-C at 1.52, C-O at 1.43, C=O at 1.21 A (+- 0.01),
+# and with tetrahedral angles the second neighbours cluster too (H-C-H 1.78, C-C-C 2.5 A).  Thousands of edges of a batch then
+# share a handful of 2-8 mA knot bins of the radial table -- the case VERDICT r3 found untested (its rank sort and one-wave-per-bin
+# transpose degenerated there).  This generator reproduces that distribution; nothing else about it is meant to be chemistry.
+_BOND = {(6, 6): 1.52, (6, 7): 1.47, (6, 8): 1.43, (6, 9): 1.35, (7, 7): 1.45, (7, 8): 1.40, (8, 8): 1.48, (7, 9): 1.36, (8, 9): 1.42,
+         (9, 9): 1.42, (1, 6): 1.09, (1, 7): 1.01, (1, 8): 0.96, (1, 9): 0.92, (1, 1): 0.74}
+_VALENCE = {1: 1, 6: 4, 7: 3, 8: 2, 9: 1}
+_TETRA = math.acos(-1.0 / 3.0)
+
+
+def _grow_molecule_clustered(z: torch.Tensor, gen: torch.Generator):
+    """(positions, species reordered heavy atoms first): a bonded tree with element-pair bond lengths (+- 0.01 A; a fifth of the C-O
+    bonds are the 1.21 A double bond) and tetrahedral angles at every atom that already has a bond."""
+    z = torch.cat([z[z != 1], z[z == 1]])
+    n = z.numel()
+    pos = torch.zeros(n, 3)
+    free = [_VALENCE[int(t)] for t in z]
+    first_bond = [None] * n                      # direction of each atom's first bond (the reference the angles are measured from)
+    placed = 1
+    while placed < n:
+        zi = int(z[placed])
+        cands = [a for a in range(placed) if free[a] > 0 and (int(z[a]) != 1 or placed == 1)]
+        if not cands:
+            cands = [a for a in range(placed) if int(z[a]) != 1] or list(range(placed))      # valences exhausted: over-bond a heavy atom
+        ok = False
+        for attempt in range(40):
+            a = cands[int(torch.randint(len(cands), (1,), generator=gen))]
+            za = int(z[a])
+            length = _BOND[(min(za, zi), max(za, zi))]
+            if {za, zi} == {6, 8} and float(torch.rand(1, generator=gen)) < 0.2:
+                length = 1.21
+            length += 0.01 * float(torch.randn(1, generator=gen))
+            rnd = torch.randn(3, generator=gen)
+            if first_bond[a] is None or attempt >= 30:
+                d = rnd / rnd.norm().clamp(min=1e-9)
+            else:                                # tetrahedral angle to the atom's first bond, random azimuth
+                u = first_bond[a]
+                perp = rnd - (rnd @ u) * u
+                perp = perp / perp.norm().clamp(min=1e-9)
+                d = math.cos(_TETRA) * u + math.sin(_TETRA) * perp
+            cand = pos[a] + length * d
+            dist = (pos[:placed] - cand).norm(dim=1)
+            dist[a] = 10.0
+            if float(dist.min()) >= (1.5 if attempt < 20 else 0.95):      # non-bonded contacts: >= 1.5 A (geminal H-H is 1.78)
+                ok = True
+                break
+        if not ok:                               # crowded: anywhere 1.0-1.55 A from some atom, as the uniform generator does
+            while True:
+                a = int(torch.randint(placed, (1,), generator=gen))
+                d = torch.randn(3, generator=gen)
+                d = d / d.norm().clamp(min=1e-9)
+                cand = pos[a] + (1.0 + 0.55 * float(torch.rand(1, generator=gen))) * d
+                if float((pos[:placed] - cand).norm(dim=1).min()) >= 0.95:
+                    break
+        pos[placed] = cand
+        free[a] -= 1
+        free[placed] -= 1
+        if first_bond[a] is None:
+            first_bond[a] = d.clone()
+        first_bond[placed] = -d
+        placed += 1
+    return pos, z
+
+
+def synth_qm9_list(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: Optional[float] = 4.0, bonds: str = "uniform"):
+    """``bonds``: "uniform" (neighbour distances U(1.0, 1.55) A in random directions) or "clustered" (element-pair
+    bond lengths +- 0.01 A and tetrahedral angles: the distance distribution of real molecules, see above)."""
+    if bonds not in ("uniform", "clustered"):
+        raise ValueError(bonds)
     gen = torch.Generator(device="cpu").manual_seed(seed)
     attrs = {"pos": ("node", "1x1o"), "species": ("node", "1x0e"), "total_energy": ("graph", "1x0e")}
     out = []
     for _ in range(n_mol):
         n = int(min(29, max(3, round(18 + 4.5 * float(torch.randn(1, generator=gen))))))
         z = _SPECIES[torch.multinomial(_PROBS, n, replacement=True, generator=gen)]
-        pos = _grow_molecule(n, gen).float()
+        if bonds == "clustered":
+            pos, z = _grow_molecule_clustered(z, gen)
+            pos = pos.float()
+        else:
+            pos = _grow_molecule(n, gen).float()
         e = 0.1 * float(torch.randn(1, generator=gen))
         if shifts is not None:
             e += float(sum(shifts[int(t)] for t in z))
@@ -58,9 +131,9 @@ def synth_qm9_list(seed: int, n_mol: int, shifts: Optional[List[float]] = None, 
     return out, attrs
 
 
-def synth_qm9(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: float = 4.0) -> Batch:
+def synth_qm9(seed: int, n_mol: int, shifts: Optional[List[float]] = None, r_max: float = 4.0, bonds: str = "uniform") -> Batch:
     """A Batch with pos, species, total_energy, edge_index (cutoff r_max), _n_nodes, _n_edges."""
-    lst, attrs = synth_qm9_list(seed, n_mol, shifts, r_max)
+    lst, attrs = synth_qm9_list(seed, n_mol, shifts, r_max, bonds)
     return Batch.from_data_list(lst, dict(attrs))
 
 

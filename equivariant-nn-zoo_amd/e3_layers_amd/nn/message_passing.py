@@ -319,18 +319,19 @@ class MessagePassing(Module):
         self.__dict__[slot] = plan
         return plan
 
-    def _stack_rows(self, cache: dict, rows, edge_radial, plan, fork: bool, use_table: bool):
+    def _stack_rows(self, cache: dict, rows, edge_radial, plan, fork: bool, use_table: bool, slope=None, bessel=None):
         """This layer's radial-MLP output rows (on the knots of the table, or per edge), from one batched evaluation of the
         MLPs of every layer that follows on the same edge embedding (``_next_mp`` chain) -- or None when the stack does not
         apply.  The first layer of a chain computes it (on the radial stream when forked) and leaves the others' rows in
-        ``cache`` (which lives as long as this forward pass's edge embedding); every layer takes its own entry out."""
+        ``cache`` (which lives as long as this forward pass's edge embedding); every layer takes its own entry out.
+        ``slope`` (force training; see ``conv_native.RadialStackFn``): the entry is then the pair (table T, slope table D)."""
         from ..backend import conv_native
 
         if not conv_native.ENABLED or conv_native.native_layer(plan) is None:
             return None
         grad = torch.is_grad_enabled()
         hit = cache.pop(id(self), None)
-        if hit is not None and hit[1] == (grad, fork):
+        if hit is not None and hit[1] == (grad, fork, slope is not None):
             return hit[0]
         sig = (plan.mlp_k0, plan.last_spec.d_in, tuple(plan.mlp_alphas), plan.mlp_act, plan.mlp_cst)
         chain, m = [], self
@@ -342,9 +343,12 @@ class MessagePassing(Module):
             fc = list(m.conv.fc.children())
             if (pl.mlp_k0, pl.last_spec.d_in, tuple(pl.mlp_alphas), pl.mlp_act, pl.mlp_cst) != sig:
                 break
-            if m is not self and (radial_table.applicable(edge_radial, fc[-1].weight) != use_table
-                                  or bool(FWD_FORK and m.conv._fork_pays(n_edges, use_table))
-                                  != bool(FWD_FORK and self.conv._fork_pays(n_edges, use_table))):
+            if m is not self and slope is not None:
+                if not radial_table.knots_for(edge_radial, fc[-1].weight, allow_grad=True):
+                    break
+            elif m is not self and (radial_table.applicable(edge_radial, fc[-1].weight) != use_table
+                                    or bool(FWD_FORK and m.conv._fork_pays(n_edges, use_table))
+                                    != bool(FWD_FORK and self.conv._fork_pays(n_edges, use_table))):
                 break
             chain.append((m, pl, fc))
             m = m.__dict__.get("_next_mp")
@@ -358,11 +362,14 @@ class MessagePassing(Module):
             side = ops.side_stream(rows.device)
             side.wait_stream(main)              # (the knot basis was evaluated on this stream)
             with ops.on_stream(side, main):     # forward AND backward of the stack live on the radial stream
-                outs = conv_native.RadialStackFn.apply(rows, plans, use_table, main, *weights)
+                outs = conv_native.RadialStackFn.apply(rows, plans, use_table, main, slope, bessel, *weights)
         else:
-            outs = conv_native.RadialStackFn.apply(rows, plans, use_table, None, *weights)
+            outs = conv_native.RadialStackFn.apply(rows, plans, use_table, None, slope, bessel, *weights)
+        if slope is not None:
+            n = len(chain)
+            outs = [(outs[i], outs[n + i]) for i in range(n)]
         for (m, _, _), out in zip(chain[1:], outs[1:]):
-            cache[id(m)] = (out, (grad, fork))
+            cache[id(m)] = (out, (grad, fork, slope is not None))
         return outs[0]
 
     def _kw_stack_rows(self, node_attrs, attrs, groups, plan, fork: bool, n_edges: int, use_table: bool):
@@ -405,12 +412,53 @@ class MessagePassing(Module):
             cache[id(m)] = (out, (grad, fork, id(groups)))
         return outs[0]
 
+    def _forward_force(self, data, out_cf: bool):
+        """The layer through the force block (``backend/conv_force.py``: differentiable twice, on the value + slope knot tables)
+        when the spherical harmonics and the radii require grad and the layer's structure is served, else None."""
+        from ..backend import conv_force
+
+        x, sh, radial = data["input_features"], data["edge_spherical"], data["edge_radial"]
+        plan = self._block_plan()
+        if plan is None or not conv_force.supported(plan, x.device):
+            return None
+        conv = self.conv
+        src = radial_table.source_of(radial)
+        if conv.sc is None or src is None or not src.r.requires_grad:
+            return None
+        attrs = data["node_attrs"]
+        key = get_row_key(attrs)
+        if not conv.sc.keyed_pays(key, x.shape[0]):
+            return None
+        fc = list(conv.fc.children())
+        knots = radial_table.knots_for(radial, fc[-1].weight, allow_grad=True)
+        if not knots:
+            return None
+        groups = row_groups(key[0], key[1])
+        topo = get_topology(data, x.shape[0])
+        bins = src.bins(knots)
+        mod = src.module()
+        b, c = mod.basis, mod.cutoff
+        slope = (radial_table.knot_radii(float(b.r_max), knots, x.device), float(b.r_max), float(b.r_min), float(c.p),
+                 int(b.one_over_r), int(c.cutoff.kind))
+        tables = self._stack_rows(src._stack, src.knot_basis(knots), radial, plan, False, True, slope=slope, bessel=b.bessel_weights)
+        if tables is None:
+            return None
+        m = None
+        if KW_STACK and ops.GRAD_READY is None:
+            m = self._kw_stack_rows(attrs, attrs, groups, plan, False, radial.shape[0], True)
+        if m is None:
+            m = ops.keyed_weights(attrs.index_select(0, groups.reps), conv.sc.weight, plan.sc_spec, plan.sc_m_off, plan.sc_ld_m)
+        return conv_force.force_block(x, m, tables[0], tables[1], sh, src.r, plan, topo, groups, bins,
+                                      bool(getattr(x, "_e3k_cf", False)), out_cf, conv.linear_1.weight, conv.tp.linear.weight)
+
     def _forward_block(self, data, out_cf: bool):
         """The layer through ``conv_block`` when it applies to this call, else None (composed path)."""
         if not conv_block.ENABLED:
             return None
         x, sh, radial = data["input_features"], data["edge_spherical"], data["edge_radial"]
-        if not x.is_cuda or sh.requires_grad:          # forces / double backward: the composed ops are differentiable twice
+        if x.is_cuda and sh.requires_grad:             # forces / double backward: the force block, else the composed ops
+            return self._forward_force(data, out_cf)
+        if not x.is_cuda:
             return None
         plan = self._block_plan()
         if plan is None:

@@ -221,26 +221,45 @@ int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* plan);
 
 /* The forward and the node-feature backward with the per-edge path weights interpolated INSIDE the kernel from the radial
  * knot table (the weights `self.fc(edge_radial)` of nn/message_passing.py:93, never materialised as [E, W]):
- * T [K + 1, W] = the radial MLP on the knots, bin / t [E] = each edge's centre knot and offset (e3k_rtable_bin).
+ * T [K + 1, W] = the radial MLP on the knots, bin [E] = each edge's knot i (stencil rows i - 1 .. i + 2), coef [E, 4] = its
+ * four interpolation weights (e3k_rtable_bins).
  * Same results as e3k_rtable_interp_fwd followed by e3k_tp_fwd / e3k_tp_bwd_x (same interpolation arithmetic).
  * e3k_tp_table_supported: 1 when the plan has this form (channel-complete plans: every group a multiple of 64 channels with
  * all its degree slots present -- the inner layers of every shipped model), else the two entry points return
  * E3K_ERR_UNSUPPORTED. */
 int e3k_tp_table_supported(const e3k_tp_plan* plan);
 int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,
-                     const float* t, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                     const float* coef, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
                      float* out, void* stream);
-int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* t,
+int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* coef,
                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N,
                        int64_t E, float* g_x, void* stream);
-/* The gradient of the table: e3k_tp_bwd_w + the first pass of e3k_rtable_interp_bwd in one kernel that walks the edges in
- * knot order (bin_ptr [K + 2] / bin_perm [E]: CSR by knot) and keeps every edge's weight gradient in registers:
- * P [K + 1, 3, W] (e3k_rtable_bwd_workspace_floats) = the per-knot partial sums, bit-identical to that pair; then
- * e3k_rtable_bwd_combine(P) -> g_T [K + 1, W].  g_w[E, W] never exists.  Plans with e3k_tp_table_supported. */
-int e3k_tp_bwd_table_partial(const e3k_tp_plan* plan, const float* x, const float* sh, const float* g_out, const int32_t* src,
-                             const int32_t* dst, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t, int64_t N,
-                             int64_t E, int32_t K, float* P, void* stream);
-int e3k_rtable_bwd_combine(const float* P, int32_t K, int32_t W, float* g_T, void* stream);
+/* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights
+ * then depend on pos through the radius, nn/message_passing.py:93).  With F = <g, TP(x[src], sh, w(T, coef))>, linear in each
+ * of (g, x, sh, T, coef), every first and second derivative is one of the walks below (plans with e3k_tp_table2_supported:
+ * channel-complete, one wave per group -- the l_max <= 2 models):
+ * D [K + 1, W] is the SLOPE table dT/dr on the knots (e3k_radial_slope_fwd), interpolated with the same weights:
+ * dw/dr[e] = sum_k coef[e,k] D[bin[e] - 1 + k]  (differentiating the weights instead would amplify the table's fp32 rounding by
+ * 1 / knot spacing: measured 7e-6 .. 4e-5 relative slope error at any knot count, against 5e-8 this way).
+ *   e3k_tp_bwd_e_table      g_sh [E, d_sh] += dF/dsh, g_r [E] += <dF/dw, dw/dr> (atomics: the caller zero-fills; either may be
+ *                           NULL), g_w [E, W] = dF/dw written when non-null -- the first backward of a force evaluation
+ *   e3k_tp_fwd_jvp_table    out = TP(x2, sh, w) + TP(x, sh2, w) + TP(x, sh, s2 * dw/dr)          (s2 [E]: the radius' partner)
+ *   e3k_tp_bwd_x_dual_table g_x = dF/dx at (sh2, w) + dF/dx at (sh, s2 * dw/dr)
+ *   e3k_tp_bwd_w_dual       g_w = dF/dw at (x2, sh) + dF/dw at (x, sh2)           (w is the open slot: no table involved) */
+int e3k_tp_table2_supported(const e3k_tp_plan* plan);
+int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
+                       const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
+                       const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream);
+int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
+                         const float* T, const float* D, const int32_t* bin, const float* coef, const float* s2,
+                         const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out,
+                         void* stream);
+int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh, const float* sh2, const float* T, const float* D,
+                            const int32_t* bin, const float* coef, const float* s2, const float* g_out, const int32_t* dst,
+                            const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
+int e3k_tp_bwd_w_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
+                      const float* g_out, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
+                      float* g_w, void* stream);
 int e3k_tp_bwd_x(const e3k_tp_plan* plan, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 
@@ -269,24 +288,32 @@ int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int3
  * Radial weights through a knot table (csrc/e3k_rtable.hip).
  * Replaces weight = fc(edge_radial) (nn/message_passing.py:74-79,93) evaluated per edge when edge_radial is
  * RadialBasisEncoding(edge_length) (nn/embedding.py:210-219): the MLP is evaluated on the K + 1 knots j * r_max / K
- * (T [K+1, W], by the caller, with the same kernels) and every edge interpolates the three knots around it
- * (quadratic Lagrange weights; error ~5e-9 relative at K = 4096, below fp32 rounding of the per-edge evaluation).
- *   e3k_rtable_bin        r [E] -> bin2 int64 [2,E] (centre knot i in [1, K-1], both rows: feed it to e3k_csr_build with
- *                         N = K + 1 to group the edges by knot; row 0 doubles as the int64 index), t [E] = r/h - i
- *   e3k_rtable_interp_fwd w[e,:] = t(t-1)/2 T[i-1,:] + (1-t^2) T[i,:] + t(t+1)/2 T[i+1,:]     (bin = int32 copy of the knots;
- *                         edges are visited in knot order, bin_perm, so that neighbouring waves share table rows)
- *   e3k_rtable_interp_bwd g_T[j,:] = sum over the edges of bins j-1, j, j+1 (bin_ptr [K+2], bin_perm [E]: CSR by knot,
- *                         ascending edge id) of their weight of knot j times g_w[e,:]; every row written; no atomics
- *                         (per-bin partial sums in the workspace, then a fixed-order combination).
+ * (T [K+1, W], by the caller, with the same kernels) and every edge interpolates the FOUR knots around it (cubic Lagrange
+ * weights: error 3/128 h^4 max|d4f|; ~1e-7 relative at K = 512 for the shipped models, the fp32 rounding of the table).
+ *   e3k_rtable_bins       r [E], h_inv = 1 / knot spacing (a power of two makes r / h and the offsets exact; the knots are then
+ *                         exactly representable too) -> bin [E] (knot i = floor(r / h) clamped to [1, K - 2]; stencil rows
+ *                         i - 1 .. i + 2),
+ *                         coef [E, 4] (the four weights), and the edges grouped
+ *                         by knot with a STABLE counting sort: bin_ptr [K + 2], bin_perm [E] (ascending edge id inside a knot),
+ *                         bin_seg [K + 2] (first segment of <= 64 edges of every knot: the transpose's work list).
+ *                         workspace: e3k_rtable_bins_workspace_ints(E, K) int32.  Three launches, no atomics, no sort.
+ *   e3k_rtable_interp_fwd w[e,:] = sum_k coef[e,k] T[bin[e] - 1 + k,:]     (edges visited in knot order, bin_perm, so that
+ *                         neighbouring waves share table rows)
+ *   e3k_rtable_interp_bwd g_T[j,:] (+)= sum over the edges whose stencil holds row j of their weight for it (times scale[e] when
+ *                         scale is given) times g_w[e,:]; every row written; no atomics: per-segment partial sums in the
+ *                         workspace, then a fixed-order combination (bit-identical run to run).
  * W must be a multiple of 4.
  * ------------------------------------------------------------------------------------------ */
-int e3k_rtable_bin(const float* r, int64_t E, float r_max, int32_t K, int64_t* bin2, float* t, void* stream);
-int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* t, int64_t E, int32_t K,
+int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K);
+int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
+                    int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream);
+int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
                           int32_t W, float* w, void* stream);
-/* workspace: e3k_rtable_bwd_workspace_floats(K, W) floats (per-bin partial sums, combined in a fixed order) */
-int64_t e3k_rtable_bwd_workspace_floats(int32_t K, int32_t W);
-int e3k_rtable_interp_bwd(const float* g_w, const int32_t* bin_ptr, const int32_t* bin_perm, const float* t, int64_t E,
-                          int32_t K, int32_t W, float* workspace, float* g_T, void* stream);
+/* workspace: e3k_rtable_bwd_workspace_floats(E, K, W) floats (per-segment partial sums, combined in a fixed order) */
+int64_t e3k_rtable_bwd_workspace_floats(int64_t E, int32_t K, int32_t W);
+int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scale, const int32_t* bin_ptr,
+                          const int32_t* bin_seg, const int32_t* bin_perm, int64_t E, int32_t K, int32_t W, float* workspace,
+                          float* g_T, int32_t accumulate, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-side elementwise kernels.
@@ -522,14 +549,14 @@ typedef struct {
                                 of those rows (g_T resp. g_w), which e3k_radial_stack_bwd takes from there */
   int32_t in_kernel;         /* table only, plans with e3k_tp_table_supported: the tensor-product kernels interpolate the
                                 path weights from T themselves (e3k_tp_fwd_table / e3k_tp_bwd_x_table): no interpolation
-                                pass, w unused (may be null); the backward needs T.  2: the backward also forms the
-                                gradient of the table with e3k_tp_bwd_table_partial (no g_w; g_w may be null) */
+                                pass, w unused (may be null); the backward needs T */
   int32_t _pad;
   const float* radial;       /* [R, k0] */
-  const int32_t* bin;        /* table: centre knot per edge, */
-  const int32_t* bin_ptr;    /*        CSR by knot (backward), */
+  const int32_t* bin;        /* table: knot per edge, */
+  const int32_t* bin_ptr;    /*        edges grouped by knot (backward), */
   const int32_t* bin_perm;
-  const float* bin_t;        /*        offset per edge */
+  const float* bin_coef;     /*        the four interpolation weights per edge [E, 4], */
+  const int32_t* bin_seg;    /*        first <= 64-edge segment of every knot [knots + 2] (e3k_rtable_bins) */
   const float* w_last;
   const float* w_hidden[4];
   float* h;                  /* [R, h] out */
@@ -593,9 +620,40 @@ typedef struct {
   float* gb_hidden[4];
   float* g_h;                /* scratch [R, h] */
   float* g_radial;           /* [R, k0] per layer (the caller sums) or NULL */
+  /* force training on the table: the gradient of the SLOPE table D = H' W_last (e3k_radial_slope_fwd) joins the table's --
+   * gb_last += H'^T g_slope here by the ordinary GEMM; g_hp = g_slope W_last^T is handed to the float64 reverse sweep of the
+   * tangent chain (e3k_slope_tangent_bwd), which adds the hidden weights' share into gb_hidden.  All NULL: no slope table. */
+  const float* g_slope;      /* [R, W] gradient of D */
+  const float* hp;           /* [R, h] H' (fp32) as e3k_radial_slope_fwd wrote it */
+  float* g_hp;               /* scratch [R, h] */
 } e3k_radial_stack_item;
+/* what the slope tables' chain needs besides the layers' weights: the knot radii, the basis and float64 scratch */
+typedef struct {
+  const float* knots;        /* [R] */
+  const float* bessel_w;     /* [k0] */
+  float r_max, r_min, p;
+  int32_t one_over_r, cutoff_kind, _pad;
+  double* acc;               /* backward: e3k_slope_tangent_bwd_scratch(n, n_hidden, k0, h) doubles */
+  float* g_bessel;           /* backward: [k0] fp32, ADDED to (NULL: the frequencies need no gradient) */
+} e3k_slope_ctx;
 int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, void* stream);
-int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, void* stream);
+/* slope: NULL unless some item carries a slope gradient */
+int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_radial_stack_item* items, int32_t n, const e3k_slope_ctx* slope,
+                         void* stream);
+/* The slope tables D_l [R, W] = d/dr fc_l(basis(r)) on the R = knots + 1 knots for the n layers of a radial stack
+ * (csrc/e3k_slope.hip): H'_l = forward-mode derivative of the hidden chain, per knot in float64 (fp32 out, hp[l] [R, h], kept for
+ * the backward) -> D_l = H'_l W_last_l (the layers' LAST_FWD GEMM sets). */
+int e3k_radial_slope_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, const e3k_slope_ctx* slope,
+                         float* const* hp, float* const* D, void* stream);
+/* pieces (also exported for tests); w_hidden[i * 4 + l]: layer l of net i */
+int e3k_slope_tangent_fwd(const float* const* w_hidden, int32_t n_nets, int32_t n_hidden, const float* alphas, const float* knots,
+                          int64_t R, const float* bessel_w, int32_t k0, int32_t H, float r_max, float r_min, float p,
+                          int32_t one_over_r, int32_t cutoff_kind, int32_t act, float cst, float* const* hp, void* stream);
+int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H);
+int e3k_slope_tangent_bwd(const float* const* w_hidden, int32_t n_nets, int32_t n_hidden, const float* alphas, const float* knots,
+                          int64_t R, const float* bessel_w, int32_t k0, int32_t H, float r_max, float r_min, float p,
+                          int32_t one_over_r, int32_t cutoff_kind, int32_t act, float cst, const float* const* g_hp, double* acc,
+                          float* const* g_hidden, float* g_bessel, void* stream);
 
 /* The per-key self-connection weights M_l = sum_v a[key, v] W_l[:, v, :] of several layers that read the same node attributes
  * (nn/message_passing.py:81-87, 100 x layers), batched: forward = one gather of the keys' representative rows + ONE launch for

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import e3ref
-from tests.util import batch_to_oracle, from_cf, oracle_like, rel_err, to_cf
+from tests.util import batch_to_oracle, from_cf, oracle_like, record_measured, rel_err, to_cf
 
 pytestmark = pytest.mark.gpu
 
@@ -277,3 +277,153 @@ def test_force_training_step_matches_oracle(dev):
         assert err < 2e-4, (name, err)
         checked += 1
     assert checked >= 10
+
+
+def _force_net(dev, n_layers=3, r_max=4.0, seed=0):
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
+    from e3_layers_amd.utils import build
+
+    cfg = featureModel(n_dim=64, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+                       num_types=10, num_layers=n_layers, r_max=r_max)
+    cfg = addForceOutput(addEnergyOutput(cfg, None, output_key="energy_total"), y="energy_total")
+    torch.manual_seed(seed)
+    prod = build(cfg).to(dev).train()
+    orc = e3ref.build(cfg)
+    orc.load_state_dict({k.replace("func.", "func.mods.", 1): v.cpu() for k, v in prod.state_dict().items()})
+    return prod, orc.double().train()
+
+
+def _force_losses(prod, orc, batch, dev, plain_backward=False):
+    from e3_layers_amd.run.parallel import backward_parameters
+
+    gen = torch.Generator().manual_seed(5)
+    f_target = torch.randn(batch["pos"].shape, dtype=torch.float64, generator=gen)
+    e_target = torch.randn(batch["_n_nodes"].shape[0], 1, dtype=torch.float64, generator=gen)
+    for p in prod.parameters():
+        p.grad = None
+    out = prod(batch.clone().to(dev))
+    loss = ((out["forces"] - f_target.float().to(dev)) ** 2).mean() + ((out["energy_total"] - e_target.float().to(dev)) ** 2).mean()
+    if plain_backward:
+        loss.backward()
+    else:
+        backward_parameters(loss, list(prod.parameters()))
+    ref = None
+    if orc is not None:
+        for p in orc.parameters():
+            p.grad = None
+        data, attrs = batch_to_oracle(batch)
+        o, _ = orc(data, attrs)
+        loss_r = ((o["forces"] - f_target) ** 2).mean() + ((o["energy_total"] - e_target) ** 2).mean()
+        loss_r.backward()
+        ref = (o, loss_r)
+    return out, loss, ref
+
+
+@pytest.mark.parametrize("n_layers", [3, 4])
+def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch, n_layers):
+    """force training on the knot table.  Energy + force model (64 channels: the table's second-order kernels
+    take channel-complete plans) in TRAINING mode on the force block (backend/conv_force.py: value table T and slope table D on
+    the table's knots, three autograd nodes per layer): forces within 1e-5 and every parameter gradient within 5e-5 of the float64
+    oracle -- d/dtheta of dE/dpos, the double backward through every kernel, WITH the table on."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)      # (a 20-molecule batch -- the keyed self-connection wants 256 nodes --: the float64 oracle's double backward is the slow part)
+    prod, orc = _force_net(dev, n_layers)
+    batch = synth_qm9(7, 20)
+    assert batch["edge_index"].shape[1] >= radial_table.layout(4.0, radial_table.KNOTS_SLOPE)[0] + 1
+    before = list(conv_force.STATS)
+    out, loss, (o, loss_r) = _force_losses(prod, orc, batch, dev)
+    assert [a - b for a, b in zip(conv_force.STATS, before)] == [n_layers, n_layers, n_layers]      # every layer ran as a force block
+    err_f, err_e = rel_err(out["forces"], o["forces"]), rel_err(out["energy_total"], o["energy_total"])
+    record_measured("force_block_table", layers=n_layers, forces=err_f, energy=err_e)
+    assert err_e < 1e-5 and err_f < 1e-5, (err_e, err_f)
+    assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5 * abs(float(loss_r.detach()))
+    ref_params = dict(orc.named_parameters())
+    checked, worst = 0, 0.0
+    for name, p in prod.named_parameters():
+        rp = ref_params[name.replace("func.", "func.mods.", 1)]
+        if rp.grad is None or float(rp.grad.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        err = rel_err(p.grad, rp.grad)
+        worst = max(worst, err)
+        assert err < 5e-5, (name, err)
+        checked += 1
+    record_measured("force_block_table_grads", layers=n_layers, worst_parameter_gradient=worst, checked=checked)
+    assert checked >= 10
+    # a plain loss.backward() (the reference's trainer) gives the same parameter gradients (d loss / d pos is not formed: warned once)
+    grads = {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None}
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        _force_losses(prod, None, batch, dev, plain_backward=True)
+    for n, p in prod.named_parameters():
+        if n in grads:
+            assert rel_err(p.grad, grads[n]) < 1e-6, n
+
+
+def test_force_block_equals_the_composed_path_and_serves_inference(dev, monkeypatch):
+    """The force block against the composed per-edge path of rounds 1-3 (E3K_FORCE_BLOCK=0) on the same weights, and forces in
+    eval mode (create_graph=False: the block's first-order backward hands back g_sh and g_r itself)."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+    prod, _ = _force_net(dev, 3)
+    batch = synth_qm9(11, 20)
+    out_b, loss_b, _ = _force_losses(prod, None, batch, dev)
+    g_b = {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None}
+    monkeypatch.setattr(conv_force, "ENABLED", 0)
+    for m in prod.modules():                     # (the plans cached the decision)
+        for slot in ("_cb_plan", "_cb_plan_add"):
+            pl = m.__dict__.get(slot)
+            if pl is not None and pl is not False:
+                pl.__dict__.pop("_force_ok", None)
+    before = list(conv_force.STATS)
+    out_c, loss_c, _ = _force_losses(prod, None, batch, dev)
+    assert conv_force.STATS == before            # composed this time
+    assert rel_err(out_b["forces"], out_c["forces"]) < 2e-5 and rel_err(out_b["energy_total"], out_c["energy_total"]) < 1e-5
+    for n, p in prod.named_parameters():
+        if n in g_b and float(p.grad.abs().max()) > 0:
+            assert rel_err(g_b[n], p.grad) < 1e-4, n
+    monkeypatch.setattr(conv_force, "ENABLED", 1)
+    for m in prod.modules():
+        for slot in ("_cb_plan", "_cb_plan_add"):
+            pl = m.__dict__.get(slot)
+            if pl is not None and pl is not False:
+                pl.__dict__.pop("_force_ok", None)
+    prod.eval()
+    before = list(conv_force.STATS)
+    f_eval = prod(batch.clone().to(dev))["forces"]
+    assert conv_force.STATS[0] - before[0] == 3 and conv_force.STATS[1] == before[1]      # block forward, no create_graph pass
+    assert not f_eval.requires_grad
+    assert rel_err(f_eval, out_b["forces"]) < 1e-6
+
+
+def test_slope_table_guard_vetoes_and_the_per_edge_path_takes_over(dev, monkeypatch):
+    """A radial MLP whose slope table would miss the budget (first layer scaled x 40: the bound grows like scale^4) is vetoed by the
+    slope guard after its first forward; the layer then runs the per-edge composed path and the forces still meet the oracle."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+    monkeypatch.setattr(radial_table, "GUARD_EVERY", 1)
+    prod, orc = _force_net(dev, 3, seed=1)
+    with torch.no_grad():
+        prod.func.layer1.conv.fc.layer0.weight.mul_(40.0)
+    orc.load_state_dict({k.replace("func.", "func.mods.", 1): v.cpu().double() for k, v in prod.state_dict().items()})
+    batch = synth_qm9(13, 20)
+    key = radial_table.last_weight(prod.func.layer1.conv.fc)
+    _force_losses(prod, None, batch, dev)                     # builds the tables; the guards' read-backs arrive
+    torch.cuda.synchronize()
+    errs = (radial_table.guard_error(key, slope=False), radial_table.guard_error(key, slope=True))
+    record_measured("slope_guard", value_bound=errs[0], slope_bound=errs[1])
+    assert errs[1] is not None and errs[1] > radial_table.GUARD_TOL, errs
+    assert not radial_table.guard_ok(key, slope=True)
+    assert radial_table.guard_ok(radial_table.last_weight(prod.func.layer0.conv.fc), slope=True)
+    before = list(conv_force.STATS)
+    out, loss, (o, loss_r) = _force_losses(prod, orc, batch, dev)
+    assert conv_force.STATS[0] - before[0] == 2               # layers 0 and 2 on the block, layer 1 per edge
+    assert rel_err(out["forces"], o["forces"]) < 2e-5

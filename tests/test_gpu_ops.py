@@ -448,6 +448,60 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
     assert rel_err(y_edges, yr_edges) < TOL
 
 
+def _cubic_coef64(r, r_max, target):
+    """float64 restatement of e3k_rtable_bins' per-edge part: knot i and the four cubic Lagrange weights (on the power-of-two
+    spacing radial_table.layout picks for the target knot count)"""
+    from e3_layers_amd.backend.radial_table import layout
+
+    knots, h = layout(r_max, target)
+    x = (r.double() / h).clamp(0, knots)
+    i = x.floor().clamp(1, knots - 2)
+    t = (x - i).unsqueeze(1)
+    c = torch.cat([-t * (t - 1) * (t - 2) / 6, (t + 1) * (t - 1) * (t - 2) / 2, -(t + 1) * t * (t - 2) / 2, (t + 1) * t * (t - 1) / 6], 1)
+    return i.long(), c
+
+
+@pytest.mark.parametrize("clustered", [False, True])
+def test_knot_bins_are_the_stable_counting_sort(dev, clustered):
+    """e3k_rtable_bins: knot, the four cubic weights, and the edges grouped by knot == a stable argsort (ascending edge id inside a
+    knot), its row pointers and the <= 64-edge segment list -- also when thousands of edges share a handful of knots (real
+    molecules: C-H 1.09 A, C-C 1.52 A; VERDICT r3: the rank sort of round 3 was O(len^2) there), and bit-identical run to run."""
+    from e3_layers_amd.backend import radial_table
+
+    gen = torch.Generator().manual_seed(3)
+    e, knots, r_max = 70_001, 512, 4.0
+    if clustered:
+        centres = torch.tensor([1.09, 1.52, 1.43, 1.21, 2.5])
+        r = centres[torch.randint(0, 5, (e,), generator=gen)] + 0.004 * torch.randn(e, generator=gen)
+    else:
+        r = torch.rand(e, generator=gen) * 4.4                      # some beyond r_max
+    r[:4] = torch.tensor([0.0, 4.0, 3.99999, 1e-4])
+    a = radial_table.build_bins(r.to(dev), r_max, knots)
+    b = radial_table.build_bins(r.to(dev), r_max, knots)
+    i_ref, c_ref = _cubic_coef64(r, r_max, knots)
+    knots = a.knots
+    assert (knots, a.spacing) == radial_table.layout(r_max, 512) and knots * a.spacing >= r_max
+    bin_cpu = a.bin.cpu().long()
+    # the spacing is a power of two: r / h and the offset inside the interval are exact in fp32 -- the knot is THE knot
+    assert torch.equal(bin_cpu, i_ref)
+    assert float((a.coef.cpu().double() - c_ref).abs().max()) < 1e-6
+    assert float((a.coef.sum(1) - 1).abs().max()) < 1e-6                             # the weights interpolate constants exactly
+    assert torch.equal(a.coef[1].cpu(), torch.tensor([0.0, 0.0, 0.0, 1.0]))          # r = r_max: the last knot
+    perm_ref = torch.argsort(bin_cpu, stable=True).int()
+    assert torch.equal(a.perm.cpu(), perm_ref)
+    cnt = torch.bincount(bin_cpu, minlength=knots + 1)            # (knots: the table's actual interval count from here on)
+    ptr_ref = torch.zeros(knots + 2, dtype=torch.int64)
+    ptr_ref[1:] = torch.cumsum(cnt, 0)
+    assert torch.equal(a.ptr.cpu().long(), ptr_ref)
+    seg_ref = torch.zeros(knots + 2, dtype=torch.int64)
+    seg_ref[1:] = torch.cumsum((cnt + 63) // 64, 0)
+    assert torch.equal(a.seg.cpu().long(), seg_ref)
+    for name in ("bin", "coef", "ptr", "perm", "seg"):
+        assert torch.equal(getattr(a, name), getattr(b, name)), name
+    if clustered:
+        assert int(cnt.max()) > 5000
+
+
 @pytest.mark.parametrize("left,out", [
     ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
     ("64x0e", "64x0e+64x1o+64x2e"),
@@ -457,16 +511,14 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
 def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
     """e3k_tp_fwd_table / e3k_tp_bwd_x_table (the path weights interpolated from the radial knot table inside the kernel) ==
     e3k_rtable_interp_fwd into w[E, W] followed by e3k_tp_fwd / e3k_tp_bwd_x, bit for bit (same interpolation arithmetic, same
-    order of accumulation); plans without the form say so."""
-    import ctypes as C
-
+    order of accumulation); the interpolation and its transpose against float64; plans without the form say so."""
     from e3_layers_amd.backend import lib as L
-    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend import ops, radial_table
     from e3_layers_amd.backend.graph import build_topology
     from e3_layers_amd.nn import TensorProductExpansion
 
     torch.manual_seed(21)
-    n, knots = 300, 256
+    n, knots, r_max = 300, 256, 5.0
     ei = _random_graph(n, 9, 14)
     e = ei.shape[1]
     mod = TensorProductExpansion(left, ("1x0e+1x1o+1x2e", "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
@@ -477,21 +529,23 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
     x = torch.randn(n, plan.d_in, device=dev)
     sh = torch.randn(e, 9, device=dev)
     g_out = torch.randn(n, plan.d_mid, device=dev)
-    table = torch.randn(knots + 1, plan.w_numel, device=dev)
-    bins = torch.randint(1, knots, (e,), device=dev, dtype=torch.int32)
-    bins[:4] = torch.tensor([1, knots - 1, 1, knots - 1], dtype=torch.int32)      # the ends of the table
-    t = torch.rand(e, device=dev) - 0.5
-    perm = torch.argsort(bins.long(), stable=True).int()
-    w = torch.empty(e, plan.w_numel, device=dev)
-    L.check(lib.e3k_rtable_interp_fwd(L.ptr(table), L.ptr(perm), L.ptr(bins), L.ptr(t), e, knots, plan.w_numel, L.ptr(w),
-                                      L.stream_ptr()), "interp")
+    r = torch.rand(e) * 5.2
+    r[:4] = torch.tensor([0.0, 5.0, 4.99999, 0.01])                                  # the ends of the table
+    bins = radial_table.build_bins(r.to(dev), r_max, knots)
+    table = torch.randn(bins.knots + 1, plan.w_numel, device=dev)
+    w = radial_table.interp_fwd_raw(table, bins)
+    i_ref, c_ref = _cubic_coef64(r, r_max, knots)
+    assert torch.equal(bins.bin.cpu().long(), i_ref)
+    t64 = table.cpu().double()
+    w_ref = sum(c_ref[:, k:k + 1] * t64[i_ref - 1 + k] for k in range(4))
+    assert rel_err(w, w_ref) < 1e-6
     ref_out = ops._tp_fwd_raw(x, sh, w, topo, plan)
     ref_gx = ops._tp_bwd_x_raw(sh, w, g_out, topo, plan)
     out_t = torch.empty_like(ref_out)
     gx_t = (torch.empty if plan.bwd_x_overwrites(dev) else torch.zeros)(n, plan.d_in, device=dev)
-    L.check(lib.e3k_tp_fwd_table(plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(topo.src),
+    L.check(lib.e3k_tp_fwd_table(plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins.bin), L.ptr(bins.coef), L.ptr(topo.src),
                                  L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(out_t), L.stream_ptr()), "e3k_tp_fwd_table")
-    L.check(lib.e3k_tp_bwd_x_table(plan.handle(dev), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(g_out), L.ptr(topo.dst),
+    L.check(lib.e3k_tp_bwd_x_table(plan.handle(dev), L.ptr(sh), L.ptr(table), L.ptr(bins.bin), L.ptr(bins.coef), L.ptr(g_out), L.ptr(topo.dst),
                                    L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx_t), L.stream_ptr()), "e3k_tp_bwd_x_table")
     torch.cuda.synchronize()
     assert torch.equal(out_t, ref_out)
@@ -499,30 +553,139 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
         assert torch.equal(gx_t, ref_gx)
     else:                                   # (atomic accumulation across groups: the order is not fixed)
         assert rel_err(gx_t, ref_gx) < 1e-6
-    # the gradient of the table: tp_bwd_w -> g_w[E, W] -> transposed interpolation == one kernel in knot order, bit for bit
-    ptr = torch.zeros(knots + 2, dtype=torch.int32, device=dev)
-    ptr[1:] = torch.cumsum(torch.bincount(bins.long(), minlength=knots + 1), 0).int()
-    g_w = torch.empty(e, plan.w_numel, device=dev)
-    L.check(lib.e3k_tp_bwd_w(plan.handle(dev), L.ptr(x), L.ptr(sh), None, L.ptr(g_out), L.ptr(topo.src), L.ptr(topo.dst_ptr),
-                             L.ptr(topo.dst_perm), n, e, L.ptr(g_w), None, L.stream_ptr()), "e3k_tp_bwd_w")
-    n_ws = int(lib.e3k_rtable_bwd_workspace_floats(knots, plan.w_numel))
-    ws_ref, ws_new = torch.empty(n_ws, device=dev), torch.full((n_ws,), float("nan"), device=dev)
-    gt_ref, gt_new = torch.empty(knots + 1, plan.w_numel, device=dev), torch.empty(knots + 1, plan.w_numel, device=dev)
-    L.check(lib.e3k_rtable_interp_bwd(L.ptr(g_w), L.ptr(ptr), L.ptr(perm), L.ptr(t), e, knots, plan.w_numel, L.ptr(ws_ref), L.ptr(gt_ref),
-                                      L.stream_ptr()), "e3k_rtable_interp_bwd")
-    L.check(lib.e3k_tp_bwd_table_partial(plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(g_out), L.ptr(topo.src), L.ptr(topo.dst), L.ptr(ptr),
-                                         L.ptr(perm), L.ptr(t), n, e, knots, L.ptr(ws_new), L.stream_ptr()), "e3k_tp_bwd_table_partial")
-    L.check(lib.e3k_rtable_bwd_combine(L.ptr(ws_new), knots, plan.w_numel, L.ptr(gt_new), L.stream_ptr()), "e3k_rtable_bwd_combine")
-    torch.cuda.synchronize()
-    assert bool(torch.isfinite(gt_new).all())
-    assert torch.equal(gt_new, gt_ref)
+    # the gradient of the table: tp_bwd_w -> g_w[E, W] -> transposed interpolation, against an index_add in float64; twice: same bits
+    g_w, _ = ops._tp_bwd_w_raw(x, sh, None, g_out, topo, plan, False, True)
+    gt_a = radial_table.interp_bwd_raw(g_w, bins)
+    gt_b = radial_table.interp_bwd_raw(g_w, bins)
+    assert torch.equal(gt_a, gt_b)
+    gt_ref = torch.zeros(bins.knots + 1, plan.w_numel, dtype=torch.float64)
+    coef64, bin64, gw64 = bins.coef.cpu().double(), bins.bin.cpu().long(), g_w.cpu().double()
+    for k in range(4):
+        gt_ref.index_add_(0, bin64 - 1 + k, coef64[:, k:k + 1] * gw64)
+    assert rel_err(gt_a, gt_ref) < 2e-6
+    scale = torch.randn(e, device=dev)                                               # ... and with a per-edge factor (the slope table's)
+    gt_s = radial_table.interp_bwd_raw(g_w, bins, scale=scale)
+    gt_ref.zero_()
+    for k in range(4):
+        gt_ref.index_add_(0, bin64 - 1 + k, (coef64[:, k] * scale.cpu().double()).unsqueeze(1) * gw64)
+    assert rel_err(gt_s, gt_ref) < 2e-6
     # a plan without the in-kernel form (odd channel count): refused, not silently wrong
     odd = TensorProductExpansion("24x0e+24x1o", ("1x0e+1x1o+1x2e", "edge_spherical"), ("24x0e+24x1o+24x2e", "edge_features"), "uvu",
                                  internal_weight=False).to(dev)
     assert lib.e3k_tp_table_supported(odd.tp.plan.handle(dev)) == 0
-    rc = lib.e3k_tp_fwd_table(odd.tp.plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins), L.ptr(t), L.ptr(topo.src),
+    rc = lib.e3k_tp_fwd_table(odd.tp.plan.handle(dev), L.ptr(x), L.ptr(sh), L.ptr(table), L.ptr(bins.bin), L.ptr(bins.coef), L.ptr(topo.src),
                               L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(out_t), L.stream_ptr())
     assert rc < 0
+
+
+@pytest.mark.parametrize("left,out", [
+    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
+    ("64x0e", "64x0e+64x1o+64x2e"),
+])
+def test_tp_table_second_order_forms_are_sums_of_first_order_kernels(dev, left, out):
+    """The kernels of force training on the table (backend/conv_force.py) against compositions of the first-order kernels:
+    e3k_tp_bwd_e_table (g_sh, g_r), e3k_tp_fwd_jvp_table, e3k_tp_bwd_x_dual_table, e3k_tp_bwd_w_dual."""
+    from e3_layers_amd.backend import conv_force, ops, radial_table
+    from e3_layers_amd.backend import lib as L
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(22)
+    n, knots, r_max = 200, 128, 5.0
+    ei = _random_graph(n, 9, 14)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, ("1x0e+1x1o+1x2e", "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    tp = mod.tp.plan
+    assert L.load().e3k_tp_table2_supported(tp.handle(dev)) == 1
+    topo = build_topology(ei.to(dev), n)
+    x, x2 = torch.randn(n, tp.d_in, device=dev), torch.randn(n, tp.d_in, device=dev)
+    sh, sh2 = torch.randn(e, 9, device=dev), torch.randn(e, 9, device=dev)
+    g = torch.randn(n, tp.d_mid, device=dev)
+    s2 = torch.randn(e, device=dev)
+    bins = radial_table.build_bins((torch.rand(e) * 5.0).to(dev), r_max, knots)
+    T, D = torch.randn(bins.knots + 1, tp.w_numel, device=dev), torch.randn(bins.knots + 1, tp.w_numel, device=dev)
+    w, dw = radial_table.interp_fwd_raw(T, bins), radial_table.interp_fwd_raw(D, bins)
+    # first backward: d/dsh through w, d/dr through dw/dr
+    g_sh, g_r = conv_force._tp_bwd_e_table(x, sh, T, D, bins, g, topo, tp)
+    g_w_ref, g_sh_ref = ops._tp_bwd_w_raw(x, sh, w, g, topo, tp, True, True)
+    assert rel_err(g_sh, g_sh_ref) < 1e-5
+    assert rel_err(g_r, (g_w_ref.double() * dw.double()).sum(1)) < 1e-5
+    # the product rule in one walk
+    jvp = conv_force._tp_fwd_jvp(x, x2, sh, sh2, T, D, bins, s2, topo, tp)
+    ref = (ops._tp_fwd_raw(x2, sh, w, topo, tp).double() + ops._tp_fwd_raw(x, sh2, w, topo, tp).double()
+           + ops._tp_fwd_raw(x, sh, s2.unsqueeze(1) * dw, topo, tp).double())
+    assert rel_err(jvp, ref) < 1e-5
+    gx = conv_force._tp_bwd_x_dual(sh, sh2, T, D, bins, s2, g, topo, tp)
+    ref = ops._tp_bwd_x_raw(sh2, w, g, topo, tp).double() + ops._tp_bwd_x_raw(sh, s2.unsqueeze(1) * dw, g, topo, tp).double()
+    assert rel_err(gx, ref) < 1e-5
+    gw = conv_force._tp_bwd_w_dual(x, x2, sh, sh2, g, topo, tp)
+    ref = (ops._tp_bwd_w_raw(x2, sh, None, g, topo, tp, False, True)[0].double()
+           + ops._tp_bwd_w_raw(x, sh2, None, g, topo, tp, False, True)[0].double())
+    assert rel_err(gw, ref) < 1e-5
+
+
+def test_slope_table_is_the_derivative_of_the_radial_mlp(dev):
+    """conv_native.RadialStackFn(slope=...): D = d/dr fc(basis(r)) on the knots (csrc/e3k_slope.hip: the hidden chain's forward-mode
+    derivative per knot in float64, last layer in fp32) against the float64 oracle's autograd derivative, and its gradient w.r.t. the
+    MLP weights and the Bessel frequencies against the oracle's double backward."""
+    from e3_layers_amd import nn as pnn
+    from e3_layers_amd.backend import conv_native, radial_table
+    from e3_layers_amd.configs import config_energy_force
+    from e3_layers_amd.utils import build
+
+    torch.manual_seed(3)
+    cfg = config_energy_force.get_config()
+    model = build(cfg.model_config).to(dev)
+    func = model.func
+    layers = [getattr(func, f"layer{i}") for i in range(2)]
+    enc = func.radial_basis
+    knots, r_max = radial_table.KNOTS_SLOPE, 5.0
+    b, c = enc.basis, enc.cutoff
+    radii = radial_table.knot_radii(r_max, knots, dev)
+    from e3_layers_amd.backend import ops
+
+    rows = ops.radial_basis(radii, b.bessel_weights, b.r_max, b.r_min, c.p, b.one_over_r, c.cutoff.kind)
+    plans = [l._block_plan() for l in layers]
+    assert all(conv_native.native_layer(p) is not None for p in plans)
+    weights = []
+    for l in layers:
+        fc = list(l.conv.fc.children())
+        weights.append(fc[-1].weight)
+        weights.extend(m.weight for m in fc[:-1])
+    knots, spacing = radial_table.layout(r_max, knots)
+    slope = (radii, r_max, float(b.r_min), float(c.p), int(b.one_over_r), int(c.cutoff.kind))
+    outs = conv_native.RadialStackFn.apply(rows, plans, True, None, slope, b.bessel_weights, *weights)
+    T, D = outs[:2], outs[2:]
+    # float64 oracle of layer l's radial MLP and its derivative along r
+    for li, l in enumerate(layers):
+        orc_enc = e3ref.RadialBasisEncoding(r_max=r_max, trainable=True, irreps_out=("8x0e", "edge_radial"), irreps_in=("1x0e", "edge_length")).double()
+        orc_enc.load_state_dict({k: v.detach().cpu().double() for k, v in enc.state_dict().items()})
+        hs = [8, 64, 64, 64, plans[li].last_spec.d_out]
+        orc_fc = e3ref.FullyConnectedNet(hs, "ssp").double()
+        orc_fc.load_state_dict({k: v.detach().cpu().double() for k, v in l.conv.fc.state_dict().items()})
+        rr = radii.cpu().double().clone().requires_grad_(True)
+        o, _ = orc_enc({"input": rr}, {"input": ("edge", "1x0e")})
+        f = orc_fc(o[next(iter(o))])
+        cols = torch.randn(f.shape[1], dtype=torch.float64)
+        (df_c,) = torch.autograd.grad((f * cols).sum(), rr, create_graph=True)        # d/dr of a random combination of the columns
+        lo, hi = int(0.6 / spacing), int(r_max / spacing) - 1                          # (no edge is shorter than 0.6 A; from r_max on the rows are flat)
+        assert rel_err(T[li][lo:hi], f[lo:hi].detach()) < 2e-6
+        got = (D[li].double().cpu() * cols).sum(1)
+        assert rel_err(got[lo:hi], df_c[lo:hi].detach()) < 2e-6, li
+        # gradients of <g, D> w.r.t. the parameters
+        gD = torch.zeros_like(D[li])
+        gD[lo:hi] = torch.randn(hi - lo, D[li].shape[1], device=dev)
+        params = [l.conv.fc.layer3.weight, l.conv.fc.layer0.weight, enc.basis.bessel_weights]
+        got_g = torch.autograd.grad(D[li], params, gD, retain_graph=True)
+        # oracle: D = d f / d r per column -> <gD, D> = sum_k sum_c gD[k, c] df_c/dr[k]: forward-mode via a dummy direction
+        eps = torch.zeros_like(rr, requires_grad=True)
+        o2, _ = orc_enc({"input": rr.detach() + eps}, {"input": ("edge", "1x0e")})
+        f2 = orc_fc(o2[next(iter(o2))])
+        (jv,) = torch.autograd.grad(f2, eps, gD.cpu().double(), create_graph=True)   # jv[k] = sum_c gD[k, c] d f_c / d r_k
+        oparams = [orc_fc.layer3.weight, orc_fc.layer0.weight, orc_enc.basis.bessel_weights]
+        ref_g = torch.autograd.grad(jv.sum(), oparams)
+        for a_, b_, nm in zip(got_g, ref_g, ("last", "first hidden", "bessel")):
+            assert rel_err(a_, b_) < 5e-5, (li, nm)
 
 
 def test_tp_repeated_sh_degree_shares_an_input_block(dev):
