@@ -18,7 +18,7 @@
 
 namespace e3k {
 
-constexpr int SL_ROWS = 8;       // knot rows per workgroup (LDS: 2 x 4 levels x 8 rows x 64 doubles + 2 x 8 x 64 = 40 KB)
+constexpr int SL_ROWS = 2;       // knot rows per workgroup (R / 2 workgroups of 64 threads per net: the chain is latency, not work)
 constexpr int SL_MAXH = 64;
 constexpr int SL_MAXL = 4;
 
@@ -87,12 +87,23 @@ __device__ __forceinline__ void basis64(double r, double w, const BasisPar& bp, 
   db_w = dA * (r / delta) * cs + A * (cs / delta - (w / delta) * (r / delta) * sn);
 }
 
+// workspace of one net: per hidden layer l [a_l | a'_l] ([R, k_l] each) then [gz_l | gz'_l] ([R, H] each); behind the last layer the
+// Bessel terms [R, k0]
+__host__ __device__ inline int64_t ws_level_offset(int l, int64_t R, int k0, int H) {
+  int64_t off = 0;
+  for (int i = 0; i < l; ++i) off += 2 * R * (i == 0 ? k0 : H) + 2 * R * H;
+  return off;
+}
+__host__ __device__ inline int64_t slope_ws_doubles(int n_hidden, int64_t R, int k0, int H) {
+  return ws_level_offset(n_hidden, R, k0, H) + R * k0;
+}
+
 struct SlopeNet {
   const float* w[SL_MAXL];      // hidden weights [k_l, H] fp32
   float* hp;                    // forward: [R, H] out (H' in fp32)
   const float* g_hp;            // backward: [R, H] in
-  double* g_w[SL_MAXL];         // backward: [k_l, H] float64 accumulators (zero-filled by the caller), NULL = not wanted
-  double* g_bw;                 // backward: [k0] float64 accumulator of the Bessel frequencies' gradient, NULL = not wanted
+  double* ws;                   // backward: per-row operands of the weight-gradient sums (slope_ws_doubles per net)
+  float* g_w[SL_MAXL];          // backward: [k_l, H] fp32, ADDED to (NULL = not wanted)
 };
 struct SlopeBatch {
   SlopeNet net[16];
@@ -192,13 +203,19 @@ __global__ void slope_tangent_kernel(SlopeBatch b, const float* __restrict__ kno
         gdz[i] = g_t[i] * cst * d1 * al;
         gz[i] = (g_v[i] * cst * d1 + g_t[i] * cst * d2 * al * dz[i]) * al;
       }
-      // weight gradient: g_W[k, j] += sum_rows a[l][row][k] gz[row] + da[l][row][k] gdz[row]
-      if (net.g_w[l]) {
-        for (int k = 0; k < kl; ++k) {
-          double s = 0.0;
-#pragma unroll
-          for (int i = 0; i < SL_ROWS; ++i) s = fma(a[l][i][k], gz[i], fma(da[l][i][k], gdz[i], s));
-          atomicAdd(net.g_w[l] + (int64_t)k * H + j, s);
+      // weight gradient: g_W[k, j] = sum_rows a[l][row][k] gz[row][j] + da[l][row][k] gdz[row][j] -- a sum over ALL knot rows: the
+      // per-row operands go to the workspace, slope_wgrad_kernel sums them (a fixed order, no atomics)
+      {
+        double* wl = net.ws + ws_level_offset(l, R, k0, H);
+        for (int i = 0; i < SL_ROWS; ++i) {
+          const int row = row0 + i;
+          if (row >= R) break;
+          if (j < kl) {
+            wl[(int64_t)row * kl + j] = a[l][i][j];
+            wl[(int64_t)R * kl + (int64_t)row * kl + j] = da[l][i][j];
+          }
+          wl[(int64_t)2 * R * kl + (int64_t)row * H + j] = gz[i];
+          wl[(int64_t)2 * R * kl + (int64_t)R * H + (int64_t)row * H + j] = gdz[i];
         }
       }
       // cotangents of the level below: ga[row][k] = sum_j gz[row][j] W[k, j] (a reduction over the threads: through LDS)
@@ -222,28 +239,46 @@ __global__ void slope_tangent_kernel(SlopeBatch b, const float* __restrict__ kno
         }
       }
     }
-    // level 0 = the basis: the Bessel frequencies
-    if (net.g_bw && j < k0) {
-      double s = 0.0;
+    // level 0 = the basis: the Bessel frequencies' per-row terms
+    if (j < k0) {
+      double* wb = net.ws + ws_level_offset(n_hidden, R, k0, H);
       for (int i = 0; i < SL_ROWS; ++i)
-        if (row0 + i < R) s += g_v[i] * bw_[i] + g_t[i] * dbw_[i];
-      atomicAdd(net.g_bw + j, s);
+        if (row0 + i < R) wb[(int64_t)(row0 + i) * k0 + j] = g_v[i] * bw_[i] + g_t[i] * dbw_[i];
     }
   }
 }
 
-// float64 accumulators -> the fp32 gradient buffers (added): one launch for all segments (grid.y = segment)
-struct AddSeg {
-  const double* src;
-  float* dst;
-  int32_t n, _pad;
-};
-struct AddBatch {
-  AddSeg seg[16 * SL_MAXL + 1];
-};
-__global__ __launch_bounds__(256) void slope_add_f64_kernel(AddBatch b) {
-  const AddSeg& sg = b.seg[blockIdx.y];
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < sg.n; i += gridDim.x * 256) sg.dst[i] += (float)sg.src[i];
+// the sums over the knot rows: grid (tiles of [k_l, H], net, level); level n_hidden = the Bessel frequencies (summed over the nets)
+__global__ __launch_bounds__(256) void slope_wgrad_kernel(SlopeBatch b, int R, int k0, int H, int n_hidden, float* __restrict__ g_bessel) {
+  const SlopeNet& net = b.net[blockIdx.y];
+  const int l = blockIdx.z;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (l == n_hidden) {      // the Bessel frequencies: one WAVE per frequency, its lanes stride the rows of all the nets (fixed order)
+    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (!g_bessel || f >= k0 || blockIdx.y != 0) return;
+    double s = 0.0;
+    for (int nn = 0; nn < (int)gridDim.y; ++nn) {
+      const double* wb = b.net[nn].ws + ws_level_offset(n_hidden, R, k0, H);
+      for (int row = lane; row < R; row += 64) s += wb[(int64_t)row * k0 + f];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) g_bessel[f] += (float)s;
+    return;
+  }
+  const int kl = l == 0 ? k0 : H;
+  if (!net.g_w[l] || idx >= kl * H) return;
+  const int k = idx / H, j = idx - k * H;
+  const double* wl = net.ws + ws_level_offset(l, R, k0, H);
+  const double* av = wl + k;
+  const double* dav = wl + (int64_t)R * kl + k;
+  const double* gz = wl + (int64_t)2 * R * kl + j;
+  const double* gdz = gz + (int64_t)R * H;
+  double s = 0.0;
+#pragma unroll 4
+  for (int row = 0; row < R; ++row)
+    s = fma(av[(int64_t)row * kl], gz[(int64_t)row * H], fma(dav[(int64_t)row * kl], gdz[(int64_t)row * H], s));
+  net.g_w[l][idx] += (float)s;
 }
 
 }  // namespace e3k
@@ -285,10 +320,12 @@ extern "C" int e3k_slope_tangent_fwd(const float* const* w_hidden, int32_t n_net
 }
 
 /* The reverse sweep: from g_hp[i] [R, H] (the gradient of H'_i) to the hidden weights' and the Bessel frequencies' gradients.
- * acc: float64 scratch of e3k_slope_tangent_bwd_scratch(n_nets, n_hidden, k0, H) doubles (zero-filled here);
- * g_hidden[i * 4 + l] (fp32 [k_l, H], ADDED to; NULL = not wanted), g_bessel (fp32 [k0], ADDED to, summed over the nets; NULL). */
-extern "C" int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H) {
-  return (int64_t)n_nets * ((int64_t)k0 * H + (int64_t)(n_hidden - 1) * H * H) + k0;
+ * acc: float64 scratch of e3k_slope_tangent_bwd_scratch(n_nets, n_hidden, k0, H, R) doubles;
+ * g_hidden[i * 4 + l] (fp32 [k_l, H], ADDED to; NULL = not wanted), g_bessel (fp32 [k0], ADDED to, summed over the nets; NULL).
+ * Two launches: the chain per knot row (value, tangent, then their cotangents: per-row operands into the scratch), then the sums
+ * over the rows (fixed order, no atomics: bit-identical run to run). */
+extern "C" int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H, int64_t R) {
+  return (int64_t)n_nets * e3k::slope_ws_doubles(n_hidden, R, k0, H);
 }
 
 extern "C" int e3k_slope_tangent_bwd(const float* const* w_hidden, int32_t n_nets, int32_t n_hidden, const float* alphas,
@@ -299,39 +336,24 @@ extern "C" int e3k_slope_tangent_bwd(const float* const* w_hidden, int32_t n_net
   if (rc != E3K_OK) return rc;
   if (!w_hidden || !alphas || !knots || !bessel_w || !g_hp || !acc || !g_hidden) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  const int64_t per_net = (int64_t)k0 * H + (int64_t)(n_hidden - 1) * H * H;
-  const int64_t total = e3k_slope_tangent_bwd_scratch(n_nets, n_hidden, k0, H);
-  if (e3k::zero_fill(acc, sizeof(double) * total, st)) return E3K_ERR_LAUNCH;
+  const int64_t per_net = e3k::slope_ws_doubles(n_hidden, R, k0, H);
   e3k::SlopeBatch b{};
-  double* g_bw = acc + (int64_t)n_nets * per_net;
   for (int i = 0; i < n_nets; ++i) {
-    double* base = acc + (int64_t)i * per_net;
     for (int l = 0; l < n_hidden; ++l) {
       if (!w_hidden[i * 4 + l]) return E3K_ERR_INVALID;
       b.net[i].w[l] = w_hidden[i * 4 + l];
-      b.net[i].g_w[l] = g_hidden[i * 4 + l] ? base : nullptr;
-      base += l == 0 ? (int64_t)k0 * H : (int64_t)H * H;
+      b.net[i].g_w[l] = g_hidden[i * 4 + l];
     }
     if (!g_hp[i]) return E3K_ERR_INVALID;
     b.net[i].g_hp = g_hp[i];
-    b.net[i].g_bw = g_bessel ? g_bw : nullptr;
+    b.net[i].ws = acc + (int64_t)i * per_net;
   }
   for (int l = 0; l < n_hidden; ++l) b.alpha[l] = alphas[l];
   const e3k::BasisPar bp{(double)r_max, (double)r_min, (double)p, one_over_r, cutoff_kind};
   dim3 grid((unsigned)((R + e3k::SL_ROWS - 1) / e3k::SL_ROWS), (unsigned)n_nets);
   hipLaunchKernelGGL(e3k::slope_tangent_kernel<true>, grid, dim3(H), 0, st, b, knots, (int)R, bessel_w, k0, H, n_hidden, bp, act, cst);
-  e3k::AddBatch ab{};
-  int n_seg = 0;
-  for (int i = 0; i < n_nets; ++i) {
-    const double* base = acc + (int64_t)i * per_net;
-    for (int l = 0; l < n_hidden; ++l) {
-      const int64_t n = l == 0 ? (int64_t)k0 * H : (int64_t)H * H;
-      if (g_hidden[i * 4 + l]) ab.seg[n_seg++] = e3k::AddSeg{base, g_hidden[i * 4 + l], (int32_t)n, 0};
-      base += n;
-    }
-  }
-  if (g_bessel) ab.seg[n_seg++] = e3k::AddSeg{g_bw, g_bessel, k0, 0};
-  if (n_seg) hipLaunchKernelGGL(e3k::slope_add_f64_kernel, dim3((unsigned)((H * H + 255) / 256), (unsigned)n_seg), dim3(256), 0, st, ab);
+  dim3 grid2((unsigned)((H * H + 255) / 256), (unsigned)n_nets, (unsigned)(n_hidden + 1));
+  hipLaunchKernelGGL(e3k::slope_wgrad_kernel, grid2, dim3(256), 0, st, b, (int)R, k0, H, n_hidden, g_bessel);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

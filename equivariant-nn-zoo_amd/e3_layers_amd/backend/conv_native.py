@@ -420,7 +420,7 @@ class RadialStackFn(torch.autograd.Function):
             if hps and any(g_slopes[i] is not None for i in live):
                 knots_r, bw = tail[n], tail[n + 1]
                 sl = _slope_ctx(ctx.slope, knots_r, bw)
-                acc = torch.empty(int(L.load().e3k_slope_tangent_bwd_scratch(len(live), n_hidden, k0, hdim)), device=dev, dtype=torch.float64)
+                acc = torch.empty(int(L.load().e3k_slope_tangent_bwd_scratch(len(live), n_hidden, k0, hdim, r)), device=dev, dtype=torch.float64)
                 sl.acc = acc.data_ptr()
                 if need[5]:
                     g_bessel = torch.zeros_like(bw)

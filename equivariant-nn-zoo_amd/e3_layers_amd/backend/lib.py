@@ -160,7 +160,7 @@ SIGNATURES = {
                                        C.POINTER(C.c_void_p), _P]),
     "e3k_slope_tangent_fwd": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I32, C.POINTER(C.c_float), _P, _I64, _P, _I32, _I32, _F, _F, _F,
                                         _I32, _I32, _I32, _F, C.POINTER(C.c_void_p), _P]),
-    "e3k_slope_tangent_bwd_scratch": (C.c_int64, [_I32, _I32, _I32, _I32]),
+    "e3k_slope_tangent_bwd_scratch": (C.c_int64, [_I32, _I32, _I32, _I32, _I64]),
     "e3k_slope_tangent_bwd": (C.c_int, [C.POINTER(C.c_void_p), _I32, _I32, C.POINTER(C.c_float), _P, _I64, _P, _I32, _I32, _F, _F, _F,
                                         _I32, _I32, _I32, _F, C.POINTER(C.c_void_p), _P, C.POINTER(C.c_void_p), _P, _P]),
     "e3k_mlp_hidden_fwd_multi": (C.c_int, [C.POINTER(MlpNet), _I32, _P, _I64, _I32, _I32, _I32, C.POINTER(C.c_float), _I32, _F, _P]),

@@ -633,7 +633,7 @@ typedef struct {
   const float* bessel_w;     /* [k0] */
   float r_max, r_min, p;
   int32_t one_over_r, cutoff_kind, _pad;
-  double* acc;               /* backward: e3k_slope_tangent_bwd_scratch(n, n_hidden, k0, h) doubles */
+  double* acc;               /* backward: e3k_slope_tangent_bwd_scratch(n, n_hidden, k0, h, R) doubles */
   float* g_bessel;           /* backward: [k0] fp32, ADDED to (NULL: the frequencies need no gradient) */
 } e3k_slope_ctx;
 int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_layer_radial* rads, int32_t n, void* stream);
@@ -649,7 +649,7 @@ int e3k_radial_slope_fwd(const e3k_layer* const* layers, const e3k_layer_radial*
 int e3k_slope_tangent_fwd(const float* const* w_hidden, int32_t n_nets, int32_t n_hidden, const float* alphas, const float* knots,
                           int64_t R, const float* bessel_w, int32_t k0, int32_t H, float r_max, float r_min, float p,
                           int32_t one_over_r, int32_t cutoff_kind, int32_t act, float cst, float* const* hp, void* stream);
-int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H);
+int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H, int64_t R);
 int e3k_slope_tangent_bwd(const float* const* w_hidden, int32_t n_nets, int32_t n_hidden, const float* alphas, const float* knots,
                           int64_t R, const float* bessel_w, int32_t k0, int32_t H, float r_max, float r_min, float p,
                           int32_t one_over_r, int32_t cutoff_kind, int32_t act, float cst, const float* const* g_hp, double* acc,

@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""The table-form tensor-product kernels of config_energy layer 3 (l_max 2, 256 molecules) in isolation, on the batch's real edge
+lengths, for several knot counts; `--pmc` runs each a few times only (for rocprofv3 --pmc passes: TCC_HIT_sum TCC_MISS_sum ...).
+    python3 tools/tp_table_bench.py [--pmc] [knots ...]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
+    sys.path.insert(0, p)
+import torch
+from e3_layers_amd.backend import conv_force, ops, radial_table
+from e3_layers_amd.backend.graph import build_topology
+from e3_layers_amd.configs import config_energy
+from e3_layers_amd.data.synthetic import synth_qm9
+from e3_layers_amd.utils import build
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+pmc = "--pmc" in sys.argv
+bonds = "clustered" if "--clustered" in sys.argv else "uniform"
+targets = [int(a) for a in args] or [512]
+dev = torch.device("cuda:0")
+torch.manual_seed(0)
+model = build(config_energy.get_config(l_max=2).model_config).to(dev)
+batch = synth_qm9(1000, 256, bonds=bonds).to(dev)
+n, e = batch["pos"].shape[0], batch["edge_index"].shape[1]
+topo = build_topology(batch["edge_index"], n)
+ei = batch["edge_index"]
+r = (batch["pos"][ei[1]] - batch["pos"][ei[0]]).norm(dim=1)
+tp = model.layer3.conv.tp.tp.plan
+x = torch.randn(n, tp.d_in, device=dev)
+sh = torch.randn(e, tp.d_sh, device=dev)
+g = torch.randn(n, tp.d_mid, device=dev)
+w = torch.randn(e, tp.w_numel, device=dev)
+
+
+def timeit(fn, reps=20):
+    if pmc:
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        return 0.0
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    s, t = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    t.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(t) * 1e3 / reps
+
+
+print(f"N={n} E={e} W={tp.w_numel} d_in={tp.d_in} d_mid={tp.d_mid} bonds={bonds}")
+print(f"streamed  tp_fwd {timeit(lambda: ops._tp_fwd_raw(x, sh, w, topo, tp)):7.1f} us   tp_bwd_x {timeit(lambda: ops._tp_bwd_x_raw(sh, w, g, topo, tp)):7.1f} us"
+      f"   tp_bwd_w {timeit(lambda: ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)):7.1f} us")
+gw, _ = ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)
+for target in targets:
+    t_bins = timeit(lambda: radial_table.build_bins(r, 4.0, target))
+    bins = radial_table.build_bins(r, 4.0, target)
+    T = torch.randn(bins.knots + 1, tp.w_numel, device=dev)
+    cnt = (bins.ptr[1:] - bins.ptr[:-1]).float()
+    t_f = timeit(lambda: conv_force._tp_fwd_table(x, sh, T, bins, topo, tp))
+    t_x = timeit(lambda: conv_force._tp_bwd_x_table(sh, T, bins, g, topo, tp))
+    t_i = timeit(lambda: radial_table.interp_fwd_raw(T, bins))
+    t_t = timeit(lambda: radial_table.interp_bwd_raw(gw, bins))
+    print(f"knots {bins.knots:5d} (table {4e-6 * (bins.knots + 1) * tp.w_numel:5.1f} MB, edges/knot mean {float(cnt[cnt > 0].mean()):6.1f} max {int(cnt.max()):5d}): "
+          f"tp_fwd_table {t_f:7.1f} us  tp_bwd_x_table {t_x:7.1f} us  interp_fwd {t_i:6.1f} us  interp_bwd {t_t:6.1f} us  bins {t_bins:5.1f} us")
