@@ -162,9 +162,11 @@ __global__ __launch_bounds__(256) void rtable_bins_place_kernel(const int32_t* _
 
 // w[e, :] = sum_k coef[e, k] T[bin[e] - 1 + k, :];  one wave per edge, 16-byte columns.  Edges are taken in KNOT order
 // (perm): the edges of a knot, handled by neighbouring waves, read the same four table rows (L1 / L2 hits).
+// T2 / w2 (optional): a second table interpolated with the same weights in the same pass (force training: the slope table)
 __global__ __launch_bounds__(256) void rtable_interp_fwd_kernel(const float* __restrict__ T, const int32_t* __restrict__ perm,
                                                                 const int32_t* __restrict__ bin, const float* __restrict__ coef,
-                                                                int64_t E, int32_t W, float* __restrict__ w) {
+                                                                int64_t E, int32_t W, float* __restrict__ w,
+                                                                const float* __restrict__ T2, float* __restrict__ w2) {
   const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (p >= E) return;
   const int lane = threadIdx.x & 63;
@@ -186,6 +188,22 @@ __global__ __launch_bounds__(256) void rtable_interp_fwd_kernel(const float* __r
     v.z = fmaf(c3, vd.z, fmaf(c2, vc.z, fmaf(c1, vb.z, c0 * va.z)));
     v.w = fmaf(c3, vd.w, fmaf(c2, vc.w, fmaf(c1, vb.w, c0 * va.w)));
     nt_store4(o + q, v);      // written once, read by the edge kernels later: streamed past the caches
+  }
+  if (T2) {
+    const int64_t d2 = T2 - T;      // (same row offsets in the second table)
+    float4* __restrict__ o2 = reinterpret_cast<float4*>(w2 + (int64_t)e * W);
+    for (int q = lane; q < (W >> 2); q += 64) {
+      const float4 va = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a) + d2)[q];
+      const float4 vb = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(b) + d2)[q];
+      const float4 vc = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(c) + d2)[q];
+      const float4 vd = reinterpret_cast<const float4*>(reinterpret_cast<const float*>(d) + d2)[q];
+      float4 v;
+      v.x = fmaf(c3, vd.x, fmaf(c2, vc.x, fmaf(c1, vb.x, c0 * va.x)));
+      v.y = fmaf(c3, vd.y, fmaf(c2, vc.y, fmaf(c1, vb.y, c0 * va.y)));
+      v.z = fmaf(c3, vd.z, fmaf(c2, vc.z, fmaf(c1, vb.z, c0 * va.z)));
+      v.w = fmaf(c3, vd.w, fmaf(c2, vc.w, fmaf(c1, vb.w, c0 * va.w)));
+      nt_store4(o2 + q, v);
+    }
   }
 }
 
@@ -315,7 +333,20 @@ extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, co
   if (E == 0) return E3K_OK;
   if (!T || !bin_perm || !bin || !coef || !w) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::rtable_interp_fwd_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T, bin_perm,
-                     bin, coef, E, W, w);
+                     bin, coef, E, W, w, (const float*)nullptr, (float*)nullptr);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+// two tables (same shape) through the same weights in one pass: w = I(coef) T, w2 = I(coef) T2
+extern "C" int e3k_rtable_interp_fwd2(const float* T, const float* T2, const int32_t* bin_perm, const int32_t* bin, const float* coef,
+                                      int64_t E, int32_t K, int32_t W, float* w, float* w2, void* stream) {
+  if (E < 0 || K < 4 || W <= 0) return E3K_ERR_INVALID;
+  if (W % 4) return E3K_ERR_UNSUPPORTED;
+  if (E == 0) return E3K_OK;
+  if (!T || !T2 || !bin_perm || !bin || !coef || !w || !w2) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::rtable_interp_fwd_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream, T, bin_perm,
+                     bin, coef, E, W, w, T2, w2);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -252,7 +252,6 @@ __global__ void slope_tangent_kernel(SlopeBatch b, const float* __restrict__ kno
 __global__ __launch_bounds__(256) void slope_wgrad_kernel(SlopeBatch b, int R, int k0, int H, int n_hidden, float* __restrict__ g_bessel) {
   const SlopeNet& net = b.net[blockIdx.y];
   const int l = blockIdx.z;
-  const int idx = blockIdx.x * 256 + threadIdx.x;
   if (l == n_hidden) {      // the Bessel frequencies: one WAVE per frequency, its lanes stride the rows of all the nets (fixed order)
     const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (!g_bessel || f >= k0 || blockIdx.y != 0) return;
@@ -266,19 +265,61 @@ __global__ __launch_bounds__(256) void slope_wgrad_kernel(SlopeBatch b, int R, i
     if (lane == 0) g_bessel[f] += (float)s;
     return;
   }
+  // hidden layer l: g_W[k, j] = sum_rows a[row][k] gz[row][j] + a'[row][k] gz'[row][j] -- a [kl x R] x [R x H] product pair in
+  // float64: 4 x 4 outputs per thread, 16-row tiles through LDS; the knot rows are split over gridDim.x workgroups whose partial
+  // sums meet in the fp32 gradient buffer through atomics (as the weight-gradient GEMMs of every Linear do: e3k_gemm_wgrad)
   const int kl = l == 0 ? k0 : H;
-  if (!net.g_w[l] || idx >= kl * H) return;
-  const int k = idx / H, j = idx - k * H;
+  if (!net.g_w[l]) return;
+  const int per = ((R + (int)gridDim.x - 1) / (int)gridDim.x + 15) / 16 * 16;
+  const int r_beg = blockIdx.x * per, r_end = r_beg + per < R ? r_beg + per : R;
+  if (r_beg >= R) return;
+  __shared__ double sA[16][SL_MAXH], sdA[16][SL_MAXH], sG[16][SL_MAXH], sdG[16][SL_MAXH];
   const double* wl = net.ws + ws_level_offset(l, R, k0, H);
-  const double* av = wl + k;
-  const double* dav = wl + (int64_t)R * kl + k;
-  const double* gz = wl + (int64_t)2 * R * kl + j;
-  const double* gdz = gz + (int64_t)R * H;
-  double s = 0.0;
+  const double* pa = wl;
+  const double* pda = wl + (int64_t)R * kl;
+  const double* pg = wl + (int64_t)2 * R * kl;
+  const double* pdg = pg + (int64_t)R * H;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // outputs k = 4 ty .. 4 ty + 3, j = 4 tx .. 4 tx + 3
+  double acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[i][q] = 0.0;
+  for (int row0 = r_beg; row0 < r_end; row0 += 16) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = threadIdx.x + 256 * q, r = e >> 6, c = e & 63, row = row0 + r;
+      const bool in = row < r_end;
+      sA[r][c] = (in && c < kl) ? pa[(int64_t)row * kl + c] : 0.0;
+      sdA[r][c] = (in && c < kl) ? pda[(int64_t)row * kl + c] : 0.0;
+      sG[r][c] = (in && c < H) ? pg[(int64_t)row * H + c] : 0.0;
+      sdG[r][c] = (in && c < H) ? pdg[(int64_t)row * H + c] : 0.0;
+    }
+    __syncthreads();
 #pragma unroll 4
-  for (int row = 0; row < R; ++row)
-    s = fma(av[(int64_t)row * kl], gz[(int64_t)row * H], fma(dav[(int64_t)row * kl], gdz[(int64_t)row * H], s));
-  net.g_w[l][idx] += (float)s;
+    for (int r = 0; r < 16; ++r) {
+      double a4[4], d4[4], g4[4], h4[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        a4[i] = sA[r][4 * ty + i];
+        d4[i] = sdA[r][4 * ty + i];
+        g4[i] = sG[r][4 * tx + i];
+        h4[i] = sdG[r][4 * tx + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = fma(a4[i], g4[q], fma(d4[i], h4[q], acc[i][q]));
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int k = 4 * ty + i, j = 4 * tx + q;
+      if (k < kl && j < H) atomicAdd(net.g_w[l] + (int64_t)k * H + j, (float)acc[i][q]);
+    }
 }
 
 }  // namespace e3k
@@ -323,7 +364,7 @@ extern "C" int e3k_slope_tangent_fwd(const float* const* w_hidden, int32_t n_net
  * acc: float64 scratch of e3k_slope_tangent_bwd_scratch(n_nets, n_hidden, k0, H, R) doubles;
  * g_hidden[i * 4 + l] (fp32 [k_l, H], ADDED to; NULL = not wanted), g_bessel (fp32 [k0], ADDED to, summed over the nets; NULL).
  * Two launches: the chain per knot row (value, tangent, then their cotangents: per-row operands into the scratch), then the sums
- * over the rows (fixed order, no atomics: bit-identical run to run). */
+ * over the rows (float64 partial sums of eight row ranges, combined by fp32 atomics as every weight-gradient GEMM here does). */
 extern "C" int64_t e3k_slope_tangent_bwd_scratch(int32_t n_nets, int32_t n_hidden, int32_t k0, int32_t H, int64_t R) {
   return (int64_t)n_nets * e3k::slope_ws_doubles(n_hidden, R, k0, H);
 }
@@ -352,7 +393,7 @@ extern "C" int e3k_slope_tangent_bwd(const float* const* w_hidden, int32_t n_net
   const e3k::BasisPar bp{(double)r_max, (double)r_min, (double)p, one_over_r, cutoff_kind};
   dim3 grid((unsigned)((R + e3k::SL_ROWS - 1) / e3k::SL_ROWS), (unsigned)n_nets);
   hipLaunchKernelGGL(e3k::slope_tangent_kernel<true>, grid, dim3(H), 0, st, b, knots, (int)R, bessel_w, k0, H, n_hidden, bp, act, cst);
-  dim3 grid2((unsigned)((H * H + 255) / 256), (unsigned)n_nets, (unsigned)(n_hidden + 1));
+  dim3 grid2(8, (unsigned)n_nets, (unsigned)(n_hidden + 1));      // (x: row splits of the hidden levels; the Bessel level uses the first two)
   hipLaunchKernelGGL(e3k::slope_wgrad_kernel, grid2, dim3(256), 0, st, b, (int)R, k0, H, n_hidden, g_bessel);
   E3K_CHECK_LAUNCH();
   return E3K_OK;

@@ -114,7 +114,7 @@ template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  constexpr bool TABLE = MODE >= 1, JVP = MODE == 2;
+  constexpr bool TABLE = MODE == 1 || MODE == 2, JVP = MODE >= 2;      // MODE 3: the JVP form on STREAMED w[e], dw/dr[e] rows
   const int u4 = u * 4;
   const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
   int woff4[S::NQ];
@@ -171,8 +171,16 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
       const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w);
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        wc[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+        wc[Q] = JVP ? buf_ld(rw, u4, woff4[Q]) : buf_ld_stream(rw, u4, woff4[Q]);      // (second-order: the rows are read by several kernels)
       });
+      if constexpr (JVP) {
+        const __amdgpu_buffer_rsrc_t rd = row_rsrc(a.w2 + (int64_t)e * a.W, row_w);
+        const float sc = sload(a.s2 + e);
+        slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          w2[Q] = sc * buf_ld(rd, u4, woff4[Q]);
+        });
+      }
     }
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
@@ -418,7 +426,7 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
 // gradient rows resident).  D is the slope of the table on the knots (the radial MLP's forward-mode derivative, evaluated
 // where rounding cannot hurt it: differentiating the fp32 table itself amplifies its rounding by 1 / knot spacing).
 // ------------------------------------------------------------------------------------------
-template <int L1, int L3MAX, int PART>
+template <int L1, int L3MAX, int PART, bool STREAM>
 __device__ __forceinline__ void tp_bwd_e_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
@@ -447,19 +455,28 @@ __device__ __forceinline__ void tp_bwd_e_body_full(const TpArgs& a, const e3k_tp
     YRegs yc;
     load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
-    const KnotRows kr = knot_rows(a, a.coef, e, row_w);
     float xc[D1];
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
-    const KnotRows2 k2 = knot_rows2(a, e, row_w);
     float wv_[S::NQ], dv_[S::NQ];
-    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
-      constexpr int Q = decltype(qc)::value;
-      wv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(kr.ra, u4, woff4[Q]), buf_ld(kr.rb, u4, woff4[Q]),
-                        buf_ld(kr.rc, u4, woff4[Q]), buf_ld(kr.rd, u4, woff4[Q]));
-      dv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(k2.ra, u4, woff4[Q]), buf_ld(k2.rb, u4, woff4[Q]),
-                        buf_ld(k2.rc, u4, woff4[Q]), buf_ld(k2.rd, u4, woff4[Q]));
-    });
+    if constexpr (STREAM) {      // w[e], dw/dr[e] materialised (a.w, a.w2: [E, W])
+      const __amdgpu_buffer_rsrc_t rw = row_rsrc(a.w + (int64_t)e * a.W, row_w), rd = row_rsrc(a.w2 + (int64_t)e * a.W, row_w);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wv_[Q] = buf_ld(rw, u4, woff4[Q]);
+        dv_[Q] = buf_ld(rd, u4, woff4[Q]);
+      });
+    } else {
+      const KnotRows kr = knot_rows(a, a.coef, e, row_w);
+      const KnotRows2 k2 = knot_rows2(a, e, row_w);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(kr.ra, u4, woff4[Q]), buf_ld(kr.rb, u4, woff4[Q]),
+                          buf_ld(kr.rc, u4, woff4[Q]), buf_ld(kr.rd, u4, woff4[Q]));
+        dv_[Q] = knot_mix(kr.c0, kr.c1, kr.c2, kr.c3, buf_ld(k2.ra, u4, woff4[Q]), buf_ld(k2.rb, u4, woff4[Q]),
+                          buf_ld(k2.rc, u4, woff4[Q]), buf_ld(k2.rd, u4, woff4[Q]));
+      });
+    }
     YRegs gy;
     gy.y0[0] = 0.0f;
 #pragma unroll
@@ -500,10 +517,10 @@ __device__ __forceinline__ void tp_bwd_e_body_full(const TpArgs& a, const e3k_tp
   }
 }
 
-template <int L1, int L3MAX, int PART, bool FULL>
+template <int L1, int L3MAX, bool STREAM, int PART, bool FULL>
 __device__ __forceinline__ void tp_bwd_e_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  static_assert(FULL, "the table-form edge backward exists for channel-complete plans only");
-  tp_bwd_e_body_full<L1, L3MAX, PART>(a, g, node, u);
+  static_assert(FULL, "the edge backward of force training exists for channel-complete plans only");
+  tp_bwd_e_body_full<L1, L3MAX, PART, STREAM>(a, g, node, u);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -515,7 +532,7 @@ template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  constexpr bool TABLE = MODE >= 1, DUAL = MODE == 2;
+  constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE >= 2;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -576,8 +593,16 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k)
           gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
-        wn[Q] = buf_ld_stream(rw, u4, woff4[Q]);
+        wn[Q] = DUAL ? buf_ld(rw, u4, woff4[Q]) : buf_ld_stream(rw, u4, woff4[Q]);
       });
+      if constexpr (DUAL) {
+        const __amdgpu_buffer_rsrc_t rd = row_rsrc(a.w2 + (int64_t)e * a.W, row_w);
+        const float sc = sload(a.s2 + e);
+        slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          w2[Q] = sc * buf_ld(rd, u4, woff4[Q]);
+        });
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -726,12 +751,12 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
 }
 // table-form edge backward (g_sh, g_coef, optionally g_w) and the dual weight gradient: channel-complete, un-split plans
-template <int MAXL, int L3MAX>
+template <int MAXL, int L3MAX, bool STREAM>
 __global__ __launch_bounds__(256) void tp_bwd_e_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   constexpr bool FULL = true, SPLIT = false;
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX)
+  E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX, STREAM)
 }
 template <int MAXL, int L3MAX>
 __global__ __launch_bounds__(256) void tp_bwd_w_dual_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
@@ -932,12 +957,22 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     // second-order forms of force training: channel-complete plans walked by one wave per group (the l_max <= 2 models)
     if (!p->full64 || p->split) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1;
+    const bool streamed = args.bin == nullptr;      // w[e] / dw[e] rows in a.w / a.w2 instead of the tables + per-edge knots
 #define E3K_TP_LAUNCH_2(ML, L3)                                                                                                         \
   switch (kind) {                                                                                                                       \
-    case TP_FWD_JVP: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;     \
-    case TP_BWD_X_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
-    case TP_BWD_E: hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                      \
-    default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                       \
+    case TP_FWD_JVP:                                                                                                                    \
+      if (streamed) hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);   \
+      else hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
+      break;                                                                                                                            \
+    case TP_BWD_X_DUAL:                                                                                                                 \
+      if (streamed) hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); \
+      else hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);          \
+      break;                                                                                                                            \
+    case TP_BWD_E:                                                                                                                      \
+      if (streamed) hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);           \
+      else hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3, false>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);                   \
+      break;                                                                                                                            \
+    default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, L3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;      \
   }
     switch (p->max_l1) {
       case 0: if (lo) { E3K_TP_LAUNCH_2(0, 0) } else { E3K_TP_LAUNCH_2(0, 3) } break;
@@ -1078,7 +1113,9 @@ extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, cons
 
 // ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------
 // With F = <g, TP(x[src], sh, w(T, coef))> (linear in each of g, x, sh, T, coef):
-// (w[e] = sum_k coef[e,k] T[bin[e]-1+k], dw/dr[e] = sum_k coef[e,k] D[bin[e]-1+k] with D the slope table)
+// (w[e] = sum_k coef[e,k] T[bin[e]-1+k], dw/dr[e] = sum_k coef[e,k] D[bin[e]-1+k] with D the slope table; with bin = coef = NULL
+//  the two are passed MATERIALISED instead: T = w [E, W], D = dw/dr [E, W] (e3k_rtable_interp_fwd of either table) -- at the batch
+//  sizes force training runs at, five or six kernels per layer read them and a 7.7 KB row per edge is a quarter of four table rows)
 //   e3k_tp_bwd_e_table   g_sh = dF/dsh, g_r = <dF/dw, dw/dr> (both ACCUMULATED with atomics: zero-fill them), optionally g_w
 //   e3k_tp_fwd_jvp_table out = TP(x2, sh, w) + TP(x, sh2, w) + TP(x, sh, s2 * dw/dr)
 //   e3k_tp_bwd_x_dual_table g_x = dF/dx at (sh2, w) + dF/dx at (sh, s2 * dw/dr)
@@ -1088,7 +1125,8 @@ extern "C" int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const
                                   const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0 || E == 0) return E3K_OK;
-  if (!x || !sh || !T || !D || !bin || !coef || !g_out || !src || !dst_ptr || !dst_perm || (!g_sh && !g_r && !g_w)) return E3K_ERR_INVALID;
+  if (!x || !sh || !T || !D || (bin != nullptr) != (coef != nullptr) || !g_out || !src || !dst_ptr || !dst_perm || (!g_sh && !g_r && !g_w))
+    return E3K_ERR_INVALID;
   e3k::TpArgs a{};
   a.x = x; a.sh = sh; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_sh = g_sh; a.g_r = g_r; a.g_w = g_w;
   a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
@@ -1102,7 +1140,8 @@ extern "C" int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, con
                                     float* out, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!x || !x2 || !out || !dst_ptr || (E > 0 && (!sh || !sh2 || !T || !D || !bin || !coef || !s2 || !src || !dst_perm))) return E3K_ERR_INVALID;
+  if (!x || !x2 || !out || !dst_ptr || (E > 0 && (!sh || !sh2 || !T || !D || (bin != nullptr) != (coef != nullptr) || !s2 || !src || !dst_perm)))
+    return E3K_ERR_INVALID;
   e3k::TpArgs a{};
   a.x = x; a.x2 = x2; a.sh = sh; a.sh2 = sh2; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.s2 = s2; a.out = out;
   a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
@@ -1115,7 +1154,8 @@ extern "C" int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh,
                                        const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !sh2 || !T || !D || !bin || !coef || !s2 || !dst || !src_perm))) return E3K_ERR_INVALID;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !sh2 || !T || !D || (bin != nullptr) != (coef != nullptr) || !s2 || !dst || !src_perm)))
+    return E3K_ERR_INVALID;
   e3k::TpArgs a{};
   a.sh = sh; a.sh2 = sh2; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.s2 = s2; a.g_out = g_out; a.g_x = g_x;
   a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;

@@ -39,6 +39,10 @@ from . import ops, radial_table
 from .conv_block import ConvBlockPlan, _grad_buffer
 
 ENABLED = int(os.environ.get("E3K_FORCE_BLOCK", "1"))
+# 1: a layer interpolates its per-edge weights w [E, W] (forward) and their slope dw/dr [E, W] (first backward) ONCE and every
+# tensor-product kernel of the three passes streams those rows; 0: every kernel gathers four rows per table and edge itself (the
+# in-kernel form of the energy step).  Five or six kernels per layer read them: 64 molecules 7.03 -> see DESIGN.md ms per step.
+MATERIALIZE = int(os.environ.get("E3K_FORCE_MATERIALIZE", "1"))
 STATS = [0, 0, 0]      # forwards, first backwards (create_graph), u-sweeps (tests)
 _WARNED = [False]
 
@@ -73,12 +77,17 @@ def _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp):
     return gx
 
 
+def _b(bins):
+    """(knot, weights) pointers of the table form, or (None, None): T / D are then the materialised rows w / dw [E, W]"""
+    return (None, None) if bins is None else (L.ptr(bins.bin), L.ptr(bins.coef))
+
+
 def _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp):
     """(g_sh [E, d_sh], g_r [E]): the gradient w.r.t. the spherical harmonics and the radius"""
     n, e = x1.shape[0], sh.shape[0]
     buf = torch.zeros(e * (tp.d_sh + 1), device=x1.device, dtype=torch.float32)      # one fill for both (atomics accumulate)
     g_sh, g_r = buf[:e * tp.d_sh].view(e, tp.d_sh), buf[e * tp.d_sh:]
-    L.check(L.load().e3k_tp_bwd_e_table(tp.handle(x1.device), L.ptr(x1), L.ptr(sh), L.ptr(T), L.ptr(D), L.ptr(bins.bin), L.ptr(bins.coef),
+    L.check(L.load().e3k_tp_bwd_e_table(tp.handle(x1.device), L.ptr(x1), L.ptr(sh), L.ptr(T), L.ptr(D), *_b(bins),
                                         L.ptr(g_mid), L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(g_sh),
                                         L.ptr(g_r), None, L.stream_ptr()), "e3k_tp_bwd_e_table")
     return g_sh, g_r
@@ -88,7 +97,7 @@ def _tp_fwd_jvp(x1, x2, sh, sh2, T, D, bins, s2, topo, tp):
     n, e = x1.shape[0], sh.shape[0]
     out = torch.empty(n, tp.d_mid, device=x1.device, dtype=torch.float32)
     L.check(L.load().e3k_tp_fwd_jvp_table(tp.handle(x1.device), L.ptr(x1), L.ptr(x2), L.ptr(sh), L.ptr(sh2), L.ptr(T), L.ptr(D),
-                                          L.ptr(bins.bin), L.ptr(bins.coef), L.ptr(s2), L.ptr(topo.src), L.ptr(topo.dst_ptr),
+                                          *_b(bins), L.ptr(s2), L.ptr(topo.src), L.ptr(topo.dst_ptr),
                                           L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd_jvp_table")
     return out
 
@@ -96,8 +105,7 @@ def _tp_fwd_jvp(x1, x2, sh, sh2, T, D, bins, s2, topo, tp):
 def _tp_bwd_x_dual(sh, sh2, T, D, bins, s2, g_mid, topo, tp):
     n, e = g_mid.shape[0], sh.shape[0]
     gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
-    L.check(L.load().e3k_tp_bwd_x_dual_table(tp.handle(sh.device), L.ptr(sh), L.ptr(sh2), L.ptr(T), L.ptr(D), L.ptr(bins.bin),
-                                             L.ptr(bins.coef), L.ptr(s2), L.ptr(g_mid), L.ptr(topo.dst), L.ptr(topo.src_ptr),
+    L.check(L.load().e3k_tp_bwd_x_dual_table(tp.handle(sh.device), L.ptr(sh), L.ptr(sh2), L.ptr(T), L.ptr(D), *_b(bins), L.ptr(s2), L.ptr(g_mid), L.ptr(topo.dst), L.ptr(topo.src_ptr),
                                              L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x_dual_table")
     return gx
 
@@ -122,11 +130,30 @@ def _gate_bwd2(conv, gy, h, spec, out_cf: bool, want_gy: bool = True, want_x: bo
 class _Cfg:
     """The non-tensor arguments of a block (one object: a single ``None`` in the backward's return)."""
 
-    __slots__ = ("plan", "topo", "groups", "bins", "in_cf", "out_cf", "sh_data")
+    __slots__ = ("plan", "topo", "groups", "bins", "in_cf", "out_cf", "sh_data", "w", "dw")
 
     def __init__(self, plan, topo, groups, bins, in_cf, out_cf, sh_data):
         self.plan, self.topo, self.groups, self.bins = plan, topo, groups, bins
         self.in_cf, self.out_cf, self.sh_data = bool(in_cf), bool(out_cf), bool(sh_data)
+        self.w = self.dw = None      # MATERIALIZE: the layer's per-edge weights / their slope [E, W], interpolated once
+
+    def weights(self, T, D=None):
+        """``D``: the slope will be needed too (the geometry requires grad): both tables in one pass"""
+        if self.w is None:
+            if D is not None and self.dw is None:
+                bins, e, width = self.bins, self.bins.bin.numel(), T.shape[1]
+                self.w = torch.empty(e, width, device=T.device, dtype=torch.float32)
+                self.dw = torch.empty(e, width, device=T.device, dtype=torch.float32)
+                L.check(L.load().e3k_rtable_interp_fwd2(L.ptr(T), L.ptr(D), L.ptr(bins.perm), L.ptr(bins.bin), L.ptr(bins.coef), e, bins.knots,
+                                                        width, L.ptr(self.w), L.ptr(self.dw), L.stream_ptr()), "e3k_rtable_interp_fwd2")
+            else:
+                self.w = radial_table.interp_fwd_raw(T, self.bins)
+        return self.w
+
+    def slopes(self, D):
+        if self.dw is None:
+            self.dw = radial_table.interp_fwd_raw(D, self.bins)
+        return self.dw
 
 
 def _to_cf(x, plan, in_cf):
@@ -149,7 +176,10 @@ class ForceBlockFn(torch.autograd.Function):
         # both readers of x_cf in one launch: the keyed self-connection and linear_1
         ops._run_segments([ops._grp_segs("fwd", x_cf, m, conv, groups, plan.sc_spec, plan.sc_m_off),
                            ops._lin_fwd_segs(x_cf, w_lin1, x1, plan.lin1_spec, 1.0, False)])
-        mid = _tp_fwd_table(x1, sh, T, bins, topo, plan.tp_plan)
+        if MATERIALIZE:
+            mid = ops._tp_fwd_raw(x1, sh, cfg.weights(T, D if ctx.needs_input_grad[4] else None), topo, plan.tp_plan)
+        else:
+            mid = _tp_fwd_table(x1, sh, T, bins, topo, plan.tp_plan)
         ops._lin_fwd_raw(mid, w_post, None, conv, plan.post_spec, plan.scale, True)      # conv += scale * Linear(mid)
         y = ops._gate_fwd_raw(conv, plan.gate_spec, cfg.out_cf)
         STATS[0] += 1
@@ -197,9 +227,14 @@ class ForceBlockFn(torch.autograd.Function):
             g_xcf = (torch.empty if plan.sc_spec.in_covered else torch.zeros)(n, plan.sc_spec.d_in, device=dev, dtype=torch.float32)
             ops._run_segments([ops._lin_dgrad_segs(g_conv, w_post, g_mid, plan.post_spec, plan.scale, False),
                                ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off)])
-            g_x1 = _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp)
-            if want_e:
-                g_sh, g_r = _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp)
+            if MATERIALIZE:
+                g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
+                if want_e:
+                    g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
+            else:
+                g_x1 = _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp)
+                if want_e:
+                    g_sh, g_r = _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp)
             if params and need[2]:
                 g_w, _ = ops._tp_bwd_w_raw(x1, sh, None, g_mid, topo, tp, False, True)
                 g_T = radial_table.interp_bwd_raw(g_w, bins)
@@ -241,8 +276,12 @@ class ForceBlockBwdFn(torch.autograd.Function):
         g_xcf = (torch.empty if plan.sc_spec.in_covered else torch.zeros)(n, plan.sc_spec.d_in, device=dev, dtype=torch.float32)
         ops._run_segments([ops._lin_dgrad_segs(g_conv, w_post, g_mid, plan.post_spec, plan.scale, False),
                            ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off)])
-        g_x1 = _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp)
-        g_sh, g_r = _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp)
+        if MATERIALIZE:
+            g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
+            g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
+        else:
+            g_x1 = _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp)
+            g_sh, g_r = _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp)
         ops._run_segments([ops._lin_dgrad_segs(g_x1, w_lin1, g_xcf, plan.lin1_spec, 1.0, True)])
         g_x = g_xcf if cfg.in_cf else ops._relayout_raw(g_xcf, plan.in_blocks, False)
         STATS[1] += 1
@@ -278,6 +317,7 @@ class ForceBlockBwdFn(torch.autograd.Function):
         u_r = L.f32c(u_r).reshape(-1) if u_r is not None else torch.zeros(e, device=dev, dtype=torch.float32)
         ret_lin1 = ret_post = g_m = None
         cot_gconv = None
+        wsegs = []
         if u_x is not None:
             a = _to_cf(L.f32c(u_x), plan, cfg.in_cf)                                   # cotangent of g_xcf
             u_gx1 = torch.empty(n, plan.lin1_spec.d_out, device=dev, dtype=torch.float32)
@@ -285,22 +325,24 @@ class ForceBlockBwdFn(torch.autograd.Function):
             # adjoints of the two input-gradient GEMMs w.r.t. their gradient operand = the forward GEMMs on `a`
             ops._run_segments([ops._grp_segs("fwd", a, m, cot_gconv, groups, plan.sc_spec, plan.sc_m_off),
                                ops._lin_fwd_segs(a, w_lin1, u_gx1, plan.lin1_spec, 1.0, False)])
-            # ... and w.r.t. their weights = weight-gradient GEMMs pairing `a` with the gradients they multiplied
-            segs = []
+            # ... and w.r.t. their weights = weight-gradient GEMMs pairing `a` with the gradients they multiplied (issued below,
+            # together with the trailing Linear's)
             if need[3]:
                 g_m = torch.zeros(tuple(m.shape), device=dev, dtype=torch.float32)
-                segs.append(ops._grp_segs("wgrad", a, g_m, g_conv, groups, plan.sc_spec, plan.sc_m_off))
+                wsegs.append(ops._grp_segs("wgrad", a, g_m, g_conv, groups, plan.sc_spec, plan.sc_m_off))
             if need[7]:
                 gb_lin1, ret_lin1 = _grad_buffer(w_lin1, True)
-                segs.append(ops._lin_wgrad_segs(a, g_x1, gb_lin1, plan.lin1_spec, 1.0))
-            if segs:
-                ops._run_segments(segs, wgrad=True)
+                wsegs.append(ops._lin_wgrad_segs(a, g_x1, gb_lin1, plan.lin1_spec, 1.0))
         else:
             u_gx1 = torch.zeros(n, plan.lin1_spec.d_out, device=dev, dtype=torch.float32)
         # tensor-product family: Phi = <u_gx1, g_x1> + <u_sh, g_sh> + <u_r, g_r> is the derivative of <g_mid, TP(x1, sh, w(r))> along
         # (u_gx1, u_sh, u_r)
-        cot_gmid = _tp_fwd_jvp(x1, u_gx1, sh, u_sh, T, D, bins, u_r, topo, tp)
-        cot_x1 = _tp_bwd_x_dual(sh, u_sh, T, D, bins, u_r, g_mid, topo, tp) if need[1] else None
+        if MATERIALIZE:
+            wv, dwv, kb = cfg.weights(T), cfg.slopes(D), None
+        else:
+            wv, dwv, kb = T, D, bins
+        cot_gmid = _tp_fwd_jvp(x1, u_gx1, sh, u_sh, wv, dwv, kb, u_r, topo, tp)
+        cot_x1 = _tp_bwd_x_dual(sh, u_sh, wv, dwv, kb, u_r, g_mid, topo, tp) if need[1] else None
         g_T = g_D = None
         if need[4]:
             g_T = radial_table.interp_bwd_raw(_tp_bwd_w_dual(x1, u_gx1, sh, u_sh, g_mid, topo, tp), bins)
@@ -315,7 +357,9 @@ class ForceBlockBwdFn(torch.autograd.Function):
             ops._lin_fwd_raw(cot_gmid, w_post, None, cot_gconv, plan.post_spec, plan.scale, True)
         if need[8]:
             gb_post, ret_post = _grad_buffer(w_post, True)
-            ops._lin_wgrad_raw(cot_gmid, g_conv, gb_post, plan.post_spec, plan.scale)
+            wsegs.append(ops._lin_wgrad_segs(cot_gmid, g_conv, gb_post, plan.post_spec, plan.scale))
+        if wsegs:
+            ops._run_segments(wsegs, wgrad=True)
         cot_gy, cot_conv = _gate_bwd2(conv, g_y, cot_gconv, plan.gate_spec, cfg.out_cf, bool(need[0]), bool(need[2]))
         return cot_gy, cot_x1, cot_conv, g_m, g_T, g_D, None, ret_lin1, ret_post, None
 

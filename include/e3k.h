@@ -245,7 +245,9 @@ int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T,
  *                           NULL), g_w [E, W] = dF/dw written when non-null -- the first backward of a force evaluation
  *   e3k_tp_fwd_jvp_table    out = TP(x2, sh, w) + TP(x, sh2, w) + TP(x, sh, s2 * dw/dr)          (s2 [E]: the radius' partner)
  *   e3k_tp_bwd_x_dual_table g_x = dF/dx at (sh2, w) + dF/dx at (sh, s2 * dw/dr)
- *   e3k_tp_bwd_w_dual       g_w = dF/dw at (x2, sh) + dF/dw at (x, sh2)           (w is the open slot: no table involved) */
+ *   e3k_tp_bwd_w_dual       g_w = dF/dw at (x2, sh) + dF/dw at (x, sh2)           (w is the open slot: no table involved)
+ * With bin = coef = NULL the first three take w and dw/dr MATERIALISED: T = w [E, W], D = dw/dr [E, W] (e3k_rtable_interp_fwd of
+ * either table): five or six kernels per layer read them, and one 7.7 KB row per edge is a quarter of four table rows. */
 int e3k_tp_table2_supported(const e3k_tp_plan* plan);
 int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
                        const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
@@ -309,6 +311,9 @@ int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* 
                     int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream);
 int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
                           int32_t W, float* w, void* stream);
+/* two tables of one shape through the same weights in one pass (force training: w from T and dw/dr from the slope table) */
+int e3k_rtable_interp_fwd2(const float* T, const float* T2, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E,
+                           int32_t K, int32_t W, float* w, float* w2, void* stream);
 /* workspace: e3k_rtable_bwd_workspace_floats(E, K, W) floats (per-segment partial sums, combined in a fixed order) */
 int64_t e3k_rtable_bwd_workspace_floats(int64_t E, int32_t K, int32_t W);
 int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scale, const int32_t* bin_ptr,
