@@ -7,6 +7,17 @@
 
 #define E3K_WAVE 64
 
+// Tuning constants of the library.  The PRODUCT build (make, __graft_entry__.build()) compiles them in: no environment variable
+// changes what libe3k.so computes or how it launches.  `make dbg` (-DE3K_DEBUG_KNOBS, libe3k_dbg.so, loaded only through
+// E3K_LIB=...) reads the same names from the environment for experiments (tools/): sweeps of tile counts, and the timing-only
+// ablation mask E3K_ABLATE, with which the library skips kernel families and returns WRONG results by design.
+#ifdef E3K_DEBUG_KNOBS
+#include <cstdlib>
+#define E3K_KNOB_INT(var, name, dflt) static const long long var = getenv(name) ? atoll(getenv(name)) : (dflt)
+#else
+#define E3K_KNOB_INT(var, name, dflt) static constexpr long long var = (dflt)
+#endif
+
 #define E3K_CHECK_LAUNCH()                          \
   do {                                              \
     hipError_t _e = hipGetLastError();              \

@@ -1035,8 +1035,8 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
   hipStream_t st = (hipStream_t)stream;
   int kind[MAX_CALL];
   int64_t plain_tiles128 = 0;
-  static const int64_t sk_min_rows = getenv("E3K_SK_MIN_ROWS") ? atoll(getenv("E3K_SK_MIN_ROWS")) : 1024;
-  static const bool splitk_on = !(getenv("E3K_SPLITK") && atoi(getenv("E3K_SPLITK")) == 0);
+  E3K_KNOB_INT(sk_min_rows, "E3K_SK_MIN_ROWS", 1024);
+  E3K_KNOB_INT(splitk_on, "E3K_SPLITK", 1);
   for (int i = 0; i < n_problems; ++i) {
     const e3k_gemm_problem& P = problems[i];
     const int rc = validate(P, false);
@@ -1089,7 +1089,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       int64_t blocks;
       int aux = 0;
       if (k == FWD_SMALLK) {
-        static const int sk_ct = getenv("E3K_SK_CT") ? atoi(getenv("E3K_SK_CT")) : e3k::SK_CT;
+        E3K_KNOB_INT(sk_ct, "E3K_SK_CT", e3k::SK_CT);
         // a block keeps its A tile and walks `aux` column tiles -- unless the problem has too few tiles to fill the chip
         // that way (the radial MLP's last layer on the knot table: 33 row tiles): then fewer columns per block
         const int64_t fill = ((M + 127) / 128) * tiles_n / 1024;
@@ -1166,8 +1166,8 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       if (P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C)) f |= 8;
       const int wn = 64 * tn;
       const int tiles = ((P.K + e3k::WK - 1) / e3k::WK) * ((P.N + wn - 1) / wn);
-      static const int kTarget = getenv("E3K_WGRAD_TARGET") ? atoi(getenv("E3K_WGRAD_TARGET")) : 1024;
-      static const int kChunks = getenv("E3K_WGRAD_CHUNKS") ? atoi(getenv("E3K_WGRAD_CHUNKS")) : 4;
+      E3K_KNOB_INT(kTarget, "E3K_WGRAD_TARGET", 1024);
+      E3K_KNOB_INT(kChunks, "E3K_WGRAD_CHUNKS", 4);
       int64_t splits = (kTarget + tiles - 1) / tiles;
       const int64_t max_splits = (M + kChunks * e3k::WR - 1) / (kChunks * e3k::WR);
       if (splits > max_splits) splits = max_splits;

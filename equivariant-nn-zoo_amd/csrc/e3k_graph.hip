@@ -7,7 +7,7 @@
 //   count   one thread per edge: int32 endpoints out, atomic histogram of both endpoints
 //   scan    one workgroup per CSR: exclusive scan of the histogram into the row pointers (+ a cursor copy)
 //   fill    one thread per edge: claims a slot in its source row and its destination row (order arbitrary)
-//   sort    one wave per (node, CSR): ranks the row's edge ids -> ascending order (rows are short: a node's degree)
+//   sort    one wave per (node, CSR): ranks the row's edge ids -> ascending order (rows are a node's degree: register tiles)
 // The result does not depend on the order in which the atomics of `fill` land.
 #include "e3k_common.h"
 
@@ -93,12 +93,21 @@ __global__ __launch_bounds__(256) void csr_sort_kernel(const int32_t* __restrict
     int rank = 0;
     for (int j = 0; j < len; ++j) rank += __shfl(v, j, 64) < v ? 1 : 0;
     if (lane < len) out[beg + rank] = v;
-  } else {                       // long rows (dense graphs): every lane ranks its elements against the whole row
-    for (int i = lane; i < len; i += 64) {
-      const int32_t v = in[beg + i];
+  } else {
+    // long rows (node degree > 64: dense graphs): tiles of 64 candidates (one per lane) are ranked against tiles of 64 row
+    // elements held in registers and broadcast lane by lane -- len^2 / 64 register-only steps (round 3: every lane re-read the
+    // whole row from memory per element, len^2 / 64 dependent loads; the knot bins of the radial table, where rows reach
+    // thousands, no longer come through here at all: csrc/e3k_rtable.hip groups them with a stable counting sort)
+    for (int i0 = 0; i0 < len; i0 += 64) {
+      const bool mine = i0 + lane < len;
+      const int32_t v = mine ? in[beg + i0 + lane] : 0x7fffffff;
       int rank = 0;
-      for (int j = 0; j < len; ++j) rank += in[beg + j] < v ? 1 : 0;
-      out[beg + rank] = v;
+      for (int j0 = 0; j0 < len; j0 += 64) {
+        const int32_t u = j0 + lane < len ? in[beg + j0 + lane] : 0x7fffffff;
+        const int m = len - j0 < 64 ? len - j0 : 64;
+        for (int j = 0; j < m; ++j) rank += __shfl(u, j, 64) < v ? 1 : 0;
+      }
+      if (mine) out[beg + rank] = v;
     }
   }
 }

@@ -99,9 +99,10 @@ namespace {
 // bit set; it answers "what would the step gain if this kernel family were free" before anyone optimises it.
 // 1: keyed-weight kernels (fwd + bwd), 2: weight-gradient GEMMs, 4: gate fwd + bwd, 8: table interpolation fwd + bwd,
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
-static const int ABLATE = getenv("E3K_ABLATE") ? atoi(getenv("E3K_ABLATE")) : 0;
-static const int BWDW_SIDE = getenv("E3K_BWDW_SIDE") ? atoi(getenv("E3K_BWDW_SIDE")) : 0;
-static const int WGRAD_LATE = getenv("E3K_WGRAD_LATE") ? atoi(getenv("E3K_WGRAD_LATE")) : 1;
+// (debug build only -- see e3k_common.h: in the product library ABLATE is the constant 0 and every `ABLATE & bit` below folds away)
+E3K_KNOB_INT(ABLATE, "E3K_ABLATE", 0);
+E3K_KNOB_INT(BWDW_SIDE, "E3K_BWDW_SIDE", 0);
+E3K_KNOB_INT(WGRAD_LATE, "E3K_WGRAD_LATE", 1);
 // the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
 static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
 

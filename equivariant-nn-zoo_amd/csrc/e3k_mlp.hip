@@ -289,7 +289,7 @@ int launch_fwd(const e3k::MlpBatch& mb, int64_t E, hipStream_t st) {
 int launch_bwd(const e3k::MlpBatch& mb, int64_t E, int n_layers, hipStream_t st) {
   const int64_t tiles = (E + e3k::MLP_BM - 1) / e3k::MLP_BM;
   if (tiles > 0x7fffffffLL) return E3K_ERR_INVALID;
-  static const int max_blocks = getenv("E3K_MLP_BLOCKS") ? atoi(getenv("E3K_MLP_BLOCKS")) : 768;
+  E3K_KNOB_INT(max_blocks, "E3K_MLP_BLOCKS", 768);
   int64_t blocks = max_blocks / mb.n;      // persistent: two to three workgroups per CU share the weight-gradient atomics
   if (blocks < 1) blocks = 1;
   if (tiles < blocks) blocks = tiles;

@@ -859,7 +859,7 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
   {
     // work list: (group, 64-channel chunk | part << 16).  A group whose enabled slots hold more than
     // E3K_TP_SPLIT_ACC accumulators (l_max = 3 models) is walked by two waves, one per slot part.
-    static const int split_acc = getenv("E3K_TP_SPLIT_ACC") ? atoi(getenv("E3K_TP_SPLIT_ACC")) : 24;
+    E3K_KNOB_INT(split_acc, "E3K_TP_SPLIT_ACC", 24);
     int64_t cap = 0;
     for (int i = 0; i < n_groups; ++i) cap += 2 * ((groups[i].mul + 63) / 64);
     if (cap > (1 << 20)) {   // the work item index packs (chunk | part << 16): far beyond any irreps this path serves

@@ -20,12 +20,14 @@ from typing import List, Optional, Sequence, Tuple
 
 import torch
 
+from .tuning import knob as _knob
+
 from . import lib as L
 from . import ops, radial_table
 from .graph import GraphTopo
 
-ENABLED = int(os.environ.get("E3K_CONV_BLOCK", "1"))
-LOOK_AHEAD = int(os.environ.get("E3K_BLOCK_LOOK_AHEAD", "1"))     # the next layer's radial branch issued one layer early
+ENABLED = _knob("E3K_CONV_BLOCK")
+LOOK_AHEAD = _knob("E3K_BLOCK_LOOK_AHEAD")     # the next layer's radial branch issued one layer early
 AHEAD_STATS = [0]      # look-ahead results consumed (tests)
 # The GEMMs of a layer that share an operand go out in one e3k_gemm_multi call each -- backward: the input gradients of the
 # trailing Linear and of the self-connection (both read the gradient of the convolution output), then linear_1's input
@@ -34,7 +36,7 @@ AHEAD_STATS = [0]      # look-ahead results consumed (tests)
 # self-connection + linear_1 (both read the node features).  Measured against one call per operator: 256 molecules 5.73
 # vs 5.79 ms, 32 molecules 3.45 vs 3.38 ms (host-bound either way) -- launches per step 263 -> 228.
 MERGE = 1
-BWD_W_ON_MAIN = int(os.environ.get("E3K_BLOCK_BWDW_MAIN", "1"))    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: beside it on the radial stream (-0.3..0.6 % per step, but the two then stretch each other: their event-timed durations double)
+BWD_W_ON_MAIN = _knob("E3K_BLOCK_BWDW_MAIN")    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: beside it on the radial stream (-0.3..0.6 % per step, but the two then stretch each other: their event-timed durations double)
 
 
 class ConvBlockPlan:

@@ -32,17 +32,19 @@ import os
 from typing import Optional
 
 import torch
+
+from .tuning import knob as _knob
 from torch.autograd.function import once_differentiable
 
 from . import lib as L
 from . import ops, radial_table
 from .conv_block import ConvBlockPlan, _grad_buffer
 
-ENABLED = int(os.environ.get("E3K_FORCE_BLOCK", "1"))
+ENABLED = _knob("E3K_FORCE_BLOCK")
 # 1: a layer interpolates its per-edge weights w [E, W] (forward) and their slope dw/dr [E, W] (first backward) ONCE and every
 # tensor-product kernel of the three passes streams those rows; 0: every kernel gathers four rows per table and edge itself (the
 # in-kernel form of the energy step).  Five or six kernels per layer read them: 64 molecules 7.03 -> see DESIGN.md ms per step.
-MATERIALIZE = int(os.environ.get("E3K_FORCE_MATERIALIZE", "1"))
+MATERIALIZE = _knob("E3K_FORCE_MATERIALIZE")
 STATS = [0, 0, 0]      # forwards, first backwards (create_graph), u-sweeps (tests)
 _WARNED = [False]
 

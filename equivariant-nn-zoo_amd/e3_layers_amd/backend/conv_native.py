@@ -16,12 +16,14 @@ import os
 from typing import List, Optional
 
 import torch
+
+from .tuning import knob as _knob
 from torch.autograd.function import once_differentiable
 
 from . import lib as L
 from . import ops, radial_table
 
-ENABLED = int(os.environ.get("E3K_LAYER_NATIVE", "1"))
+ENABLED = _knob("E3K_LAYER_NATIVE")
 AHEAD_STATS = [0]
 PROF_KINDS = {"tp_fwd": 0, "tp_bwd_x": 1, "tp_bwd_w": 2, "rtable_fwd": 3, "rtable_bwd": 4, "radial_last_fwd": 5}
 _LAYERS: List["NativeLayer"] = []      # every layer object created (bench.py arms / reads their per-kernel timers)
@@ -196,11 +198,11 @@ class _Carve:
 # 1: layers on the knot table whose tensor-product plan has the in-kernel form (e3k_tp_table_supported: the l_max 2 models)
 # interpolate their path weights inside tp_fwd / tp_bwd_x: no interpolation pass, no w[E, W] (0.2-0.3 GB a layer at 256
 # molecules) written, read twice and kept for the backward
-TP_TABLE = int(os.environ.get("E3K_TP_TABLE", "1"))
+TP_TABLE = _knob("E3K_TP_TABLE")
 # 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
-FWD_SC_MAIN = int(os.environ.get("E3K_FWD_SC_MAIN", "0"))
+FWD_SC_MAIN = _knob("E3K_FWD_SC_MAIN")
 # 1: the addend of an addend-form layer (ConvBlockPlan.addend) is accumulated on in place instead of being copied into the block's buffer
-ADDEND_INPLACE = int(os.environ.get("E3K_ADDEND_INPLACE", "1"))
+ADDEND_INPLACE = _knob("E3K_ADDEND_INPLACE")
 
 
 def in_kernel_table(plan, table, dev) -> bool:
@@ -274,7 +276,7 @@ def _slope_ctx(slope, knots_r, bessel_w) -> L.SlopeCtx:
 STACK_STATS = [0, 0]      # stack evaluations so far, layers in the most recent one (tests)
 # E3K_HOST_TIMING=1: host seconds inside the layer functions, split into the C call and the Python around it
 # (tools/host_split.py --layer-timing prints them): [fwd total, fwd C call, bwd total, bwd C call, calls]
-HOST_TIMING = [0.0, 0.0, 0.0, 0.0, 0] if os.environ.get("E3K_HOST_TIMING") == "1" else None
+HOST_TIMING = [0.0, 0.0, 0.0, 0.0, 0] if _knob("E3K_HOST_TIMING") == 1 else None
 
 
 class RadialStackFn(torch.autograd.Function):

@@ -13,9 +13,11 @@ from typing import Optional, Sequence
 
 import torch
 
+from .tuning import knob as _knob
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.normpath(os.path.join(_HERE, "..", "..", "csrc"))
-LIB_PATH = os.environ.get("E3K_LIB", os.path.join(CSRC_DIR, "libe3k.so"))  # E3K_LIB: debug builds only
+LIB_PATH = _knob("E3K_LIB") or os.path.join(CSRC_DIR, "libe3k.so")  # E3K_LIB: debug builds only
 
 TP_MAXQ = 8
 

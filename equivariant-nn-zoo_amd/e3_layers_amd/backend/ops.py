@@ -21,6 +21,8 @@ from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+
+from .tuning import knob as _knob
 from torch.autograd.function import once_differentiable
 
 import weakref
@@ -57,7 +59,7 @@ class timed_launch:
 _side_streams: Dict[int, "torch.cuda.Stream"] = {}
 # E3K_FWD_FORK=2: also fork while a HIP graph is being captured (multi-stream capture).  ROCm's graph executor did not
 # run the captured branches concurrently (8.45 vs 8.35 ms at 256 molecules), so the default keeps captures single-stream.
-FORK_IN_CAPTURE = _os.environ.get("E3K_FWD_FORK") == "2"
+FORK_IN_CAPTURE = _knob("E3K_FWD_FORK") == 2
 
 
 def side_stream(device, which: int = 0) -> "torch.cuda.Stream":
@@ -120,8 +122,8 @@ GRAD_SINK: Dict[Tuple[int, int], Tuple[torch.Tensor, "weakref.ref"]] = {}
 # weight tensors of a layer once every kernel that adds into their sunk gradients has been ENQUEUED (on whichever
 # stream) -- the listener starts that slice's all-reduce behind them while the backward of the earlier layers goes on.
 GRAD_READY = None
-WGRAD_SIDE = int(_os.environ.get("E3K_WGRAD_SIDE", "1"))            # sunk weight gradients of the Linears run on a side stream
-WGRAD_SIDE_MIN_ROWS = int(_os.environ.get("E3K_WGRAD_SIDE_MIN_ROWS", "2048"))
+WGRAD_SIDE = _knob("E3K_WGRAD_SIDE")            # sunk weight gradients of the Linears run on a side stream
+WGRAD_SIDE_MIN_ROWS = _knob("E3K_WGRAD_SIDE_MIN_ROWS")
 class _Mode:
     """A process-wide mode flag with an owner.  These flags steer the e3k autograd functions from OUTSIDE a forward or
     backward call (a fork scope around a convolution, a gradient-selection scope around ``autograd.grad`` /

@@ -31,16 +31,18 @@ from typing import Optional
 
 import torch
 
+from .tuning import knob as _knob
+
 from . import lib as L
 from . import ops
 
-ENABLED = int(os.environ.get("E3K_RADIAL_TABLE", "1"))
+ENABLED = _knob("E3K_RADIAL_TABLE")
 # Target knot counts over [0, r_max]; the spacing actually used is the power of two at or below r_max / target (``layout``):
 # r / h, the offset inside a knot interval and the knot radii k h are then EXACT in fp32 -- with an arbitrary spacing their
 # rounding (6e-8 relative, i.e. 3e-5 of an interval at knot 500) shows up as 1e-6 in the interpolated weights.
-KNOTS = int(os.environ.get("E3K_RADIAL_KNOTS", "512"))                  # r_max 4: 512 intervals of 2^-7 A; r_max 5: 640
-KNOTS_SLOPE = int(os.environ.get("E3K_RADIAL_KNOTS_SLOPE", "512"))       # ... when the radii require grad (value + slope tables)
-MIN_EDGES_PER_KNOT = float(os.environ.get("E3K_RADIAL_MIN_EDGES_PER_KNOT", "4"))      # below this the per-edge MLP is the cheaper one
+KNOTS = _knob("E3K_RADIAL_KNOTS")                  # r_max 4: 512 intervals of 2^-7 A; r_max 5: 640
+KNOTS_SLOPE = _knob("E3K_RADIAL_KNOTS_SLOPE")       # ... when the radii require grad (value + slope tables)
+MIN_EDGES_PER_KNOT = _knob("E3K_RADIAL_MIN_EDGES_PER_KNOT")      # below this the per-edge MLP is the cheaper one
 
 
 def layout(r_max: float, target: int):
@@ -179,8 +181,8 @@ def applicable(edge_radial, w_last=None) -> bool:
 # to pinned memory without a sync and looked at on a later call: above GUARD_TOL the table is switched off for that MLP
 # (per-edge evaluation from then on) with a warning.  The slope table of force training has a guard of its own (same rule on
 # D, relative to max|D|: what is interpolated there is the slope).
-GUARD_TOL = float(os.environ.get("E3K_RADIAL_TABLE_TOL", "1e-6"))
-GUARD_EVERY = int(os.environ.get("E3K_RADIAL_TABLE_CHECK_EVERY", "64"))
+GUARD_TOL = _knob("E3K_RADIAL_TABLE_TOL")
+GUARD_EVERY = _knob("E3K_RADIAL_TABLE_CHECK_EVERY")
 _C4 = 3.0 / 128.0
 
 

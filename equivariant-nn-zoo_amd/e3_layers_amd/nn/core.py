@@ -17,6 +17,8 @@ import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
+
+from ..backend.tuning import knob as _knob
 from torch import nn
 
 from ..backend import lib as L
@@ -191,7 +193,7 @@ class FullyConnectedNet(nn.Sequential):
         self.hs = hs
         self.act_name = name
         # hidden chain in one launch (csrc/e3k_mlp.hip) when the widths fit; E3K_FUSED_MLP=0 keeps the per-layer ops
-        self.fused_hidden = (len(hs) >= 3 and name is not None and os.environ.get("E3K_FUSED_MLP", "1") != "0"
+        self.fused_hidden = (len(hs) >= 3 and name is not None and _knob("E3K_FUSED_MLP") != 0
                              and ops.mlp_hidden_supported(hs[0], hs[1:-1], name))
 
     def forward(self, x):
@@ -236,7 +238,7 @@ class FullyConnectedTensorProduct(nn.Module):
                                   all(i in cov_i for i in range(len(self.irreps_in1))))
 
     # keyed attrs: use the per-key contracted weights when there are few keys and many rows
-    KEY_MAX = int(os.environ.get("E3K_KEY_MAX", "256"))
+    KEY_MAX = _knob("E3K_KEY_MAX")
     KEY_MIN_ROWS = 256
     KEY_MIN_ROWS_PER_KEY = 8
 

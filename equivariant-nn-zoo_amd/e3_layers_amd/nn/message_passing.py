@@ -24,6 +24,8 @@ import weakref
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
+
+from ..backend.tuning import knob as _knob
 from torch import Tensor
 
 from ..backend import conv_block, ops, radial_table
@@ -38,8 +40,8 @@ from .sequential import Module
 
 # 1 (default): the edge-side branch of a convolution (radial MLP) runs on a side stream next to the node-side branch
 # (relayout, self-connection, linear_1); autograd replays the same split in the backward.  Measured +6 % on the bench.
-FWD_FORK = int(os.environ.get("E3K_FWD_FORK", "1"))
-FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connection runs on a third stream (+7 % on the bench)
+FWD_FORK = _knob("E3K_FWD_FORK")
+FWD_FORK_SC = _knob("E3K_FWD_FORK_SC")   # 1: the self-connection runs on a third stream (+7 % on the bench)
 # The fork pays when the branches are long enough to hide the extra stream switches (≈ 0.3 ms of host time per
 # step): the yardstick is the size of the per-edge weight tensor, edges x weight_numel, counted in edges of a
 # 1920-weight layer (n_dim 64, l_max 2).  Measured: config_energy 256 molecules (69 k x 1920) +12 %, protein
@@ -47,38 +49,38 @@ FWD_FORK_SC = int(os.environ.get("E3K_FWD_FORK_SC", "1"))   # 1: the self-connec
 # Round 3, with the radial MLP on the knot table (its branch is then a few launches over 2 049 rows, not per-edge GEMMs):
 # config_energy 96 / 128 / 160 molecules run 17 / 6 / 1 % FASTER on one stream, 192 / 256 molecules 8 % faster forked --
 # layers on the table use the larger yardstick.
-FORK_MIN_EDGES = int(os.environ.get("E3K_FORK_MIN_EDGES", "25000"))
+FORK_MIN_EDGES = _knob("E3K_FORK_MIN_EDGES")
 # Last third of round 3, with the stacks on one stream at every size: 192 molecules run faster on ONE stream (4.38 vs 4.52 ms),
 # 384 / 512 molecules 4-5 % faster forked (6.73 vs 7.03, 8.25 vs 8.68); 256 molecules depend on the HOST: forked 5.00 vs 5.26 ms
 # on an idle one, 5.23 vs 5.24 on a loaded one, where the fork's extra host work (4.0 instead of 2.6 ms per step) leaves no
 # slack.  Layers on the table fork from 60 000 edges; bench.py times both layouts and keeps the faster (E3K_FORK_MIN_EDGES_TABLE).
-FORK_MIN_EDGES_TABLE = int(os.environ.get("E3K_FORK_MIN_EDGES_TABLE", "60000"))
+FORK_MIN_EDGES_TABLE = _knob("E3K_FORK_MIN_EDGES_TABLE")
 _FORK_REF_WIDTH = 1920
 # 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
 # as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next.
 # Measured at 256 molecules: step 7.06 -> 6.91 ms (-2 %), but the HBM-bound tensor product then shares the memory
 # system with an MFMA GEMM that writes 0.5 GB: 134 -> 182 us per launch (roofline 0.64 -> 0.47).  Opt-in; issuing it
 # only after the tensor product (under the node-side launches) changed nothing.
-RADIAL_AHEAD = int(os.environ.get("E3K_RADIAL_AHEAD", "0"))
+RADIAL_AHEAD = _knob("E3K_RADIAL_AHEAD")
 # 1: consecutive MessagePassing layers pass their node features in the channel-fastest layout (MessagePassing._emit_cf)
-CF_CHAIN = int(os.environ.get("E3K_CF_CHAIN", "1"))
+CF_CHAIN = _knob("E3K_CF_CHAIN")
 AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 # 1: the radial MLPs of all the layers that read one edge embedding run as one batch on the knot table (first layer of
 # the chain), see MessagePassing._stack_rows
-RADIAL_STACK = int(os.environ.get("E3K_RADIAL_STACK", "1"))
+RADIAL_STACK = _knob("E3K_RADIAL_STACK")
 # ... while the step is launch-bound: with more edges than this every layer runs its own MLP (its backward then overlaps
 # the earlier layers' backward instead of forming one tail behind the first layer's; measured cross-over)
-STACK_MAX_EDGES = int(os.environ.get("E3K_STACK_MAX_EDGES", "50000"))
+STACK_MAX_EDGES = _knob("E3K_STACK_MAX_EDGES")
 # 1: likewise the per-key self-connection weights M_l of all the layers that read one node_attrs tensor
 # (MessagePassing._kw_stack_rows); not while the all-reduce is overlapped with the backward (run/parallel.py): the
 # self-connection weights are most of a layer's parameters and their gradients would then only exist at the very end
 # 1: a layer whose self-connection has general (un-keyed) node attributes still runs as a fused block: the self-connection is
 # computed by ops.fctp outside and handed in as an addend (MessagePassing._forward_block_addend)
-CF_CHAIN_NORM = int(os.environ.get("E3K_CF_CHAIN_NORM", "1"))      # cf hand-over through LayerNormalization
-BLOCK_ADDEND = int(os.environ.get("E3K_BLOCK_ADDEND", "1"))
-ADDEND_FORK = int(os.environ.get("E3K_ADDEND_FORK", "1"))
-KW_STACK = int(os.environ.get("E3K_KW_STACK", "1"))
-KW_STACK_MAX_EDGES = int(os.environ.get("E3K_KW_STACK_MAX_EDGES", "1000000000"))      # (192 / 256 molecules: -0.10 / -0.03 ms: no limit)
+CF_CHAIN_NORM = _knob("E3K_CF_CHAIN_NORM")      # cf hand-over through LayerNormalization
+BLOCK_ADDEND = _knob("E3K_BLOCK_ADDEND")
+ADDEND_FORK = _knob("E3K_ADDEND_FORK")
+KW_STACK = _knob("E3K_KW_STACK")
+KW_STACK_MAX_EDGES = _knob("E3K_KW_STACK_MAX_EDGES")      # (192 / 256 molecules: -0.10 / -0.03 ms: no limit)
 
 
 def _stream_alias(t: Tensor, stream) -> Tensor:

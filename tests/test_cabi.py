@@ -90,3 +90,37 @@ def test_product_path_has_no_oracle_import():
                 text = open(os.path.join(base, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), os.path.join(base, f)
                 assert "/root/reference" not in text, os.path.join(base, f)
+
+
+def test_switches_live_in_one_table_and_the_product_library_reads_no_environment():
+    """the C library's tuning constants are compile-time in the product build (getenv only behind
+    E3K_DEBUG_KNOBS: `make dbg`), and the Python package reads the environment in backend/tuning.py only -- every knob it reads is
+    documented there."""
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "equivariant-nn-zoo_amd", "csrc")
+    for fn in sorted(os.listdir(csrc)):
+        if not fn.endswith((".hip", ".h")):
+            continue
+        text = open(os.path.join(csrc, fn)).read()
+        if fn == "e3k_common.h":
+            assert text.count("getenv") >= 1 and "#ifdef E3K_DEBUG_KNOBS" in text
+            continue
+        assert "getenv" not in text, fn
+    pkg = os.path.join(root, "equivariant-nn-zoo_amd", "e3_layers_amd")
+    used = set()
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if not fn.endswith(".py"):
+                continue
+            text = open(os.path.join(dirpath, fn)).read()
+            if fn != "tuning.py":
+                assert "os.environ" not in text and "getenv" not in text, os.path.join(dirpath, fn)
+            used |= set(re.findall(r'_knob\("(E3K_[A-Z0-9_]+)"\)', text))
+    sys.path.insert(0, os.path.join(root, "equivariant-nn-zoo_amd"))
+    from e3_layers_amd.backend import tuning
+
+    assert used and used <= set(tuning.KNOBS), used - set(tuning.KNOBS)
+    assert set(tuning.KNOBS) - used == set(), set(tuning.KNOBS) - used      # no documented knob that nothing reads
+    assert all(len(doc) > 10 and kind in ("path", "threshold", "accuracy", "debug") for _, kind, doc in tuning.KNOBS.values())

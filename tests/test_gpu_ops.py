@@ -288,7 +288,7 @@ def test_topology_matches_stable_sort(dev):
     assert int(ptr[-1]) == ei.shape[1]
 
 
-@pytest.mark.parametrize("n,deg,shuffle", [(37, 7, False), (500, 15, True), (3, 150, True), (64, 1, True), (9, 0, False)])
+@pytest.mark.parametrize("n,deg,shuffle", [(37, 7, False), (500, 15, True), (3, 150, True), (64, 1, True), (9, 0, False), (40, 300, True)])
 def test_device_csr_build_is_the_stable_sort(dev, n, deg, shuffle):
     """csrc/e3k_graph.hip (count -> scan -> fill -> per-row rank sort) against the torch construction (stable argsort /
     bincount / cumsum / searchsorted) on the host: every list bit-identical, whatever order the fill atomics landed in.
@@ -500,6 +500,16 @@ def test_knot_bins_are_the_stable_counting_sort(dev, clustered):
         assert torch.equal(getattr(a, name), getattr(b, name)), name
     if clustered:
         assert int(cnt.max()) > 5000
+    # the transposed interpolation over these bins: an ordered sum per knot (segments of <= 64 edges combined in order) -- the same
+    # bits run to run, and the float64 index_add within rounding
+    width = 64
+    g_w = torch.randn(e, width, generator=gen).to(dev)
+    gt_a, gt_b = radial_table.interp_bwd_raw(g_w, a), radial_table.interp_bwd_raw(g_w, b)
+    assert torch.equal(gt_a, gt_b)
+    gt_ref = torch.zeros(knots + 1, width, dtype=torch.float64)
+    for k in range(4):
+        gt_ref.index_add_(0, bin_cpu - 1 + k, c_ref[:, k:k + 1] * g_w.cpu().double())
+    assert rel_err(gt_a, gt_ref) < 2e-6
 
 
 @pytest.mark.parametrize("left,out", [
