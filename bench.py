@@ -43,8 +43,8 @@ import torch.distributed as dist
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (the clock an MFMA loop sustains is lower)
-# rocprofv3 --pmc passes over this command at the two l_max values (tools/collect_profiles_r03.sh, tools/summarize_profiles_r03.py)
-TRAFFIC_FILES = {2: "profiles/r03_tp_traffic.json", 3: "profiles/r03_lmax3_tp_traffic.json"}
+# rocprofv3 --pmc passes over this command at the two l_max values (tools/collect_profiles_r04.sh, tools/summarize_profiles_r04.py)
+TRAFFIC_FILES = {2: "profiles/r04_tp_traffic.json", 3: "profiles/r04_lmax3_tp_traffic.json"}
 
 
 def parse():
@@ -522,7 +522,9 @@ def main():
         # (several ranks: the replay has only been exercised with two ranks on one GPU over gloo, never over RCCL on a multi-GPU
         #  box -- there it is tried on request only: E3K_BENCH_AUTO=try-graph, or --graph-fresh to pin it)
         host_bound = world == 1 and host_ref / n_ref >= 0.85 * ref_step
-        if host_bound or os.environ.get("E3K_BENCH_AUTO") == "try-graph":
+        # (force training issues ~360 launches from Python per step: the replay is tried whatever the host's share was in the few
+        #  reference steps -- on a shared box that share swings between 0.7 and 0.95 from run to run)
+        if host_bound or (world == 1 and cfg_kind == "energy_force") or os.environ.get("E3K_BENCH_AUTO") == "try-graph":
             made = None
             try:
                 made = make_bucket()
