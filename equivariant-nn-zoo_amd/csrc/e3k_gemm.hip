@@ -129,25 +129,23 @@ struct BRegs {
   float4 v[2];
 };
 
-// B tile (BK x BN) global -> registers (vector modes only; issued early, written to LDS late)
+// B tile (BK x BN) global -> registers (vector modes only; issued early, written to LDS late).  ONE load statement per
+// register whatever the mode: with a load in each arm of `if (bmode == 1) ... else ...` the two arms write the same
+// registers, the structurised control flow keeps an edge from one arm into the other, and the compiler protects the second
+// arm's zero-initialisation with s_waitcnt vmcnt(0) -- which, on the forward path, waited for the A loads issued just
+// before, i.e. the K-step prefetch never overlapped the MFMAs (found in round 4 with timing-only ablations: the phases of
+// these kernels added up).
 __device__ __forceinline__ void load_b_regs(const e3k_gemm_problem& P, int bmode, int k0, int n0, BRegs& r) {
   const int t = threadIdx.x;
-  if (bmode == 1) {
+  const bool m1 = bmode == 1;
 #pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int k = (t >> 4) + 16 * pass, nq = (t & 15) * 4;
-      r.v[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (k0 + k < P.K && n0 + nq < P.N)
-        r.v[pass] = *reinterpret_cast<const float4*>(P.B + (int64_t)(k0 + k) * P.b_k + (n0 + nq));
-    }
-  } else {  // bmode == 2: B^T view, contiguous along k
-    const int n = t & 63, kq = (t >> 6) * 8;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = kq + 4 * h;
-      r.v[h] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (n0 + n < P.N && k0 + k < P.K) r.v[h] = *reinterpret_cast<const float4*>(P.B + (int64_t)(n0 + n) * P.b_n + (k0 + k));
-    }
+  for (int pass = 0; pass < 2; ++pass) {
+    // mode 1: row k = (t >> 4) + 16 pass, columns nq..nq+3;  mode 2 (B^T view, contiguous along k): column n = t & 63, k = kq + 4 pass
+    const int k = m1 ? (t >> 4) + 16 * pass : (t >> 6) * 8 + 4 * pass;
+    const int n = m1 ? (t & 15) * 4 : (t & 63);
+    const int64_t off = m1 ? (int64_t)(k0 + k) * P.b_k + (n0 + n) : (int64_t)(n0 + n) * P.b_n + (k0 + k);
+    r.v[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (k0 + k < P.K && n0 + n < P.N) r.v[pass] = *reinterpret_cast<const float4*>(P.B + off);
   }
 }
 
@@ -277,6 +275,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   const float* ap = As + (wm * 32 + (lane & 31)) * LDA + (lane >> 5);
   const float* bp = Bs + (lane >> 5) * LDB + wn * (BN / WN) + (lane & 31);
   auto mfma_tile = [&]() {
+#ifdef E3K_DEBUG_KNOBS
+    if (flags & 16) return;    // timing only: no MFMAs
+#endif
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       const float a = ap[kk];
@@ -340,8 +341,231 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
       __syncthreads();
     }
   }
+#ifdef E3K_DEBUG_KNOBS
+  if (flags & 32) return;      // timing only: no stores
+#endif
   store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
 }
+
+#ifdef E3K_DEBUG_KNOBS
+// ---------------------------------------------------------------------------------------
+// EXPERIMENT (built only with -DE3K_DEBUG_KNOBS, `make dbg`; E3K_GEMM_PERSIST=1): measured slower than gemm_kernel, see
+// DESIGN.md section 5 "Built, measured, not adopted (round 4)".
+// persistent forward / dgrad (round 4): every workgroup walks tiles T = blockIdx, blockIdx + grid, ... of the launch's
+// (problem, 128-row tile, 64-column tile) list as ONE sequence of K-steps, software-pipelined ACROSS tiles.
+//
+// Why: timing-only ablations of gemm_kernel on the node-side Linears (tools/gemm_probe_r04.sh) show its three phases ADD
+// UP -- trailing Linear forward 67 us = skeleton + loads 24 + MFMA 31 + stores 12; its input gradient 96 us = 30 + 27 +
+// 40 -- although three or four workgroups share every CU: identical tiles launched together stay in lockstep, so all of
+// them load, then all multiply, then all store.  Overlap has to come from inside the workgroup: here the loads run two
+// K-steps ahead of the MFMAs (registers, then the other LDS stage) whichever tile the step belongs to, the stores of a
+// finished tile are issued and never waited for, and there is one barrier per K-step.  Per-tile state that outlives the
+// load phase (output row offsets, epilogue constants) sits in LDS rings of four tiles.
+// ---------------------------------------------------------------------------------------
+struct EpiDesc {
+  float* C;
+  const float* bias;
+  long long c_n;
+  float alpha, act_cst;
+  int N, n0, accumulate, act;
+};
+
+__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmBatch gb, const int total_tiles) {
+  constexpr int BM_ = 128, NT = 2;
+  __shared__ float As[2][BM_ * LDA];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
+  __shared__ long long rowC[4][BM_];
+  __shared__ EpiDesc epi[4];
+  if ((int)blockIdx.x >= total_tiles) return;
+  const int t = threadIdx.x, lane = t & 63, wm = t >> 6;
+  const int kq = (t & 7) * 4;
+
+  // ---- load side: the tile whose K-steps are being fetched.  What a K-step needs is kept in plain scalars and per-thread
+  // element offsets set up once per tile (the problem descriptor itself stays in the kernel-argument segment: held as a
+  // struct it does not fit the scalar registers next to the loop's state and the compiler re-read it field by field,
+  // s_load + s_waitcnt lgkmcnt(0), in every K-step)
+  int ld_tile = blockIdx.x;            // tile index in the launch; >= total_tiles: nothing left to load
+  int ld_slot = 0;                     // ring slot (tile counter mod 4) of the tile being loaded
+  int ld_k = 0, l_K = 0;               // next k0 to load, K of the tile's problem
+  int l_bmode = 1;
+  const float* pa[4];                  // this thread's four A rows at column kq of the next K-step (nullptr: row out of range)
+  const float* pb[2];                  // its two B float4s of the next K-step (nullptr: column out of range)
+  int b_step = 0;                      // elements between consecutive K-steps of B
+  int bk_lim[2];                       // k of the B loads relative to k0 (a load is valid while k0 + bk_lim < K)
+  auto open_tile = [&]() {             // block-uniform control flow
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < GEMM_MAXP; ++i)
+      if (i < gb.n && ld_tile >= gb.tile_start[i]) pi = i;
+    pi = uniform(pi);
+    const e3k_gemm_problem& LP = gb.p[pi];
+    l_bmode = uniform((gb.flags[pi] >> 1) & 3);
+    l_K = uniform(LP.K);
+    const int local = ld_tile - gb.tile_start[pi];
+    const int tiles_n = (LP.N + BN - 1) / BN;
+    const int row0 = (local / tiles_n) * BM_;
+    const int n0 = (local % tiles_n) * BN;
+    const int M = LP.M1 * LP.M2;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      const int R = row0 + (t >> 3) + 32 * p;
+      pa[p] = nullptr;
+      if (R < M) {
+        const int r1 = R / LP.M2, r2 = R - r1 * LP.M2;
+        pa[p] = LP.A + (long long)r1 * LP.a_r1 + (long long)r2 * LP.a_r2 + kq;
+      }
+    }
+    const bool m1 = l_bmode == 1;
+    b_step = uniform(m1 ? BK * (int)LP.b_k : BK);
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int k = m1 ? (t >> 4) + 16 * pass : (t >> 6) * 8 + 4 * pass;
+      const int n = m1 ? (t & 15) * 4 : (t & 63);
+      bk_lim[pass] = k;
+      pb[pass] = (n0 + n < LP.N) ? LP.B + (m1 ? (long long)k * LP.b_k + (n0 + n) : (long long)(n0 + n) * LP.b_n + k) : nullptr;
+    }
+    if (t < BM_) {
+      const int R = row0 + t;
+      long long oc = -1;
+      if (R < M) {
+        const int r1 = R / LP.M2, r2 = R - r1 * LP.M2;
+        oc = (long long)r1 * LP.c_r1 + (long long)r2 * LP.c_r2;
+      }
+      rowC[ld_slot][t] = oc;
+    }
+    if (t == 0) {
+      EpiDesc e;
+      e.C = LP.C; e.bias = LP.bias; e.c_n = LP.c_n; e.alpha = LP.alpha; e.act_cst = LP.act_cst;
+      e.N = LP.N; e.n0 = n0; e.accumulate = LP.accumulate; e.act = LP.act;
+      epi[ld_slot] = e;
+    }
+    ld_k = 0;
+  };
+  float4 ra[4];
+  BRegs rb;
+  // fetches the next K-step of the sequence into registers; returns slot << 3 | B mode << 1 | (last step of its tile),
+  // or -1 when the sequence has ended
+  auto gload = [&]() -> int {
+    if (ld_tile >= total_tiles) return -1;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pa[p] && ld_k + kq < l_K) ra[p] = *reinterpret_cast<const float4*>(pa[p]);
+      pa[p] = pa[p] ? pa[p] + BK : nullptr;
+    }
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      rb.v[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (pb[pass] && ld_k + bk_lim[pass] < l_K) rb.v[pass] = *reinterpret_cast<const float4*>(pb[pass]);
+      pb[pass] = pb[pass] ? pb[pass] + b_step : nullptr;
+    }
+    ld_k += BK;
+    const int last = ld_k >= l_K ? 1 : 0;
+    const int tag = (ld_slot << 3) | (l_bmode << 1) | last;
+    if (last) {
+      ld_tile += gridDim.x;
+      ld_slot = (ld_slot + 1) & 3;
+      if (ld_tile < total_tiles) open_tile();
+    }
+    return tag;
+  };
+  auto lstore = [&](int buf, int tag) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+      float* d = &As[buf][((t >> 3) + 32 * p) * LDA + kq];
+      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
+    }
+    store_b_regs((tag >> 1) & 3, rb, Bs[buf]);
+  };
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  open_tile();
+  int tag0 = gload();
+  lstore(0, tag0);
+  int tag1 = gload();
+  __syncthreads();
+  int buf = 0;
+  const int aoff = (wm * 32 + (lane & 31)) * LDA + (lane >> 5);
+  const int boff = (lane >> 5) * LDB + (lane & 31);
+  while (tag0 >= 0) {
+    int tag2 = -1;
+#ifdef E3K_DEBUG_KNOBS
+    const int abl = gb.flags[0];
+    if (tag1 >= 0) {
+      if (!(abl & 64)) lstore(buf ^ 1, tag1);
+      if (abl & 32) {           // timing only: the sequence advances without loading
+        ld_k += BK;
+        const bool last = ld_k >= l_K;
+        tag2 = (ld_slot << 3) | (l_bmode << 1) | (last ? 1 : 0);
+        if (ld_tile >= total_tiles) tag2 = -1;
+        else if (last) { ld_tile += gridDim.x; ld_slot = (ld_slot + 1) & 3; if (ld_tile < total_tiles) open_tile(); }
+      } else tag2 = gload();
+    }
+    if (!(abl & 16)) {
+#else
+    if (tag1 >= 0) {
+      lstore(buf ^ 1, tag1);
+      tag2 = gload();
+    }
+    {
+#endif
+    const float* ap = &As[buf][aoff];
+    const float* bp = &Bs[buf][boff];
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = ap[kk];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB + 32 * j], acc[j], 0, 0, 0);
+    }
+    }
+    if (tag0 & 1) {      // the tile is complete: write it out (not waited for) and start the next accumulation
+      const int slot = tag0 >> 3;
+      const EpiDesc e = epi[slot];
+      int n[NT];
+      bool ok[NT];
+      float bias[NT];
+      long long cn[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        n[j] = e.n0 + 32 * j + (lane & 31);
+        ok[j] = n[j] < e.N;
+        bias[j] = (e.bias && ok[j]) ? e.bias[n[j]] : 0.f;
+        cn[j] = (long long)n[j] * e.c_n;
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const long long off = rowC[slot][wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)];
+        if (off >= 0) {
+          float* c = e.C + off;
+#pragma unroll
+          for (int j = 0; j < NT; ++j) {
+            if (ok[j]) {
+              float v = fmaf(e.alpha, acc[j][i], bias[j]);
+              if (e.accumulate) v += c[cn[j]];
+              if (e.act == 1) v = e.act_cst * (fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))) - 0.6931471805599453f);
+              c[cn[j]] = v;
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+    }
+    __syncthreads();
+    tag0 = tag1;
+    tag1 = tag2;
+    buf ^= 1;
+  }
+}
+
+#endif  // E3K_DEBUG_KNOBS
 
 // ---------------------------------------------------------------------------------------
 // few rows, long K (the radial MLP's dgrad on the knot table: 4097 x 64 outputs, K ~ 2000): a 64-row tile grid would
@@ -872,6 +1096,330 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
 }
 
 // ---------------------------------------------------------------------------------------
+// wgrad, software-pipelined form (round 4).  What the round's measurements say about the form above on the node-side
+// problems (4 608 nodes, K = 384, N = 64, rows 3 or 5 per node): its time is a fixed 8-19 us per 64-row chunk and
+// workgroup whatever the number of co-resident workgroups -- the loop is one load latency long per chunk (loads issued
+// one chunk ahead, behind a barrier, waited for in front of the next) -- and it pays 16 KB of float atomics per 256 rows
+// (the chip adds 1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").  Here: (i) two LDS stages, the
+// loads of chunk c + 2 in flight while chunk c is in the matrix pipe: one barrier per chunk and two chunk times for a
+// load to land; (ii) tile 128 k x 64 n (WKW = 4 waves along k, two accumulators each: the G fragment pair is reused by
+// every wave, A is still read once) or 64 k x 64 n (WKW = 2) for K <= 64; (iii) the launch is sized to ~2 workgroups per
+// CU with EQUAL row ranges per workgroup (splits proportional to the problem's rows), so a workgroup adds its tile once
+// per ~1/512 of the launch's work.
+// ---------------------------------------------------------------------------------------
+constexpr int W2R = 32;   // rows per chunk
+template <int WKW>
+__device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float* As_, float* Gs_) {
+  constexpr int TK = 32 * WKW;            // k per tile
+  constexpr int WNW = 4 / WKW;            // waves along n
+  constexpr int NT = 2 / WNW;             // accumulators per wave (tile is 64 n wide)
+  constexpr int LDA2 = TK + 4, LDG2 = 64 + 4;
+  constexpr int APASS = (W2R * TK / 4) / 256;     // float4 loads of A per thread and chunk (4 or 2)
+  constexpr int AROWS = 256 / (TK / 4);           // rows covered by one pass (8 or 16)
+  float (*As)[W2R * LDA2] = reinterpret_cast<float (*)[W2R * LDA2]>(As_);
+  float (*Gs)[W2R * LDG2] = reinterpret_cast<float (*)[W2R * LDG2]>(Gs_);
+  const e3k_gemm_problem& P = bp_.P;
+  const int local = bp_.local;
+  const int M = P.M1 * P.M2, M2 = P.M2;
+  const int tiles_k = (P.K + TK - 1) / TK, tiles_n = (P.N + 63) / 64;
+  const int splits = bp_.aux;
+  const int tile = local % (tiles_k * tiles_n), split = local / (tiles_k * tiles_n);
+  const int k0 = (tile / tiles_n) * TK, n0 = (tile % tiles_n) * 64;
+  const int chunk_rows = ((M + splits - 1) / splits + W2R - 1) / W2R * W2R;
+  const int rbeg = split * chunk_rows;
+  const int rend = (rbeg + chunk_rows < M) ? rbeg + chunk_rows : M;
+  if (rbeg >= M) return;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wk = wv % WKW, wn = wv / WKW;
+  const int qR = W2R / M2, remR = W2R - qR * M2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // this thread's rows of a chunk: A pass p -> row (t / (TK/4)) + AROWS*p, G pass p -> row (t >> 4) + 16*p; row pointers
+  // advance by constant 64-bit deltas (one chunk down, and the wrap of the component index r2)
+  int aR[APASS], ar2[APASS], gR[2], gr2[2];
+  const float* pa[APASS];
+  const float* pg[2];
+  const int64_t dA = (int64_t)qR * P.a_r1 + (int64_t)remR * P.a_r2, wA = P.a_r1 - (int64_t)M2 * P.a_r2;
+  const int64_t dG = (int64_t)qR * P.c_r1 + (int64_t)remR * P.c_r2, wG = P.c_r1 - (int64_t)M2 * P.c_r2;
+  const int acol = (t % (TK / 4)) * 4, gcol = (t & 15) * 4;
+  const bool a_in = k0 + acol < P.K, g_in = n0 + gcol < P.N;
+#pragma unroll
+  for (int p = 0; p < APASS; ++p) {
+    aR[p] = rbeg + t / (TK / 4) + AROWS * p;
+    const int r1 = aR[p] / M2;
+    ar2[p] = aR[p] - r1 * M2;
+    pa[p] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol;
+  }
+#pragma unroll
+  for (int p = 0; p < 2; ++p) {
+    gR[p] = rbeg + (t >> 4) + 16 * p;
+    const int r1 = gR[p] / M2;
+    gr2[p] = gR[p] - r1 * M2;
+    pg[p] = P.C + (int64_t)r1 * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol;
+  }
+  float4 ra[APASS], rg[2];
+  auto gload = [&]() {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p) {
+      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (aR[p] < rend && a_in) ra[p] = *reinterpret_cast<const float4*>(pa[p]);
+      aR[p] += W2R; ar2[p] += remR; pa[p] += dA;
+      if (ar2[p] >= M2) { ar2[p] -= M2; pa[p] += wA; }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+      rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (gR[p] < rend && g_in) rg[p] = *reinterpret_cast<const float4*>(pg[p]);
+      gR[p] += W2R; gr2[p] += remR; pg[p] += dG;
+      if (gr2[p] >= M2) { gr2[p] -= M2; pg[p] += wG; }
+    }
+  };
+  auto lstore = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < APASS; ++p)
+      *reinterpret_cast<float4*>(&As[st][(t / (TK / 4) + AROWS * p) * LDA2 + acol]) = ra[p];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) *reinterpret_cast<float4*>(&Gs[st][((t >> 4) + 16 * p) * LDG2 + gcol]) = rg[p];
+  };
+  const int n_chunks = (rend - rbeg + W2R - 1) / W2R;
+  gload();
+  lstore(0);
+  if (n_chunks > 1) gload();
+  __syncthreads();
+  const int aoff = (lane >> 5) * LDA2 + wk * 32 + (lane & 31);
+  const int goff = (lane >> 5) * LDG2 + wn * (32 * NT) + (lane & 31);
+  for (int c = 0; c < n_chunks; ++c) {
+    const int st = c & 1;
+    if (c + 1 < n_chunks) lstore(st ^ 1);
+#ifdef E3K_DEBUG_KNOBS
+    if (c + 2 < n_chunks && !(bp_.flags & 32)) gload();
+    if (bp_.flags & 16) { __syncthreads(); continue; }
+#else
+    if (c + 2 < n_chunks) gload();
+#endif
+    const float* ap = &As[st][aoff];
+    const float* gp = &Gs[st][goff];
+#pragma unroll
+    for (int rr = 0; rr < W2R; rr += 2) {
+      const float a = ap[rr * LDA2];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gp[rr * LDG2 + 32 * j], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (32 * NT) + 32 * j + (lane & 31);
+    if (n < P.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + wk * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (k < P.K) atomicAdd(const_cast<float*>(P.B) + (int64_t)k * P.b_k + (int64_t)n * P.b_n, P.alpha * acc[j][i]);
+      }
+    }
+  }
+}
+
+// one kernel for both tile shapes (a call's K > 64 and K <= 64 problems share a launch); registers and LDS are the wide form's
+__global__ __launch_bounds__(256, 2) void gemm_wgrad2_kernel(const GemmBatch gb) {
+  __shared__ __attribute__((aligned(16))) float As[2 * W2R * (128 + 4)];
+  __shared__ __attribute__((aligned(16))) float Gs[2 * W2R * (64 + 4)];
+  const BlockProblem bp_ = fetch_problem(gb);
+  if (bp_.P.K > 64) gemm_wgrad2_body<4>(bp_, As, Gs);
+  else gemm_wgrad2_body<2>(bp_, As, Gs);
+}
+
+#ifdef E3K_DEBUG_KNOBS
+// ---------------------------------------------------------------------------------------
+// EXPERIMENT (built only with -DE3K_DEBUG_KNOBS; E3K_WGRAD2=2): as fast as the register-staged form above, not faster.
+// wgrad, one workgroup per CU with a ring of LDS stages filled by LDS-direct loads (global_load_lds_dwordx4: no staging
+// registers, so three chunks can be in flight per workgroup).  Why: the pipelined form above at 3 workgroups per CU is
+// launch 6 us + max(loads 28, MFMA 27) + 19 us of float atomics that all arrive when the workgroups finish together
+// (768 tiles of 32 KB = 25 MB at the chip's 1.3 TB/s of atomic bytes); a third of the workgroups, each with three times
+// the rows, adds a third of the bytes.  Lanes whose row or column is out of range load from a block of zeros (G) or a
+// clamped row (A), so every lane issues the same number of loads per chunk and s_waitcnt vmcnt(N) can leave exactly
+// the younger chunks in flight.  Unpadded LDS rows (LDS-direct writes 1 KB contiguous per wave instruction): the A / G
+// fragment reads are 2-way bank conflicts, 4 cycles instead of 2 per ds_read_b32 beside a 64-cycle MFMA.
+// ---------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) float e3k_zero_row[128];   // zero-initialised (static storage)
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// s_waitcnt lgkmcnt(0) that the values read by the ds_read asm statements above it flow through
+template <int NT>
+__device__ __forceinline__ void lds_wait(float (&a)[8], float (&g)[8][NT]) {
+  if constexpr (NT == 2)
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(g[0][0]), "+v"(g[0][1]),
+                   "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[3][0]), "+v"(g[3][1]), "+v"(g[4][0]), "+v"(g[4][1]),
+                   "+v"(g[5][0]), "+v"(g[5][1]), "+v"(g[6][0]), "+v"(g[6][1]), "+v"(g[7][0]), "+v"(g[7][1])
+                 :
+                 : "memory");
+  else
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(g[0][0]), "+v"(g[1][0]),
+                   "+v"(g[2][0]), "+v"(g[3][0]), "+v"(g[4][0]), "+v"(g[5][0]), "+v"(g[6][0]), "+v"(g[7][0])
+                 :
+                 : "memory");
+}
+
+template <int WKW, int W3R, int W3S>
+__device__ __forceinline__ void gemm_wgrad3_body(const BlockProblem& bp_, float* As, float* Gs) {
+  constexpr int TK = 32 * WKW;
+  constexpr int WNW = 4 / WKW, NT = 2 / WNW;
+  constexpr int A_STAGE = W3R * TK, G_STAGE = W3R * 64;      // floats
+  constexpr int A_INSTR = A_STAGE / 256, G_INSTR = G_STAGE / 256;   // wave instructions (1 KB each) per stage
+  constexpr int APW = A_INSTR / 4, GPW = G_INSTR / 4;        // per wave
+  constexpr int A_RPI = 256 / TK;                            // rows per wave instruction (2 or 4)
+  constexpr int L = APW + GPW;                               // loads per thread and chunk
+  const e3k_gemm_problem& P = bp_.P;
+  const int local = bp_.local;
+  const int M = P.M1 * P.M2, M2 = P.M2;
+  const int tiles_k = (P.K + TK - 1) / TK, tiles_n = (P.N + 63) / 64;
+  const int splits = bp_.aux;
+  const int tile = local % (tiles_k * tiles_n), split = local / (tiles_k * tiles_n);
+  const int k0 = (tile / tiles_n) * TK, n0 = (tile % tiles_n) * 64;
+  const int chunk_rows = ((M + splits - 1) / splits + W3R - 1) / W3R * W3R;
+  const int rbeg = split * chunk_rows;
+  const int rend = (rbeg + chunk_rows < M) ? rbeg + chunk_rows : M;
+  if (rbeg >= M) return;
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int wk = wv % WKW, wn = wv / WKW;
+  const int qR = W3R / M2, remR = W3R - qR * M2;
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
+
+  // wave instruction i of a stage: A rows A_RPI*i + lane / (TK/4), G rows 4*i + lane / 16; this wave issues i = wv + 4*p.
+  // Row pointers advance by constant 64-bit deltas (one chunk down, and the wrap of the component index r2): the address
+  // arithmetic of a chunk is a dozen adds per load, not two 64-bit multiplies -- it runs on the SIMD that issues the MFMAs
+  int aR[APW], ar2[APW], gR[GPW], gr2[GPW];
+  const float* pa[APW];
+  const float* pg[GPW];
+  const int64_t dA = (int64_t)qR * P.a_r1 + (int64_t)remR * P.a_r2, wA = P.a_r1 - (int64_t)M2 * P.a_r2;
+  const int64_t dG = (int64_t)qR * P.c_r1 + (int64_t)remR * P.c_r2, wG = P.c_r1 - (int64_t)M2 * P.c_r2;
+  const int acol = (lane % (TK / 4)) * 4, gcol = (lane & 15) * 4;
+  const bool a_in = k0 + acol < P.K, g_in = n0 + gcol < P.N;
+#pragma unroll
+  for (int p = 0; p < APW; ++p) {
+    aR[p] = rbeg + A_RPI * (wv + 4 * p) + lane / (TK / 4);
+    const int r1 = aR[p] / M2;
+    ar2[p] = aR[p] - r1 * M2;
+    pa[p] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol;
+  }
+#pragma unroll
+  for (int p = 0; p < GPW; ++p) {
+    gR[p] = rbeg + 4 * (wv + 4 * p) + (lane >> 4);
+    const int r1 = gR[p] / M2;
+    gr2[p] = gR[p] - r1 * M2;
+    pg[p] = P.C + (int64_t)r1 * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol;
+  }
+  const int last = rend - 1, last1 = last / M2, last2 = last - last1 * M2;
+  const float* a_last = P.A + (int64_t)last1 * P.a_r1 + (int64_t)last2 * P.a_r2 + k0 + acol;
+  auto issue = [&](int st) {
+#pragma unroll
+    for (int p = 0; p < APW; ++p) {
+      const float* src = a_in ? (aR[p] < rend ? pa[p] : a_last) : e3k_zero_row + acol;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(As + st * A_STAGE + (wv + 4 * p) * 256), 16, 0, 0);
+      aR[p] += W3R; ar2[p] += remR; pa[p] += dA;
+      if (ar2[p] >= M2) { ar2[p] -= M2; pa[p] += wA; }
+    }
+#pragma unroll
+    for (int p = 0; p < GPW; ++p) {
+      const float* src = (g_in && gR[p] < rend) ? pg[p] : e3k_zero_row + gcol;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(Gs + st * G_STAGE + (wv + 4 * p) * 256), 16, 0, 0);
+      gR[p] += W3R; gr2[p] += remR; pg[p] += dG;
+      if (gr2[p] >= M2) { gr2[p] -= M2; pg[p] += wG; }
+    }
+  };
+  const int n_chunks = (rend - rbeg + W3R - 1) / W3R;
+  issue(0);
+  if (n_chunks > 1) issue(1);
+  if (n_chunks > 2) issue(2);
+  const int aoff = (lane >> 5) * TK + wk * 32 + (lane & 31);
+  const int goff = (lane >> 5) * 64 + wn * (32 * NT) + (lane & 31);
+  const uint32_t a_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)As + (uint32_t)aoff * 4;
+  const uint32_t g_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Gs + (uint32_t)goff * 4;
+  for (int c = 0; c < n_chunks; ++c) {
+    if (c + 2 < n_chunks) wait_vm<2 * L>();
+    else if (c + 1 < n_chunks) wait_vm<L>();
+    else wait_vm<0>();
+    __builtin_amdgcn_s_barrier();          // chunk c is in LDS for every wave; every wave is done with chunk c - 1
+    asm volatile("" ::: "memory");
+#ifdef E3K_DEBUG_KNOBS
+    if (bp_.flags & 32) {       // timing only: no loads after the first three chunks
+      if (c + 3 < n_chunks) { wait_vm<0>(); }
+    } else if (c + 3 < n_chunks) issue((c + 3) % W3S);
+    if (bp_.flags & 16) continue;
+#else
+    if (c + 3 < n_chunks) issue((c + 3) % W3S);
+#endif
+    // operand fetch through inline asm: the compiler cannot tell which LDS stage an LDS-direct load writes and would put
+    // s_waitcnt vmcnt(0) in front of every ds_read it knows about -- draining the ring
+    const uint32_t ab = a_lds + (uint32_t)((c % W3S) * A_STAGE * 4), gb_ = g_lds + (uint32_t)((c % W3S) * G_STAGE * 4);
+    float av[2][8], gv[2][8][NT];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[0][i]) : "v"(ab), "n"(2 * i * TK * 4));
+#pragma unroll
+      for (int j = 0; j < NT; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gv[0][i][j]) : "v"(gb_), "n"(2 * i * 256 + 128 * j));
+    }
+#pragma unroll
+    for (int h = 0; h < W3R / 16; ++h) {
+      lds_wait(av[h & 1], gv[h & 1]);
+      if (h + 1 < W3R / 16) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[(h + 1) & 1][i]) : "v"(ab), "n"((16 * (h + 1) + 2 * i) * TK * 4));
+#pragma unroll
+          for (int j = 0; j < NT; ++j)
+            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gv[(h + 1) & 1][i][j]) : "v"(gb_), "n"((16 * (h + 1) + 2 * i) * 256 + 128 * j));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h & 1][i], gv[h & 1][i][j], acc[j], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int n = n0 + wn * (32 * NT) + 32 * j + (lane & 31);
+    if (n < P.N) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + wk * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (k < P.K) atomicAdd(const_cast<float*>(P.B) + (int64_t)k * P.b_k + (int64_t)n * P.b_n, P.alpha * acc[j][i]);
+      }
+    }
+  }
+}
+
+template <int W3R, int W3S, int OCC>
+__global__ __launch_bounds__(256, OCC) void gemm_wgrad3_kernel(const GemmBatch gb) {
+  __shared__ __attribute__((aligned(16))) float As[W3S * W3R * 128];
+  __shared__ __attribute__((aligned(16))) float Gs[W3S * W3R * 64];
+  const BlockProblem bp_ = fetch_problem(gb);
+  if (bp_.P.K > 64) gemm_wgrad3_body<4, W3R, W3S>(bp_, As, Gs);
+  else gemm_wgrad3_body<2, W3R, W3S>(bp_, As, Gs);
+}
+
+#endif  // E3K_DEBUG_KNOBS
+
+// ---------------------------------------------------------------------------------------
 // small helpers: column sums and the self-connection backward reduction
 // ---------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G, int64_t rows, int cols, int64_t ld,
@@ -983,6 +1531,15 @@ __global__ __launch_bounds__(256) void fctp_reduce_kernel(const float* __restric
 namespace {
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+int cu_count() {      // compute units of the current device (launches sized to the chip)
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  }
+  return n;
+}
+
 template <class K>
 int launch_batch(K kernel, const e3k::GemmBatch& gb, int blocks, hipStream_t st) {
   hipLaunchKernelGGL(kernel, dim3(blocks), dim3(256), 0, st, gb);
@@ -1013,7 +1570,7 @@ int b_mode(const e3k_gemm_problem& P) {
   return 0;
 }
 
-enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_KINDS };
+enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_PERSIST, FWD_KINDS };
 
 struct Batcher {
   e3k::GemmBatch gb{};
@@ -1051,6 +1608,28 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);   // keyed: the groups partition these rows
     }
   }
+  // plain problems with vector-loadable operands: the persistent kernel when the launch holds enough tiles for every
+  // workgroup slot to walk a sequence of them (below that the one-tile-per-workgroup kernels start sooner)
+#ifdef E3K_DEBUG_KNOBS
+  E3K_KNOB_INT(kPersist, "E3K_GEMM_PERSIST", 0);
+  E3K_KNOB_INT(kPersistMin, "E3K_GEMM_PERSIST_MIN_TILES", 1024);
+  const int n_cu = cu_count();
+  if (kPersist) {
+    int64_t ptiles = 0;
+    auto persistable = [&](int i) {
+      const e3k_gemm_problem& P = problems[i];
+      return kind[i] == FWD_PLAIN && a_vec(P) && b_mode(P) != 0 && !(reps && reps[i] > 1) && !P.row_index && (int64_t)P.M1 * P.M2 > 0;
+    };
+    for (int i = 0; i < n_problems; ++i)
+      if (persistable(i)) ptiles += (((int64_t)problems[i].M1 * problems[i].M2 + 127) / 128) * ((problems[i].N + e3k::BN - 1) / e3k::BN);
+    if (ptiles >= kPersistMin)
+      for (int i = 0; i < n_problems; ++i)
+        if (persistable(i)) {
+          kind[i] = FWD_PERSIST;
+          plain_tiles128 -= (((int64_t)problems[i].M1 * problems[i].M2 + 127) / 128) * ((problems[i].N + e3k::BN - 1) / e3k::BN);
+        }
+  }
+#endif
   // launches that would leave most of the 256 CUs without a third workgroup use 64-row tiles
   const bool small_grid = plain_tiles128 < 3 * 256;
   for (int k = 0; k < FWD_KINDS; ++k) {
@@ -1068,6 +1647,14 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
           break;
         case FWD_SMALLK: rc = launch_batch(e3k::gemm_smallk_kernel, b.gb, b.blocks, st); break;
         case FWD_SPLITK: rc = launch_batch(e3k::gemm_splitk_kernel, b.gb, b.blocks, st); break;
+#ifdef E3K_DEBUG_KNOBS
+        case FWD_PERSIST: {
+          E3K_KNOB_INT(kPersistOcc, "E3K_GEMM_PERSIST_WG_PER_CU", 2);
+          const int grid = b.blocks < (int)kPersistOcc * n_cu ? b.blocks : (int)kPersistOcc * n_cu;
+          hipLaunchKernelGGL(e3k::gemm_persist_kernel, dim3(grid), dim3(256), 0, st, b.gb, b.blocks);
+          break;
+        }
+#endif
         default: rc = launch_batch(e3k::gemm_outer_kernel, b.gb, b.blocks, st); break;
       }
       b.reset();
@@ -1109,7 +1696,8 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       gb.p[gb.n] = P;
       gb.reps[gb.n] = rp;
       gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
-      gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1);
+      E3K_KNOB_INT(kAblF, "E3K_GEMM_ABLATE", 0);
+      gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1) | (int)kAblF;
       gb.aux[gb.n] = aux;
       gb.tile_start[gb.n] = b.blocks;
       b.blocks += (int)blocks;
@@ -1137,6 +1725,113 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
     const int rc = validate(problems[i], true);
     if (rc != E3K_OK) return rc;
   }
+  // plain problems with 16-byte-loadable operands: the pipelined kernel, one launch per tile shape, every workgroup the
+  // same number of rows (the launch is sized to kBlocks workgroups in total)
+  E3K_KNOB_INT(kV2, "E3K_WGRAD2", 1);
+  E3K_KNOB_INT(kBlocks, "E3K_WGRAD2_BLOCKS", 0);
+  E3K_KNOB_INT(kMinChunks, "E3K_WGRAD2_MIN_CHUNKS", 2);
+  bool taken[MAX_CALL] = {};
+  if (n_problems > MAX_CALL) return E3K_ERR_INVALID;
+  auto g_vec = [](const e3k_gemm_problem& P) {
+    return P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C);
+  };
+#ifdef E3K_DEBUG_KNOBS
+  if (kV2 == 2) {
+    const int n_cu = cu_count();
+    E3K_KNOB_INT(kBlocks3, "E3K_WGRAD3_BLOCKS", 0);
+    E3K_KNOB_INT(kCfg3, "E3K_WGRAD3_CFG", 0);
+    const int chunk3 = kCfg3 == 1 ? 64 : 32;
+    const double target = kBlocks3 > 0 ? (double)kBlocks3 : (double)n_cu * (kCfg3 == 2 ? 2 : 1);
+    auto eligible = [&](int i) {
+      const e3k_gemm_problem& P = problems[i];
+      return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && !(reps && reps[i] > 1) && !P.row_index && a_vec(P) && g_vec(P);
+    };
+    auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
+    double total = 0;
+    for (int i = 0; i < n_problems; ++i)
+      if (eligible(i)) total += (double)problems[i].M1 * problems[i].M2 * tiles_of(problems[i]);
+    Batcher b;
+    auto flush3 = [&]() -> int {
+      if (!b.blocks) { b.reset(); return E3K_OK; }
+      b.gb.tile_start[b.gb.n] = b.blocks;
+      const int rc = kCfg3 == 1   ? launch_batch(e3k::gemm_wgrad3_kernel<64, 3, 1>, b.gb, b.blocks, st)
+                     : kCfg3 == 2 ? launch_batch(e3k::gemm_wgrad3_kernel<32, 3, 2>, b.gb, b.blocks, st)
+                                  : launch_batch(e3k::gemm_wgrad3_kernel<32, 4, 1>, b.gb, b.blocks, st);
+      b.reset();
+      return rc;
+    };
+    for (int i = 0; i < n_problems && total > 0; ++i) {
+      if (!eligible(i)) continue;
+      const e3k_gemm_problem& P = problems[i];
+      const int64_t M = (int64_t)P.M1 * P.M2;
+      taken[i] = true;
+      int64_t splits = (int64_t)(target * (double)M / total);
+      const int64_t max_splits = (M + kMinChunks * chunk3 - 1) / (kMinChunks * chunk3);
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+      e3k::GemmBatch& gb = b.gb;
+      gb.p[gb.n] = P;
+      gb.reps[gb.n] = 1;
+      gb.key_stride[gb.n] = 0;
+      E3K_KNOB_INT(kAbl3, "E3K_WGRAD2_ABLATE", 0);
+      gb.flags[gb.n] = 9 | (int)kAbl3;
+      gb.aux[gb.n] = (int)splits;
+      gb.tile_start[gb.n] = b.blocks;
+      b.blocks += tiles_of(P) * (int)splits;
+      if (++gb.n == e3k::GEMM_MAXP) {
+        const int rc = flush3();
+        if (rc != E3K_OK) return rc;
+      }
+    }
+    const int rc = flush3();
+    if (rc != E3K_OK) return rc;
+  }
+#endif
+  if (kV2 == 1) {
+    const int n_cu2 = cu_count();
+    const double target = kBlocks > 0 ? (double)kBlocks : 3.0 * n_cu2;   // three co-resident workgroups per CU: one round
+    auto eligible = [&](int i) {
+      const e3k_gemm_problem& P = problems[i];
+      return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && !(reps && reps[i] > 1) && !P.row_index && a_vec(P) && g_vec(P);
+    };
+    auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
+    double total = 0;   // rows x tiles over the problems of this launch
+    for (int i = 0; i < n_problems; ++i)
+      if (eligible(i)) total += (double)problems[i].M1 * problems[i].M2 * tiles_of(problems[i]);
+    Batcher b;
+    auto flush2 = [&]() -> int {
+      if (!b.blocks) { b.reset(); return E3K_OK; }
+      b.gb.tile_start[b.gb.n] = b.blocks;
+      const int rc = launch_batch(e3k::gemm_wgrad2_kernel, b.gb, b.blocks, st);
+      b.reset();
+      return rc;
+    };
+    for (int i = 0; i < n_problems && total > 0; ++i) {
+      if (!eligible(i)) continue;
+      const e3k_gemm_problem& P = problems[i];
+      const int64_t M = (int64_t)P.M1 * P.M2;
+      taken[i] = true;
+      int64_t splits = (int64_t)(target * (double)M / total);      // rounded down: the launch stays within one round
+      const int64_t max_splits = (M + kMinChunks * e3k::W2R - 1) / (kMinChunks * e3k::W2R);
+      if (splits > max_splits) splits = max_splits;
+      if (splits < 1) splits = 1;
+      e3k::GemmBatch& gb = b.gb;
+      gb.p[gb.n] = P;
+      gb.reps[gb.n] = 1;
+      gb.key_stride[gb.n] = 0;
+      E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
+      gb.flags[gb.n] = 9 | (int)kAbl;
+      gb.aux[gb.n] = (int)splits;
+      gb.tile_start[gb.n] = b.blocks;
+      b.blocks += tiles_of(P) * (int)splits;
+      if (++gb.n == e3k::GEMM_MAXP) {
+        const int rc = flush2();
+        if (rc != E3K_OK) return rc;
+      }
+    }
+    const int rc = flush2();
+    if (rc != E3K_OK) return rc;
+  }
   for (int mode = 0; mode < 4; ++mode) {  // (outer: x (x) attrs formed on the fly?, 128-wide output tile?)
     const bool outer = mode & 1;
     const int tn = (mode & 2) ? 2 : 1;
@@ -1157,6 +1852,7 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
     };
     for (int i = 0; i < n_problems; ++i) {
       const e3k_gemm_problem& P = problems[i];
+      if (taken[i]) continue;
       if ((P.V > 0) != outer) continue;
       if ((P.N >= 128 ? 2 : 1) != tn) continue;
       const int64_t M = (int64_t)P.M1 * P.M2;

@@ -53,3 +53,21 @@ for K in (64, 128, 256, 384, 512, 768, 1024):
         out = torch.empty(rows, 64, device=dev)
         us = timeit(lambda: ops._lin_fwd_raw(x, ww, None, out, sp, 1.0, False))
         print(f"one problem rows {rows} N 64 K {K:5d}: {us:7.1f} us  {2.0 * rows * 64 * K / us / 1e6:6.1f} TF/s")
+
+# the same K = 384, N = 64 problem (dim 3: rows = 3 n) read out of row strides from compact to the real mid width:
+# is the time of these GEMMs a function of how far apart the 1.5 KB runs of A lie in memory?
+K = 384
+for d_in in (K * 3, 2 * K * 3, 6528, 8192):
+    ins = ops.LinInstr(0, 0, K, 64, 3, 0, 1.0, 0, 0)
+    sp = ops.LinearSpec(d_in, 64 * 3, [ins], "cf", "cf", [], True, d_in == K * 3, K * 64)
+    x = torch.randn(n, d_in, device=dev)
+    ww = torch.randn(K * 64, device=dev)
+    out = torch.empty(n, 64 * 3, device=dev)
+    g = torch.randn(n, 64 * 3, device=dev)
+    gww = torch.zeros(K * 64, device=dev)
+    fl = 2.0 * n * 3 * K * 64
+    for name, fn in (("fwd", lambda: ops._lin_fwd_raw(x, ww, None, out, sp, 1.0, False)),
+                     ("dgrad", lambda: ops._lin_dgrad_raw(g, ww, sp, 1.0)),
+                     ("wgrad", lambda: ops._lin_wgrad_raw(x, g, gww, sp, 1.0))):
+        us = timeit(fn)
+        print(f"stride scan K 384 dim 3 rows {3 * n} d_in {d_in:5d} {name:6s}: {us:7.1f} us  {fl / us / 1e6:6.1f} TF/s")
