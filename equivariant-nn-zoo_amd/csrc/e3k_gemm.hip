@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
 // per ~1/512 of the launch's work.
 // ---------------------------------------------------------------------------------------
 constexpr int W2R = 32;   // rows per chunk
-template <int WKW>
+template <int WKW, bool IDX>
 __device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float* As_, float* Gs_) {
   constexpr int TK = 32 * WKW;            // k per tile
   constexpr int WNW = 4 / WKW;            // waves along n
@@ -1139,9 +1139,12 @@ __device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float*
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
-  // this thread's rows of a chunk: A pass p -> row (t / (TK/4)) + AROWS*p, G pass p -> row (t >> 4) + 16*p; row pointers
-  // advance by constant 64-bit deltas (one chunk down, and the wrap of the component index r2)
-  int aR[APASS], ar2[APASS], gR[2], gr2[2];
+  // this thread's rows of a chunk: A pass p -> row (t / (TK/4)) + AROWS*p, G pass p -> row (t >> 4) + 16*p.  Plain problems:
+  // row pointers advance by constant 64-bit deltas (one chunk down, and the wrap of the component index r2).  Gathered
+  // rows (IDX: the keyed self-connection, rows = the nodes of one key through row_index): the node index of a row is
+  // fetched one chunk ahead, behind the chunk's float4 loads, so that it has landed with them
+  int aR[APASS], ar1[APASS], ar2[APASS], gR[2], gr1[2], gr2[2];
+  int ia[APASS], ig[2];
   const float* pa[APASS];
   const float* pg[2];
   const int64_t dA = (int64_t)qR * P.a_r1 + (int64_t)remR * P.a_r2, wA = P.a_r1 - (int64_t)M2 * P.a_r2;
@@ -1151,32 +1154,54 @@ __device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float*
 #pragma unroll
   for (int p = 0; p < APASS; ++p) {
     aR[p] = rbeg + t / (TK / 4) + AROWS * p;
-    const int r1 = aR[p] / M2;
-    ar2[p] = aR[p] - r1 * M2;
-    pa[p] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol;
+    ar1[p] = aR[p] / M2;
+    ar2[p] = aR[p] - ar1[p] * M2;
+    pa[p] = P.A + (int64_t)ar1[p] * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol;
+    ia[p] = (IDX && aR[p] < rend) ? P.row_index[ar1[p]] : 0;
   }
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
     gR[p] = rbeg + (t >> 4) + 16 * p;
-    const int r1 = gR[p] / M2;
-    gr2[p] = gR[p] - r1 * M2;
-    pg[p] = P.C + (int64_t)r1 * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol;
+    gr1[p] = gR[p] / M2;
+    gr2[p] = gR[p] - gr1[p] * M2;
+    pg[p] = P.C + (int64_t)gr1[p] * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol;
+    ig[p] = (IDX && gR[p] < rend) ? P.row_index[gr1[p]] : 0;
   }
   float4 ra[APASS], rg[2];
   auto gload = [&]() {
 #pragma unroll
     for (int p = 0; p < APASS; ++p) {
       ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (aR[p] < rend && a_in) ra[p] = *reinterpret_cast<const float4*>(pa[p]);
-      aR[p] += W2R; ar2[p] += remR; pa[p] += dA;
-      if (ar2[p] >= M2) { ar2[p] -= M2; pa[p] += wA; }
+      if constexpr (IDX) {
+        if (aR[p] < rend && a_in)
+          ra[p] = *reinterpret_cast<const float4*>(P.A + (int64_t)ia[p] * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol);
+        aR[p] += W2R; ar1[p] += qR; ar2[p] += remR;
+        if (ar2[p] >= M2) { ar2[p] -= M2; ++ar1[p]; }
+      } else {
+        if (aR[p] < rend && a_in) ra[p] = *reinterpret_cast<const float4*>(pa[p]);
+        aR[p] += W2R; ar2[p] += remR; pa[p] += dA;
+        if (ar2[p] >= M2) { ar2[p] -= M2; pa[p] += wA; }
+      }
     }
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
       rg[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gR[p] < rend && g_in) rg[p] = *reinterpret_cast<const float4*>(pg[p]);
-      gR[p] += W2R; gr2[p] += remR; pg[p] += dG;
-      if (gr2[p] >= M2) { gr2[p] -= M2; pg[p] += wG; }
+      if constexpr (IDX) {
+        if (gR[p] < rend && g_in)
+          rg[p] = *reinterpret_cast<const float4*>(P.C + (int64_t)ig[p] * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol);
+        gR[p] += W2R; gr1[p] += qR; gr2[p] += remR;
+        if (gr2[p] >= M2) { gr2[p] -= M2; ++gr1[p]; }
+      } else {
+        if (gR[p] < rend && g_in) rg[p] = *reinterpret_cast<const float4*>(pg[p]);
+        gR[p] += W2R; gr2[p] += remR; pg[p] += dG;
+        if (gr2[p] >= M2) { gr2[p] -= M2; pg[p] += wG; }
+      }
+    }
+    if constexpr (IDX) {      // node indices of the NEXT chunk's rows
+#pragma unroll
+      for (int p = 0; p < APASS; ++p) ia[p] = aR[p] < rend ? P.row_index[ar1[p]] : 0;
+#pragma unroll
+      for (int p = 0; p < 2; ++p) ig[p] = gR[p] < rend ? P.row_index[gr1[p]] : 0;
     }
   };
   auto lstore = [&](int st) {
@@ -1230,8 +1255,13 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad2_kernel(const GemmBatch gb)
   __shared__ __attribute__((aligned(16))) float As[2 * W2R * (128 + 4)];
   __shared__ __attribute__((aligned(16))) float Gs[2 * W2R * (64 + 4)];
   const BlockProblem bp_ = fetch_problem(gb);
-  if (bp_.P.K > 64) gemm_wgrad2_body<4>(bp_, As, Gs);
-  else gemm_wgrad2_body<2>(bp_, As, Gs);
+  if (bp_.P.row_index) {
+    if (bp_.P.K > 64) gemm_wgrad2_body<4, true>(bp_, As, Gs);
+    else gemm_wgrad2_body<2, true>(bp_, As, Gs);
+  } else {
+    if (bp_.P.K > 64) gemm_wgrad2_body<4, false>(bp_, As, Gs);
+    else gemm_wgrad2_body<2, false>(bp_, As, Gs);
+  }
 }
 
 #ifdef E3K_DEBUG_KNOBS
@@ -1792,10 +1822,12 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
     const double target = kBlocks > 0 ? (double)kBlocks : 3.0 * n_cu2;   // three co-resident workgroups per CU: one round
     auto eligible = [&](int i) {
       const e3k_gemm_problem& P = problems[i];
-      return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && !(reps && reps[i] > 1) && !P.row_index && a_vec(P) && g_vec(P);
+      return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && a_vec(P) && g_vec(P);
     };
     auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
-    double total = 0;   // rows x tiles over the problems of this launch
+    // rows x tiles over the problems of this launch (a keyed problem's key groups partition its M1 rows: it counts once,
+    // every key gets the splits of the whole and the workgroups past a key's last row exit)
+    double total = 0;
     for (int i = 0; i < n_problems; ++i)
       if (eligible(i)) total += (double)problems[i].M1 * problems[i].M2 * tiles_of(problems[i]);
     Batcher b;
@@ -1810,6 +1842,7 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       if (!eligible(i)) continue;
       const e3k_gemm_problem& P = problems[i];
       const int64_t M = (int64_t)P.M1 * P.M2;
+      const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       taken[i] = true;
       int64_t splits = (int64_t)(target * (double)M / total);      // rounded down: the launch stays within one round
       const int64_t max_splits = (M + kMinChunks * e3k::W2R - 1) / (kMinChunks * e3k::W2R);
@@ -1817,13 +1850,13 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       if (splits < 1) splits = 1;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
-      gb.reps[gb.n] = 1;
-      gb.key_stride[gb.n] = 0;
+      gb.reps[gb.n] = rp;
+      gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
       E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
       gb.flags[gb.n] = 9 | (int)kAbl;
       gb.aux[gb.n] = (int)splits;
       gb.tile_start[gb.n] = b.blocks;
-      b.blocks += tiles_of(P) * (int)splits;
+      b.blocks += tiles_of(P) * (int)splits * rp;
       if (++gb.n == e3k::GEMM_MAXP) {
         const int rc = flush2();
         if (rc != E3K_OK) return rc;
