@@ -1,6 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-timeout 1500 python3 -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py -x -q -m gpu 2>&1 | tail -2
-D=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so
-python3 tools/ab_bench.py "new:" "oldwgrad:E3K_LIB=$D,E3K_WGRAD2=0" --rounds 3 --steps 40 2>&1 | tail -3 | tee gpurun_out/ab_wgrad.txt
-bash tools/trace_graph.sh 2>&1 | tail -28 | tee gpurun_out/trace_wgrad2.txt
+export E3K_LIB=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so
+E3K_SK_NATURAL=1 timeout 900 python3 -m pytest tests/test_gpu_ops.py -x -q -m gpu -k "gemm or linear or lin or mlp or radial" 2>&1 | tail -2
+out=gpurun_out/gemm_probe.txt; : > $out
+for a in 0 1; do
+  echo "== SK_NATURAL $a" >> $out
+  E3K_SK_NATURAL=$a timeout 120 python3 tools/postlin_bench.py 256 2>&1 | grep "radial last\|N 64 K    64" >> $out
+done
+cat $out

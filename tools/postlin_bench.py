@@ -71,3 +71,13 @@ for d_in in (K * 3, 2 * K * 3, 6528, 8192):
                      ("wgrad", lambda: ops._lin_wgrad_raw(x, g, gww, sp, 1.0))):
         us = timeit(fn)
         print(f"stride scan K 384 dim 3 rows {3 * n} d_in {d_in:5d} {name:6s}: {us:7.1f} us  {fl / us / 1e6:6.1f} TF/s")
+
+# the per-edge last layer of a radial MLP without the knot table (the protein score net: ~18 000 edges, 64 hidden, W = 1 920):
+# output-stream bound -- 138 MB written per launch
+for rows, W in ((18000, 1920), (72000, 1920)):
+    sp = ops.LinearSpec(64, W, [ops.LinInstr(0, 0, 64, W, 1, 0, 1.0)], "e3nn", "e3nn", [], True, True, 64 * W)
+    x = torch.randn(rows, 64, device=dev)
+    ww = torch.randn(64 * W, device=dev)
+    out = torch.empty(rows, W, device=dev)
+    us = timeit(lambda: ops._lin_fwd_raw(x, ww, None, out, sp, 1.0, False))
+    print(f"radial last layer rows {rows} K 64 N {W}: {us:7.1f} us  {rows * W * 4 / us / 1e6:6.2f} TB/s written  {2.0 * rows * 64 * W / us / 1e6:6.1f} TF/s")
