@@ -211,7 +211,12 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
   });
 }
 
-template <int L1, int L3MAX, int MODE, int PART, bool FULL>
+// HALF (plans that are not channel-complete, groups of at most 32 channels -- the 32-channel score nets): lanes 32-63 of the
+// wave would idle behind `u < mul`; instead the two lane halves walk the node's edge list two edges at a time (half h takes
+// edges t + h), everything that was wave-uniform per edge -- edge id, source row, sh, the weight row -- becomes a per-lane
+// value (two distinct addresses per wave instruction, 128 contiguous bytes each), and the halves' partial sums are added
+// across lanes l and l ^ 32 once per node.
+template <int L1, int L3MAX, int MODE, int PART, bool FULL, bool HALF = false>
 __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   static_assert(FULL || MODE == 0, "the table forms exist for FULL plans only");
   if constexpr (FULL) {
@@ -221,7 +226,16 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
-  const bool active = FULL || u < mul;
+  if constexpr (!FULL && !HALF) {
+    if (mul <= 32) {
+      tp_fwd_body<L1, L3MAX, MODE, PART, FULL, true>(a, g, node, u);
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int h = HALF ? lane >> 5 : 0;
+  const int uu = HALF ? (lane & 31) : u;
+  const bool lane_on = FULL || uu < mul;
   const unsigned mask = g.mask;
 
   float acc[S::TOTAL];
@@ -231,19 +245,28 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   // no software pipeline (loads of edge t+1 before edge t is consumed): it costs a second register set and
   // occupancy buys more here -- measured 178 vs 186 us (l_max 2), 432 vs 438 us (l_max 3)
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int s = uniform(a.nbr[e]);
+  for (int t = beg; t < end; t += HALF ? 2 : 1) {
+    int e, s;
+    bool active = lane_on;
+    if constexpr (HALF) {
+      const bool ev = t + h < end;
+      e = a.perm[ev ? t + h : t];
+      s = a.nbr[e];
+      active = lane_on && ev;
+    } else {
+      e = uniform(a.perm[t]);
+      s = uniform(a.nbr[e]);
+    }
     YRegs yc;
     load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
-    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform
-    const float* __restrict__ wr = a.w + (int64_t)e * a.W;                    // wave-uniform
+    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform (per lane half under HALF)
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W;
     float xc[D1], wc[S::NQ];
 #pragma unroll
-    for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
+    for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[uu] : 0.0f;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
-      if (FULL || (mask & (1u << Q))) wc[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + u) : 0.0f;
+      if (FULL || (mask & (1u << Q))) wc[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + uu) : 0.0f;
     });
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
@@ -257,14 +280,24 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
       }
     });
   }
-  if (active) {
+  if constexpr (HALF) {
+    slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+      constexpr int Q = decltype(qc)::value;
+      constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+      if (mask & (1u << Q)) {
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] += __shfl_xor(acc[OFF + k], 32, 64);
+      }
+    });
+  }
+  if (lane_on && h == 0) {
     float* __restrict__ orow = a.out + (int64_t)node * a.d_mid;
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
       constexpr int Q = decltype(qc)::value;
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
       if (FULL || (mask & (1u << Q))) {
 #pragma unroll
-        for (int k = 0; k < 2 * L3 + 1; ++k) (orow + g.out_off[Q] + k * g.out_stride[Q])[u] = acc[OFF + k];
+        for (int k = 0; k < 2 * L3 + 1; ++k) (orow + g.out_off[Q] + k * g.out_stride[Q])[uu] = acc[OFF + k];
       }
     });
   }
@@ -329,15 +362,26 @@ __device__ __forceinline__ void wave_add9(const float (&v9)[9], float* __restric
 // ------------------------------------------------------------------------------------------
 // DUAL (FULL plans, no g_sh): the weight gradient of the product's derivative along (x2, sh2) --
 //   g_w[e] = coeff * <g_mid[dst], xy(x2[src], sh) + xy(x[src], sh2)> -- one of the second-order terms of force training.
-template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL, bool DUAL = false>
-__device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
+template <int L1, bool WITH_SH, int L3MAX, int PART, bool FULL, bool DUAL = false, bool HALF = false>
+__device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u_) {
   static_assert(!DUAL || (FULL && !WITH_SH), "the dual form is built for channel-complete plans, weight gradient only");
+  static_assert(!HALF || (!FULL && !WITH_SH), "two edges per wave: weight gradient only (g_sh is a reduction over the whole wave)");
   // (the buffer-addressed form of tp_fwd / tp_bwd_x was tried here too: 71 instead of 60 VGPRs, 7 instead of 8 waves per SIMD,
   //  the step 3-5 % slower -- this kernel keeps the flat row pointers; it has no scalar-register spills to begin with)
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
-  const bool active = FULL || u < mul;
+  if constexpr (!FULL && !WITH_SH && !HALF) {
+    if (mul <= 32) {      // two edges per wave, see tp_fwd_body (every edge writes its own g_w row: nothing to fold)
+      tp_bwd_w_body<L1, WITH_SH, L3MAX, PART, FULL, DUAL, true>(a, g, node, u_);
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int h = HALF ? lane >> 5 : 0;
+  const int u = HALF ? (lane & 31) : u_;
+  const bool lane_on = FULL || u < mul;
+  bool active = lane_on;
   const unsigned mask = g.mask;
 
   // incoming gradient of this node's group outputs, resident for the whole edge walk
@@ -353,12 +397,20 @@ __device__ __forceinline__ void tp_bwd_w_body(const TpArgs& a, const e3k_tp_grou
     });
   }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int s = uniform(a.nbr[e]);
+  for (int t = beg; t < end; t += HALF ? 2 : 1) {
+    int e, s;
+    if constexpr (HALF) {
+      const bool ev = t + h < end;
+      e = a.perm[ev ? t + h : t];
+      s = a.nbr[e];
+      active = lane_on && ev;
+    } else {
+      e = uniform(a.perm[t]);
+      s = uniform(a.nbr[e]);
+    }
     YRegs yc, y2;
     load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
-    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform
+    const float* __restrict__ xr = a.x + (int64_t)s * a.d_in + g.x_off;      // wave-uniform (per lane half under HALF)
     float xc[D1], x2c[DUAL ? D1 : 1];
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = active ? (xr + i * mul)[u] : 0.0f;
@@ -627,7 +679,7 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   }
 }
 
-template <int L1, int L3MAX, int MODE, int PART, bool FULL>
+template <int L1, int L3MAX, int MODE, int PART, bool FULL, bool HALF = false>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   static_assert(FULL || MODE == 0, "the table forms exist for FULL plans only");
   if constexpr (FULL) {
@@ -637,7 +689,16 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
-  const bool active = FULL || u < mul;
+  if constexpr (!FULL && !HALF) {
+    if (mul <= 32) {      // two edges per wave, see tp_fwd_body
+      tp_bwd_x_body<L1, L3MAX, MODE, PART, FULL, true>(a, g, node, u);
+      return;
+    }
+  }
+  const int lane = threadIdx.x & 63;
+  const int h = HALF ? lane >> 5 : 0;
+  const int uu = HALF ? (lane & 31) : u;
+  const bool lane_on = FULL || uu < mul;
   const unsigned mask = g.mask;
 
   float gx[D1];
@@ -645,13 +706,22 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   // (a one-deep software pipeline measured the same: 495 vs 498 us at l_max 2)
-  for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int d = uniform(a.nbr[e]);
+  for (int t = beg; t < end; t += HALF ? 2 : 1) {
+    int e, d;
+    bool active = lane_on;
+    if constexpr (HALF) {
+      const bool ev = t + h < end;
+      e = a.perm[ev ? t + h : t];
+      d = a.nbr[e];
+      active = lane_on && ev;
+    } else {
+      e = uniform(a.perm[t]);
+      d = uniform(a.nbr[e]);
+    }
     YRegs yc;
     load_y(yc, a.sh + (int64_t)e * a.d_sh, g);
-    const float* __restrict__ wr = a.w + (int64_t)e * a.W;                 // wave-uniform
-    const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid;       // wave-uniform
+    const float* __restrict__ wr = a.w + (int64_t)e * a.W;                 // wave-uniform (per lane half under HALF)
+    const float* __restrict__ grow = a.g_out + (int64_t)d * a.d_mid;
     // every row of the edge is requested before the first one is used (registers are not what limits these kernels'
     // occupancy; a load consumed right behind its issue leaves one row in flight per wave)
     float gn[S::TOTAL], wn[S::NQ];
@@ -660,8 +730,8 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
       if (FULL || (mask & (1u << Q))) {
 #pragma unroll
-        for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? (grow + g.out_off[Q] + k * g.out_stride[Q])[u] : 0.0f;
-        wn[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + u) : 0.0f;
+        for (int k = 0; k < 2 * L3 + 1; ++k) gn[OFF + k] = active ? (grow + g.out_off[Q] + k * g.out_stride[Q])[uu] : 0.0f;
+        wn[Q] = active ? E3K_STREAM_LOAD((wr + g.w_off[Q]) + uu) : 0.0f;
       }
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -676,13 +746,17 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
       }
     });
   }
-  if (active) {
+  if constexpr (HALF) {
+#pragma unroll
+    for (int i = 0; i < D1; ++i) gx[i] += __shfl_xor(gx[i], 32, 64);
+  }
+  if (lane_on && h == 0) {
     float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
 #pragma unroll
     for (int i = 0; i < D1; ++i) {
-      if (PART == 2 && !a.x_shared) (gxr + i * mul)[u] = gx[i];
-      else atomicAdd(gxr + i * mul + u, gx[i]);   // two waves per group (a + b is order independent) or several groups on
-                                                  // one input block (repeated sh degree): g_x is pre-zeroed
+      if (PART == 2 && !a.x_shared) (gxr + i * mul)[uu] = gx[i];
+      else atomicAdd(gxr + i * mul + uu, gx[i]);   // two waves per group (a + b is order independent) or several groups on
+                                                   // one input block (repeated sh degree): g_x is pre-zeroed
     }
   }
 }

@@ -400,13 +400,17 @@ def test_batch_from_device_resident_samples(dev):
     assert torch.equal(on_dev[3]["pos"].cpu(), host[3]["pos"])
 
 
-@pytest.mark.parametrize("mul,left,out", [
-    (16, "16x0e+16x1o+16x2e", "16x0e+16x1o+16x2e+16x1e+16x3o"),
-    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),
-    (96, "96x1o+96x3e", "96x0e+96x1o+96x2e+96x3e+96x2o"),
-    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o"),
+@pytest.mark.parametrize("mul,left,out,sh_grad", [
+    (16, "16x0e+16x1o+16x2e", "16x0e+16x1o+16x2e+16x1e+16x3o", True),
+    # <= 32 channels: the two lane halves of a wave walk two edges at a time (odd degrees leave the last trip half empty);
+    # without a gradient for sh the weight-gradient kernel takes that form too
+    (32, "32x0e+32x1o+32x1e+32x2e", "32x0e+32x1o+32x1e+32x2e+32x2o", False),
+    (24, "24x0e+24x1o+24x2e", "24x0e+24x1o+24x2e+24x3o", False),
+    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", True),
+    (96, "96x1o+96x3e", "96x0e+96x1o+96x2e+96x3e+96x2o", True),
+    (64, "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o+64x3e+64x3o", True),
 ])
-def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
+def test_tp_fused_against_unfused_oracle(dev, mul, left, out, sh_grad):
     """fused gather + uvu product + per-destination reduce + node-side Linear  ==  the
     reference's gather -> TensorProduct -> per-edge Linear -> scatter (oracle, float64)."""
     from e3_layers_amd.backend import ops
@@ -427,7 +431,7 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
     sh = e3ref.spherical_harmonics([0, 1, 2], vec)
     w = torch.randn(e, mod.tp.weight_numel, dtype=torch.float64)
     xin = to_cf(x, left).float().to(dev).requires_grad_(True)
-    shin = sh.float().to(dev).requires_grad_(True)
+    shin = sh.float().to(dev).requires_grad_(sh_grad)
     win = w.float().to(dev).requires_grad_(True)
     topo = build_topology(ei.to(dev), n)
     mid = mod.tp.fused(xin, shin, win, topo)
@@ -436,11 +440,14 @@ def test_tp_fused_against_unfused_oracle(dev, mul, left, out):
     yr = e3ref.scatter(ref(left=xr[ei[0]], right=shr, weight=wr), ei[1], dim_size=n)
     assert rel_err(y, yr) < TOL
     seed = torch.randn_like(yr)
-    gx, gsh, gw, gl = _grads(y, [xin, shin, win, mod.linear.weight], seed.float().to(dev))
     rx, rsh, rw, rl = _grads(yr, [xr, shr, wr, ref.linear.weight], seed)
+    if sh_grad:
+        gx, gsh, gw, gl = _grads(y, [xin, shin, win, mod.linear.weight], seed.float().to(dev))
+        assert rel_err(gsh, rsh) < GTOL
+    else:
+        gx, gw, gl = _grads(y, [xin, win, mod.linear.weight], seed.float().to(dev))
     assert rel_err(from_cf(gx.cpu(), left), rx) < GTOL
     assert rel_err(gw, rw) < GTOL
-    assert rel_err(gsh, rsh) < GTOL
     assert rel_err(gl, rl) < GTOL
     # the per-sample module API (no reduction) agrees with the oracle too
     y_edges = mod(left=x[ei[0]].float().to(dev), right=sh.float().to(dev), weight=w.float().to(dev))
