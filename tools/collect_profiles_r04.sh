@@ -40,4 +40,16 @@ bash tools/collect_lines_r04.sh > $OUT/lines.log 2>&1
 # 6. measured errors of the model-level parity tests (tests/util.py: record_measured)
 rm -f $OUT/parity_measured.jsonl
 E3K_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl python3 -m pytest tests/test_gpu_model.py tests/test_gpu_double_backward.py -q -m gpu -k "protein or diffusion or bench_path or guard or backbone or force_block or threshold" > $OUT/parity_tests.log 2>&1
+# 7. the GEMM kernels in isolation (layer-3 trailing Linear of config_energy, 4 608 nodes): times, and the timing-only ablations
+#    of the dbg library (no MFMA / no loads / no stores) that show the phases of the LDS-tiled kernels adding up; the persistent
+#    and LDS-direct experiment kernels beside the shipped ones
+python3 tools/postlin_bench.py 256 > $OUT/gemm_postlin_bench.txt 2>&1
+D=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so
+{
+  for a in 0 16 32 48; do echo "== gemm_kernel  E3K_GEMM_ABLATE=$a (16: no MFMA, 32: no stores)"; E3K_LIB=$D E3K_GEMM_ABLATE=$a python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear fwd\|post-linear dgrad"; done
+  for a in 0 16 32 48; do echo "== gemm_wgrad2_kernel  E3K_WGRAD2_ABLATE=$a (16: no MFMA, 32: no loads)"; E3K_LIB=$D E3K_WGRAD2_ABLATE=$a python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"; done
+  echo "== the round-3 weight-gradient kernel (E3K_WGRAD2=0)"; E3K_LIB=$D E3K_WGRAD2=0 python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"
+  for c in 0 1 2; do echo "== LDS-direct ring weight gradient (E3K_WGRAD2=2, configuration $c)"; E3K_LIB=$D E3K_WGRAD2=2 E3K_WGRAD3_CFG=$c python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"; done
+  for w in 1 2 3; do echo "== persistent forward / dgrad (E3K_GEMM_PERSIST=1, $w workgroups per CU)"; E3K_LIB=$D E3K_GEMM_PERSIST=1 E3K_GEMM_PERSIST_MIN_TILES=1 E3K_GEMM_PERSIST_WG_PER_CU=$w python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear fwd\|post-linear dgrad\|K  1024"; done
+} > $OUT/gemm_phase_ablation.txt 2>&1
 ls $OUT; tail -c 600 $OUT/bench_default.json
