@@ -204,7 +204,10 @@ __device__ __forceinline__ void fill_row_tables(const e3k_gemm_problem& P, int r
   }
 }
 
-// stores NT 32x32 accumulators of one wave: rows wrow0.., columns ncol0 + 32*j
+// stores NT 32x32 accumulators of one wave: rows wrow0.., columns ncol0 + 32*j.  Accumulating problems (C += ...) read ALL
+// their old values first and store afterwards: written as load-add-store per element the compiler must assume that a store
+// aliases the next element's load and waits for every load on its own -- 32 dependent memory round trips per wave (the
+// input gradient of linear_1 on top of the self-connection's: 137 us for 0.7 GFLOP, found in round 4's launch census).
 template <int NT>
 __device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x16 (&acc)[NT], const long long* rowC,
                                           int wrow0, int ncol0) {
@@ -220,11 +223,51 @@ __device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x1
     bias[j] = (P.bias && ok[j]) ? P.bias[n[j]] : 0.f;
     cn[j] = (long long)n[j] * P.c_n;
   }
+  long long off[16];
+  bool inside = true;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
-    const long long off = rowC[wrow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)];
-    if (off < 0) continue;
-    float* c = P.C + off;
+    off[i] = rowC[wrow0 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)];
+    inside = inside && off[i] >= 0;
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j) inside = inside && ok[j];
+  if (__all(inside)) {
+    // interior tile (almost all of them): straight-line code -- every old value requested, then every result stored; with a
+    // predicate around each element the compiler waits (vmcnt(0), which also covers the stores issued so far) per element
+    float v[NT][16];
+    if (P.accumulate) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j][i] = P.C[off[i] + cn[j]];
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j][i] += fmaf(P.alpha, acc[j][i], bias[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j][i] = fmaf(P.alpha, acc[j][i], bias[j]);
+    }
+    if (P.act == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) v[j][i] = epilogue_act(P, v[j][i]);
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) P.C[off[i] + cn[j]] = v[j][i];
+    return;
+  }
+  // edge tile: per-element predicates
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    if (off[i] < 0) continue;
+    float* c = P.C + off[i];
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
       if (ok[j]) {

@@ -1,9 +1,7 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-export E3K_LIB=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so
-out=gpurun_out/gemm_probe.txt; : > $out
-for a in 1 2 4 8 15 30; do
-  echo "== SK_CT $a" >> $out
-  E3K_SK_CT=$a timeout 120 python3 tools/postlin_bench.py 256 2>&1 | grep "radial last" >> $out
-done
-cat $out
+timeout 900 python3 -m pytest tests/test_gpu_ops.py -x -q -m gpu 2>&1 | tail -2
+for a in "" "--config energy_force" "--config diffusion" "--config diffusion_CA" "--lmax 3"; do
+  echo "== $a"; python3 bench.py --no-cpu-baseline --steps 40 $a 2>/dev/null | tail -1 | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d.get('ms_per_step_repeats',{}).get('median'))"
+done 2>&1 | tee gpurun_out/lines_now.txt
+bash tools/trace_graph.sh 2>&1 | tail -26 | tee gpurun_out/trace_now.txt
