@@ -1798,86 +1798,36 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
     const int rc = validate(problems[i], true);
     if (rc != E3K_OK) return rc;
   }
-  // plain problems with 16-byte-loadable operands: the pipelined kernel, one launch per tile shape, every workgroup the
-  // same number of rows (the launch is sized to kBlocks workgroups in total)
+  // Problems with 16-byte-loadable operands (plain and keyed; not the outer-product form): the pipelined kernel, ONE launch
+  // sized to one round of workgroups (three per CU), every workgroup the same number of rows -- splits proportional to a
+  // problem's rows.  A keyed problem's key groups partition its M1 rows: it counts once, every key gets the splits of the
+  // whole, and the workgroups past a key's last row exit.
   E3K_KNOB_INT(kV2, "E3K_WGRAD2", 1);
   E3K_KNOB_INT(kBlocks, "E3K_WGRAD2_BLOCKS", 0);
   E3K_KNOB_INT(kMinChunks, "E3K_WGRAD2_MIN_CHUNKS", 2);
+  E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
   bool taken[MAX_CALL] = {};
   if (n_problems > MAX_CALL) return E3K_ERR_INVALID;
   auto g_vec = [](const e3k_gemm_problem& P) {
     return P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C);
   };
-#ifdef E3K_DEBUG_KNOBS
-  if (kV2 == 2) {
-    const int n_cu = cu_count();
-    E3K_KNOB_INT(kBlocks3, "E3K_WGRAD3_BLOCKS", 0);
-    E3K_KNOB_INT(kCfg3, "E3K_WGRAD3_CFG", 0);
-    const int chunk3 = kCfg3 == 1 ? 64 : 32;
-    const double target = kBlocks3 > 0 ? (double)kBlocks3 : (double)n_cu * (kCfg3 == 2 ? 2 : 1);
+  auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
+  // launch(gb, blocks) for every batch of up to GEMM_MAXP eligible problems, `target` workgroups in total, `chunk` rows per
+  // pipeline stage; gathered: keyed / row-indexed problems are eligible too
+  auto equal_rows = [&](auto launch, double target, int chunk, bool gathered) -> int {
     auto eligible = [&](int i) {
       const e3k_gemm_problem& P = problems[i];
-      return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && !(reps && reps[i] > 1) && !P.row_index && a_vec(P) && g_vec(P);
-    };
-    auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
-    double total = 0;
-    for (int i = 0; i < n_problems; ++i)
-      if (eligible(i)) total += (double)problems[i].M1 * problems[i].M2 * tiles_of(problems[i]);
-    Batcher b;
-    auto flush3 = [&]() -> int {
-      if (!b.blocks) { b.reset(); return E3K_OK; }
-      b.gb.tile_start[b.gb.n] = b.blocks;
-      const int rc = kCfg3 == 1   ? launch_batch(e3k::gemm_wgrad3_kernel<64, 3, 1>, b.gb, b.blocks, st)
-                     : kCfg3 == 2 ? launch_batch(e3k::gemm_wgrad3_kernel<32, 3, 2>, b.gb, b.blocks, st)
-                                  : launch_batch(e3k::gemm_wgrad3_kernel<32, 4, 1>, b.gb, b.blocks, st);
-      b.reset();
-      return rc;
-    };
-    for (int i = 0; i < n_problems && total > 0; ++i) {
-      if (!eligible(i)) continue;
-      const e3k_gemm_problem& P = problems[i];
-      const int64_t M = (int64_t)P.M1 * P.M2;
-      taken[i] = true;
-      int64_t splits = (int64_t)(target * (double)M / total);
-      const int64_t max_splits = (M + kMinChunks * chunk3 - 1) / (kMinChunks * chunk3);
-      if (splits > max_splits) splits = max_splits;
-      if (splits < 1) splits = 1;
-      e3k::GemmBatch& gb = b.gb;
-      gb.p[gb.n] = P;
-      gb.reps[gb.n] = 1;
-      gb.key_stride[gb.n] = 0;
-      E3K_KNOB_INT(kAbl3, "E3K_WGRAD2_ABLATE", 0);
-      gb.flags[gb.n] = 9 | (int)kAbl3;
-      gb.aux[gb.n] = (int)splits;
-      gb.tile_start[gb.n] = b.blocks;
-      b.blocks += tiles_of(P) * (int)splits;
-      if (++gb.n == e3k::GEMM_MAXP) {
-        const int rc = flush3();
-        if (rc != E3K_OK) return rc;
-      }
-    }
-    const int rc = flush3();
-    if (rc != E3K_OK) return rc;
-  }
-#endif
-  if (kV2 == 1) {
-    const int n_cu2 = cu_count();
-    const double target = kBlocks > 0 ? (double)kBlocks : 3.0 * n_cu2;   // three co-resident workgroups per CU: one round
-    auto eligible = [&](int i) {
-      const e3k_gemm_problem& P = problems[i];
+      if (!gathered && ((reps && reps[i] > 1) || P.row_index)) return false;
       return P.V == 0 && (int64_t)P.M1 * P.M2 > 0 && a_vec(P) && g_vec(P);
     };
-    auto tiles_of = [](const e3k_gemm_problem& P) { return ((P.K + (P.K > 64 ? 127 : 63)) / (P.K > 64 ? 128 : 64)) * ((P.N + 63) / 64); };
-    // rows x tiles over the problems of this launch (a keyed problem's key groups partition its M1 rows: it counts once,
-    // every key gets the splits of the whole and the workgroups past a key's last row exit)
-    double total = 0;
+    double total = 0;      // rows x tiles over the problems of this launch
     for (int i = 0; i < n_problems; ++i)
       if (eligible(i)) total += (double)problems[i].M1 * problems[i].M2 * tiles_of(problems[i]);
     Batcher b;
-    auto flush2 = [&]() -> int {
+    auto flush = [&]() -> int {
       if (!b.blocks) { b.reset(); return E3K_OK; }
       b.gb.tile_start[b.gb.n] = b.blocks;
-      const int rc = launch_batch(e3k::gemm_wgrad2_kernel, b.gb, b.blocks, st);
+      const int rc = launch(b.gb, b.blocks);
       b.reset();
       return rc;
     };
@@ -1888,24 +1838,42 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       taken[i] = true;
       int64_t splits = (int64_t)(target * (double)M / total);      // rounded down: the launch stays within one round
-      const int64_t max_splits = (M + kMinChunks * e3k::W2R - 1) / (kMinChunks * e3k::W2R);
+      const int64_t max_splits = (M + kMinChunks * chunk - 1) / (kMinChunks * chunk);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
       gb.reps[gb.n] = rp;
       gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
-      E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
       gb.flags[gb.n] = 9 | (int)kAbl;
       gb.aux[gb.n] = (int)splits;
       gb.tile_start[gb.n] = b.blocks;
       b.blocks += tiles_of(P) * (int)splits * rp;
       if (++gb.n == e3k::GEMM_MAXP) {
-        const int rc = flush2();
+        const int rc = flush();
         if (rc != E3K_OK) return rc;
       }
     }
-    const int rc = flush2();
+    return flush();
+  };
+  const int n_cu = cu_count();
+#ifdef E3K_DEBUG_KNOBS
+  if (kV2 == 2) {      // experiment: the LDS-direct ring kernel (plain problems only)
+    E3K_KNOB_INT(kBlocks3, "E3K_WGRAD3_BLOCKS", 0);
+    E3K_KNOB_INT(kCfg3, "E3K_WGRAD3_CFG", 0);
+    const int rc = equal_rows(
+        [&](const e3k::GemmBatch& gb, int blocks) {
+          return kCfg3 == 1   ? launch_batch(e3k::gemm_wgrad3_kernel<64, 3, 1>, gb, blocks, st)
+                 : kCfg3 == 2 ? launch_batch(e3k::gemm_wgrad3_kernel<32, 3, 2>, gb, blocks, st)
+                              : launch_batch(e3k::gemm_wgrad3_kernel<32, 4, 1>, gb, blocks, st);
+        },
+        kBlocks3 > 0 ? (double)kBlocks3 : (double)n_cu * (kCfg3 == 2 ? 2 : 1), kCfg3 == 1 ? 64 : 32, false);
+    if (rc != E3K_OK) return rc;
+  }
+#endif
+  if (kV2 == 1) {
+    const int rc = equal_rows([&](const e3k::GemmBatch& gb, int blocks) { return launch_batch(e3k::gemm_wgrad2_kernel, gb, blocks, st); },
+                              kBlocks > 0 ? (double)kBlocks : 3.0 * n_cu, e3k::W2R, true);
     if (rc != E3K_OK) return rc;
   }
   for (int mode = 0; mode < 4; ++mode) {  // (outer: x (x) attrs formed on the fly?, 128-wide output tile?)
