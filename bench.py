@@ -584,11 +584,18 @@ def main():
 
     host_enqueue = [0.0]
 
+    # The timed region records HIP event pairs around the DOMINANT kernel only (`tp_fwd`: the `roofline` block's
+    # achieved figure is measured live, on the launching stream); event pairs around every other launch of interest cost the
+    # eager step 3 % (4.85 vs 4.69 ms: a region without them, `ms_per_step_repeats`) -- the secondary kernels' durations
+    # come from a short eager pass behind the timed regions, as they do for a replayed graph.
+    DOMINANT = ("tp_fwd",)
+
     def timed_region():
         ops.PROFILE = {} if graph is None else None
+        ops.PROFILE_ONLY = set(DOMINANT)
         if graph is None:
             for nl in conv_native._LAYERS:
-                nl.profile(args.steps + 8)
+                nl.profile(args.steps + 8, kinds=DOMINANT)
         fence()
         waited0 = opt.waited_seconds
         t0 = time.perf_counter()
@@ -599,6 +606,7 @@ def main():
         fence()
         seconds = time.perf_counter() - t0
         recs, ops.PROFILE = ops.PROFILE, None
+        ops.PROFILE_ONLY = None
         if graph is None:
             recs = native_records(recs)
         return max_over_ranks(seconds), recs, out
@@ -619,15 +627,18 @@ def main():
             run()
         fence()
         repeats.append(max_over_ranks(time.perf_counter() - t0) / args.steps)
-    if graph is not None:  # per-kernel events cannot be read back from a replayed graph: eager pass for the roofline block
-        ops.PROFILE = {}
-        for nl in conv_native._LAYERS:
-            nl.profile(16)
-        for _ in range(min(args.steps, 5)):
-            step()
-        torch.cuda.synchronize()
-        records, ops.PROFILE = ops.PROFILE, None
-        records = native_records(records)
+    # eager pass for the roofline block: every kernel kind when the step was a replayed graph (per-kernel events cannot be
+    # read back from a replay), the secondary kinds otherwise (the dominant kernel keeps the timed region's records)
+    live = {k: v for k, v in (records or {}).items() if k in DOMINANT} if graph is None else {}
+    ops.PROFILE = {}
+    for nl in conv_native._LAYERS:
+        nl.profile(16)
+    for _ in range(min(args.steps, 5)):
+        step()
+    torch.cuda.synchronize()
+    records, ops.PROFILE = ops.PROFILE, None
+    records = native_records(records)
+    records.update(live)
 
     # ---- outside the timed region: the pieces of a step on their own (rank 0 reports them) -------------------------
     def event_ms(fn, n):

@@ -71,6 +71,7 @@ struct e3k_layer {
   int n_ev;
   mutable ProfRing prof[PROF_KINDS];
   int prof_cap = 0;
+  unsigned prof_mask = ~0u;      // kinds that record event pairs while prof_cap > 0
 };
 
 namespace {
@@ -79,7 +80,7 @@ struct Timed {   // records an event pair around one launch when the layer is be
   int kind, slot;
   hipStream_t st;
   Timed(const e3k_layer* L_, int kind_, void* st_, int64_t n, int64_t e) : L(L_), kind(kind_), slot(-1), st((hipStream_t)st_) {
-    if (L->prof_cap <= 0) return;
+    if (L->prof_cap <= 0 || !((L->prof_mask >> kind) & 1u)) return;
     ProfRing& r = L->prof[kind];
     if (r.count >= L->prof_cap) return;
     slot = r.count++;
@@ -101,8 +102,12 @@ namespace {
 // 16: radial MLP hidden chain + last layer (fwd + bwd), 32: tp_bwd_x, 64: input-gradient GEMMs
 // (debug build only -- see e3k_common.h: in the product library ABLATE is the constant 0 and every `ABLATE & bit` below folds away)
 E3K_KNOB_INT(ABLATE, "E3K_ABLATE", 0);
-E3K_KNOB_INT(BWDW_SIDE, "E3K_BWDW_SIDE", 0);
-E3K_KNOB_INT(WGRAD_LATE, "E3K_WGRAD_LATE", 1);
+// where the backward's side work runs (re-measured in round 4 after the GEMM kernels got shorter, tools/ab_bench.py, 2-3
+// interleaved rounds per variant): tp_bwd_w on the radial stream + the weight gradients beside tp_bwd_x (1 / 0) against
+// tp_bwd_w on the main stream + the weight gradients behind tp_bwd_x (0 / 1, round 3's choice): 256 molecules eager 4.815 vs
+// 4.846 ms, l_max 3 7.32 vs 7.51, config_diffusion_CA 9.12 vs 9.60, config_diffusion and the replayed steps within noise
+E3K_KNOB_INT(BWDW_SIDE, "E3K_BWDW_SIDE", 1);
+E3K_KNOB_INT(WGRAD_LATE, "E3K_WGRAD_LATE", 0);
 // the tensor-product kernels interpolate the path weights from the knot table themselves (no w[E, W])
 static inline bool in_kernel_table(const e3k_layer_desc& d, const e3k_layer_radial& r) { return r.use_table && r.in_kernel; }
 
@@ -250,9 +255,16 @@ extern "C" void e3k_layer_destroy(e3k_layer* L) {
   delete L;
 }
 
+extern "C" int e3k_layer_profile_mask(e3k_layer* L, int32_t capacity, uint32_t kinds) {
+  const int rc = e3k_layer_profile(L, capacity);
+  if (rc == E3K_OK) L->prof_mask = kinds;
+  return rc;
+}
+
 extern "C" int e3k_layer_profile(e3k_layer* L, int32_t capacity) {
   if (!L || capacity < 0) return E3K_ERR_INVALID;
   prof_free(L);
+  L->prof_mask = ~0u;
   for (int k = 0; k < PROF_KINDS && capacity > 0; ++k) {
     ProfRing& r = L->prof[k];
     r.beg.resize(capacity);
@@ -423,7 +435,8 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   };
   // WGRAD_LATE: the weight-gradient GEMMs start BEHIND tp_bwd_x (all three Linears in one call) instead of beside it: the
   // gather-bound tp_bwd_x then runs alone, the MFMA-bound weight gradients beside the HBM-bound tp_bwd_w (256 molecules
-  // 5.34 -> 5.30 ms, 192: 4.51 -> 4.47, one launch less per layer; E3K_WGRAD_LATE=0 restores the early start)
+  // 5.34 -> 5.30 ms, 192: 4.51 -> 4.47, one launch less per layer in round 3; with round 4's kernels the early start wins
+  // again -- see the knobs' comment at the top -- and is the default)
   const bool wgrad_late = WGRAD_LATE && side3 != main && need_x1;
   if (side3 != main && (need_post || want_sc) && !wgrad_late) {
     E3K_TRY(edge(L, 0, main, side3));

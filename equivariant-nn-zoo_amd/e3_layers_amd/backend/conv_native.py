@@ -131,9 +131,11 @@ class NativeLayer:
         return h
 
     # ---- per-kernel timers (bench.py) ----
-    def profile(self, capacity: int) -> None:
+    def profile(self, capacity: int, kinds=None) -> None:
+        """Arms ``capacity`` event pairs per kernel kind (0 disarms); ``kinds``: only these (names of ``PROF_KINDS``)."""
+        mask = 0xFFFFFFFF if kinds is None else sum(1 << PROF_KINDS[k] for k in kinds)
         for h in self.handles.values():
-            L.check(L.load().e3k_layer_profile(h, capacity), "e3k_layer_profile")
+            L.check(L.load().e3k_layer_profile_mask(h, capacity, mask), "e3k_layer_profile_mask")
 
     def profile_read(self, kind: str):
         out = []

@@ -176,6 +176,7 @@ SIGNATURES = {
     "e3k_kw_stack_bwd_workspace": (C.c_int64, [C.POINTER(C.c_void_p), _I32, _I32]),
     "e3k_kw_stack_bwd": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(KwStackItem), _I32, _P, _P, _P, _I64, _I32, _P, _P, _P, _P]),
     "e3k_layer_profile": (C.c_int, [_P, _I32]),
+    "e3k_layer_profile_mask": (C.c_int, [_P, _I32, C.c_uint32]),
     "e3k_layer_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),

@@ -34,6 +34,7 @@ from .graph import GraphTopo
 # events recorded on the LAUNCHING stream (the convolution branches run on side streams, which an event pair on
 # torch's current stream taken by the caller would not see); None = no profiling.
 PROFILE: Optional[Dict[str, list]] = None
+PROFILE_ONLY = None      # a set of kernel names: only these are recorded (the timed region times the dominant kernel alone)
 
 
 class timed_launch:
@@ -45,7 +46,7 @@ class timed_launch:
         self.name, self.meta, self.ev0 = name, meta, None
 
     def __enter__(self):
-        if PROFILE is not None:
+        if PROFILE is not None and (PROFILE_ONLY is None or self.name in PROFILE_ONLY):
             self.ev0 = torch.cuda.Event(enable_timing=True)
             self.ev0.record()
 

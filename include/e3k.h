@@ -689,6 +689,9 @@ int e3k_kw_stack_bwd(const e3k_layer* const* layers, const e3k_kw_stack_item* it
 #define E3K_PROF_RTABLE_BWD 4
 #define E3K_PROF_RADIAL_LAST_FWD 5
 int e3k_layer_profile(e3k_layer* layer, int32_t capacity);
+/* the same, recording only the kinds whose bit is set in `kinds` (bit = E3K_PROF_* value): a timed region that wants the
+ * dominant kernel's durations live without event pairs around every other launch */
+int e3k_layer_profile_mask(e3k_layer* layer, int32_t capacity, uint32_t kinds);
 int e3k_layer_profile_read(e3k_layer* layer, int32_t kind, float* ms, int64_t* n, int64_t* e, int32_t cap);
 
 #ifdef __cplusplus
