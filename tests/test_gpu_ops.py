@@ -105,6 +105,88 @@ def test_linear_large_shapes(dev):
     assert rel_err(gw, rw) < GTOL
 
 
+@pytest.mark.parametrize("m1,m2,k,n,gathered", [
+    (1000, 3, 384, 64, False),     # the trailing Linear's shape: three 128-wide k tiles, rows = (node, m)
+    (777, 5, 192, 256, False),     # second k tile half empty, four column tiles
+    (333, 1, 64, 64, False),       # narrow form (K <= 64)
+    (95, 3, 448, 192, False),      # k tail (448 = 3.5 tiles), rows not a multiple of the 32-row chunk
+    (1, 1, 64, 64, False),         # a single row
+    (1200, 3, 64, 128, True),      # gathered rows (the keyed self-connection's groups): node indices fetched one chunk ahead
+    (640, 5, 192, 64, True),
+])
+def test_gemm_wgrad_through_the_c_abi(dev, m1, m2, k, n, gathered):
+    """e3k_gemm_wgrad: B[k, n] += alpha * sum_rows A[row, k] G[row, n] for strided (node, component) rows, against float64
+    torch -- the pipelined kernel's tile shapes, tails and the gathered-row form (csrc/e3k_gemm.hip: gemm_wgrad2_kernel)."""
+    from e3_layers_amd.backend import lib as L
+
+    torch.manual_seed(m1 + k + n)
+    nodes = m1 + 37 if gathered else m1
+    d_a, d_g = m2 * k + 16, m2 * n + 8        # row widths with slack: the blocks do not fill the rows
+    a = torch.randn(nodes, d_a, device=dev)
+    g = torch.randn(nodes, d_g, device=dev)
+    out = torch.randn(k, n, device=dev)
+    want = out.double().cpu()
+    idx = torch.randperm(nodes)[:m1].to(torch.int32) if gathered else None
+    rows = idx.long() if gathered else torch.arange(m1)
+    a_blk = a.cpu().double()[rows][:, 8:8 + m2 * k].reshape(m1 * m2, k)          # cf layout inside the block: [m][k]
+    g_blk = g.cpu().double()[rows][:, 4:4 + m2 * n].reshape(m1 * m2, n)
+    want = want + 0.37 * a_blk.t() @ g_blk
+    p = L.GemmProblem()
+    p.A, p.A2, p.B, p.C, p.bias = a.data_ptr() + 4 * 8, None, out.data_ptr(), g.data_ptr() + 4 * 4, None
+    idx_dev = idx.to(dev) if gathered else None
+    p.row_index = idx_dev.data_ptr() if gathered else None
+    p.group_dev = None
+    p.M1, p.M2, p.N, p.K, p.V, p.accumulate = m1, m2, n, k, 0, 1
+    p.a_r1, p.a_r2, p.a_k = d_a, k, 1
+    p.b_k, p.b_n = n, 1
+    p.c_r1, p.c_r2, p.c_n = d_g, n, 1
+    p.alpha, p.act, p.act_cst = 0.37, 0, 1.0
+    arr = (L.GemmProblem * 1)(p)
+    L.check(L.load().e3k_gemm_wgrad(arr, 1, L.stream_ptr()), "e3k_gemm_wgrad")
+    torch.cuda.synchronize()
+    assert rel_err(out, want) < 2e-6
+
+
+@pytest.mark.parametrize("m1,m2,k,n,accumulate,bias", [
+    (1000, 3, 192, 64, 1, False),     # interior tiles, accumulating epilogue (all old values requested, then all stored)
+    (1000, 3, 192, 64, 0, True),
+    (333, 5, 96, 200, 1, True),       # edge tiles in rows and columns (per-element predicates), K tail
+    (130, 1, 64, 72, 1, False),       # 64-row tiles of the small-grid form, column tail
+    (4700, 1, 384, 64, 1, False),     # enough tiles for the 128-row form
+])
+def test_gemm_forward_epilogues_through_the_c_abi(dev, m1, m2, k, n, accumulate, bias):
+    """e3k_gemm: C[(r1, r2), n] = alpha * A B (+ C) (+ bias) on strided rows against float64 torch: interior and edge tiles of
+    store_acc (csrc/e3k_gemm.hip), with and without the read-modify-write."""
+    from e3_layers_amd.backend import lib as L
+
+    torch.manual_seed(m1 + k + n + accumulate)
+    d_a, d_c = m2 * k + 12, m2 * n + 20
+    a = torch.randn(m1, d_a, device=dev)
+    b = torch.randn(k, n, device=dev)
+    c = torch.randn(m1, d_c, device=dev)
+    bv = torch.randn(n, device=dev) if bias else None
+    want = c.double().cpu().clone()
+    a_blk = a.cpu().double()[:, 4:4 + m2 * k].reshape(m1 * m2, k)
+    prod = 0.71 * a_blk @ b.cpu().double()
+    if bias:
+        prod = prod + bv.cpu().double()
+    blk = want[:, 8:8 + m2 * n].reshape(m1 * m2, n)
+    want[:, 8:8 + m2 * n] = ((blk + prod) if accumulate else prod).reshape(m1, m2 * n)
+    p = L.GemmProblem()
+    p.A, p.A2, p.B, p.C = a.data_ptr() + 4 * 4, None, b.data_ptr(), c.data_ptr() + 4 * 8
+    p.bias = bv.data_ptr() if bias else None
+    p.row_index, p.group_dev = None, None
+    p.M1, p.M2, p.N, p.K, p.V, p.accumulate = m1, m2, n, k, 0, accumulate
+    p.a_r1, p.a_r2, p.a_k = d_a, k, 1
+    p.b_k, p.b_n = n, 1
+    p.c_r1, p.c_r2, p.c_n = d_c, n, 1
+    p.alpha, p.act, p.act_cst = 0.71, 0, 1.0
+    arr = (L.GemmProblem * 1)(p)
+    L.check(L.load().e3k_gemm(arr, 1, L.stream_ptr()), "e3k_gemm")
+    torch.cuda.synchronize()
+    assert rel_err(c, want) < 2e-6      # (the columns outside the block are part of the comparison: they must be untouched)
+
+
 @pytest.mark.parametrize("rows,width", [(4097, 1920), (700, 960), (33, 260)])
 def test_fully_connected_net_few_rows_wide_output(dev, rows, width):
     """The radial MLP on the knot table: few rows, a wide last layer -- its dgrad is the split-K kernel (K = width),
