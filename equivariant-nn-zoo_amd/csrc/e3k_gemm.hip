@@ -1703,8 +1703,13 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
         }
   }
 #endif
-  // launches that would leave most of the 256 CUs without a third workgroup use 64-row tiles
-  const bool small_grid = plain_tiles128 < 3 * 256;
+  // 64-row tiles (gemm_kernel<2>) unless the launch holds at least kSmallGrid 128-row tiles.  Round 3 switched to 128-row
+  // tiles from three per CU; re-measured in round 4 (tools/ab_bench.py, 2-3 interleaved rounds): the 64-row form wins at
+  // every size met -- trailing Linear forward 56 vs 62 us (twice the tiles: the unequal-K problems of a launch spread more
+  // evenly over the CUs), 256 molecules 4.65 vs 4.69 ms, l_max 3 7.03 vs 7.16, the protein net 8.99 vs 9.09 -- so the
+  // threshold now sits above anything a layer issues and gemm_kernel<4> is the form kept for launches beyond it.
+  E3K_KNOB_INT(kSmallGrid, "E3K_GEMM_SMALL_GRID_TILES", 1 << 20);
+  const bool small_grid = plain_tiles128 < kSmallGrid;
   for (int k = 0; k < FWD_KINDS; ++k) {
     Batcher b;
     auto flush = [&]() -> int {
