@@ -1146,9 +1146,12 @@ __global__ __launch_bounds__(256) void gemm_wgrad_kernel(const GemmBatch gb) {
 // (the chip adds 1.3 TB/s of atomic bytes, MI355X_MICROARCH.md "Global float atomics").  Here: (i) two LDS stages, the
 // loads of chunk c + 2 in flight while chunk c is in the matrix pipe: one barrier per chunk and two chunk times for a
 // load to land; (ii) tile 128 k x 64 n (WKW = 4 waves along k, two accumulators each: the G fragment pair is reused by
-// every wave, A is still read once) or 64 k x 64 n (WKW = 2) for K <= 64; (iii) the launch is sized to ~2 workgroups per
-// CU with EQUAL row ranges per workgroup (splits proportional to the problem's rows), so a workgroup adds its tile once
-// per ~1/512 of the launch's work.
+// every wave, A is still read once) or 64 k x 64 n (WKW = 2) for K <= 64; (iii) the launch is sized to ONE round of
+// workgroups -- three per CU, what LDS admits -- with EQUAL row ranges per workgroup (splits proportional to a problem's
+// rows), so a workgroup adds its tile once per ~1/768 of the launch's work (measured: 256 / 512 / 768 / 1 024 workgroups
+// 70 / 73 / 59 / 72 us on the trailing Linear: a second, partial round costs what it saves); (iv) row pointers advanced by
+// constant 64-bit deltas instead of two 64-bit multiplies per load and chunk; gathered rows (IDX) through node indices
+// fetched one chunk ahead.
 // ---------------------------------------------------------------------------------------
 constexpr int W2R = 32;   // rows per chunk
 template <int WKW, bool IDX>
