@@ -754,7 +754,7 @@ def test_radial_table_in_the_model_equals_per_edge_radial_mlp(dev, monkeypatch, 
         assert rel_err(g_tab[k], g_ref[k]) < 5e-5, k
 
 
-@pytest.mark.parametrize("bonds,molecules", [("uniform", 64), ("clustered", 64), ("uniform", 256)])
+@pytest.mark.parametrize("bonds,molecules", [("clustered", 64), ("uniform", 256)])      # (uniform at 64 molecules: the threshold sweep below)
 def test_bench_path_against_the_float64_oracle(dev, monkeypatch, bonds, molecules):
     """(``bonds="clustered"``: element-pair bond lengths +- 0.01 A and tetrahedral angles -- the distance distribution of real
     molecules, hundreds of edges in single knot bins of the radial table: VERDICT r3 item 4.  ``molecules=256``: the bench's own
