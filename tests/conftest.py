@@ -11,6 +11,12 @@ for p in (ROOT, os.path.join(ROOT, "equivariant-nn-zoo_amd")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the float64 oracle's op sizes (a few thousand rows) do not use a 256-core host: beyond ~32 threads the intra-op pool
+    # only adds fork / join time (the 256-molecule parity case: 186 s with the default pool, 94 s with 32)
+    import torch
+
+    if torch.get_num_threads() > 32:
+        torch.set_num_threads(32)
 
 
 @pytest.fixture(scope="session")
