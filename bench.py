@@ -142,17 +142,15 @@ def launch_ranks(args) -> int:
     ``torch.multiprocessing.spawn`` of ``train.py:272,280-304``), relays their output, and prints rank 0's JSON line ONCE, with
     the CPU baseline of the same run (measured here, after the ranks have finished, so that it does not disturb their hosts'
     launch rates) added to it.  A rank that fails makes the elastic agent end its siblings; the agent's exit code is ours."""
-    import socket
     import subprocess
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env["E3K_BENCH_CHILD"] = "1"
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
+    # rendezvous: the agent's own store on a port the OS hands out (endpoint port 0) -- nothing is picked here by binding and
+    # closing a socket, which another job on a shared box could grab in between (ADVICE r4)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--rdzv-backend=c10d",
+           "--rdzv-endpoint=127.0.0.1:0", "--local-addr", "127.0.0.1", os.path.abspath(__file__)] + [a for a in sys.argv[1:]]
     proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True, bufsize=1)
     line = None
     try:
@@ -176,7 +174,7 @@ def launch_ranks(args) -> int:
     result = json.loads(line)
     if not args.no_cpu_baseline and args.config == "energy" and os.environ.get("E3K_BENCH_DRY_RUN") is None:
         result["cpu_baseline"] = cpu_baseline(args.cpu_budget)
-    result.setdefault("config", {})["launcher"] = f"bench.py started {args.gpus} rank processes itself (torch.distributed.run, 127.0.0.1:{port})"
+    result.setdefault("config", {})["launcher"] = f"bench.py started {args.gpus} rank processes itself (torch.distributed.run, c10d rendezvous on 127.0.0.1)"
     print(json.dumps(result), flush=True)
     return 0
 
@@ -296,9 +294,11 @@ def main():
             target = batch["total_energy"]          # the model writes its prediction under the same key of the same Batch
             return 1e3 * torch.nn.functional.mse_loss(model(batch)["total_energy"], target)
         if cfg_kind == "energy_force":                  # config_energy_force.py:18 loss_coeffs
+            # (the model writes its graph energy under "energy", config_energy_force.py:73; the synthetic target travels as
+            #  "total_energy" -- until round 5 this line compared the target with itself: the energy term was identically zero)
             e_t, f_t = batch["total_energy"], batch["forces_target"]
             out = model(batch)
-            return 1e3 * ((out["total_energy"] - e_t) ** 2).mean() + 3e4 * ((out["forces"] - f_t) ** 2).mean()
+            return 1e3 * ((out["energy"] - e_t) ** 2).mean() + 3e4 * ((out["forces"] - f_t) ** 2).mean()
         return sde_loss(sde, model, batch, generator=gen)[0]
 
     # setup, not a step of the workload: libe3k.so is loaded, the TP plans are created and the code objects of every
@@ -421,7 +421,7 @@ def main():
             else:      # config_energy_force.py:18 loss_coeffs; the force term is a mean over the REAL nodes' components
                 f_t, wn = batch["forces_target"], batch["_node_weight"]
                 out = model(batch)
-                loss = (1e3 * (((out["total_energy"] - target) ** 2) * weight).sum()
+                loss = (1e3 * (((out["energy"] - target) ** 2) * weight).sum()
                         + 3e4 * (((out["forces"] - f_t) ** 2) * (wn / 3.0)).sum())
                 flat.zero()
                 backward_parameters(loss, opt.params)

@@ -77,4 +77,10 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
 }  // namespace e3k

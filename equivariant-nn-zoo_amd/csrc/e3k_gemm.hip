@@ -391,223 +391,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 }
 
 #ifdef E3K_DEBUG_KNOBS
-// ---------------------------------------------------------------------------------------
-// EXPERIMENT (built only with -DE3K_DEBUG_KNOBS, `make dbg`; E3K_GEMM_PERSIST=1): measured slower than gemm_kernel, see
-// DESIGN.md section 5 "Built, measured, not adopted (round 4)".
-// persistent forward / dgrad (round 4): every workgroup walks tiles T = blockIdx, blockIdx + grid, ... of the launch's
-// (problem, 128-row tile, 64-column tile) list as ONE sequence of K-steps, software-pipelined ACROSS tiles.
-//
-// Why: timing-only ablations of gemm_kernel on the node-side Linears (tools/gemm_probe_r04.sh) show its three phases ADD
-// UP -- trailing Linear forward 67 us = skeleton + loads 24 + MFMA 31 + stores 12; its input gradient 96 us = 30 + 27 +
-// 40 -- although three or four workgroups share every CU: identical tiles launched together stay in lockstep, so all of
-// them load, then all multiply, then all store.  Overlap has to come from inside the workgroup: here the loads run two
-// K-steps ahead of the MFMAs (registers, then the other LDS stage) whichever tile the step belongs to, the stores of a
-// finished tile are issued and never waited for, and there is one barrier per K-step.  Per-tile state that outlives the
-// load phase (output row offsets, epilogue constants) sits in LDS rings of four tiles.
-// ---------------------------------------------------------------------------------------
-struct EpiDesc {
-  float* C;
-  const float* bias;
-  long long c_n;
-  float alpha, act_cst;
-  int N, n0, accumulate, act;
-};
-
-__global__ __launch_bounds__(256, 2) void gemm_persist_kernel(const GemmBatch gb, const int total_tiles) {
-  constexpr int BM_ = 128, NT = 2;
-  __shared__ float As[2][BM_ * LDA];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK * LDB];
-  __shared__ long long rowC[4][BM_];
-  __shared__ EpiDesc epi[4];
-  if ((int)blockIdx.x >= total_tiles) return;
-  const int t = threadIdx.x, lane = t & 63, wm = t >> 6;
-  const int kq = (t & 7) * 4;
-
-  // ---- load side: the tile whose K-steps are being fetched.  What a K-step needs is kept in plain scalars and per-thread
-  // element offsets set up once per tile (the problem descriptor itself stays in the kernel-argument segment: held as a
-  // struct it does not fit the scalar registers next to the loop's state and the compiler re-read it field by field,
-  // s_load + s_waitcnt lgkmcnt(0), in every K-step)
-  int ld_tile = blockIdx.x;            // tile index in the launch; >= total_tiles: nothing left to load
-  int ld_slot = 0;                     // ring slot (tile counter mod 4) of the tile being loaded
-  int ld_k = 0, l_K = 0;               // next k0 to load, K of the tile's problem
-  int l_bmode = 1;
-  const float* pa[4];                  // this thread's four A rows at column kq of the next K-step (nullptr: row out of range)
-  const float* pb[2];                  // its two B float4s of the next K-step (nullptr: column out of range)
-  int b_step = 0;                      // elements between consecutive K-steps of B
-  int bk_lim[2];                       // k of the B loads relative to k0 (a load is valid while k0 + bk_lim < K)
-  auto open_tile = [&]() {             // block-uniform control flow
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < GEMM_MAXP; ++i)
-      if (i < gb.n && ld_tile >= gb.tile_start[i]) pi = i;
-    pi = uniform(pi);
-    const e3k_gemm_problem& LP = gb.p[pi];
-    l_bmode = uniform((gb.flags[pi] >> 1) & 3);
-    l_K = uniform(LP.K);
-    const int local = ld_tile - gb.tile_start[pi];
-    const int tiles_n = (LP.N + BN - 1) / BN;
-    const int row0 = (local / tiles_n) * BM_;
-    const int n0 = (local % tiles_n) * BN;
-    const int M = LP.M1 * LP.M2;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      const int R = row0 + (t >> 3) + 32 * p;
-      pa[p] = nullptr;
-      if (R < M) {
-        const int r1 = R / LP.M2, r2 = R - r1 * LP.M2;
-        pa[p] = LP.A + (long long)r1 * LP.a_r1 + (long long)r2 * LP.a_r2 + kq;
-      }
-    }
-    const bool m1 = l_bmode == 1;
-    b_step = uniform(m1 ? BK * (int)LP.b_k : BK);
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int k = m1 ? (t >> 4) + 16 * pass : (t >> 6) * 8 + 4 * pass;
-      const int n = m1 ? (t & 15) * 4 : (t & 63);
-      bk_lim[pass] = k;
-      pb[pass] = (n0 + n < LP.N) ? LP.B + (m1 ? (long long)k * LP.b_k + (n0 + n) : (long long)(n0 + n) * LP.b_n + k) : nullptr;
-    }
-    if (t < BM_) {
-      const int R = row0 + t;
-      long long oc = -1;
-      if (R < M) {
-        const int r1 = R / LP.M2, r2 = R - r1 * LP.M2;
-        oc = (long long)r1 * LP.c_r1 + (long long)r2 * LP.c_r2;
-      }
-      rowC[ld_slot][t] = oc;
-    }
-    if (t == 0) {
-      EpiDesc e;
-      e.C = LP.C; e.bias = LP.bias; e.c_n = LP.c_n; e.alpha = LP.alpha; e.act_cst = LP.act_cst;
-      e.N = LP.N; e.n0 = n0; e.accumulate = LP.accumulate; e.act = LP.act;
-      epi[ld_slot] = e;
-    }
-    ld_k = 0;
-  };
-  float4 ra[4];
-  BRegs rb;
-  // fetches the next K-step of the sequence into registers; returns slot << 3 | B mode << 1 | (last step of its tile),
-  // or -1 when the sequence has ended
-  auto gload = [&]() -> int {
-    if (ld_tile >= total_tiles) return -1;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pa[p] && ld_k + kq < l_K) ra[p] = *reinterpret_cast<const float4*>(pa[p]);
-      pa[p] = pa[p] ? pa[p] + BK : nullptr;
-    }
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      rb.v[pass] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (pb[pass] && ld_k + bk_lim[pass] < l_K) rb.v[pass] = *reinterpret_cast<const float4*>(pb[pass]);
-      pb[pass] = pb[pass] ? pb[pass] + b_step : nullptr;
-    }
-    ld_k += BK;
-    const int last = ld_k >= l_K ? 1 : 0;
-    const int tag = (ld_slot << 3) | (l_bmode << 1) | last;
-    if (last) {
-      ld_tile += gridDim.x;
-      ld_slot = (ld_slot + 1) & 3;
-      if (ld_tile < total_tiles) open_tile();
-    }
-    return tag;
-  };
-  auto lstore = [&](int buf, int tag) {
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-      float* d = &As[buf][((t >> 3) + 32 * p) * LDA + kq];
-      d[0] = ra[p].x; d[1] = ra[p].y; d[2] = ra[p].z; d[3] = ra[p].w;
-    }
-    store_b_regs((tag >> 1) & 3, rb, Bs[buf]);
-  };
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-
-  open_tile();
-  int tag0 = gload();
-  lstore(0, tag0);
-  int tag1 = gload();
-  __syncthreads();
-  int buf = 0;
-  const int aoff = (wm * 32 + (lane & 31)) * LDA + (lane >> 5);
-  const int boff = (lane >> 5) * LDB + (lane & 31);
-  while (tag0 >= 0) {
-    int tag2 = -1;
-#ifdef E3K_DEBUG_KNOBS
-    const int abl = gb.flags[0];
-    if (tag1 >= 0) {
-      if (!(abl & 64)) lstore(buf ^ 1, tag1);
-      if (abl & 32) {           // timing only: the sequence advances without loading
-        ld_k += BK;
-        const bool last = ld_k >= l_K;
-        tag2 = (ld_slot << 3) | (l_bmode << 1) | (last ? 1 : 0);
-        if (ld_tile >= total_tiles) tag2 = -1;
-        else if (last) { ld_tile += gridDim.x; ld_slot = (ld_slot + 1) & 3; if (ld_tile < total_tiles) open_tile(); }
-      } else tag2 = gload();
-    }
-    if (!(abl & 16)) {
-#else
-    if (tag1 >= 0) {
-      lstore(buf ^ 1, tag1);
-      tag2 = gload();
-    }
-    {
-#endif
-    const float* ap = &As[buf][aoff];
-    const float* bp = &Bs[buf][boff];
-#pragma unroll
-    for (int kk = 0; kk < BK; kk += 2) {
-      const float a = ap[kk];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bp[kk * LDB + 32 * j], acc[j], 0, 0, 0);
-    }
-    }
-    if (tag0 & 1) {      // the tile is complete: write it out (not waited for) and start the next accumulation
-      const int slot = tag0 >> 3;
-      const EpiDesc e = epi[slot];
-      int n[NT];
-      bool ok[NT];
-      float bias[NT];
-      long long cn[NT];
-#pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        n[j] = e.n0 + 32 * j + (lane & 31);
-        ok[j] = n[j] < e.N;
-        bias[j] = (e.bias && ok[j]) ? e.bias[n[j]] : 0.f;
-        cn[j] = (long long)n[j] * e.c_n;
-      }
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const long long off = rowC[slot][wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)];
-        if (off >= 0) {
-          float* c = e.C + off;
-#pragma unroll
-          for (int j = 0; j < NT; ++j) {
-            if (ok[j]) {
-              float v = fmaf(e.alpha, acc[j][i], bias[j]);
-              if (e.accumulate) v += c[cn[j]];
-              if (e.act == 1) v = e.act_cst * (fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))) - 0.6931471805599453f);
-              c[cn[j]] = v;
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < NT; ++j)
-#pragma unroll
-        for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-    }
-    __syncthreads();
-    tag0 = tag1;
-    tag1 = tag2;
-    buf ^= 1;
-  }
-}
-
+#include "../../tools/experiments/gemm_persist_kernel.inc"      // (debug build only: the persistent work-list experiment)
 #endif  // E3K_DEBUG_KNOBS
 
 // ---------------------------------------------------------------------------------------
@@ -1311,188 +1095,7 @@ __global__ __launch_bounds__(256, 2) void gemm_wgrad2_kernel(const GemmBatch gb)
 }
 
 #ifdef E3K_DEBUG_KNOBS
-// ---------------------------------------------------------------------------------------
-// EXPERIMENT (built only with -DE3K_DEBUG_KNOBS; E3K_WGRAD2=2): as fast as the register-staged form above, not faster.
-// wgrad, one workgroup per CU with a ring of LDS stages filled by LDS-direct loads (global_load_lds_dwordx4: no staging
-// registers, so three chunks can be in flight per workgroup).  Why: the pipelined form above at 3 workgroups per CU is
-// launch 6 us + max(loads 28, MFMA 27) + 19 us of float atomics that all arrive when the workgroups finish together
-// (768 tiles of 32 KB = 25 MB at the chip's 1.3 TB/s of atomic bytes); a third of the workgroups, each with three times
-// the rows, adds a third of the bytes.  Lanes whose row or column is out of range load from a block of zeros (G) or a
-// clamped row (A), so every lane issues the same number of loads per chunk and s_waitcnt vmcnt(N) can leave exactly
-// the younger chunks in flight.  Unpadded LDS rows (LDS-direct writes 1 KB contiguous per wave instruction): the A / G
-// fragment reads are 2-way bank conflicts, 4 cycles instead of 2 per ds_read_b32 beside a 64-cycle MFMA.
-// ---------------------------------------------------------------------------------------
-__device__ __attribute__((aligned(16))) float e3k_zero_row[128];   // zero-initialised (static storage)
-
-template <int N>
-__device__ __forceinline__ void wait_vm() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
-
-// s_waitcnt lgkmcnt(0) that the values read by the ds_read asm statements above it flow through
-template <int NT>
-__device__ __forceinline__ void lds_wait(float (&a)[8], float (&g)[8][NT]) {
-  if constexpr (NT == 2)
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(g[0][0]), "+v"(g[0][1]),
-                   "+v"(g[1][0]), "+v"(g[1][1]), "+v"(g[2][0]), "+v"(g[2][1]), "+v"(g[3][0]), "+v"(g[3][1]), "+v"(g[4][0]), "+v"(g[4][1]),
-                   "+v"(g[5][0]), "+v"(g[5][1]), "+v"(g[6][0]), "+v"(g[6][1]), "+v"(g[7][0]), "+v"(g[7][1])
-                 :
-                 : "memory");
-  else
-    asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(a[4]), "+v"(a[5]), "+v"(a[6]), "+v"(a[7]), "+v"(g[0][0]), "+v"(g[1][0]),
-                   "+v"(g[2][0]), "+v"(g[3][0]), "+v"(g[4][0]), "+v"(g[5][0]), "+v"(g[6][0]), "+v"(g[7][0])
-                 :
-                 : "memory");
-}
-
-template <int WKW, int W3R, int W3S>
-__device__ __forceinline__ void gemm_wgrad3_body(const BlockProblem& bp_, float* As, float* Gs) {
-  constexpr int TK = 32 * WKW;
-  constexpr int WNW = 4 / WKW, NT = 2 / WNW;
-  constexpr int A_STAGE = W3R * TK, G_STAGE = W3R * 64;      // floats
-  constexpr int A_INSTR = A_STAGE / 256, G_INSTR = G_STAGE / 256;   // wave instructions (1 KB each) per stage
-  constexpr int APW = A_INSTR / 4, GPW = G_INSTR / 4;        // per wave
-  constexpr int A_RPI = 256 / TK;                            // rows per wave instruction (2 or 4)
-  constexpr int L = APW + GPW;                               // loads per thread and chunk
-  const e3k_gemm_problem& P = bp_.P;
-  const int local = bp_.local;
-  const int M = P.M1 * P.M2, M2 = P.M2;
-  const int tiles_k = (P.K + TK - 1) / TK, tiles_n = (P.N + 63) / 64;
-  const int splits = bp_.aux;
-  const int tile = local % (tiles_k * tiles_n), split = local / (tiles_k * tiles_n);
-  const int k0 = (tile / tiles_n) * TK, n0 = (tile % tiles_n) * 64;
-  const int chunk_rows = ((M + splits - 1) / splits + W3R - 1) / W3R * W3R;
-  const int rbeg = split * chunk_rows;
-  const int rend = (rbeg + chunk_rows < M) ? rbeg + chunk_rows : M;
-  if (rbeg >= M) return;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int wk = wv % WKW, wn = wv / WKW;
-  const int qR = W3R / M2, remR = W3R - qR * M2;
-
-  f32x16 acc[NT];
-#pragma unroll
-  for (int j = 0; j < NT; ++j)
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
-
-  // wave instruction i of a stage: A rows A_RPI*i + lane / (TK/4), G rows 4*i + lane / 16; this wave issues i = wv + 4*p.
-  // Row pointers advance by constant 64-bit deltas (one chunk down, and the wrap of the component index r2): the address
-  // arithmetic of a chunk is a dozen adds per load, not two 64-bit multiplies -- it runs on the SIMD that issues the MFMAs
-  int aR[APW], ar2[APW], gR[GPW], gr2[GPW];
-  const float* pa[APW];
-  const float* pg[GPW];
-  const int64_t dA = (int64_t)qR * P.a_r1 + (int64_t)remR * P.a_r2, wA = P.a_r1 - (int64_t)M2 * P.a_r2;
-  const int64_t dG = (int64_t)qR * P.c_r1 + (int64_t)remR * P.c_r2, wG = P.c_r1 - (int64_t)M2 * P.c_r2;
-  const int acol = (lane % (TK / 4)) * 4, gcol = (lane & 15) * 4;
-  const bool a_in = k0 + acol < P.K, g_in = n0 + gcol < P.N;
-#pragma unroll
-  for (int p = 0; p < APW; ++p) {
-    aR[p] = rbeg + A_RPI * (wv + 4 * p) + lane / (TK / 4);
-    const int r1 = aR[p] / M2;
-    ar2[p] = aR[p] - r1 * M2;
-    pa[p] = P.A + (int64_t)r1 * P.a_r1 + (int64_t)ar2[p] * P.a_r2 + k0 + acol;
-  }
-#pragma unroll
-  for (int p = 0; p < GPW; ++p) {
-    gR[p] = rbeg + 4 * (wv + 4 * p) + (lane >> 4);
-    const int r1 = gR[p] / M2;
-    gr2[p] = gR[p] - r1 * M2;
-    pg[p] = P.C + (int64_t)r1 * P.c_r1 + (int64_t)gr2[p] * P.c_r2 + n0 + gcol;
-  }
-  const int last = rend - 1, last1 = last / M2, last2 = last - last1 * M2;
-  const float* a_last = P.A + (int64_t)last1 * P.a_r1 + (int64_t)last2 * P.a_r2 + k0 + acol;
-  auto issue = [&](int st) {
-#pragma unroll
-    for (int p = 0; p < APW; ++p) {
-      const float* src = a_in ? (aR[p] < rend ? pa[p] : a_last) : e3k_zero_row + acol;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(As + st * A_STAGE + (wv + 4 * p) * 256), 16, 0, 0);
-      aR[p] += W3R; ar2[p] += remR; pa[p] += dA;
-      if (ar2[p] >= M2) { ar2[p] -= M2; pa[p] += wA; }
-    }
-#pragma unroll
-    for (int p = 0; p < GPW; ++p) {
-      const float* src = (g_in && gR[p] < rend) ? pg[p] : e3k_zero_row + gcol;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(Gs + st * G_STAGE + (wv + 4 * p) * 256), 16, 0, 0);
-      gR[p] += W3R; gr2[p] += remR; pg[p] += dG;
-      if (gr2[p] >= M2) { gr2[p] -= M2; pg[p] += wG; }
-    }
-  };
-  const int n_chunks = (rend - rbeg + W3R - 1) / W3R;
-  issue(0);
-  if (n_chunks > 1) issue(1);
-  if (n_chunks > 2) issue(2);
-  const int aoff = (lane >> 5) * TK + wk * 32 + (lane & 31);
-  const int goff = (lane >> 5) * 64 + wn * (32 * NT) + (lane & 31);
-  const uint32_t a_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)As + (uint32_t)aoff * 4;
-  const uint32_t g_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float*)Gs + (uint32_t)goff * 4;
-  for (int c = 0; c < n_chunks; ++c) {
-    if (c + 2 < n_chunks) wait_vm<2 * L>();
-    else if (c + 1 < n_chunks) wait_vm<L>();
-    else wait_vm<0>();
-    __builtin_amdgcn_s_barrier();          // chunk c is in LDS for every wave; every wave is done with chunk c - 1
-    asm volatile("" ::: "memory");
-#ifdef E3K_DEBUG_KNOBS
-    if (bp_.flags & 32) {       // timing only: no loads after the first three chunks
-      if (c + 3 < n_chunks) { wait_vm<0>(); }
-    } else if (c + 3 < n_chunks) issue((c + 3) % W3S);
-    if (bp_.flags & 16) continue;
-#else
-    if (c + 3 < n_chunks) issue((c + 3) % W3S);
-#endif
-    // operand fetch through inline asm: the compiler cannot tell which LDS stage an LDS-direct load writes and would put
-    // s_waitcnt vmcnt(0) in front of every ds_read it knows about -- draining the ring
-    const uint32_t ab = a_lds + (uint32_t)((c % W3S) * A_STAGE * 4), gb_ = g_lds + (uint32_t)((c % W3S) * G_STAGE * 4);
-    float av[2][8], gv[2][8][NT];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[0][i]) : "v"(ab), "n"(2 * i * TK * 4));
-#pragma unroll
-      for (int j = 0; j < NT; ++j) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gv[0][i][j]) : "v"(gb_), "n"(2 * i * 256 + 128 * j));
-    }
-#pragma unroll
-    for (int h = 0; h < W3R / 16; ++h) {
-      lds_wait(av[h & 1], gv[h & 1]);
-      if (h + 1 < W3R / 16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(av[(h + 1) & 1][i]) : "v"(ab), "n"((16 * (h + 1) + 2 * i) * TK * 4));
-#pragma unroll
-          for (int j = 0; j < NT; ++j)
-            asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(gv[(h + 1) & 1][i][j]) : "v"(gb_), "n"((16 * (h + 1) + 2 * i) * 256 + 128 * j));
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 8; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[h & 1][i], gv[h & 1][i][j], acc[j], 0, 0, 0);
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < NT; ++j) {
-    const int n = n0 + wn * (32 * NT) + 32 * j + (lane & 31);
-    if (n < P.N) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int k = k0 + wk * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        if (k < P.K) atomicAdd(const_cast<float*>(P.B) + (int64_t)k * P.b_k + (int64_t)n * P.b_n, P.alpha * acc[j][i]);
-      }
-    }
-  }
-}
-
-template <int W3R, int W3S, int OCC>
-__global__ __launch_bounds__(256, OCC) void gemm_wgrad3_kernel(const GemmBatch gb) {
-  __shared__ __attribute__((aligned(16))) float As[W3S * W3R * 128];
-  __shared__ __attribute__((aligned(16))) float Gs[W3S * W3R * 64];
-  const BlockProblem bp_ = fetch_problem(gb);
-  if (bp_.P.K > 64) gemm_wgrad3_body<4, W3R, W3S>(bp_, As, Gs);
-  else gemm_wgrad3_body<2, W3R, W3S>(bp_, As, Gs);
-}
-
+#include "../../tools/experiments/gemm_wgrad3_kernel.inc"       // (debug build only: the LDS-ring weight-gradient experiment)
 #endif  // E3K_DEBUG_KNOBS
 
 // ---------------------------------------------------------------------------------------

@@ -296,7 +296,121 @@ __global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __
   *out = acc;
 }
 
+// ---- a-posteriori bound of the interpolation error, on the device, per weight COLUMN ---------------------------------------
+// Cubic Lagrange interpolation on knots h apart is off by at most 3/128 h^4 max|f|; on the table h^4 f is the fourth
+// difference, so for column c
+//     err_c <= 3/128 max_i |T[i+4,c] - 4 T[i+3,c] + 6 T[i+2,c] - 4 T[i+1,c] + T[i,c]|
+// and the estimate is max_c err_c / max(max_i |T[i,c]|, floor * max|T|): relative to the column's OWN scale (a column a thousand
+// times smaller than the largest must not hide a thousand times the relative error behind it), floored at `floor` of the table's
+// largest entry (a column that contributes nothing has no relative error worth a veto).  One launch for up to 16 tables (the
+// radial stack's layers): a workgroup = 64 columns x 4 row quarters; the LAST workgroup of a table (ticket counter in the
+// table's state) reduces the per-column maxima to the estimate.  state [4]: [0] running maximum of the estimate since the host
+// last reset it (what a replayed HIP graph leaves behind: the captured step never re-enters Python), [1] the estimate of this
+// launch, [2] ticket counter (self-resetting), [3] unused.  A non-finite table entry gives +inf.
+struct GuardArgs {
+  const float* T[16];
+  float* state[16];
+  float* scratch[16];     // [2 W]: column maxima of |T| and of |fourth difference|
+  int32_t W[16];
+  int32_t rows;
+  float floor_rel, c4;
+};
+
+__device__ __forceinline__ void atomic_max_pos(float* p, float v) {      // v >= 0 (or +inf): the bit patterns order like the values
+  atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
+}
+
+__global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
+  __shared__ float s_col[4][64], s_d4[4][64];
+  __shared__ int s_last;
+  const int tb = blockIdx.y;
+  const int W = a.W[tb];
+  const int n_chunks = (W + 63) / 64;
+  if ((int)blockIdx.x >= n_chunks) return;
+  const float* __restrict__ T = a.T[tb];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int col = blockIdx.x * 64 + lane;
+  const int rows = a.rows;
+  // row quarter q covers fourth differences starting at rows [lo, hi): reads rows lo .. hi + 3
+  const int n_d4 = rows - 4;
+  const int per = (n_d4 + 3) / 4;
+  const int lo = q * per, hi = (lo + per < n_d4) ? lo + per : n_d4;
+  float cmax = 0.f, dmax = 0.f;
+  bool bad = false;
+  if (col < W && lo < hi) {
+    float v0 = T[(int64_t)lo * W + col], v1 = T[(int64_t)(lo + 1) * W + col], v2 = T[(int64_t)(lo + 2) * W + col],
+          v3 = T[(int64_t)(lo + 3) * W + col];
+    cmax = fmaxf(fmaxf(fabsf(v0), fabsf(v1)), fmaxf(fabsf(v2), fabsf(v3)));
+    bad = !(fabsf(v0) < INFINITY) || !(fabsf(v1) < INFINITY) || !(fabsf(v2) < INFINITY) || !(fabsf(v3) < INFINITY);
+    for (int i = lo; i < hi; ++i) {
+      const float v4 = T[(int64_t)(i + 4) * W + col];
+      bad = bad || !(fabsf(v4) < INFINITY);
+      cmax = fmaxf(cmax, fabsf(v4));
+      const float d4 = (v4 + v0) - 4.f * (v3 + v1) + 6.f * v2;
+      dmax = fmaxf(dmax, fabsf(d4));
+      v0 = v1; v1 = v2; v2 = v3; v3 = v4;
+    }
+  }
+  s_col[q][lane] = bad ? INFINITY : cmax;
+  s_d4[q][lane] = bad ? INFINITY : dmax;
+  __syncthreads();
+  float* __restrict__ scratch = a.scratch[tb];
+  if (q == 0 && col < W) {
+    scratch[col] = fmaxf(fmaxf(s_col[0][lane], s_col[1][lane]), fmaxf(s_col[2][lane], s_col[3][lane]));
+    scratch[W + col] = fmaxf(fmaxf(s_d4[0][lane], s_d4[1][lane]), fmaxf(s_d4[2][lane], s_d4[3][lane]));
+  }
+  __threadfence();
+  __syncthreads();
+  int* counter = reinterpret_cast<int*>(a.state[tb] + 2);
+  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == n_chunks - 1) ? 1 : 0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  // the table's last workgroup: global maximum, then the worst column
+  float g = 0.f;
+  for (int c = threadIdx.x; c < W; c += 256) g = fmaxf(g, __builtin_nontemporal_load(scratch + c));
+  g = wave_max_f(g);
+  __shared__ float s_red[4];
+  if (lane == 0) s_red[q] = g;
+  __syncthreads();
+  g = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float fl = fmaxf(a.floor_rel * g, 1e-30f);
+  float est = 0.f;
+  for (int c = threadIdx.x; c < W; c += 256) {
+    const float cm = __builtin_nontemporal_load(scratch + c), dm = __builtin_nontemporal_load(scratch + W + c);
+    const float e = (dm < INFINITY && cm < INFINITY) ? a.c4 * dm / fmaxf(cm, fl) : INFINITY;
+    est = fmaxf(est, e);
+  }
+  est = wave_max_f(est);
+  __syncthreads();
+  if (lane == 0) s_red[q] = est;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    est = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    a.state[tb][1] = est;
+    atomic_max_pos(a.state[tb], est);
+    *counter = 0;
+  }
+}
+
 }  // namespace e3k
+
+extern "C" int e3k_rtable_guard(const float* const* tables, float* const* states, float* const* scratch, const int32_t* widths,
+                                int32_t n, int32_t rows, float floor_rel, void* stream) {
+  if (!tables || !states || !scratch || !widths || n <= 0 || n > 16 || rows < 0 || !(floor_rel >= 0.f)) return E3K_ERR_INVALID;
+  if (rows < 5) return E3K_OK;      // no fourth difference to look at
+  e3k::GuardArgs a{};
+  int wmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!tables[i] || !states[i] || !scratch[i] || widths[i] <= 0) return E3K_ERR_INVALID;
+    a.T[i] = tables[i]; a.state[i] = states[i]; a.scratch[i] = scratch[i]; a.W[i] = widths[i];
+    wmax = widths[i] > wmax ? widths[i] : wmax;
+  }
+  a.rows = rows; a.floor_rel = floor_rel; a.c4 = 3.0f / 128.0f;
+  hipLaunchKernelGGL(e3k::rtable_guard_kernel, dim3((unsigned)((wmax + 63) / 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
 
 extern "C" int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K) {
   const int64_t n_chunks = (E + e3k::RT_CHUNK - 1) / e3k::RT_CHUNK;

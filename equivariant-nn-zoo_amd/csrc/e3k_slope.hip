@@ -253,16 +253,20 @@ __global__ __launch_bounds__(256) void slope_wgrad_kernel(SlopeBatch b, int R, i
   const SlopeNet& net = b.net[blockIdx.y];
   const int l = blockIdx.z;
   if (l == n_hidden) {      // the Bessel frequencies: one WAVE per frequency, its lanes stride the rows of all the nets (fixed order)
-    const int f = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (!g_bessel || f >= k0 || blockIdx.y != 0) return;
-    double s = 0.0;
-    for (int nn = 0; nn < (int)gridDim.y; ++nn) {
-      const double* wb = b.net[nn].ws + ws_level_offset(n_hidden, R, k0, H);
-      for (int row = lane; row < R; row += 64) s += wb[(int64_t)row * k0 + f];
-    }
+    // (frequencies strided over the grid: k0 may be up to H = 64 while gridDim.x * 4 = 32 -- ADVICE r4: with one frequency per wave
+    //  and no stride the slope table's share of g_bessel[32:] was silently dropped)
+    const int lane = threadIdx.x & 63;
+    if (!g_bessel || blockIdx.y != 0) return;
+    for (int f = blockIdx.x * 4 + (threadIdx.x >> 6); f < k0; f += (int)gridDim.x * 4) {
+      double s = 0.0;
+      for (int nn = 0; nn < (int)gridDim.y; ++nn) {
+        const double* wb = b.net[nn].ws + ws_level_offset(n_hidden, R, k0, H);
+        for (int row = lane; row < R; row += 64) s += wb[(int64_t)row * k0 + f];
+      }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) g_bessel[f] += (float)s;
+      for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+      if (lane == 0) g_bessel[f] += (float)s;
+    }
     return;
   }
   // hidden layer l: g_W[k, j] = sum_rows a[row][k] gz[row][j] + a'[row][k] gz'[row][j] -- a [kl x R] x [R x H] product pair in

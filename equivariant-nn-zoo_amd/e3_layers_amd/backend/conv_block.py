@@ -36,7 +36,6 @@ AHEAD_STATS = [0]      # look-ahead results consumed (tests)
 # self-connection + linear_1 (both read the node features).  Measured against one call per operator: 256 molecules 5.73
 # vs 5.79 ms, 32 molecules 3.45 vs 3.38 ms (host-bound either way) -- launches per step 263 -> 228.
 MERGE = 1
-BWD_W_ON_MAIN = _knob("E3K_BLOCK_BWDW_MAIN")    # 1: tp_bwd_w behind tp_bwd_x on the main stream (as composed); 0: beside it on the radial stream (-0.3..0.6 % per step, but the two then stretch each other: their event-timed durations double)
 
 
 class ConvBlockPlan:

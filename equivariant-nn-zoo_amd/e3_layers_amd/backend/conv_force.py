@@ -47,12 +47,26 @@ ENABLED = _knob("E3K_FORCE_BLOCK")
 MATERIALIZE = _knob("E3K_FORCE_MATERIALIZE")
 STATS = [0, 0, 0]      # forwards, first backwards (create_graph), u-sweeps (tests)
 _WARNED = [False]
+_DECLINE = [0]
+
+
+class declined:
+    """``with conv_force.declined():`` -- layers built inside take the composed path.  ``GradientOutput`` uses it when the
+    differentiation variable required grad BEFORE it was called (the caller wants d loss / d pos of a force loss: relaxation,
+    adversarial or structure gradients -- third derivatives of the layer, which the block does not form; ADVICE r4: it used to
+    hand back a partial gradient behind a one-time warning)."""
+
+    def __enter__(self):
+        _DECLINE[0] += 1
+
+    def __exit__(self, *exc):
+        _DECLINE[0] -= 1
 
 
 def supported(plan: ConvBlockPlan, dev) -> bool:
     """Layers the force block serves: keyed self-connection inside the block, a tensor-product plan with the table's
     second-order kernels (channel-complete, one wave per group: the l_max <= 2 models)."""
-    if not ENABLED or plan is None or plan.addend or plan.sc_spec is None:
+    if not ENABLED or _DECLINE[0] or plan is None or plan.addend or plan.sc_spec is None:
         return False
     hit = plan.__dict__.get("_force_ok")
     if hit is None:
@@ -212,7 +226,9 @@ class ForceBlockFn(torch.autograd.Function):
         # ---- first-order backward (the final pass of a training step: "v-sweep"; or forces without create_graph)
         topo, groups, bins, tp = cfg.topo, cfg.groups, cfg.bins, plan.tp_plan
         params = not ops.INPUTS_ONLY
-        want_e = (need[4] or need[5]) and not (ops.PARAMS_ONLY and cfg.sh_data)
+        # (behind a u-sweep -- cotangents of x1 / conv arrive -- the geometry gradient would lack the third-derivative terms: none is
+        #  handed back rather than a partial one; the u-sweep has said so)
+        want_e = (need[4] or need[5]) and not (ops.PARAMS_ONLY and cfg.sh_data) and g_x1_in is None and g_conv_in is None
         dev, n = conv.device, conv.shape[0]
         if g_y is not None:
             g_conv = ops._gate_bwd_raw(conv, L.f32c(g_y), plan.gate_spec, cfg.out_cf)

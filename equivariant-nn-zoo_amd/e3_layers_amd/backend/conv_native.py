@@ -201,8 +201,6 @@ class _Carve:
 # interpolate their path weights inside tp_fwd / tp_bwd_x: no interpolation pass, no w[E, W] (0.2-0.3 GB a layer at 256
 # molecules) written, read twice and kept for the backward
 TP_TABLE = _knob("E3K_TP_TABLE")
-# 1 (experiment): the forward self-connection GEMM goes out with linear_1 on the main stream instead of beside the tensor product
-FWD_SC_MAIN = _knob("E3K_FWD_SC_MAIN")
 # 1: the addend of an addend-form layer (ConvBlockPlan.addend) is accumulated on in place instead of being copied into the block's buffer
 ADDEND_INPLACE = _knob("E3K_ADDEND_INPLACE")
 
@@ -337,9 +335,9 @@ class RadialStackFn(torch.autograd.Function):
         L.check(L.load().e3k_radial_stack_fwd(handles, rads, n, L.stream_ptr()), "e3k_radial_stack_fwd")
         STACK_STATS[0] += 1
         STACK_STATS[1] = n
-        if use_table:
-            for plan, out, i in zip(plans, outs, range(n)):
-                radial_table.guard(plan.guard_key if plan.guard_key is not None else weights[i * per], out)
+        if use_table:      # one launch for the tables of all the layers (recorded with every build while a graph is captured)
+            radial_table.guard_many([(plan.guard_key if plan.guard_key is not None else weights[i * per], out, False)
+                                     for i, (plan, out) in enumerate(zip(plans, outs))])
         hps, slopes = [], []
         if slope is not None:
             if not use_table:
@@ -353,8 +351,8 @@ class RadialStackFn(torch.autograd.Function):
                                                   (C.c_void_p * n)(*[t.data_ptr() for t in slopes]), L.stream_ptr()),
                     "e3k_radial_slope_fwd")
             ctx.n_slope = n
-            for plan, d_tab, i in zip(plans, slopes, range(n)):
-                radial_table.guard(plan.guard_key if plan.guard_key is not None else weights[i * per], d_tab, slope=True)
+            radial_table.guard_many([(plan.guard_key if plan.guard_key is not None else weights[i * per], d_tab, True)
+                                     for i, (plan, d_tab) in enumerate(zip(plans, slopes))])
         if keep:
             extra = (knots_r, bw) if slope is not None else ()
             ctx.save_for_backward(rows, *bufs, *weights, *hps, *extra)
@@ -549,7 +547,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         main = torch.cuda.current_stream(dev)
         fork = bool(fork) and not torch.cuda.is_current_stream_capturing()
         side = ops.side_stream(dev, 0) if fork else main
-        side2 = ops.side_stream(dev, 1) if (fork and not FWD_SC_MAIN) else main
+        side2 = ops.side_stream(dev, 1) if fork else main
         keep = any(ctx.needs_input_grad)
         has_sc = plan.sc_spec is not None
         addend = None

@@ -73,8 +73,14 @@ def _check_pending_flags() -> None:
     asynchronously and is looked at once its copy has landed -- by the next build, by the optimizer step
     (``FusedAdamEMA.step`` polls), or by ``check_indices()`` (blocking: evaluation, before a graph capture, tests)."""
     while _pending_flags and _pending_flags[0][0].query():
-        _, host, msg = _pending_flags.pop(0)
+        _, host, msg, sticky = _pending_flags.pop(0)
         if int(host[0]) != 0:
+            if sticky is not None:
+                # a persistent (captured-step) flag: reported ONCE, then cleared -- a caller that catches the error and skips the
+                # batch must not see it again on every later, valid batch (ADVICE r4).  Copies of the same flag already in flight
+                # are dropped with it.
+                sticky.zero_()
+                _pending_flags[:] = [p for p in _pending_flags if p[3] is not sticky]
             raise ValueError(msg)
 
 
@@ -107,16 +113,21 @@ def capture_flag(device) -> torch.Tensor:
     return f
 
 
-def poll_capture_flags() -> None:
-    """After a graph replay: send the persistent flags to the host (no sync; they are looked at with the other deferred flags)."""
-    for f in _capture_flags.values():
-        defer_flag(f, "a batch fed through a captured (graph-replayed) step held node ids outside [0, num_nodes) in its edge_index "
-                      "(such edges were attached to node 0) or row keys outside [0, n_keys) (such rows were dropped from the keyed "
-                      "self-connection)")
+def poll_capture_flags(device=None) -> None:
+    """After a graph replay on ``device`` (default: the current one): send that device's persistent flag to the host (no sync; it
+    is looked at with the other deferred flags, and cleared once it has been reported)."""
+    idx = torch.cuda.current_device() if device is None else (device.index if device.index is not None else torch.cuda.current_device())
+    f = _capture_flags.get(idx)
+    if f is not None:
+        with torch.cuda.device(idx):
+            defer_flag(f, "a batch fed through a captured (graph-replayed) step held node ids outside [0, num_nodes) in its edge_index "
+                          "(such edges were attached to node 0) or row keys outside [0, n_keys) (such rows were dropped from the keyed "
+                          "self-connection)", sticky=f)
 
 
-def defer_flag(flag: torch.Tensor, message: str) -> None:
-    """Registers a device int32 [1] error flag (non-zero = bad input) to be read back without a sync."""
+def defer_flag(flag: torch.Tensor, message: str, sticky: Optional[torch.Tensor] = None) -> None:
+    """Registers a device int32 [1] error flag (non-zero = bad input) to be read back without a sync.  ``sticky``: the persistent
+    flag this copy was taken from (zeroed when a non-zero copy is reported)."""
     global _flag_ring, _flag_next
     if torch.cuda.is_current_stream_capturing():
         # recorded into the graph: every replay folds this build's flag into the device's persistent one (sticky: a bad batch
@@ -136,7 +147,7 @@ def defer_flag(flag: torch.Tensor, message: str) -> None:
     host.copy_(flag, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
-    _pending_flags.append((ev, host, message))
+    _pending_flags.append((ev, host, message, sticky))
 
 
 def _build_topology_device(edge_index: torch.Tensor, num_nodes: int) -> GraphTopo:

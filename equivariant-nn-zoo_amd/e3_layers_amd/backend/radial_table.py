@@ -171,26 +171,46 @@ def applicable(edge_radial, w_last=None) -> bool:
 
 # ---- a-posteriori guard of the interpolation error ---------------------------------------------------------------------
 # Cubic Lagrange interpolation on knots h apart, evaluated in the middle interval of its four knots, is off by at most
-# 3/128 h^4 max|f(4)|; on the table itself h^4 f(4) is the fourth finite difference, so
-#     err <= 3/128 max|T[i+4] - 4 T[i+3] + 6 T[i+2] - 4 T[i+1] + T[i]|
-# -- read off the table rows the forward has just computed, relative to max|T|.  ~1e-7 for the shipped models at random
-# init on 512 knots (8 Bessel functions through a smooth MLP: the fp32 rounding of the rows, whose fourth difference carries
-# 16 eps, is most of it); it grows like (frequency x weight scale)^4, so a 32-function basis, grown Bessel frequencies or
-# large trained weights can push it towards the 1e-5 parity budget.  The bound is evaluated on the device the first time an
-# MLP's table is built and every GUARD_EVERY-th time after (a few elementwise passes over 4 MB on the radial stream), copied
-# to pinned memory without a sync and looked at on a later call: above GUARD_TOL the table is switched off for that MLP
-# (per-edge evaluation from then on) with a warning.  The slope table of force training has a guard of its own (same rule on
-# D, relative to max|D|: what is interpolated there is the slope).
+# 3/128 h^4 max|f(4)|; on the table itself h^4 f(4) is the fourth finite difference, so for weight column c
+#     err_c <= 3/128 max_i |T[i+4,c] - 4 T[i+3,c] + 6 T[i+2,c] - 4 T[i+1,c] + T[i,c]|
+# -- read off the table rows the forward has just computed (``e3k_rtable_guard``: one launch for all the tables of a radial
+# stack), relative to the column's OWN largest entry, floored at GUARD_COL_FLOOR of the table's largest (round 5: until then the
+# bound was global, max|d4 T| / max|T| -- a column a thousand times smaller than the largest could be off by 1e-3 relative and
+# pass).  ~1e-7 for the shipped models at random init on 512 knots (8 Bessel functions through a smooth MLP: the fp32 rounding of
+# the rows, whose fourth difference carries 16 eps, is most of it); it grows like (frequency x weight scale)^4, so a 32-function
+# basis, grown Bessel frequencies or large trained weights can push it towards the 1e-5 parity budget.
+#
+# Who looks at it:
+#   eager steps     the estimate of the first build and of every GUARD_EVERY-th after travels to pinned memory without a sync and
+#                   is read on a later call;
+#   replayed steps  (``run/graph_step.CapturedStep``: a HIP graph never re-enters this module) the kernel is PART of the captured
+#                   step: every replay folds its estimate into a persistent per-MLP device maximum, which the replay loop sends
+#                   to the host every GUARD_EVERY-th replay (``poll_replay``) -- the weights move under Adam while the graph
+#                   replays, and the bound grows like scale^4.
+# Above GUARD_TOL the table is switched off for that MLP (per-edge evaluation from then on, a warning, ``VETO_EPOCH`` advances:
+# a CapturedStep re-captures itself without the table).  The slope table of force training has a guard of its own (same rule on
+# D, relative to its own columns: what is interpolated there is the slope).
 GUARD_TOL = _knob("E3K_RADIAL_TABLE_TOL")
 GUARD_EVERY = _knob("E3K_RADIAL_TABLE_CHECK_EVERY")
-_C4 = 3.0 / 128.0
+GUARD_COL_FLOOR = _knob("E3K_RADIAL_TABLE_COL_FLOOR")
+VETO_EPOCH = [0]      # advances whenever a guard switches a table off (captured steps compare it with its value at capture time)
 
 
 class _Guard:
-    __slots__ = ("calls", "pending", "ok", "last", "__weakref__")
+    __slots__ = ("calls", "pending", "ok", "last", "dev", "scratch", "what", "__weakref__")
 
-    def __init__(self):
-        self.calls, self.pending, self.ok, self.last = 0, [], True, None
+    def __init__(self, what: str):
+        self.calls, self.pending, self.ok, self.last, self.what = 0, [], True, None, what
+        self.dev = self.scratch = None      # device state [4] (running max, last estimate, ticket, -) and the kernel's column scratch
+
+    def device_state(self, device, width: int):
+        """Allocated OUTSIDE any capture (persistent across replays); None while capturing if it does not exist yet."""
+        if self.dev is None or self.dev.device != device or self.scratch.numel() < 2 * width:
+            if torch.cuda.is_current_stream_capturing():
+                return None
+            self.dev = torch.zeros(4, dtype=torch.float32, device=device)
+            self.scratch = torch.empty(2 * width, dtype=torch.float32, device=device)
+        return self.dev
 
 
 _GUARDS: dict = {}      # (id(weight), slope) -> (weak reference to the weight, its guard): tensors compare elementwise, so they
@@ -204,12 +224,12 @@ def _guard_of(w_last, slope: bool = False, create: bool = False):
         return hit[1]
     if not create:
         return None
-    g = _Guard()
+    g = _Guard("slope" if slope else "value")
     _GUARDS[key] = (weakref.ref(w_last, lambda _r, key=key: _GUARDS.pop(key, None)), g)
     return g
 
 
-def _poll(g: _Guard, what: str = "value") -> None:
+def _poll(g: _Guard, what: str = None) -> None:
     if torch.cuda.is_current_stream_capturing():
         return                             # Event.query() is not allowed while a stream captures (it would invalidate the capture);
                                            # ``drain_guards()`` empties the lists before CapturedStep starts recording
@@ -220,21 +240,22 @@ def _poll(g: _Guard, what: str = "value") -> None:
             if g.ok:
                 import warnings
 
-                warnings.warn(f"radial knot table ({what}): interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e}: this "
+                warnings.warn(f"radial knot table ({g.what}): interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e}: this "
                               "radial MLP is evaluated per edge from now on (E3K_RADIAL_KNOTS / E3K_RADIAL_KNOTS_SLOPE raise the "
                               "resolution)")
+                VETO_EPOCH[0] += 1
             g.ok = False
 
 
 def drain_guards() -> None:
     """Read back every pending guard estimate (call after a device synchronisation, before a graph capture: no event may be
     queried while the stream records -- ``run/graph_step.CapturedStep`` does)."""
-    for (_, slope), (ref, g) in list(_GUARDS.items()):
+    for _, (ref, g) in list(_GUARDS.items()):
         if ref() is None:
             continue
         for ev, _ in g.pending:
             ev.synchronize()
-        _poll(g, "slope" if slope else "value")
+        _poll(g)
 
 
 def guard_ok(w_last, slope: bool = False) -> bool:
@@ -243,7 +264,7 @@ def guard_ok(w_last, slope: bool = False) -> bool:
     for kind in ((False, True) if slope else (False,)):
         g = _guard_of(w_last, kind)
         if g is not None:
-            _poll(g, "slope" if kind else "value")
+            _poll(g)
             ok = ok and g.ok
     return ok
 
@@ -257,22 +278,92 @@ def guard_error(w_last, slope: bool = False):
     return g.last
 
 
+_HOST_RING = None      # pinned float slots for the read-backs, allocated once (a pinned allocation synchronises the device)
+_HOST_NEXT = 0
+_HOST_SLOTS = 512
+
+
+def _host_slot() -> torch.Tensor:
+    global _HOST_RING, _HOST_NEXT
+    if _HOST_RING is None:
+        _HOST_RING = torch.zeros(_HOST_SLOTS, dtype=torch.float32).pin_memory()
+    slot = _HOST_RING[_HOST_NEXT:_HOST_NEXT + 1]
+    _HOST_NEXT = (_HOST_NEXT + 1) % _HOST_SLOTS
+    return slot
+
+
+def _send(g: _Guard, index: int, reset: bool) -> None:
+    """state[index] -> pinned memory behind everything enqueued on the current stream; ``reset``: the running maximum starts over"""
+    host = _host_slot()
+    host.copy_(g.dev[index:index + 1], non_blocking=True)
+    if reset:
+        g.dev[0:1].zero_()
+    ev = torch.cuda.Event()
+    ev.record()
+    g.pending.append((ev, host))
+
+
+def guard_many(items) -> None:
+    """``items``: [(last-layer weight (the guard's key), table [rows, W], slope: bool)] -- tables of one row count, just computed on
+    the current stream.  Eager: the first call and every GUARD_EVERY-th launch the estimate kernel and send its result home;
+    while a stream captures: the kernel is recorded with EVERY build (each replay then updates the persistent maxima)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    todo = []
+    for w_last, table, slope in items:
+        g = _guard_of(w_last, slope, create=True)
+        g.calls += 1
+        _poll(g)
+        if table.shape[0] < 5 or not table.is_cuda:
+            continue
+        if not capturing and (g.calls - 1) % max(GUARD_EVERY, 1) != 0:
+            continue
+        if g.device_state(table.device, table.shape[1]) is None:
+            continue                       # first seen inside a capture: CapturedStep's eager warm-up creates the states
+        todo.append((g, table.detach()))
+    if not todo:
+        return
+    import ctypes as C
+
+    lib = L.load()
+    by_rows = {}
+    for g, t in todo:                      # (one stack: one row count; value and slope tables of force training share it too)
+        by_rows.setdefault(t.shape[0], []).append((g, t))
+    for rows, group in by_rows.items():
+        for base in range(0, len(group), 16):
+            part = group[base:base + 16]
+            n = len(part)
+            tabs = (C.c_void_p * n)(*[t.data_ptr() for _, t in part])
+            states = (C.c_void_p * n)(*[g.dev.data_ptr() for g, _ in part])
+            scr = (C.c_void_p * n)(*[g.scratch.data_ptr() for g, _ in part])
+            widths = (C.c_int32 * n)(*[t.shape[1] for _, t in part])
+            L.check(lib.e3k_rtable_guard(tabs, states, scr, widths, n, rows, float(GUARD_COL_FLOOR), L.stream_ptr()), "e3k_rtable_guard")
+    if not capturing:
+        for g, _ in todo:
+            _send(g, 1, reset=False)
+
+
 def guard(w_last, table: torch.Tensor, slope: bool = False) -> None:
     """Call with the table just computed (on the stream that computed it)."""
-    g = _guard_of(w_last, slope, create=True)
-    g.calls += 1
-    _poll(g, "slope" if slope else "value")
-    if (g.calls - 1) % max(GUARD_EVERY, 1) != 0 or torch.cuda.is_current_stream_capturing() or table.shape[0] < 5:
-        return
-    with torch.no_grad():
-        t = table.detach()
-        d4 = t[4:] - 4.0 * t[3:-1] + 6.0 * t[2:-2] - 4.0 * t[1:-3] + t[:-4]
-        est = (d4.abs().amax() * _C4 / t.abs().amax().clamp_min(1e-30)).reshape(1)
-        host = torch.empty(1, dtype=torch.float32).pin_memory()
-        host.copy_(est, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record()
-    g.pending.append((ev, host))
+    guard_many([(w_last, table, slope)])
+
+
+def poll_replay(every: int = None) -> bool:
+    """For the loop that replays a captured step (``CapturedStep.__call__``, after the replay, on its stream): looks at the
+    estimates that have arrived, and on the first call and every ``every``-th (default GUARD_EVERY) sends every guard's running
+    maximum home and restarts it.  True when a table has been switched off since the last call (the caller re-captures)."""
+    epoch = VETO_EPOCH[0]
+    every = max(int(GUARD_EVERY if every is None else every), 1)
+    _REPLAYS[0] += 1
+    for _, (ref, g) in list(_GUARDS.items()):
+        if ref() is None or g.dev is None:
+            continue
+        _poll(g)
+        if (_REPLAYS[0] - 1) % every == 0 and g.ok and g.dev.device.index == torch.cuda.current_device():
+            _send(g, 0, reset=True)
+    return VETO_EPOCH[0] != epoch
+
+
+_REPLAYS = [0]
 
 
 def interp_fwd_raw(table: torch.Tensor, bins: KnotBins) -> torch.Tensor:

@@ -29,9 +29,6 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_ADDEND_INPLACE": (1, "path", "the addend tensor itself is the block's pre-gate buffer (no copy)"),
     "E3K_ADDEND_FORK": (1, "path", "addend blocks fork their radial branch under the same edge-count rule as keyed blocks"),
     "E3K_BLOCK_LOOK_AHEAD": (1, "path", "a forked layer issues the next layer's radial branch behind its own tensor product"),
-    "E3K_BLOCK_BWDW_MAIN": (1, "path", "Python block only: tp_bwd_w behind tp_bwd_x on the main stream"),
-    "E3K_RADIAL_AHEAD": (0, "path", "composed path only: the next convolution's radial MLP issued one layer early (measured: no gain)"),
-    "E3K_FWD_SC_MAIN": (0, "path", "native layer: forward self-connection GEMM on the main stream (measured: neutral)"),
     "E3K_CF_CHAIN": (1, "path", "consecutive MessagePassing layers hand their features over channel-fastest"),
     "E3K_CF_CHAIN_NORM": (1, "path", "... also through LayerNormalization"),
     "E3K_FUSED_MLP": (1, "path", "hidden chain of the radial MLP in one launch (csrc/e3k_mlp.hip); 0: one GEMM + activation per layer"),
@@ -55,7 +52,8 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_RADIAL_KNOTS_SLOPE": (512, "accuracy", "... of the value + slope tables of force training"),
     "E3K_RADIAL_MIN_EDGES_PER_KNOT": (4.0, "threshold", "the table applies from this many edges per table row"),
     "E3K_RADIAL_TABLE_TOL": (1e-6, "accuracy", "a-posteriori interpolation-error bound above which an MLP's table is switched off"),
-    "E3K_RADIAL_TABLE_CHECK_EVERY": (64, "debug", "the guard is evaluated every this-many table builds"),
+    "E3K_RADIAL_TABLE_CHECK_EVERY": (64, "debug", "eager: the guard is evaluated every this-many table builds; replayed graphs: its running maximum is read every this-many replays"),
+    "E3K_RADIAL_TABLE_COL_FLOOR": (2.0 ** -7, "accuracy", "the guard's bound is relative to each weight column's own scale, floored at this fraction of the table's largest entry"),
     # ---- debug ----
     "E3K_HOST_TIMING": (0, "debug", "host seconds inside the layer functions (tools/host_split.py)"),
     "E3K_LIB": ("", "debug", "path of the shared library to load instead of csrc/libe3k.so (make dbg: libe3k_dbg.so)"),

@@ -56,15 +56,8 @@ FORK_MIN_EDGES = _knob("E3K_FORK_MIN_EDGES")
 # slack.  Layers on the table fork from 60 000 edges; bench.py times both layouts and keeps the faster (E3K_FORK_MIN_EDGES_TABLE).
 FORK_MIN_EDGES_TABLE = _knob("E3K_FORK_MIN_EDGES_TABLE")
 _FORK_REF_WIDTH = 1920
-# 1: the radial MLP of the NEXT convolution (it depends on the edge embedding alone) is issued on the side stream
-# as soon as this layer's own has been, so it runs under this layer's tensor product instead of in front of the next.
-# Measured at 256 molecules: step 7.06 -> 6.91 ms (-2 %), but the HBM-bound tensor product then shares the memory
-# system with an MFMA GEMM that writes 0.5 GB: 134 -> 182 us per launch (roofline 0.64 -> 0.47).  Opt-in; issuing it
-# only after the tensor product (under the node-side launches) changed nothing.
-RADIAL_AHEAD = _knob("E3K_RADIAL_AHEAD")
 # 1: consecutive MessagePassing layers pass their node features in the channel-fastest layout (MessagePassing._emit_cf)
 CF_CHAIN = _knob("E3K_CF_CHAIN")
-AHEAD_STATS = [0]     # look-ahead weights consumed (tests)
 # 1: the radial MLPs of all the layers that read one edge embedding run as one batch on the knot table (first layer of
 # the chain), see MessagePassing._stack_rows
 RADIAL_STACK = _knob("E3K_RADIAL_STACK")
@@ -140,15 +133,6 @@ class FactorizedConvolution(Module):
         self._out_blocks = tuple(irreps_blocks(f_out))
 
     _next_conv = None      # set by SequentialGraphNetwork
-    _prefetched = None     # (edge embedding, weights, ready event, grad mode) issued by the previous convolution
-
-    @staticmethod
-    def _issue_ahead(nxt, radial, side, main):
-        with ops.on_stream(side, main):
-            w_next = nxt.fc(_stream_alias(radial, side))
-            ev_next = torch.cuda.Event()
-            ev_next.record(side)
-        nxt._prefetched = (radial, w_next, ev_next, torch.is_grad_enabled())
 
     def _fork_pays(self, n_edges: int, table: bool = False) -> bool:
         # enough per-edge weights in this layer, or so many edges that even the narrow first layer is worth it
@@ -175,22 +159,14 @@ class FactorizedConvolution(Module):
                 main = torch.cuda.current_stream(x.device)
                 side = ops.side_stream(x.device)
                 radial = data["edge_radial"]
-                pref, self._prefetched = self._prefetched, None
-                if pref is not None and pref[0] is radial and pref[3] == torch.is_grad_enabled():
-                    weight, ready = pref[1], pref[2]      # issued one layer ago
-                    AHEAD_STATS[0] += 1
-                else:
-                    side.wait_stream(main)
-                    with ops.on_stream(side, main):
-                        weight = (radial_table.table_weights(self.fc, radial) if table
-                                  else self.fc(_stream_alias(radial, side)))
-                        ready = torch.cuda.Event()
-                        ready.record(side)
-                nxt = self._next_conv if RADIAL_AHEAD else None
-                if nxt is not None and not nxt._fork_pays(radial.shape[0], bool(table)):
-                    nxt = None
-                if nxt is not None:
-                    self._issue_ahead(nxt, radial, side, main)
+                # (issuing the NEXT convolution's radial MLP here, one layer early -- rounds 1-4's E3K_RADIAL_AHEAD -- measured no gain
+                #  on this composed path and was removed in round 5; the fused block has its own look-ahead)
+                side.wait_stream(main)
+                with ops.on_stream(side, main):
+                    weight = (radial_table.table_weights(self.fc, radial) if table
+                              else self.fc(_stream_alias(radial, side)))
+                    ready = torch.cuda.Event()
+                    ready.record(side)
                 x_cf = x if in_cf else ops.relayout(x, self._in_blocks, True)
                 sc = None
                 if self.sc is not None and FWD_FORK_SC:

@@ -28,7 +28,16 @@ class GradientOutput(Module):
         wrt = self.inputKeyMap(data)["x"]
         old = wrt.requires_grad
         wrt.requires_grad_(True)
-        output = self.func(data)
+        if old and self.training:
+            # the caller differentiates w.r.t. ``x`` itself (it required grad before this call) and the graph of the gradient is
+            # kept: d loss / d x of a loss on the gradients needs third derivatives of the layers -- the force block
+            # (backend/conv_force.py) does not form them, the composed per-kernel path does
+            from ..backend import conv_force
+
+            with conv_force.declined():
+                output = self.func(data)
+        else:
+            output = self.func(data)
         # only d y / d x is asked for: the backward functions skip every Parameter gradient of this pass
         with ops.inputs_only_backward():
             (grad,) = torch.autograd.grad(self.inputKeyMap(output)["y"].sum(), wrt, create_graph=self.training)

@@ -28,37 +28,61 @@ class CapturedStep:
         if not torch.cuda.is_available():
             raise RuntimeError("CapturedStep needs a HIP device: there is no CPU fallback for graph replay")
         self.fn = fn
-        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
-        # warm-up on a side stream: lazy initialisation (plans, side streams, allocator pools) must not be captured
+        self.generators = tuple(generators)
+        self.dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.recaptures = 0      # how often a knot-table veto made this step record itself again (tests, logs)
+        self._capture(max(1, warmup))
+
+    def _eager(self, n: int):
+        """``n`` eager runs of ``fn`` on a side stream: lazy initialisation (plans, side streams, allocator pools, the guards' device
+        state) must not be captured."""
+        dev = self.dev
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
+        out = None
         with torch.cuda.stream(side):
-            for _ in range(max(1, warmup)):
-                out = fn()
+            for _ in range(n):
+                out = self.fn()
         torch.cuda.current_stream(dev).wait_stream(side)
-        del out
+        return out
+
+    def _capture(self, warmup: int, keep_last: bool = False):
+        dev = self.dev
+        out = self._eager(warmup)
+        if not keep_last:
+            out = None
         torch.cuda.synchronize(dev)
-        from ..backend.graph import check_indices
+        from ..backend.graph import capture_flag, check_indices
 
         check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
         from ..backend import radial_table
 
         radial_table.drain_guards()      # ... and the knot-table guards' pending read-backs (no Event.query() inside a capture)
-        from ..backend.graph import capture_flag
-
         capture_flag(dev)                # the persistent flag the captured index checks fold into (ADVICE r3: a bad batch fed
                                          # through a replay must raise, as it does on the eager path)
+        self._veto_epoch = radial_table.VETO_EPOCH[0]
         self.graph = torch.cuda.CUDAGraph()
-        for g in generators:
+        for g in self.generators:
             self.graph.register_generator_state(g)
         with torch.cuda.graph(self.graph):
-            self.out = fn()
+            self.out = self.fn()
+        return out
 
     def __call__(self):
-        self.graph.replay()
+        from ..backend import radial_table
         from ..backend.graph import poll_capture_flags
 
-        poll_capture_flags()             # (one 4-byte async copy: read by the next build / optimizer step / check_indices())
+        if radial_table.VETO_EPOCH[0] != self._veto_epoch:
+            # A knot table this graph interpolates from has been switched off (its error bound, which the captured step evaluates on
+            # the device with every replay, passed the tolerance: the weights moved under the optimizer).  The graph still holds the
+            # table kernels: this call runs the step EAGERLY once (the vetoed layer takes its per-edge path -- also the warm-up of
+            # that path) and records the step again; later calls replay the new graph.
+            self.recaptures += 1
+            out = self._capture(1, keep_last=True)
+            return out
+        self.graph.replay()
+        poll_capture_flags(self.dev)     # (one 4-byte async copy: read by the next build / optimizer step / check_indices())
+        radial_table.poll_replay()       # every N-th replay: the guards' running maxima travel home (no sync)
         return self.out
 
 

@@ -23,18 +23,31 @@ from ..backend import lib as L
 from .parallel import FlatGradients, flat_layout
 
 
-def layout_moves(mine, theirs):
+def layout_moves(mine, theirs, assume_same_order: bool = False):
     """How to copy a checkpoint's flat vectors (layout ``theirs``) into an optimizer's (layout ``mine``): None = identical
-    layouts (plain copies), else [(dst offset, src offset, numel)] matched by name; raises when the two cannot be matched."""
+    layouts (plain copies), else [(dst offset, src offset, numel)] matched by name; raises when the two cannot be matched.
+    ``assume_same_order``: the caller vouches that the checkpoint was written for the same parameters in the same order -- the
+    way in for checkpoints without a layout (written before round 4) or without names."""
     if theirs is None:
+        if assume_same_order:
+            return None
         raise ValueError("checkpoint without a parameter layout (written before round 4): it cannot be told whether its "
-                         "flat vectors follow this optimizer's parameter order -- re-save it with the current code")
+                         "flat vectors follow this optimizer's parameter order -- load it with assume_same_order=True if it was "
+                         "written by an optimizer built over the same parameters in the same order, or re-save it with the current code")
     mine = [(int(o), int(n), tuple(sh), nm) for o, n, sh, nm in mine]
     theirs = [(int(o), int(n), tuple(sh), nm) for o, n, sh, nm in theirs]
     same_shapes = [(o, n, sh) for o, n, sh, _ in mine] == [(o, n, sh) for o, n, sh, _ in theirs]
     named_m, named_t = all(nm is not None for *_, nm in mine), all(nm is not None for *_, nm in theirs)
-    if same_shapes and (not (named_m and named_t) or [nm for *_, nm in mine] == [nm for *_, nm in theirs]):
+    if same_shapes and named_m and named_t and [nm for *_, nm in mine] == [nm for *_, nm in theirs]:
         return None
+    if same_shapes and not (named_m and named_t):
+        # equal shape sequences do not prove equal ORDER (several identical layers: flat_param_order(model) and
+        # model.parameters() hold same-shaped tensors in different places) -- without names on both sides only the caller can tell
+        if assume_same_order or len({(n, sh) for _, n, sh, _ in mine}) == len(mine):      # (all shapes distinct: the order IS determined)
+            return None
+        raise ValueError("checkpoint and optimizer have the same sequence of parameter shapes but names are missing on one side and "
+                         "several parameters share a shape: the order cannot be verified -- build both FusedAdamEMA objects with "
+                         "names=, or load with assume_same_order=True")
     if named_m and named_t:
         src = {nm: (o, n, sh) for o, n, sh, nm in theirs}
         if set(src) != {nm for *_, nm in mine}:
@@ -168,12 +181,15 @@ class FusedAdamEMA:
                               ema_decay=self.ema_decay, ema_use_num_updates=self.ema_use_num_updates,
                               max_grad_norm=self.max_grad_norm, skip_nonfinite=self.skip_nonfinite)}
 
-    def load_state_dict(self, sd: dict) -> None:
+    def load_state_dict(self, sd: dict, assume_same_order: bool = False) -> None:
         """The flat vectors carry no structure of their own: the checkpoint's ``layout`` must be this optimizer's (same
         parameters in the same order), or both sides must carry names, in which case every slice is copied to where its
         parameter lives here.  Anything else raises -- equal lengths do not make two layouts the same
-        (``flat_param_order(model)`` and ``model.parameters()`` hold the same tensors in different orders)."""
-        moves = layout_moves(self.layout(), sd.get("layout"))
+        (``flat_param_order(model)`` and ``model.parameters()`` hold the same tensors in different orders) -- unless the caller
+        passes ``assume_same_order=True`` (layout-less checkpoints of earlier rounds; checkpoints without names)."""
+        moves = layout_moves(self.layout(), sd.get("layout"), assume_same_order)
+        if moves is None and sd["flat"].numel() != self.flat.numel():
+            raise ValueError(f"checkpoint holds {sd['flat'].numel()} parameters, this optimizer {self.flat.numel()}")
 
         def put(dst, src_t):
             if moves is None:

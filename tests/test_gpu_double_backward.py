@@ -364,6 +364,69 @@ def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch,
             assert rel_err(p.grad, grads[n]) < 1e-6, n
 
 
+def test_force_training_shipped_config_matches_oracle(dev):
+    """BASELINE configs[2] AS SHIPPED (``e3_layers/configs/config_energy_force.py:19,37-43``: r_max 5.0 -- value and
+    slope tables of 641 knot rows --, 5 layers, 20 species types, 16 attribute channels) in TRAINING mode (``nn/output.py:31-53``:
+    ``create_graph=True``, the force loss differentiated again), 24 molecules with the SHIPPED thresholds (nothing patched: the batch
+    has more than 4 edges per table row and more than 256 nodes): energies and forces within 1e-5, every parameter gradient within
+    5e-5 of the float64 oracle, all five layers on the force block.  This is the path ``bench.py --config energy_force`` times (the
+    u-sweep / v-sweep on the 640-interval tables)."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.configs import config_energy_force
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.parallel import backward_parameters
+    from e3_layers_amd.utils import build
+
+    tree = config_energy_force.get_config().model_config
+    assert (tree.r_max, tree.num_layers, tree.n_dim, tree.l_max, tree.node_attrs) == (5.0, 5, 64, 2, "16x0e")
+    torch.manual_seed(0)
+    prod = build(tree).to(dev).train()
+    orc = e3ref.build(tree)
+    orc.load_state_dict({k.replace("func.", "func.mods.", 1): v.cpu() for k, v in prod.state_dict().items()})
+    orc = orc.double().train()
+    batch = synth_qm9(2000, 24, r_max=5.0)
+    n_edges, n_nodes = batch["edge_index"].shape[1], batch["pos"].shape[0]
+    rows = radial_table.layout(5.0, radial_table.KNOTS_SLOPE)[0] + 1
+    assert rows == 641 and n_edges >= radial_table.MIN_EDGES_PER_KNOT * rows and n_nodes >= 256, (rows, n_edges, n_nodes)
+    # the oracle first: its energies anchor the energy target (the model carries per-species shifts of -3.7 eV per atom: a target
+    # far from the prediction would make the energy term a thousand times the force term and the test blind to the double backward)
+    data, attrs = batch_to_oracle(batch)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(threads, 32))
+    try:
+        o, _ = orc(data, attrs)
+        gen = torch.Generator().manual_seed(5)
+        f_target = o["forces"].detach() + torch.randn(batch["pos"].shape, dtype=torch.float64, generator=gen)
+        e_target = o["energy"].detach() + torch.randn(o["energy"].shape, dtype=torch.float64, generator=gen)
+        loss_r = ((o["forces"] - f_target) ** 2).mean() + ((o["energy"] - e_target) ** 2).mean()
+        loss_r.backward()
+    finally:
+        torch.set_num_threads(threads)
+    before = list(conv_force.STATS)
+    out = prod(batch.clone().to(dev))
+    loss = ((out["forces"] - f_target.float().to(dev)) ** 2).mean() + ((out["energy"] - e_target.float().to(dev)) ** 2).mean()
+    backward_parameters(loss, list(prod.parameters()))
+    torch.cuda.synchronize()
+    assert [a - b for a, b in zip(conv_force.STATS, before)] == [5, 5, 5]      # five force blocks: forward, first backward, u-sweep
+    err_f, err_e = rel_err(out["forces"], o["forces"]), rel_err(out["energy"], o["energy"])
+    record_measured("force_shipped_config", molecules=24, edges=n_edges, forces=err_f, energy=err_e)
+    assert err_e < 1e-5 and err_f < 1e-5, (err_e, err_f)
+    ref_params = dict(orc.named_parameters())
+    checked, worst, worst_name = 0, 0.0, None
+    for name, p in prod.named_parameters():
+        rp = ref_params[name.replace("func.", "func.mods.", 1)]
+        if rp.grad is None or float(rp.grad.abs().max()) == 0.0:
+            continue
+        assert p.grad is not None, name
+        err = rel_err(p.grad, rp.grad)
+        if err > worst:
+            worst, worst_name = err, name
+        checked += 1
+    record_measured("force_shipped_config_grads", worst_parameter_gradient=worst, worst_parameter=worst_name, checked=checked)
+    assert worst < 5e-5, (worst_name, worst)
+    assert checked >= 40
+
+
 def test_force_block_equals_the_composed_path_and_serves_inference(dev, monkeypatch):
     """The force block against the composed per-edge path of rounds 1-3 (E3K_FORCE_BLOCK=0) on the same weights, and forces in
     eval mode (create_graph=False: the block's first-order backward hands back g_sh and g_r itself)."""
@@ -427,3 +490,37 @@ def test_slope_table_guard_vetoes_and_the_per_edge_path_takes_over(dev, monkeypa
     out, loss, (o, loss_r) = _force_losses(prod, orc, batch, dev)
     assert conv_force.STATS[0] - before[0] == 2               # layers 0 and 2 on the block, layer 1 per edge
     assert rel_err(out["forces"], o["forces"]) < 2e-5
+
+
+def test_position_gradient_of_a_force_loss_takes_the_composed_path(dev, monkeypatch):
+    """a caller whose ``pos`` required grad BEFORE ``GradientOutput`` wants d(loss)/d(pos) of a force loss (third
+    derivatives of the layers).  The force block does not form them -- it used to hand back a partial gradient behind a one-time
+    warning; now ``GradientOutput`` declines the block for such a call and the composed path delivers the complete gradient:
+    checked against the float64 oracle."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)      # (without the decline this batch WOULD run on the force block)
+    prod, orc = _force_net(dev, 2)
+    batch = synth_qm9(17, 16)
+    assert batch["pos"].shape[0] >= 256
+    gen = torch.Generator().manual_seed(5)
+    f_target = torch.randn(batch["pos"].shape, dtype=torch.float64, generator=gen)
+    b = batch.clone().to(dev)
+    b["pos"].requires_grad_(True)
+    before = list(conv_force.STATS)
+    out = prod(b)
+    assert conv_force.STATS == before                                # declined: composed layers
+    loss = ((out["forces"] - f_target.float().to(dev)) ** 2).mean()
+    (g_pos,) = torch.autograd.grad(loss, b["pos"])
+    data, attrs = batch_to_oracle(batch)
+    data["pos"].requires_grad_(True)
+    o, _ = orc(data, attrs)
+    loss_r = ((o["forces"] - f_target) ** 2).mean()
+    (g_ref,) = torch.autograd.grad(loss_r, data["pos"])
+    assert rel_err(out["forces"], o["forces"]) < 2e-5
+    assert rel_err(g_pos, g_ref) < 2e-4
+    # the same model without a position gradient asked for runs on the block
+    out2 = prod(batch.clone().to(dev))
+    assert conv_force.STATS[0] - before[0] == 2
+    assert rel_err(out2["forces"], out["forces"]) < 2e-5

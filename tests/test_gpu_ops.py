@@ -723,18 +723,26 @@ def test_tp_table_second_order_forms_are_sums_of_first_order_kernels(dev, left, 
     assert rel_err(gw, ref) < 1e-5
 
 
-def test_slope_table_is_the_derivative_of_the_radial_mlp(dev):
+@pytest.mark.parametrize("n_basis", [8, 48])
+def test_slope_table_is_the_derivative_of_the_radial_mlp(dev, n_basis):
     """conv_native.RadialStackFn(slope=...): D = d/dr fc(basis(r)) on the knots (csrc/e3k_slope.hip: the hidden chain's forward-mode
     derivative per knot in float64, last layer in fp32) against the float64 oracle's autograd derivative, and its gradient w.r.t. the
-    MLP weights and the Bessel frequencies against the oracle's double backward."""
+    MLP weights and the Bessel frequencies against the oracle's double backward.  ``n_basis=48``: more than 32 trainable Bessel
+    frequencies (the frequency level of the weight-gradient kernel summed only the first 32)."""
     from e3_layers_amd import nn as pnn
     from e3_layers_amd.backend import conv_native, radial_table
     from e3_layers_amd.configs import config_energy_force
+    from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
     from e3_layers_amd.utils import build
 
     torch.manual_seed(3)
-    cfg = config_energy_force.get_config()
-    model = build(cfg.model_config).to(dev)
+    if n_basis == 8:
+        tree = config_energy_force.get_config().model_config
+    else:
+        tree = addForceOutput(addEnergyOutput(featureModel(n_dim=64, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e",
+                                                           edge_radial=f"{n_basis}x0e", num_types=20, num_layers=2, r_max=5.0),
+                                              None, output_key="energy"))
+    model = build(tree).to(dev)
     func = model.func
     layers = [getattr(func, f"layer{i}") for i in range(2)]
     enc = func.radial_basis
@@ -757,9 +765,9 @@ def test_slope_table_is_the_derivative_of_the_radial_mlp(dev):
     T, D = outs[:2], outs[2:]
     # float64 oracle of layer l's radial MLP and its derivative along r
     for li, l in enumerate(layers):
-        orc_enc = e3ref.RadialBasisEncoding(r_max=r_max, trainable=True, irreps_out=("8x0e", "edge_radial"), irreps_in=("1x0e", "edge_length")).double()
+        orc_enc = e3ref.RadialBasisEncoding(r_max=r_max, trainable=True, irreps_out=(f"{n_basis}x0e", "edge_radial"), irreps_in=("1x0e", "edge_length")).double()
         orc_enc.load_state_dict({k: v.detach().cpu().double() for k, v in enc.state_dict().items()})
-        hs = [8, 64, 64, 64, plans[li].last_spec.d_out]
+        hs = [n_basis, 64, 64, 64, plans[li].last_spec.d_out]
         orc_fc = e3ref.FullyConnectedNet(hs, "ssp").double()
         orc_fc.load_state_dict({k: v.detach().cpu().double() for k, v in l.conv.fc.state_dict().items()})
         rr = radii.cpu().double().clone().requires_grad_(True)

@@ -412,4 +412,10 @@ def test_optimizer_checkpoint_layout_is_verified_or_remapped_by_name():
         layout_moves(a, [(0, 6, (2, 3), "w1"), (64, 4, (4,), "b"), (128, 6, (2, 3), "other")])
     with pytest.raises(ValueError):
         layout_moves(a, [(0, 6, (3, 2), "w1"), (64, 4, (4,), "b"), (128, 6, (2, 3), "w2")][::-1])
-    assert layout_moves([(o, n, sh, None) for o, n, sh, _ in a], a) is None      # same order, names on one side only
+    # same shape sequence, names on one side only, two parameters of one shape: the order cannot be verified ...
+    with pytest.raises(ValueError):
+        layout_moves([(o, n, sh, None) for o, n, sh, _ in a], a)
+    assert layout_moves([(o, n, sh, None) for o, n, sh, _ in a], a, assume_same_order=True) is None      # ... unless the caller vouches
+    assert layout_moves(a, None, assume_same_order=True) is None                   # the way in for pre-round-4 checkpoints
+    d = [(0, 6, (2, 3), "w1"), (64, 4, (4,), "b")]
+    assert layout_moves([(o, n, sh, None) for o, n, sh, _ in d], d) is None       # all shapes distinct: the sequence determines the order

@@ -219,3 +219,24 @@ def test_bench_launches_its_own_ranks():
                          capture_output=True, text=True, timeout=240)
     assert bad.returncode != 0
     assert not [l for l in bad.stdout.splitlines() if l.startswith("{")]
+
+
+def test_bench_launcher_with_eight_ranks():
+    """the first real 8-GPU run must not also be the first 8-PROCESS run of the launcher.  ``python bench.py
+    --gpus 8`` in dry-run mode: eight fresh rank processes rendezvous over gloo on 127.0.0.1 (the launcher's own c10d store, port
+    handed out by the OS), all-reduce, one JSON line."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["E3K_BENCH_DRY_RUN"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    ok = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"], env=env,
+                        capture_output=True, text=True, timeout=600)
+    assert ok.returncode == 0, ok.stderr[-2000:]
+    lines = [l for l in ok.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, ok.stdout
+    res = json.loads(lines[0])
+    assert res["n_gpus"] == 8 and "launcher" in res["config"]
