@@ -254,7 +254,7 @@ def main():
         opt_kw = dict(ema_decay=cfg.ema_decay if cfg.use_ema else None, ema_use_num_updates=cfg.ema_use_num_updates)
     elif cfg_kind == "energy_force":
         cfg = config_energy_force.get_config()
-        make = lambda k: synth_qm9(2000 + 17 * k + rank, args.batch, r_max=5.0, bonds=args.bonds)
+        make = lambda k: synth_qm9(2000 + 17 * k + rank, args.batch, config_energy_force.SHIFTS, r_max=5.0, bonds=args.bonds)
         opt_kw = {}
     elif cfg_kind == "diffusion":
         cfg = config_diffusion.get_config()

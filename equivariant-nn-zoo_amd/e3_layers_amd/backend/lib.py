@@ -219,7 +219,7 @@ SIGNATURES = {
     "e3k_rtable_interp_fwd2": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),
     "e3k_rtable_interp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P]),
-    "e3k_rtable_guard": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _P]),
+    "e3k_rtable_guard": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _F, _P]),
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),
     "e3k_act_bwd_from_output": (C.c_int, [_P, _P, _I64, _I32, _F, _P, _P]),

@@ -60,19 +60,25 @@ class CapturedStep:
         radial_table.drain_guards()      # ... and the knot-table guards' pending read-backs (no Event.query() inside a capture)
         capture_flag(dev)                # the persistent flag the captured index checks fold into (a bad batch fed
                                          # through a replay must raise, as it does on the eager path)
-        self._veto_epoch = radial_table.VETO_EPOCH[0]
         self.graph = torch.cuda.CUDAGraph()
         for g in self.generators:
             self.graph.register_generator_state(g)
-        with torch.cuda.graph(self.graph):
-            self.out = self.fn()
+        radial_table.CAPTURE_LOG = []
+        try:
+            with torch.cuda.graph(self.graph):
+                self.out = self.fn()
+            self._guards = tuple(radial_table.CAPTURE_LOG)      # the knot-table guards this graph evaluates with every replay
+        finally:
+            radial_table.CAPTURE_LOG = None
+        self._replays = 0
+        self._vetoed = False
         return out
 
     def __call__(self):
         from ..backend import radial_table
         from ..backend.graph import poll_capture_flags
 
-        if radial_table.VETO_EPOCH[0] != self._veto_epoch:
+        if self._vetoed:
             # A knot table this graph interpolates from has been switched off (its error bound, which the captured step evaluates on
             # the device with every replay, passed the tolerance: the weights moved under the optimizer).  The graph still holds the
             # table kernels: this call runs the step EAGERLY once (the vetoed layer takes its per-edge path -- also the warm-up of
@@ -81,8 +87,10 @@ class CapturedStep:
             out = self._capture(1, keep_last=True)
             return out
         self.graph.replay()
+        self._replays += 1
         poll_capture_flags(self.dev)     # (one 4-byte async copy: read by the next build / optimizer step / check_indices())
-        radial_table.poll_replay()       # every N-th replay: the guards' running maxima travel home (no sync)
+        if self._guards:                 # every N-th replay: the guards' running maxima travel home (no sync)
+            self._vetoed = radial_table.poll_replay(self._guards, self._replays)
         return self.out
 
 

@@ -320,15 +320,18 @@ int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scal
                           const int32_t* bin_seg, const int32_t* bin_perm, int64_t E, int32_t K, int32_t W, float* workspace,
                           float* g_T, int32_t accumulate, void* stream);
 
-/* A-posteriori bound of the table's interpolation error, evaluated ON THE DEVICE, per weight column (the reference evaluates
- * fc(edge_radial) exactly on every edge, nn/message_passing.py:74-79,93: the table must know when it stops being a stand-in):
- *     est = max_c  3/128 max_i |4th difference of T[:, c] at i| / max(max_i |T[i, c]|, floor_rel * max |T|)
+/* A-posteriori bound of the table's interpolation error, evaluated ON THE DEVICE (the reference evaluates fc(edge_radial)
+ * exactly on every edge, nn/message_passing.py:74-79,93: the table must know when it stops being a stand-in).  With
+ * err_c = 3/128 max_i |4th difference of T[:, c] at i| (cubic Lagrange on the table's knots):
+ *     table-wide ratio  est_g = max_c err_c / max |T|
+ *     per-column ratio  est_c = max_c err_c / max(max_i |T[i, c]|, floor_rel * max |T|)
+ *     reported          est   = max(est_g, col_weight * est_c)        (col_weight = table-wide tolerance / per-column tolerance)
  * for up to 16 tables of `rows` rows in ONE launch (the layers of a radial stack).  states[t] float [4]: [0] running maximum of
  * est since the caller last zeroed it (atomic max: survives HIP-graph replays, which never re-enter the host code that would
- * read a per-launch value), [1] est of this launch, [2] internal ticket counter (zero it once at allocation), [3] unused.
- * scratch[t] float [2 * widths[t]].  A non-finite table entry gives est = +inf.  rows < 5: nothing to do. */
+ * read a per-launch value), [1] est of this launch, [2] internal ticket counter (zero it once at allocation), [3] est_c of this
+ * launch.  scratch[t] float [2 * widths[t]].  A non-finite table entry gives est = +inf.  rows < 5: nothing to do. */
 int e3k_rtable_guard(const float* const* tables, float* const* states, float* const* scratch, const int32_t* widths, int32_t n,
-                     int32_t rows, float floor_rel, void* stream);
+                     int32_t rows, float floor_rel, float col_weight, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-side elementwise kernels.

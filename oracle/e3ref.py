@@ -1044,8 +1044,10 @@ class GradientOutput(nn.Module):
 
     def forward(self, data: dict, attrs: dict):
         data = dict(data)
-        x = data[self.x_key].detach().clone().requires_grad_(True)
-        data[self.x_key] = x
+        x = data[self.x_key]
+        if not x.requires_grad:      # (nn/output.py:33-35 flips requires_grad on the caller's tensor and back; a private leaf does the
+            x = x.detach().clone().requires_grad_(True)      # same without touching it.  A caller's tensor that already requires
+        data[self.x_key] = x                                 # grad is used as it is: gradients of the output flow back to it)
         out, oattrs = self.func(data, attrs)
         (g,) = torch.autograd.grad(out[self.y_key].sum(), x, create_graph=self.training)
         out[self.g_key] = self.sign * g

@@ -501,7 +501,7 @@ def test_position_gradient_of_a_force_loss_takes_the_composed_path(dev, monkeypa
     from e3_layers_amd.data.synthetic import synth_qm9
 
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)      # (without the decline this batch WOULD run on the force block)
-    prod, orc = _force_net(dev, 2)
+    prod, orc = _force_net(dev, 3)
     batch = synth_qm9(17, 16)
     assert batch["pos"].shape[0] >= 256
     gen = torch.Generator().manual_seed(5)
@@ -522,5 +522,5 @@ def test_position_gradient_of_a_force_loss_takes_the_composed_path(dev, monkeypa
     assert rel_err(g_pos, g_ref) < 2e-4
     # the same model without a position gradient asked for runs on the block
     out2 = prod(batch.clone().to(dev))
-    assert conv_force.STATS[0] - before[0] == 2
+    assert conv_force.STATS[0] - before[0] == 3
     assert rel_err(out2["forces"], out["forces"]) < 2e-5
