@@ -682,7 +682,8 @@ def main():
         w_term = 4 * plan.w_numel
         extra = 0
         if variant == "B" and kind != "tp_bwd_w":
-            w_term, extra = 20, 4 * table_rows * plan.w_numel      # knot (4 B) + four interpolation weights (16 B) per edge; the table once
+            # knot (4 B) + four interpolation weights (16 B) per edge; the table once -- 12-byte records when the kernels read it packed
+            w_term, extra = 20, (12 if conv_native.TP_TABLE_PACKED else 4) * table_rows * plan.w_numel
         if kind == "tp_fwd":        # x[src] gather + sh + w + out rows
             return e * (4 * plan.d_in + 4 * plan.d_sh + w_term + 16) + n * 4 * plan.d_mid + extra
         if kind == "tp_bwd_w":      # x[src] gather + sh + g_w stream + g_mid rows
@@ -713,8 +714,10 @@ def main():
             out.update({"achieved": round(ach_b, 1), "frac": round(ach_b / HBM_PEAK_GBS, 4),
                         "avg_launch_algorithmic_MB": round(tot_bb / n / 1e6, 2), "launches_with_in_kernel_table": n_tab,
                         "bytes_model": "SURVEY 8d variant B (weights produced in the kernel from the knot table)",
-                        "note": "in-kernel knot-table form: E x W is not streamed from HBM (L2 gathers of a "
-                                f"<= {4 * table_rows * max(m[2].w_numel for _, _, m in recs) / 1e6:.1f} MB table per layer); frac = the bytes "
+                        "note": "in-kernel knot-table form: E x W is not streamed from HBM (L2 / Infinity-Cache gathers of a "
+                                f"<= {(12 if conv_native.TP_TABLE_PACKED else 4) * table_rows * max(m[2].w_numel for _, _, m in recs) / 1e6:.1f} MB "
+                                + ("packed table (one 12-byte record per knot and weight) per layer" if conv_native.TP_TABLE_PACKED else "table per layer")
+                                + "); frac = the bytes "
                                 "this form must move / time / 8 TB/s; variant_A_frac = the module-API operation's bytes (E x W streamed) "
                                 "/ time, as reported in rounds 1-3"})
         return out

@@ -169,6 +169,12 @@ int edge(const e3k_layer* L, int slot, void* producer, void* consumer) {
   return E3K_OK;
 }
 
+// the in-kernel table in its packed form (12-byte records, e3k_rtable_pack): behind whatever wrote T, on the radial stream
+int pack_table(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
+  if (!in_kernel_table(L->d, r) || !r.P) return E3K_OK;
+  return e3k_rtable_pack(r.T, r.knots, L->d.W, r.P, st);
+}
+
 int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
   const e3k_layer_desc& d = L->d;
   if (r.R == 0 || r.E == 0) return E3K_OK;
@@ -177,7 +183,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
       Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
       E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_coef, r.E, r.knots, d.W, r.w, st));
     }
-    return E3K_OK;
+    return pack_table(L, r, st);
   }
   float* zs[4] = {r.z[0], r.z[1], r.z[2], r.z[3]};
   if (!(ABLATE & 16))
@@ -192,7 +198,7 @@ int radial_fwd(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
     Timed t(L, E3K_PROF_RTABLE_FWD, st, r.R, r.E);
     E3K_TRY(e3k_rtable_interp_fwd(r.T, r.bin_perm, r.bin, r.bin_coef, r.E, r.knots, d.W, r.w, st));
   }
-  return E3K_OK;
+  return pack_table(L, r, st);
 }
 
 }  // namespace
@@ -346,7 +352,10 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   E3K_TRY(edge(L, 2, side, main));           // the per-edge weights
   {
     Timed t(L, E3K_PROF_TP_FWD, main, a->N, a->E);
-    if (in_kernel_table(d, a->rad))
+    if (in_kernel_table(d, a->rad) && a->rad.P)
+      E3K_TRY(e3k_tp_fwd_ptable(d.tp, a->x1, a->sh, a->rad.P, a->rad.bin, a->rad.bin_coef, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
+                                a->mid, main));
+    else if (in_kernel_table(d, a->rad))
       E3K_TRY(e3k_tp_fwd_table(d.tp, a->x1, a->sh, a->rad.T, a->rad.bin, a->rad.bin_coef, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
                                a->mid, main));
     else
@@ -450,6 +459,8 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
       return E3K_ERR_LAUNCH;
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
     if (ABLATE & 32) {
+    } else if (in_kernel_table(d, r) && r.P) {
+      E3K_TRY(e3k_tp_bwd_x_ptable(d.tp, a->sh, r.P, r.bin, r.bin_coef, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
     } else if (in_kernel_table(d, r)) {
       E3K_TRY(e3k_tp_bwd_x_table(d.tp, a->sh, r.T, r.bin, r.bin_coef, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
     } else {

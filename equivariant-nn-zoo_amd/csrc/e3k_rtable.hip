@@ -296,10 +296,83 @@ __global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __
   *out = acc;
 }
 
+// ---- the table PACKED for the tensor-product kernels (round 5) -------------------------------------------------------------
+// The in-kernel form of the tensor product (e3k_tp_fwd_table) gathers FOUR 4-byte values per (edge, weight) -- rows i-1 .. i+2 of T,
+// 7.7 KB apart -- and is bound by what an L1 can fill from L2 (35 KB per edge).  The same cubic, written as
+// its Taylor polynomial about the middle of the knot interval, needs its two leading coefficients in fp32 and the two small ones
+// only in fp16: 12 bytes per (knot, weight) in ONE row, two loads per slot instead of four dword loads out of four rows, 23 KB per edge.
+//     p_i(t) = a L0(t) + b L1(t) + c L2(t) + d L3(t),  (a, b, c, d) = T[i-1 .. i+2],  t in [0, 1) the offset inside interval i
+//            = d0 + s (d1 + s (d2 + s d3)),            s = t - 1/2 in [-1/2, 1/2)
+//     c0 = b, c1 = -a/3 - b/2 + c - d/6, c2 = a/2 - b + c/2, c3 = -a/6 + b/2 - c/2 + d/6          (monomials in t)
+//     d0 = c0 + c1/2 + c2/4 + c3/8, d1 = c1 + c2 + 3/4 c3, d2 = c2 + 3/2 c3, d3 = c3
+// formed in float64 from the fp32 rows and rounded ONCE.  Record: {d0: f32, d1: f32, (d2 * 2^10 : f16 | d3 * 2^16 : f16 << 16)};
+// a table row holds its W (d0, d1) pairs first (8 W bytes), then its W f16 pairs (4 W bytes): the kernels read a slot with one
+// dwordx2 and one dword load, each contiguous over the wave.  (One dwordx3 load of an interleaved record would be one instruction
+// less; this compiler's __builtin_amdgcn_raw_buffer_load_b96 returns its third element as a copy of the first.)
+// Sizes at 512 knots (h = 2^-7 A): d1 ~ 5e-2, d2 ~ 1e-3, d3 ~ 2e-5 of the values, so the fixed scales put d2 and d3 near 1 in
+// fp16 (normal range 2^-14 .. 2^16: thirty binades either way; below it the ABSOLUTE error is < 2^-24 / scale, above it the entry
+// is +-inf and the guard -- whose fourth-difference bound would have fired long before -- vetoes the table).  Rounding of the fp16
+// pair (11 significant bits: relative 2^-11), after economisation (see the kernel): <= 2^-11 (|d2| / 8 + |d3| / 32): 6e-8 of the
+// values at random init, beside 1e-7 of interpolation error and 6e-8 of fp32 rounding; e3k_rtable_guard bounds it (`pack_weight`).  Evaluation (same three fused
+// multiply-adds in e3k_tp.hip and in rtable_interp_packed_kernel: bit-identical):
+//     s = (c2 - c0 + 2 c3) - 1/2 from the edge's Lagrange weights (sum_k x_k L_k(t) = t for x = (-1, 0, 1, 2)),
+//     w = fma(s, fma(s * 2^-10, fma(s * 2^-6, D3, D2), d1), d0).
+// Knots outside [1, K - 2] are never an edge's knot (e3k_rtable_bins clamps): their records are zero.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+constexpr float PK_S2 = 1024.f, PK_S3 = 65536.f;      // scales of d2 and d3 in the record (powers of two: exact)
+
+__global__ __launch_bounds__(256) void rtable_pack_kernel(const float* __restrict__ T, int32_t K, int32_t W, uint32_t* __restrict__ P) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)(K + 1) * W) return;
+  const int i = (int)(q / W), col = (int)(q - (int64_t)i * W);
+  uint32_t* row = P + 3 * (int64_t)i * W;      // [W][2] (d0, d1), then [W] f16 pairs
+  if (i < 1 || i > K - 2) {
+    row[2 * col] = row[2 * col + 1] = row[2 * W + col] = 0u;
+    return;
+  }
+  const double a = T[q - W], b = T[q], c = T[q + W], d = T[q + 2 * (int64_t)W];
+  const double c1 = -a / 3.0 - b / 2.0 + c - d / 6.0, c2 = a / 2.0 - b + c / 2.0, c3 = -a / 6.0 + b / 2.0 - c / 2.0 + d / 6.0;
+  const double e2 = c2 + 1.5 * c3;
+  f16x2 h;
+  h.x = (_Float16)(float)(e2 * (double)PK_S2);
+  h.y = (_Float16)(float)(c3 * (double)PK_S3);
+  // what fp16 dropped, r2 s^2 + r3 s^3, is not lost but ECONOMISED into the fp32 coefficients: on |s| <= 1/2 the best constant for
+  // s^2 is 1/8 and the best multiple of s for s^3 is 3/16 s (Chebyshev), leaving |r2| / 8 + |r3| / 32 instead of |r2| / 4 + |r3| / 8
+  const double r2 = e2 - (double)(float)h.x / (double)PK_S2, r3 = c3 - (double)(float)h.y / (double)PK_S3;
+  const float d0 = (float)(b + c1 / 2.0 + c2 / 4.0 + c3 / 8.0 + r2 / 8.0), d1 = (float)(c1 + c2 + 0.75 * c3 + 3.0 * r3 / 16.0);
+  row[2 * col] = __float_as_uint(d0);
+  row[2 * col + 1] = __float_as_uint(d1);
+  row[2 * W + col] = __builtin_bit_cast(uint32_t, h);
+}
+
+__device__ __forceinline__ float packed_eval(float s, float s2, float s3, float d0, float d1, uint32_t pk) {
+  const f16x2 h = __builtin_bit_cast(f16x2, pk);
+  return fmaf(s, fmaf(s2, fmaf(s3, (float)h.y, (float)h.x), d1), d0);
+}
+
+// w[e, :] from the packed table (the materialised counterpart of the packed in-kernel form: tests pin the two to the same bits)
+__global__ __launch_bounds__(256) void rtable_interp_packed_kernel(const uint32_t* __restrict__ P, const int32_t* __restrict__ perm,
+                                                                   const int32_t* __restrict__ bin, const float* __restrict__ coef,
+                                                                   int64_t E, int32_t W, float* __restrict__ w) {
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= E) return;
+  const int lane = threadIdx.x & 63;
+  const int e = uniform(perm[p]);
+  const int i = uniform(bin[e]);
+  const float* __restrict__ cp = coef + 4 * (int64_t)e;
+  const float c0 = __uint_as_float(uniform((int)__float_as_uint(cp[0]))), c2 = __uint_as_float(uniform((int)__float_as_uint(cp[2])));
+  const float c3 = __uint_as_float(uniform((int)__float_as_uint(cp[3])));
+  const float s = fmaf(2.f, c3, c2 - c0) - 0.5f, s2 = s * (1.f / PK_S2), s3 = s * (PK_S2 / PK_S3);
+  const uint32_t* __restrict__ row = P + 3 * (int64_t)i * W;
+  float* __restrict__ o = w + (int64_t)e * W;
+  for (int q = lane; q < W; q += 64) o[q] = packed_eval(s, s2, s3, __uint_as_float(row[2 * q]), __uint_as_float(row[2 * q + 1]), row[2 * W + q]);
+}
+
 // ---- a-posteriori bound of the interpolation error, on the device, per weight COLUMN ---------------------------------------
 // Cubic Lagrange interpolation on knots h apart is off by at most 3/128 h^4 max|f|; on the table h^4 f is the fourth
 // difference, so for column c
 //     err_c <= 3/128 max_i |T[i+4,c] - 4 T[i+3,c] + 6 T[i+2,c] - 4 T[i+1,c] + T[i,c]|
+// (+ for the PACKED table the fp16 rounding of its two small coefficients: 2^-11 (|2nd difference| / 16 + |3rd difference| / 192))
 // and TWO ratios are formed: the table-wide one, max_c err_c / max|T| (what the forward's parity feels: every column's error against
 // the scale of the weights it is summed with), and the per-column one, max_c err_c / max(max_i |T[i,c]|, floor * max|T|) -- a column's
 // error against its OWN scale (a column a thousand times smaller than the largest must not hide a thousand times the relative
@@ -316,10 +389,10 @@ __global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __
 struct GuardArgs {
   const float* T[16];
   float* state[16];
-  float* scratch[16];     // [2 W]: column maxima of |T| and of |fourth difference|
+  float* scratch[16];     // [2 W]: column maxima of |T| and of the error bound
   int32_t W[16];
   int32_t rows;
-  float floor_rel, c4, col_weight;
+  float floor_rel, c4, col_weight, pack_weight;      // pack_weight: 1 when the kernels read the PACKED table (fp16 rounding of d2, d3), else 0
 };
 
 __device__ __forceinline__ void atomic_max_pos(float* p, float v) {      // v >= 0 (or +inf): the bit patterns order like the values
@@ -353,7 +426,10 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
       bad = bad || !(fabsf(v4) < INFINITY);
       cmax = fmaxf(cmax, fabsf(v4));
       const float d4 = (v4 + v0) - 4.f * (v3 + v1) + 6.f * v2;
-      dmax = fmaxf(dmax, fabsf(d4));
+      // packed table: d2 ~ (second difference) / 2 and d3 ~ (third difference) / 6 are stored in fp16 (relative rounding 2^-11); what
+      // is dropped enters economised: |r2| / 8 + |r3| / 32 (e3k::rtable_pack_kernel)
+      const float d2 = (v1 + v3) - 2.f * v2, d3 = (v3 - v0) - 3.f * (v2 - v1);
+      dmax = fmaxf(dmax, a.c4 * fabsf(d4) + a.pack_weight * (1.f / 2048.f) * (fabsf(d2) * (1.f / 16.f) + fabsf(d3) * (1.f / 192.f)));
       v0 = v1; v1 = v2; v2 = v3; v3 = v4;
     }
   }
@@ -385,8 +461,8 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   for (int c = threadIdx.x; c < W; c += 256) {
     const float cm = __builtin_nontemporal_load(scratch + c), dm = __builtin_nontemporal_load(scratch + W + c);
     const bool fin = dm < INFINITY && cm < INFINITY;
-    est_c = fmaxf(est_c, fin ? a.c4 * dm / fmaxf(cm, fl) : INFINITY);
-    est_g = fmaxf(est_g, fin ? a.c4 * dm / gs : INFINITY);
+    est_c = fmaxf(est_c, fin ? dm / fmaxf(cm, fl) : INFINITY);
+    est_g = fmaxf(est_g, fin ? dm / gs : INFINITY);
   }
   est_c = wave_max_f(est_c);
   est_g = wave_max_f(est_g);
@@ -408,7 +484,7 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
 }  // namespace e3k
 
 extern "C" int e3k_rtable_guard(const float* const* tables, float* const* states, float* const* scratch, const int32_t* widths,
-                                int32_t n, int32_t rows, float floor_rel, float col_weight, void* stream) {
+                                int32_t n, int32_t rows, float floor_rel, float col_weight, int32_t packed, void* stream) {
   if (!tables || !states || !scratch || !widths || n <= 0 || n > 16 || rows < 0 || !(floor_rel >= 0.f) || !(col_weight >= 0.f))
     return E3K_ERR_INVALID;
   if (rows < 5) return E3K_OK;      // no fourth difference to look at
@@ -419,8 +495,29 @@ extern "C" int e3k_rtable_guard(const float* const* tables, float* const* states
     a.T[i] = tables[i]; a.state[i] = states[i]; a.scratch[i] = scratch[i]; a.W[i] = widths[i];
     wmax = widths[i] > wmax ? widths[i] : wmax;
   }
-  a.rows = rows; a.floor_rel = floor_rel; a.c4 = 3.0f / 128.0f; a.col_weight = col_weight;
+  a.rows = rows; a.floor_rel = floor_rel; a.c4 = 3.0f / 128.0f; a.col_weight = col_weight; a.pack_weight = packed ? 1.f : 0.f;
   hipLaunchKernelGGL(e3k::rtable_guard_kernel, dim3((unsigned)((wmax + 63) / 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_rtable_pack(const float* T, int32_t K, int32_t W, void* P, void* stream) {
+  if (K < 4 || W <= 0) return E3K_ERR_INVALID;
+  if (!T || !P) return E3K_ERR_INVALID;
+  const int64_t q = (int64_t)(K + 1) * W;
+  hipLaunchKernelGGL(e3k::rtable_pack_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, K, W,
+                     static_cast<uint32_t*>(P));
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_rtable_interp_packed(const void* P, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E,
+                                        int32_t K, int32_t W, float* w, void* stream) {
+  if (E < 0 || K < 4 || W <= 0) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!P || !bin_perm || !bin || !coef || !w) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::rtable_interp_packed_kernel, dim3((unsigned)((E + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+                     static_cast<const uint32_t*>(P), bin_perm, bin, coef, E, W, w);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

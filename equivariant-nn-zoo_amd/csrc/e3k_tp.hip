@@ -110,11 +110,50 @@ __device__ __forceinline__ float knot_mix(float c0, float c1, float c2, float c3
   return fmaf(c3, vd, fmaf(c2, vc, fmaf(c1, vb, c0 * va)));
 }
 
+// MODE 4 (packed table, round 5): the same cubic from 12 bytes per (knot, weight) in ONE table row -- {d0, d1: f32; d2 * 2^10,
+// d3 * 2^16: f16}, the Taylor coefficients about the middle of the knot interval (e3k_rtable_pack; a row = its W (d0, d1) pairs, then
+// its W f16 pairs) -- one dwordx2 + one dword load per slot instead of four dword loads out of four rows: 23 instead of 31 KB of
+// table per edge through L1, half the table's VMEM instructions.  a.w is then the packed table [K + 1, 3 W] (dwords).
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+struct PackedRec {
+  float d0, d1;
+  unsigned int pk;
+};
+struct KnotPacked {
+  __amdgpu_buffer_rsrc_t r;
+  float s, s2, s3;
+};
+__device__ __forceinline__ KnotPacked knot_packed(const TpArgs& a, int e, int row_p) {
+  const int i = uniform(a.bin[e]);
+  const float* __restrict__ cp = a.coef + 4 * (int64_t)e;
+  const float c0 = sload(cp), c2 = sload(cp + 2), c3 = sload(cp + 3);
+  KnotPacked k;
+  k.r = row_rsrc(a.w + 3 * (int64_t)i * a.W, row_p);
+  k.s = fmaf(2.f, c3, c2 - c0) - 0.5f;      // t = sum_k x_k L_k(t), x = (-1, 0, 1, 2); s = t - 1/2
+  k.s2 = k.s * (1.f / 1024.f);
+  k.s3 = k.s * (1.f / 64.f);
+  return k;
+}
+// slot at weight offset woff4 (bytes of a 4-byte column) of the row, lane channel u4 = 4 u; pk_base = 8 W (bytes)
+__device__ __forceinline__ PackedRec buf_ld_rec(__amdgpu_buffer_rsrc_t r, int u4, int woff4, int pk_base) {
+  const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, u4 * 2, woff4 * 2, 0);
+  PackedRec p;
+  p.d0 = __uint_as_float(v[0]);
+  p.d1 = __uint_as_float(v[1]);
+  p.pk = __builtin_amdgcn_raw_buffer_load_b32(r, u4, pk_base + woff4, 0);
+  return p;
+}
+__device__ __forceinline__ float packed_mix(const KnotPacked& k, const PackedRec& v) {      // the order of e3k::packed_eval (e3k_rtable.hip)
+  const f16x2 h = __builtin_bit_cast(f16x2, v.pk);
+  return fmaf(k.s, fmaf(k.s2, fmaf(k.s3, (float)h.y, (float)h.x), v.d1), v.d0);
+}
+
 template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  constexpr bool TABLE = MODE == 1 || MODE == 2, JVP = MODE >= 2;      // MODE 3: the JVP form on STREAMED w[e], dw/dr[e] rows
+  constexpr bool TABLE = MODE == 1 || MODE == 2, JVP = MODE == 2 || MODE == 3;      // MODE 3: the JVP form on STREAMED w[e], dw/dr[e] rows
+  constexpr bool PACKED = MODE == 4;
   const int u4 = u * 4;
   const int xoff4 = uniform(g.x_off * 4), mul4 = uniform(g.mul * 4);
   int woff4[S::NQ];
@@ -144,7 +183,18 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
 #pragma unroll
       for (int i = 0; i < D1; ++i) x2c[i] = buf_ld(rx2, u4, xoff4 + i * mul4);
     }
-    if constexpr (TABLE) {
+    if constexpr (PACKED) {
+      const KnotPacked kp = knot_packed(a, e, row_w * 3);
+      PackedRec rec[S::NQ];
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2);
+      });
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wc[Q] = packed_mix(kp, rec[Q]);
+      });
+    } else if constexpr (TABLE) {
       const KnotRows kr = knot_rows(a, a.coef, e, row_w);
       float wa[S::NQ], wb[S::NQ], wcc[S::NQ], wd[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -584,7 +634,8 @@ template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE >= 2;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
+  constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE == 2 || MODE == 3;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
+  constexpr bool PACKED = MODE == 4;                                                // MODE 4: w from the packed table (see tp_fwd_body_full)
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -609,7 +660,23 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
     float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
-    if constexpr (TABLE) {
+    if constexpr (PACKED) {
+      const KnotPacked kp = knot_packed(a, e, row_w * 3);
+      PackedRec rec[S::NQ];
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        constexpr int L3 = S::L3[Q], OFF = S::OFF[Q];
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k)
+          gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
+        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2);
+      });
+      __builtin_amdgcn_sched_barrier(0);
+      slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+        constexpr int Q = decltype(qc)::value;
+        wn[Q] = packed_mix(kp, rec[Q]);
+      });
+    } else if constexpr (TABLE) {
       const KnotRows kr = knot_rows(a, a.coef, e, row_w);
       float wa[S::NQ], wb[S::NQ], wcc[S::NQ], wd[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -804,8 +871,10 @@ __device__ __forceinline__ void tp_bwd_w_dual_body(const TpArgs& a, const e3k_tp
 
 // MODE: 0 = per-edge weights streamed from w[E, W]; 1 = interpolated from the knot table inside the kernel; 2 = the table
 // form's second-order (JVP / DUAL) variant -- FULL plans only for 1 and 2
+// (packed form, l_max <= 2 plans: 67 VGPRs as the compiler first allocates them -- one step over the 64 of eight waves per SIMD; asked
+//  for eight, it fits without spilling)
 template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
-__global__ __launch_bounds__(256) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+__global__ __launch_bounds__(256, (MODE == 4 && MAXL <= 2 && L3MAX <= 2) ? 8 : 1) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_fwd_body, L3MAX, MODE)
@@ -1016,7 +1085,8 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 }
 
 namespace {
-enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL };
+enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL,
+              TP_FWD_PACKED, TP_BWD_X_PACKED };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -1058,13 +1128,17 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     E3K_CHECK_LAUNCH();
     return E3K_OK;
   }
-  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE) {      // channel-complete (FULL) plans, split or not
+  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE || kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED) {      // channel-complete (FULL) plans, split or not
     if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
 #define E3K_TP_LAUNCH_T(ML, L3, SP)                                                                                                     \
   {                                                                                                                                     \
     if (kind == TP_FWD_TABLE)                                                                                                           \
       hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, 1>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);              \
+    else if (kind == TP_FWD_PACKED)                                                                                                     \
+      hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, 4>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);              \
+    else if (kind == TP_BWD_X_PACKED)                                                                                                   \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 4>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
     else                                                                                                                                \
       hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 1>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
   }
@@ -1183,6 +1257,33 @@ extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, cons
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_TABLE, a, plan, N, (hipStream_t)stream);
+}
+
+// ---- ... and from the PACKED table (e3k_rtable_pack: one 12-byte record per (knot, weight); same plans as the table form) ---------
+extern "C" int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const float* sh, const void* P, const int32_t* bin,
+                                 const float* coef, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
+                                 int64_t E, float* out, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !P || !bin || !coef || !src || !dst_perm))) return E3K_ERR_INVALID;
+  if ((int64_t)plan->w_numel * 12 > 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = static_cast<const float*>(P); a.bin = bin; a.coef = coef; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_FWD_PACKED, a, plan, N, (hipStream_t)stream);
+}
+
+extern "C" int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const float* sh, const void* P, const int32_t* bin, const float* coef,
+                                   const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm,
+                                   int64_t N, int64_t E, float* g_x, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !P || !bin || !coef || !dst || !src_perm))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.sh = sh; a.w = static_cast<const float*>(P); a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_X_PACKED, a, plan, N, (hipStream_t)stream);
 }
 
 // ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------

@@ -205,6 +205,16 @@ TP_TABLE = _knob("E3K_TP_TABLE")
 ADDEND_INPLACE = _knob("E3K_ADDEND_INPLACE")
 
 
+# 1: ... from the table PACKED into one 12-byte record per (knot, weight) (e3k_rtable_pack: the cubic's Taylor coefficients about the
+# middle of the knot interval, the two small ones in fp16): one dwordx3 load per path slot instead of four dword loads out of four
+# rows; 0: the four-row form of round 4
+TP_TABLE_PACKED = _knob("E3K_TP_TABLE_PACKED")
+
+
+def _packed_buffer(rows: int, width: int, dev) -> torch.Tensor:
+    return torch.empty(rows, width, 3, device=dev, dtype=torch.int32)
+
+
 def in_kernel_table(plan, table, dev) -> bool:
     if not TP_TABLE or table is None:
         return False
@@ -222,7 +232,7 @@ def _table_fields(rad: L.LayerRadial, table) -> None:
     rad.bin_coef, rad.bin_seg = table.coef.data_ptr(), table.seg.data_ptr()
 
 
-def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, keep: bool, w_last, w_hidden, buf, carve, w, t_tab):
+def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, keep: bool, w_last, w_hidden, buf, carve, w, t_tab, p_tab=None):
     r = edge_radial.shape[0]
     rad.R, rad.E, rad.keep = r, n_edges, int(keep)
     rad.use_table = int(table is not None)
@@ -239,9 +249,10 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
             rad.z[i] = _ptr(buf, carve.off[f"z{i}"])
     rad.w = _ptr(w)
     rad.in_kernel = 1 if w is None else 0
+    rad.P = p_tab.data_ptr() if (p_tab is not None and w is None) else None
 
 
-def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
+def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w, p_tab=None):
     """Radial argument block of a layer whose MLP rows ``pre`` came from the stack: with the table the layer interpolates
     ``pre`` (= T) into ``w``; without, ``pre`` is ``w``."""
     rad.R, rad.E, rad.keep, rad.have_rows = pre.shape[0], n_edges, 0, 1
@@ -251,6 +262,7 @@ def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w):
         rad.T = pre.data_ptr()
         rad.w = _ptr(w)
         rad.in_kernel = 1 if w is None else 0
+        rad.P = p_tab.data_ptr() if (p_tab is not None and w is None) else None
     else:
         rad.w = pre.data_ptr()
 
@@ -511,7 +523,8 @@ class KwStackFn(torch.autograd.Function):
 
 
 def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
-    """Buffers of one radial branch: (activations buffer, its carve, w [E, W], table rows [R, W] or None)."""
+    """Buffers of one radial branch: (activations buffer, its carve, w [E, W], table rows [R, W] or None); the packed table of the
+    in-kernel form rides on the table rows as ``t_tab._e3k_packed``."""
     r, hdim, width = edge_radial.shape[0], plan.last_spec.d_in, plan.last_spec.d_out
     carve = _Carve()
     carve.add("h", r * hdim)
@@ -521,6 +534,8 @@ def _radial_alloc(plan, edge_radial, table, n_edges: int, keep: bool, dev):
     buf = carve.alloc(dev)
     w = None if in_kernel_table(plan, table, dev) else torch.empty(n_edges, width, device=dev, dtype=torch.float32)
     t_tab = torch.empty(r, width, device=dev, dtype=torch.float32) if table is not None else None
+    if t_tab is not None and w is None and TP_TABLE_PACKED:
+        t_tab._e3k_packed = _packed_buffer(r, width, dev)
     return buf, carve, w, t_tab
 
 
@@ -572,11 +587,14 @@ class NativeConvBlockFn(torch.autograd.Function):
         # --- radial branch: this layer's (or the look-ahead's result), and the next layer's look-ahead
         pref, plan.prefetched = plan.prefetched, None
         mode = "stack" if stack else "native"
-        own_table = rbuf = rcarve = t_tab = None
+        own_table = rbuf = rcarve = t_tab = p_tab = None
         inker = in_kernel_table(plan, table, dev)
         if stack and inker:
             w = None                                 # the tensor-product kernels read the table rows themselves
-            _stack_radial_struct(a.rad, plan, pre, table, e, None)
+            if TP_TABLE_PACKED:
+                with conv_block._on(side, main):     # (packed behind the stack's rows, on the radial stream)
+                    p_tab = _packed_buffer(pre.shape[0], plan.last_spec.d_out, dev)
+            _stack_radial_struct(a.rad, plan, pre, table, e, None, p_tab)
         elif stack and table is None:
             w = pre                                  # per-edge weights straight from the stack
             _stack_radial_struct(a.rad, plan, pre, None, e, None)
@@ -596,7 +614,8 @@ class NativeConvBlockFn(torch.autograd.Function):
                 rbuf, rcarve, w, t_tab = _radial_alloc(plan, edge_radial, table, e, keep, dev)
             own_table = t_tab
         if not stack:
-            _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab)
+            p_tab = getattr(t_tab, "_e3k_packed", None) if t_tab is not None else None
+            _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab, p_tab)
         nxt_keep = None
         if stack and nxt is not None and fork and conv_block.LOOK_AHEAD and table is not None and not inker:
             plan_n, pre_n = nxt
@@ -615,7 +634,8 @@ class NativeConvBlockFn(torch.autograd.Function):
                 with conv_block._on(side, main):
                     nbuf, ncarve, w_n, t_n = _radial_alloc(plan_n, edge_radial, table, e, keep, dev)
                 rad_n = L.LayerRadial()
-                _radial_struct(rad_n, plan_n, edge_radial, table, e, keep, w_last_n, w_hidden_n, nbuf, ncarve, w_n, t_n)
+                _radial_struct(rad_n, plan_n, edge_radial, table, e, keep, w_last_n, w_hidden_n, nbuf, ncarve, w_n, t_n,
+                               getattr(t_n, "_e3k_packed", None) if t_n is not None else None)
                 a.next, a.next_rad = nl_n.handle(dev), C.pointer(rad_n)
                 nxt_keep = (rad_n, nbuf, ncarve, w_n, t_n, plan_n, w_last_n)
         # --- node side buffers: one allocation
@@ -679,6 +699,8 @@ class NativeConvBlockFn(torch.autograd.Function):
                                                    #  input-gradient GEMM reads it on this one)
             if w is None:
                 (pre if stack else t_tab).record_stream(main)      # (the table: allocated on the radial stream, read by the tensor product)
+                if p_tab is not None:
+                    p_tab.record_stream(main)
             elif w is not pre:
                 w.record_stream(main)
             else:
@@ -698,7 +720,8 @@ class NativeConvBlockFn(torch.autograd.Function):
             plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))
         if keep:
             ctx.save_for_backward(x if (in_cf or not need_relayout) else None, edge_radial, sh, buf, rbuf, w, w_lin1, w_post, w_sc,
-                                  w_last, t_tab if (w is None and not stack) else None, addend if addend_inplace else m_pre, *w_hidden)
+                                  w_last, t_tab if (w is None and not stack) else None, addend if addend_inplace else m_pre, *w_hidden,
+                                  p_tab)
             ctx.cfg = (plan, topo, groups, bool(in_cf), bool(out_cf), fork, len(w_hidden), table, carve, rcarve, need_relayout)
             ctx.stack = stack
             ctx.attrs_shape = tuple(node_attrs.shape) if (has_sc and not have_m) else None
@@ -720,6 +743,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             if gy is None:
                 gy = torch.zeros(conv_ext.shape[0], plan.gate_spec.out_dim, device=conv_ext.device, dtype=torch.float32)
         w_hidden = saved[12:12 + n_hidden]
+        p_tab = saved[12 + n_hidden]                 # the packed table of the in-kernel form (or None)
         need = ctx.needs_input_grad
         need_x, need_attrs, need_radial, need_sh = need[0], need[1], need[2], need[3]
         stack, need_pre = ctx.stack, need[12]
@@ -767,10 +791,10 @@ class NativeConvBlockFn(torch.autograd.Function):
                 a.a_rep, a.m, a.w_sc = _ptr(buf, off["a_rep"]), _ptr(buf, off["m"]), w_sc.data_ptr()
             a.perm, a.bounds, a.reps, a.n_keys = groups.perm.data_ptr(), groups.bounds.data_ptr(), groups.reps.data_ptr(), groups.n_keys
         if stack:
-            _stack_radial_struct(a.rad, plan, edge_radial, table, e, w)      # (edge_radial: the layer's pre-computed rows)
+            _stack_radial_struct(a.rad, plan, edge_radial, table, e, w, p_tab)      # (edge_radial: the layer's pre-computed rows)
         else:
             _radial_struct(a.rad, plan, edge_radial, table, e, True, w_last, w_hidden, rbuf, rcarve, w,
-                           None if table is None else (w if w is not None else t_keep))
+                           None if table is None else (w if w is not None else t_keep), p_tab)
             if w is not None:
                 a.rad.T = None
         a.gy = gy.data_ptr()

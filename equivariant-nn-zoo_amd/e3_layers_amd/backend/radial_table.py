@@ -343,8 +343,10 @@ def guard_many(items) -> None:
             states = (C.c_void_p * n)(*[g.dev.data_ptr() for g, _ in part])
             scr = (C.c_void_p * n)(*[g.scratch.data_ptr() for g, _ in part])
             widths = (C.c_int32 * n)(*[t.shape[1] for _, t in part])
+            # (packed = 1 always: the bound then also covers the fp16 rounding of the packed in-kernel form -- a few 1e-8 -- whether or not
+            #  this table is read packed: one rule for every path, independent of which kernels a batch's size selects)
             L.check(lib.e3k_rtable_guard(tabs, states, scr, widths, n, rows, float(GUARD_COL_FLOOR), float(GUARD_TOL) / float(GUARD_TOL_COL),
-                                         L.stream_ptr()), "e3k_rtable_guard")
+                                         1, L.stream_ptr()), "e3k_rtable_guard")
     if not capturing:
         for g, _ in todo:
             _send(g, 1, reset=False)
@@ -383,6 +385,24 @@ def interp_fwd_raw(table: torch.Tensor, bins: KnotBins) -> torch.Tensor:
     with ops.timed_launch("rtable_fwd", (e, bins.knots, width)):
         L.check(L.load().e3k_rtable_interp_fwd(L.ptr(table), L.ptr(bins.perm), L.ptr(bins.bin), L.ptr(bins.coef), e, bins.knots, width,
                                                L.ptr(w), L.stream_ptr()), "e3k_rtable_interp_fwd")
+    return w
+
+
+def pack_raw(table: torch.Tensor, knots: int) -> torch.Tensor:
+    """P [knots + 1, W, 3] int32: the table packed for the tensor-product kernels (``e3k_rtable_pack``: 12-byte Taylor records)."""
+    table = L.f32c(table)
+    L.require_cuda(table)
+    packed = torch.empty(table.shape[0], table.shape[1], 3, device=table.device, dtype=torch.int32)
+    L.check(L.load().e3k_rtable_pack(L.ptr(table), int(knots), table.shape[1], L.ptr(packed), L.stream_ptr()), "e3k_rtable_pack")
+    return packed
+
+
+def interp_packed_raw(packed: torch.Tensor, bins: KnotBins) -> torch.Tensor:
+    """w [E, W] from the packed table, with the arithmetic of the packed in-kernel form (bit-identical to it)."""
+    e, width = bins.bin.numel(), packed.shape[1]
+    w = torch.empty(e, width, device=packed.device, dtype=torch.float32)
+    L.check(L.load().e3k_rtable_interp_packed(L.ptr(packed), L.ptr(bins.perm), L.ptr(bins.bin), L.ptr(bins.coef), e, bins.knots, width,
+                                              L.ptr(w), L.stream_ptr()), "e3k_rtable_interp_packed")
     return w
 
 

@@ -234,6 +234,13 @@ int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, c
 int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* coef,
                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N,
                        int64_t E, float* g_x, void* stream);
+/* ... and from the PACKED table P [K + 1, W, 3] (e3k_rtable_pack) -- same plans, same results up to the fp16 rounding stated there */
+int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const float* sh, const void* P, const int32_t* bin, const float* coef,
+                      const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out,
+                      void* stream);
+int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const float* sh, const void* P, const int32_t* bin, const float* coef,
+                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E,
+                        float* g_x, void* stream);
 /* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights
  * then depend on pos through the radius, nn/message_passing.py:93).  With F = <g, TP(x[src], sh, w(T, coef))>, linear in each
  * of (g, x, sh, T, coef), every first and second derivative is one of the walks below (plans with e3k_tp_table2_supported:
@@ -320,9 +327,22 @@ int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scal
                           const int32_t* bin_seg, const int32_t* bin_perm, int64_t E, int32_t K, int32_t W, float* workspace,
                           float* g_T, int32_t accumulate, void* stream);
 
+/* The table packed for the tensor-product kernels: 12 bytes per (knot, weight) in ONE row -- the cubic through rows i-1 .. i+2 as
+ * its Taylor polynomial about the middle of knot interval i, {d0: f32, d1: f32, d2 * 2^10: f16, d3 * 2^16: f16} -- instead of four
+ * 4-byte values in four rows 4 W bytes apart: e3k_tp_fwd_ptable / e3k_tp_bwd_x_ptable read one dwordx2 and one dword per path slot
+ * and edge (23 instead of 31 KB of table per edge through L1).  P [K + 1, 3 W] dwords: a row = its W (d0, d1) pairs, then its W
+ * f16 pairs.  Same function as the four-row form up to the fp16
+ * rounding of the two small coefficients (economised into the fp32 pair: <= 2^-11 (|d2| / 8 + |d3| / 32), ~6e-8 of the values on
+ * 512 knots).
+ * e3k_rtable_interp_packed materialises w[e, :] from P with the kernels' own arithmetic (bit-identical; tests). */
+int e3k_rtable_pack(const float* T, int32_t K, int32_t W, void* P, void* stream);
+int e3k_rtable_interp_packed(const void* P, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
+                             int32_t W, float* w, void* stream);
+
 /* A-posteriori bound of the table's interpolation error, evaluated ON THE DEVICE (the reference evaluates fc(edge_radial)
  * exactly on every edge, nn/message_passing.py:74-79,93: the table must know when it stops being a stand-in).  With
- * err_c = 3/128 max_i |4th difference of T[:, c] at i| (cubic Lagrange on the table's knots):
+ * err_c = 3/128 max_i |4th difference of T[:, c] at i| (cubic Lagrange on the table's knots; packed != 0: plus the fp16 rounding of
+ * the packed table's two small coefficients, 2^-11 (|2nd difference| / 16 + |3rd difference| / 192)):
  *     table-wide ratio  est_g = max_c err_c / max |T|
  *     per-column ratio  est_c = max_c err_c / max(max_i |T[i, c]|, floor_rel * max |T|)
  *     reported          est   = max(est_g, col_weight * est_c)        (col_weight = table-wide tolerance / per-column tolerance)
@@ -331,7 +351,7 @@ int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scal
  * read a per-launch value), [1] est of this launch, [2] internal ticket counter (zero it once at allocation), [3] est_c of this
  * launch.  scratch[t] float [2 * widths[t]].  A non-finite table entry gives est = +inf.  rows < 5: nothing to do. */
 int e3k_rtable_guard(const float* const* tables, float* const* states, float* const* scratch, const int32_t* widths, int32_t n,
-                     int32_t rows, float floor_rel, float col_weight, void* stream);
+                     int32_t rows, float floor_rel, float col_weight, int32_t packed, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Node-side elementwise kernels.
@@ -581,6 +601,8 @@ typedef struct {
   float* z[4];               /* [R, h] pre-activations (keep) */
   float* T;                  /* table: [R, W] out; without the table unused */
   float* w;                  /* [E, W] out */
+  void* P;                   /* in_kernel only: the table packed for the tensor-product kernels [R, W, 3] dwords (e3k_rtable_pack),
+                              * written behind T by the forward, read by tp_fwd / tp_bwd_x; NULL: they gather four rows of T */
 } e3k_layer_radial;
 
 typedef struct {

@@ -652,6 +652,35 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
         assert torch.equal(gx_t, ref_gx)
     else:                                   # (atomic accumulation across groups: the order is not fixed)
         assert rel_err(gx_t, ref_gx) < 1e-6
+    # ---- the PACKED table (round 5: e3k_rtable_pack -> e3k_tp_fwd_ptable / e3k_tp_bwd_x_ptable): one 12-byte Taylor record per (knot,
+    # weight), the cubic's two small coefficients in fp16.  (i) the packed in-kernel forms == interpolate-from-the-packed-table, then
+    # multiply, bit for bit (the evaluation order this form is pinned to); (ii) the packed interpolation against the float64 cubic:
+    # within the fp16 rounding of the two small terms, relative to the table's scale; on a SMOOTH table (what the kernels see) 2e-7.
+    from e3_layers_amd.backend import conv_force
+
+    # (on a SMOOTH table -- what the kernels see; the fixed fp16 scales of the record assume third differences ~1e-5 of the values,
+    #  a table of independent normal rows overflows them, and the guard would veto it)
+    radii = torch.arange(bins.knots + 1, dtype=torch.float64) * bins.spacing
+    cols = torch.arange(plan.w_numel, dtype=torch.float64)
+    smooth = (torch.sin(radii[:, None] * (1.0 + 5.0 * cols[None, :] / plan.w_numel)) * torch.exp(-0.2 * radii[:, None])).float().to(dev)
+    packed = radial_table.pack_raw(smooth, bins.knots)
+    w_p = radial_table.interp_packed_raw(packed, bins)
+    assert bool(torch.isfinite(w_p).all())
+    out_p = conv_force._tp_fwd_ptable(x, sh, packed, bins, topo, plan)
+    gx_p = conv_force._tp_bwd_x_ptable(sh, packed, bins, g_out, topo, plan)
+    torch.cuda.synchronize()
+    assert torch.equal(out_p, ops._tp_fwd_raw(x, sh, w_p, topo, plan))
+    if plan.bwd_x_overwrites(dev):
+        assert torch.equal(gx_p, ops._tp_bwd_x_raw(sh, w_p, g_out, topo, plan))
+    else:
+        assert rel_err(gx_p, ops._tp_bwd_x_raw(sh, w_p, g_out, topo, plan)) < 1e-6
+    s64 = smooth.cpu().double()
+    ws_ref = sum(c_ref[:, k:k + 1] * s64[i_ref - 1 + k] for k in range(4))
+    inner = (r > 0.1) & (r < r_max)          # (beyond the ends the cubic is extrapolated: |s| up to 3/2)
+    # (this table: 6 rad/A on knots 2^-6 A apart -- d2 = 4e-3 of the values, four times the shipped models' on their 2^-7 A knots:
+    #  2^-11 d2 / 8 = 2.7e-7, plus the fp32 roundings)
+    assert float((w_p.cpu().double() - ws_ref)[inner].abs().max()) < 5e-7 * float(s64.abs().max())
+    assert float((w_p.cpu().double() - ws_ref).abs().max()) < 2e-6 * float(s64.abs().max())
     # the gradient of the table: tp_bwd_w -> g_w[E, W] -> transposed interpolation, against an index_add in float64; twice: same bits
     g_w, _ = ops._tp_bwd_w_raw(x, sh, None, g_out, topo, plan, False, True)
     gt_a = radial_table.interp_bwd_raw(g_w, bins)

@@ -23,7 +23,7 @@ def est(table, floor):
     state = torch.zeros(4, device=dev)
     scratch = torch.empty(2 * table.shape[1], device=dev)
     L.check(lib.e3k_rtable_guard((C.c_void_p * 1)(table.data_ptr()), (C.c_void_p * 1)(state.data_ptr()), (C.c_void_p * 1)(scratch.data_ptr()),
-                                 (C.c_int32 * 1)(table.shape[1]), 1, table.shape[0], float(floor), 0.0, L.stream_ptr()), "guard")
+                                 (C.c_int32 * 1)(table.shape[1]), 1, table.shape[0], float(floor), 0.0, 1, L.stream_ptr()), "guard")
     torch.cuda.synchronize()
     return float(state[3]) if floor < 1.0 else float(state[1])      # per-column ratio; floor 1.0: the table-wide ratio
 

@@ -61,7 +61,11 @@ for target in targets:
     cnt = (bins.ptr[1:] - bins.ptr[:-1]).float()
     t_f = timeit(lambda: conv_force._tp_fwd_table(x, sh, T, bins, topo, tp))
     t_x = timeit(lambda: conv_force._tp_bwd_x_table(sh, T, bins, g, topo, tp))
+    P = radial_table.pack_raw(T, bins.knots)
+    t_p = timeit(lambda: radial_table.pack_raw(T, bins.knots))
+    t_fp = timeit(lambda: conv_force._tp_fwd_ptable(x, sh, P, bins, topo, tp))
+    t_xp = timeit(lambda: conv_force._tp_bwd_x_ptable(sh, P, bins, g, topo, tp))
     t_i = timeit(lambda: radial_table.interp_fwd_raw(T, bins))
     t_t = timeit(lambda: radial_table.interp_bwd_raw(gw, bins))
     print(f"knots {bins.knots:5d} (table {4e-6 * (bins.knots + 1) * tp.w_numel:5.1f} MB, edges/knot mean {float(cnt[cnt > 0].mean()):6.1f} max {int(cnt.max()):5d}): "
-          f"tp_fwd_table {t_f:7.1f} us  tp_bwd_x_table {t_x:7.1f} us  interp_fwd {t_i:6.1f} us  interp_bwd {t_t:6.1f} us  bins {t_bins:5.1f} us")
+          f"tp_fwd_table {t_f:7.1f} us  tp_bwd_x_table {t_x:7.1f} us  PACKED fwd {t_fp:7.1f} us  bwd_x {t_xp:7.1f} us  pack {t_p:5.1f} us  interp_fwd {t_i:6.1f} us  interp_bwd {t_t:6.1f} us  bins {t_bins:5.1f} us")
