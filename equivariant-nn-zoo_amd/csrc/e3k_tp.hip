@@ -831,12 +831,29 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
 // ------------------------------------------------------------------------------------------
 // one launch per pass: a wave looks up its work item and branches (wave-uniformly) on the input degree
 // ------------------------------------------------------------------------------------------
+// Work order.  0: node-major -- XCD x owns a contiguous slice of the (node, group-chunk) list, a workgroup = four consecutive items
+// (mostly the groups of ONE node).  1 (table forms): group-major inside the XCD's node slice -- XCD x owns nodes [x N / 8, (x + 1) N / 8)
+// and walks them group-chunk by group-chunk, a workgroup = four consecutive NODES of one group-chunk: at any time an XCD's L2 then
+// holds the table columns of ONE group (2.4 of the packed table's 11.8 MB) beside that group's feature columns of its own nodes.
 #define E3K_TP_PROLOGUE                                                        \
-  const int b = xcd_remap(blockIdx.x, gridDim.x);                              \
-  const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);                    \
-  if (item >= a.n_items) return;                                               \
-  const int node = uniform((int)(item / n_gc));                                \
-  const int gci = uniform((int)(item % n_gc));                                 \
+  int node_, gci_;                                                             \
+  if (a.order == 0) {                                                          \
+    const int b = xcd_remap(blockIdx.x, gridDim.x);                            \
+    const int64_t item = (int64_t)b * 4 + (threadIdx.x >> 6);                  \
+    if (item >= a.n_items) return;                                             \
+    node_ = (int)(item / n_gc);                                                \
+    gci_ = (int)(item % n_gc);                                                 \
+  } else {                                                                     \
+    const int64_t n_nodes = a.n_items / n_gc;                                  \
+    const int xcd = blockIdx.x & 7;                                            \
+    const int64_t n0 = xcd * n_nodes / 8, nx = (xcd + 1) * n_nodes / 8 - n0;   \
+    const int64_t j = (int64_t)(blockIdx.x >> 3) * 4 + (threadIdx.x >> 6);     \
+    if (j >= nx * n_gc) return;                                                \
+    gci_ = (int)(j / nx);                                                      \
+    node_ = (int)(n0 + j % nx);                                                \
+  }                                                                            \
+  const int node = uniform(node_);                                             \
+  const int gci = uniform(gci_);                                               \
   const int2 gcv = gc[gci];                                                    \
   const e3k_tp_group& g = groups[uniform(gcv.x)];                              \
   const int part = uniform(gcv.y) >> 16;                                        \
@@ -1094,7 +1111,12 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   if (!n_gc || N <= 0) return E3K_OK;
   e3k::TpArgs args = a;
   args.n_items = N * n_gc;
-  const int64_t blocks = (args.n_items + 3) / 4;
+  int64_t blocks = (args.n_items + 3) / 4;
+  // (packed table, layer 3 of config_energy at 256 molecules, isolated: forward 163 -> 151 us, input gradient 221 -> 215; inside the
+  //  step 124 -> 118 and 194 -> 187; the four-row form, whose 3.9 MB table stays in L2 either way, gains nothing: 187 / 188 us)
+  E3K_KNOB_INT(tp_order, "E3K_TP_ORDER", 1);
+  args.order = (tp_order && (kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED) && N >= 64) ? 1 : 0;
+  if (args.order) blocks = 8 * ((((N + 7) / 8) * n_gc + 3) / 4);      // eight equal sub-grids, one per XCD (blocks b, b + 8, .. share one)
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
   if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL) {

@@ -55,6 +55,7 @@ struct TpArgs {
   float* g_r;          // [E]: gradient w.r.t. the radius (tp_bwd_e), accumulated with one atomic per wave and edge
   int32_t d_in, d_sh, W, d_mid;
   int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
+  int32_t order;       // work order of the launch (E3K_TP_PROLOGUE): 0 node-major, 1 group-major inside an XCD's node slice
   int64_t n_items;
 };
 
