@@ -231,6 +231,42 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(const int64_t* __restr
 }
 }  // namespace e3k
 
+// ---- edge records (round 5): everything the tensor-product kernels need to know about the t-th edge of a CSR walk in ONE aligned
+// 64-byte block -- {neighbour node, knot, four interpolation weights, nine spherical harmonics, edge id} -- in the order of the walk.
+// The kernels used to chase perm[t] -> e -> {nbr[e], bin[e], coef[e], sh[e]} (three dependent scalar round trips per edge and wave,
+// in front of the row loads whose addresses they feed); a record is one s_load_dwordx16 whose address follows from the loop
+// counter, so the next edge's record is fetched while this edge is computed.  Built once per batch and direction (4.4 MB at 70 k
+// edges), shared by every layer.
+namespace e3k {
+__global__ __launch_bounds__(256) void edge_records_kernel(const int32_t* __restrict__ perm, const int32_t* __restrict__ nbr,
+                                                           const int32_t* __restrict__ bin, const float* __restrict__ coef,
+                                                           const float* __restrict__ sh, int d_sh, int64_t E, int32_t* __restrict__ rec) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one thread per dword of the records
+  if (q >= E * 16) return;
+  const int64_t t = q >> 4;
+  const int f = (int)(q & 15);
+  const int e = perm[t];
+  int32_t v = 0;
+  if (f == 0) v = nbr[e];
+  else if (f == 1) v = bin ? bin[e] : 0;
+  else if (f < 6) v = coef ? __float_as_int(coef[4 * (int64_t)e + (f - 2)]) : 0;
+  else if (f < 15) v = (f - 6) < d_sh ? __float_as_int(sh[(int64_t)e * d_sh + (f - 6)]) : 0;
+  else v = e;
+  rec[q] = v;
+}
+}  // namespace e3k
+
+extern "C" int e3k_edge_records(const int32_t* perm, const int32_t* nbr, const int32_t* bin, const float* coef, const float* sh,
+                                int32_t d_sh, int64_t E, int32_t* rec, void* stream) {
+  if (E < 0 || d_sh <= 0 || d_sh > 9 || (bin != nullptr) != (coef != nullptr)) return E3K_ERR_INVALID;
+  if (E == 0) return E3K_OK;
+  if (!perm || !nbr || !sh || !rec || (reinterpret_cast<uintptr_t>(rec) & 63)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::edge_records_kernel, dim3((unsigned)((E * 16 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, perm, nbr, bin,
+                     coef, sh, d_sh, E, rec);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
 extern "C" int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int32_t* bounds, int64_t* reps,
                               int32_t* bad_flag, void* stream) {
   if (R < 0 || K <= 0) return E3K_ERR_INVALID;

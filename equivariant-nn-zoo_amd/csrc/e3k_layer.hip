@@ -353,8 +353,7 @@ extern "C" int e3k_layer_fwd(const e3k_layer* L, const e3k_layer_fwd_args* a) {
   {
     Timed t(L, E3K_PROF_TP_FWD, main, a->N, a->E);
     if (in_kernel_table(d, a->rad) && a->rad.P)
-      E3K_TRY(e3k_tp_fwd_ptable(d.tp, a->x1, a->sh, a->rad.P, a->rad.bin, a->rad.bin_coef, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
-                                a->mid, main));
+      E3K_TRY(e3k_tp_fwd_ptable(d.tp, a->x1, a->rad.P, a->rad.erec_dst, a->dst_ptr, a->N, a->E, a->mid, main));
     else if (in_kernel_table(d, a->rad))
       E3K_TRY(e3k_tp_fwd_table(d.tp, a->x1, a->sh, a->rad.T, a->rad.bin, a->rad.bin_coef, a->src, a->dst_ptr, a->dst_perm, a->N, a->E,
                                a->mid, main));
@@ -460,7 +459,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
     if (ABLATE & 32) {
     } else if (in_kernel_table(d, r) && r.P) {
-      E3K_TRY(e3k_tp_bwd_x_ptable(d.tp, a->sh, r.P, r.bin, r.bin_coef, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
+      E3K_TRY(e3k_tp_bwd_x_ptable(d.tp, r.P, r.erec_src, a->g_mid, a->src_ptr, a->N, a->E, a->g_x1, main));
     } else if (in_kernel_table(d, r)) {
       E3K_TRY(e3k_tp_bwd_x_table(d.tp, a->sh, r.T, r.bin, r.bin_coef, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, main));
     } else {

@@ -110,6 +110,10 @@ __device__ __forceinline__ float knot_mix(float c0, float c1, float c2, float c3
   return fmaf(c3, vd, fmaf(c2, vc, fmaf(c1, vb, c0 * va)));
 }
 
+#ifdef E3K_DEBUG_KNOBS
+static int g_tp_ablate_host = 0;      // timing-only ablation mask of the packed-table forward (tools/tp_table_bench.py --ablate): 1 no table
+                                      // loads, 2 no x row loads, 4 no CG arithmetic -- wrong results by design; travels in TpArgs.ablate
+#endif
 // MODE 4 (packed table, round 5): the same cubic from 12 bytes per (knot, weight) in ONE table row -- {d0, d1: f32; d2 * 2^10,
 // d3 * 2^16: f16}, the Taylor coefficients about the middle of the knot interval (e3k_rtable_pack; a row = its W (d0, d1) pairs, then
 // its W f16 pairs) -- one dwordx2 + one dword load per slot instead of four dword loads out of four rows: 23 instead of 31 KB of
@@ -123,19 +127,50 @@ struct KnotPacked {
   __amdgpu_buffer_rsrc_t r;
   float s, s2, s3;
 };
-__device__ __forceinline__ KnotPacked knot_packed(const TpArgs& a, int e, int row_p) {
-  const int i = uniform(a.bin[e]);
-  const float* __restrict__ cp = a.coef + 4 * (int64_t)e;
-  const float c0 = sload(cp), c2 = sload(cp + 2), c3 = sload(cp + 3);
+// the t-th edge of the walk as one aligned 64-byte record (e3k_edge_records): a single s_load_dwordx16 whose address follows from
+// the loop counter -- the packed-table kernels fetch edge t + 1's record while edge t is computed
+struct EdgeRec {
+  int nbr, bin;
+  float c0, c1, c2, c3;
+  float y[9];
+  int e;
+};
+__device__ __forceinline__ EdgeRec load_rec(const int32_t* __restrict__ erec, int t) {
+  const int32_t* __restrict__ p = static_cast<const int32_t*>(__builtin_assume_aligned(erec + 16 * (int64_t)t, 64));
+  EdgeRec r;
+  r.nbr = uniform(p[0]);
+  r.bin = uniform(p[1]);
+  r.c0 = __int_as_float(uniform(p[2])); r.c1 = __int_as_float(uniform(p[3]));
+  r.c2 = __int_as_float(uniform(p[4])); r.c3 = __int_as_float(uniform(p[5]));
+#pragma unroll
+  for (int j = 0; j < 9; ++j) r.y[j] = __int_as_float(uniform(p[6 + j]));
+  r.e = uniform(p[15]);
+  return r;
+}
+__device__ __forceinline__ void rec_y(YRegs& y, const EdgeRec& r) {
+  y.y0[0] = r.y[0];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) y.y1[j] = r.y[1 + j];
+#pragma unroll
+  for (int j = 0; j < 5; ++j) y.y2[j] = r.y[4 + j];
+}
+__device__ __forceinline__ KnotPacked knot_packed_rec(const TpArgs& a, const EdgeRec& r, int row_p) {
   KnotPacked k;
-  k.r = row_rsrc(a.w + 3 * (int64_t)i * a.W, row_p);
-  k.s = fmaf(2.f, c3, c2 - c0) - 0.5f;      // t = sum_k x_k L_k(t), x = (-1, 0, 1, 2); s = t - 1/2
+  k.r = row_rsrc(a.w + 3 * (int64_t)r.bin * a.W, row_p);
+  k.s = fmaf(2.f, r.c3, r.c2 - r.c0) - 0.5f;      // t = sum_k x_k L_k(t), x = (-1, 0, 1, 2); s = t - 1/2
   k.s2 = k.s * (1.f / 1024.f);
   k.s3 = k.s * (1.f / 64.f);
   return k;
 }
 // slot at weight offset woff4 (bytes of a 4-byte column) of the row, lane channel u4 = 4 u; pk_base = 8 W (bytes)
-__device__ __forceinline__ PackedRec buf_ld_rec(__amdgpu_buffer_rsrc_t r, int u4, int woff4, int pk_base) {
+__device__ __forceinline__ PackedRec buf_ld_rec(__amdgpu_buffer_rsrc_t r, int u4, int woff4, int pk_base, int ablate = 0) {
+#ifdef E3K_DEBUG_KNOBS
+  if (ablate & 1) {      // timing only: no table loads
+    PackedRec p;
+    p.d0 = __int_as_float(u4 + woff4); p.d1 = 1.f; p.pk = (unsigned)pk_base;
+    return p;
+  }
+#endif
   const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, u4 * 2, woff4 * 2, 0);
   PackedRec p;
   p.d0 = __uint_as_float(v[0]);
@@ -168,14 +203,33 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
 #pragma unroll
   for (int i = 0; i < S::TOTAL; ++i) acc[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  EdgeRec cur{};
+  if constexpr (PACKED) {
+    if (beg < end) cur = load_rec(a.erec, beg);
+  }
   for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int s = uniform(a.nbr[e]);
+    int e, s;
     YRegs yc, y2;
-    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    EdgeRec nxt{};
+    if constexpr (PACKED) {      // this edge's record arrived during the previous edge; the next one's is requested now
+      nxt = load_rec(a.erec, t + 1 < end ? t + 1 : t);
+      e = cur.e;
+      s = cur.nbr;
+      rec_y(yc, cur);
+    } else {
+      e = uniform(a.perm[t]);
+      s = uniform(a.nbr[e]);
+      load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    }
     if constexpr (JVP) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rx = row_rsrc(a.x + (int64_t)s * a.d_in, row_x);
     float xc[D1], x2c[JVP ? D1 : 1], wc[S::NQ], w2[JVP ? S::NQ : 1];
+#ifdef E3K_DEBUG_KNOBS
+    if (PACKED && (a.ablate & 2)) {
+#pragma unroll
+      for (int i = 0; i < D1; ++i) xc[i] = __int_as_float(s + i);
+    } else
+#endif
 #pragma unroll
     for (int i = 0; i < D1; ++i) xc[i] = buf_ld(rx, u4, xoff4 + i * mul4);
     if constexpr (JVP) {
@@ -184,11 +238,11 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
       for (int i = 0; i < D1; ++i) x2c[i] = buf_ld(rx2, u4, xoff4 + i * mul4);
     }
     if constexpr (PACKED) {
-      const KnotPacked kp = knot_packed(a, e, row_w * 3);
+      const KnotPacked kp = knot_packed_rec(a, cur, row_w * 3);
       PackedRec rec[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
-        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2);
+        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2, a.ablate);
       });
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
@@ -237,6 +291,12 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
       constexpr int L2 = S::L2[Q], L3 = S::L3[Q], OFF = S::OFF[Q];
       const float wv = wc[Q] * cf[Q];
       float tt[2 * L3 + 1];
+#ifdef E3K_DEBUG_KNOBS
+      if (PACKED && (a.ablate & 4)) {
+#pragma unroll
+        for (int k = 0; k < 2 * L3 + 1; ++k) tt[k] = xc[k % D1] + yc.y0[0];
+      } else
+#endif
       CG<L1, L2, L3>::xy(xc, yref<L2>(yc), tt);
       if constexpr (JVP) {
         // d/d(eps) [ w(r + eps s2) * xy(x + eps x2, y + eps y2) ] at eps = 0
@@ -251,6 +311,7 @@ __device__ __forceinline__ void tp_fwd_body_full(const TpArgs& a, const e3k_tp_g
         for (int k = 0; k < 2 * L3 + 1; ++k) acc[OFF + k] = fmaf(wv, tt[k], acc[OFF + k]);
       }
     });
+    if constexpr (PACKED) cur = nxt;
   }
   float* __restrict__ orow = a.out + (int64_t)node * a.d_mid;
   slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -652,16 +713,29 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
+  EdgeRec cur{};
+  if constexpr (PACKED) {
+    if (beg < end) cur = load_rec(a.erec, beg);
+  }
   for (int t = beg; t < end; ++t) {
-    const int e = uniform(a.perm[t]);
-    const int d = uniform(a.nbr[e]);
+    int e, d;
     YRegs yc, y2;
-    load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    EdgeRec nxt{};
+    if constexpr (PACKED) {      // (records in the order of the source-CSR walk: nbr = the edge's destination)
+      nxt = load_rec(a.erec, t + 1 < end ? t + 1 : t);
+      e = cur.e;
+      d = cur.nbr;
+      rec_y(yc, cur);
+    } else {
+      e = uniform(a.perm[t]);
+      d = uniform(a.nbr[e]);
+      load_y_full(yc, a.sh + (int64_t)e * a.d_sh);
+    }
     if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
     float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
     if constexpr (PACKED) {
-      const KnotPacked kp = knot_packed(a, e, row_w * 3);
+      const KnotPacked kp = knot_packed_rec(a, cur, row_w * 3);
       PackedRec rec[S::NQ];
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
         constexpr int Q = decltype(qc)::value;
@@ -737,6 +811,7 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
         CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
       }
     });
+    if constexpr (PACKED) cur = nxt;
   }
   float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
 #pragma unroll
@@ -890,8 +965,13 @@ __device__ __forceinline__ void tp_bwd_w_dual_body(const TpArgs& a, const e3k_tp
 // form's second-order (JVP / DUAL) variant -- FULL plans only for 1 and 2
 // (packed form, l_max <= 2 plans: 67 VGPRs as the compiler first allocates them -- one step over the 64 of eight waves per SIMD; asked
 //  for eight, it fits without spilling)
+#ifdef E3K_DEBUG_KNOBS
+#define E3K_TP_FWD_WAVES(MODE, MAXL, L3MAX) 1      // (the debug build's ablation branches do not fit 64 registers)
+#else
+#define E3K_TP_FWD_WAVES(MODE, MAXL, L3MAX) ((MODE == 4 && MAXL <= 2 && L3MAX <= 2) ? 8 : 1)
+#endif
 template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
-__global__ __launch_bounds__(256, (MODE == 4 && MAXL <= 2 && L3MAX <= 2) ? 8 : 1) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+__global__ __launch_bounds__(256, E3K_TP_FWD_WAVES(MODE, MAXL, L3MAX)) void tp_fwd_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                      const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_fwd_body, L3MAX, MODE)
@@ -1089,6 +1169,13 @@ extern "C" int e3k_tp_plan_create(const e3k_tp_group* groups, int32_t n_groups, 
   return E3K_OK;
 }
 
+#ifdef E3K_DEBUG_KNOBS
+extern "C" int e3k_dbg_tp_ablate(int mask) {
+  e3k::g_tp_ablate_host = mask;
+  return 0;
+}
+#endif
+
 extern "C" int e3k_tp_bwd_x_overwrites(const e3k_tp_plan* p) {
   // every element of g_x is stored exactly once: one group per input block, all of [0, d_in) covered, single-wave groups
   return (p && !p->split && !p->x_shared && p->x_cols == p->d_in) ? 1 : 0;
@@ -1116,6 +1203,9 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   //  step 124 -> 118 and 194 -> 187; the four-row form, whose 3.9 MB table stays in L2 either way, gains nothing: 187 / 188 us)
   E3K_KNOB_INT(tp_order, "E3K_TP_ORDER", 1);
   args.order = (tp_order && (kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED) && N >= 64) ? 1 : 0;
+#ifdef E3K_DEBUG_KNOBS
+  args.ablate = e3k::g_tp_ablate_host;
+#endif
   if (args.order) blocks = 8 * ((((N + 7) / 8) * n_gc + 3) / 4);      // eight equal sub-grids, one per XCD (blocks b, b + 8, .. share one)
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
@@ -1281,28 +1371,28 @@ extern "C" int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, cons
   return launch_all(TP_BWD_X_TABLE, a, plan, N, (hipStream_t)stream);
 }
 
-// ---- ... and from the PACKED table (e3k_rtable_pack: one 12-byte record per (knot, weight); same plans as the table form) ---------
-extern "C" int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const float* sh, const void* P, const int32_t* bin,
-                                 const float* coef, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N,
-                                 int64_t E, float* out, void* stream) {
+// ---- ... and from the PACKED table (e3k_rtable_pack: 12 bytes per (knot, weight); same plans as the table form), walking EDGE
+// RECORDS (e3k_edge_records over the destination CSR for the forward, over the source CSR for the input gradient) -----------------
+extern "C" int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_dst,
+                                 const int32_t* dst_ptr, int64_t N, int64_t E, float* out, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!x || !out || !dst_ptr || (E > 0 && (!sh || !P || !bin || !coef || !src || !dst_perm))) return E3K_ERR_INVALID;
-  if ((int64_t)plan->w_numel * 12 > 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
+  if (!x || !out || !dst_ptr || (E > 0 && (!P || !erec_dst))) return E3K_ERR_INVALID;
+  if ((int64_t)plan->w_numel * 12 > 0x7fffffffLL || (reinterpret_cast<uintptr_t>(erec_dst) & 63)) return E3K_ERR_UNSUPPORTED;
   e3k::TpArgs a{};
-  a.x = x; a.sh = sh; a.w = static_cast<const float*>(P); a.bin = bin; a.coef = coef; a.out = out; a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
+  a.x = x; a.w = static_cast<const float*>(P); a.erec = erec_dst; a.out = out; a.ptr = dst_ptr;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_FWD_PACKED, a, plan, N, (hipStream_t)stream);
 }
 
-extern "C" int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const float* sh, const void* P, const int32_t* bin, const float* coef,
-                                   const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm,
-                                   int64_t N, int64_t E, float* g_x, void* stream) {
+extern "C" int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* erec_src, const float* g_out,
+                                   const int32_t* src_ptr, int64_t N, int64_t E, float* g_x, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
-  if (!g_out || !g_x || !src_ptr || (E > 0 && (!sh || !P || !bin || !coef || !dst || !src_perm))) return E3K_ERR_INVALID;
+  if (!g_out || !g_x || !src_ptr || (E > 0 && (!P || !erec_src))) return E3K_ERR_INVALID;
+  if (reinterpret_cast<uintptr_t>(erec_src) & 63) return E3K_ERR_UNSUPPORTED;
   e3k::TpArgs a{};
-  a.sh = sh; a.w = static_cast<const float*>(P); a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_x = g_x; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.w = static_cast<const float*>(P); a.erec = erec_src; a.g_out = g_out; a.g_x = g_x; a.ptr = src_ptr;
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_PACKED, a, plan, N, (hipStream_t)stream);

@@ -53,8 +53,10 @@ struct TpArgs {
   const float* sh2;    // [E, d_sh]
   const float* s2;     // [E]: the radius' partner (a cotangent): the third term's weights are s2[e] * dw/dr[e]
   float* g_r;          // [E]: gradient w.r.t. the radius (tp_bwd_e), accumulated with one atomic per wave and edge
+  const int32_t* erec; // FULL kernels, optional: the walk's edge records [E, 16] (e3k_edge_records) -- perm, nbr, bin, coef, sh are then unused
   int32_t d_in, d_sh, W, d_mid;
   int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
+  int32_t ablate;      // debug build only: timing-only ablation mask (0 in the product library)
   int32_t order;       // work order of the launch (E3K_TP_PROLOGUE): 0 node-major, 1 group-major inside an XCD's node slice
   int64_t n_items;
 };

@@ -97,18 +97,16 @@ def _tp_fwd_ptable(x1, sh, packed, bins, topo, tp):
     """the forward from the PACKED table (``radial_table.pack_raw``)"""
     n, e = x1.shape[0], sh.shape[0]
     out = torch.empty(n, tp.d_mid, device=x1.device, dtype=torch.float32)
-    L.check(L.load().e3k_tp_fwd_ptable(tp.handle(x1.device), L.ptr(x1), L.ptr(sh), L.ptr(packed), L.ptr(bins.bin), L.ptr(bins.coef),
-                                       L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(out), L.stream_ptr()),
-            "e3k_tp_fwd_ptable")
+    L.check(L.load().e3k_tp_fwd_ptable(tp.handle(x1.device), L.ptr(x1), L.ptr(packed), L.ptr(bins.records(topo, sh, "dst")),
+                                       L.ptr(topo.dst_ptr), n, e, L.ptr(out), L.stream_ptr()), "e3k_tp_fwd_ptable")
     return out
 
 
 def _tp_bwd_x_ptable(sh, packed, bins, g_mid, topo, tp):
     n, e = g_mid.shape[0], sh.shape[0]
     gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
-    L.check(L.load().e3k_tp_bwd_x_ptable(tp.handle(sh.device), L.ptr(sh), L.ptr(packed), L.ptr(bins.bin), L.ptr(bins.coef), L.ptr(g_mid),
-                                         L.ptr(topo.dst), L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()),
-            "e3k_tp_bwd_x_ptable")
+    L.check(L.load().e3k_tp_bwd_x_ptable(tp.handle(sh.device), L.ptr(packed), L.ptr(bins.records(topo, sh, "src")), L.ptr(g_mid),
+                                         L.ptr(topo.src_ptr), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x_ptable")
     return gx
 
 

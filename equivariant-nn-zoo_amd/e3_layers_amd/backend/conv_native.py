@@ -616,6 +616,8 @@ class NativeConvBlockFn(torch.autograd.Function):
         if not stack:
             p_tab = getattr(t_tab, "_e3k_packed", None) if t_tab is not None else None
             _radial_struct(a.rad, plan, edge_radial, table, e, keep, w_last, w_hidden, rbuf, rcarve, w, t_tab, p_tab)
+        if p_tab is not None:      # the packed kernels walk edge records (once per batch: the first layer builds them, on this stream)
+            a.rad.erec_dst = table.records(topo, sh, "dst").data_ptr()
         nxt_keep = None
         if stack and nxt is not None and fork and conv_block.LOOK_AHEAD and table is not None and not inker:
             plan_n, pre_n = nxt
@@ -797,6 +799,8 @@ class NativeConvBlockFn(torch.autograd.Function):
                            None if table is None else (w if w is not None else t_keep), p_tab)
             if w is not None:
                 a.rad.T = None
+        if p_tab is not None:
+            a.rad.erec_src = table.records(topo, sh, "src").data_ptr()
         a.gy = gy.data_ptr()
         # ---- gradient buffers: the flat gradient buffer (sink) or zero-filled temporaries handed back to autograd
         rets = {}

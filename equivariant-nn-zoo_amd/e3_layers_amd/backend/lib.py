@@ -90,7 +90,7 @@ class LayerRadial(C.Structure):
     _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
                 ("have_rows", C.c_int32), ("in_kernel", C.c_int32), ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
                 ("bin_coef", C.c_void_p), ("bin_seg", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
-                ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p), ("P", C.c_void_p)]
+                ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p), ("erec_dst", C.c_void_p), ("erec_src", C.c_void_p), ("P", C.c_void_p)]
 
 
 class RadialStackItem(C.Structure):
@@ -204,8 +204,9 @@ SIGNATURES = {
     "e3k_tp_table_supported": (C.c_int, [_P]),
     "e3k_tp_fwd_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
-    "e3k_tp_fwd_ptable": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
-    "e3k_tp_bwd_x_ptable": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_fwd_ptable": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_x_ptable": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_edge_records": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _P, _P]),
     "e3k_tp_table2_supported": (C.c_int, [_P]),
     "e3k_tp_bwd_e_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "e3k_tp_fwd_jvp_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),

@@ -60,11 +60,32 @@ class KnotBins:
     i - 1 .. i + 2), ``coef`` [E, 4] (the four weights), the edges grouped by knot -- ``ptr`` [K + 2], ``perm`` [E] (ascending
     edge id inside a knot), ``seg`` [K + 2] (first <= 64-edge segment of every knot) -- and the knot count."""
 
-    __slots__ = ("bin", "coef", "ptr", "perm", "seg", "knots", "spacing", "_buf", "__weakref__")
+    __slots__ = ("bin", "coef", "ptr", "perm", "seg", "knots", "spacing", "_buf", "_rec", "__weakref__")
 
     def __init__(self, bin, coef, ptr, perm, seg, knots: int, spacing: float, buf=None):
         self.bin, self.coef, self.ptr, self.perm, self.seg, self.knots, self.spacing = bin, coef, ptr, perm, seg, int(knots), float(spacing)
         self._buf = buf
+        self._rec = {}
+
+    def records(self, topo, sh: torch.Tensor, walk: str) -> torch.Tensor:
+        """The batch's EDGE RECORDS [E, 16] int32 (``e3k_edge_records``) for the walk over the destination CSR (``walk="dst"``: the
+        forward, neighbour = source) or over the source CSR (``"src"``: the input gradient, neighbour = destination): per edge of
+        the walk ONE 64-byte block {neighbour, knot, four interpolation weights, nine spherical harmonics, edge id} -- what the
+        packed-table tensor-product kernels read instead of chasing perm -> edge -> {src, bin, coef, sh}.  Built once per batch and
+        walk (on the current stream), shared by all the layers."""
+        perm, nbr = (topo.dst_perm, topo.src) if walk == "dst" else (topo.src_perm, topo.dst)
+        key = (walk, sh.data_ptr(), sh._version, perm.data_ptr())
+        hit = self._rec.get(key)
+        if hit is None:
+            sh = L.f32c(sh.detach())
+            e = perm.numel()
+            if sh.dim() != 2 or sh.shape[0] != e or sh.shape[1] > 9:
+                raise ValueError(f"edge records take [E, <= 9] spherical harmonics, got {tuple(sh.shape)} for {e} edges")
+            rec = torch.empty(max(e, 1), 16, dtype=torch.int32, device=sh.device)
+            L.check(L.load().e3k_edge_records(L.ptr(perm), L.ptr(nbr), L.ptr(self.bin), L.ptr(self.coef), L.ptr(sh), sh.shape[1], e,
+                                              L.ptr(rec), L.stream_ptr()), "e3k_edge_records")
+            hit = self._rec[key] = (rec, sh)      # (sh kept: its address is part of the key)
+        return hit[0]
 
     def tensors(self):
         """The distinct allocations behind the views (what ``record_stream`` has to see)."""

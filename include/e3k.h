@@ -234,13 +234,13 @@ int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, c
 int e3k_tp_bwd_x_table(const e3k_tp_plan* plan, const float* sh, const float* T, const int32_t* bin, const float* coef,
                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N,
                        int64_t E, float* g_x, void* stream);
-/* ... and from the PACKED table P [K + 1, W, 3] (e3k_rtable_pack) -- same plans, same results up to the fp16 rounding stated there */
-int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const float* sh, const void* P, const int32_t* bin, const float* coef,
-                      const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out,
-                      void* stream);
-int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const float* sh, const void* P, const int32_t* bin, const float* coef,
-                        const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E,
-                        float* g_x, void* stream);
+/* ... and from the PACKED table P [K + 1, 3 W] (e3k_rtable_pack) -- same plans, same results up to the fp16 rounding stated there --
+ * walking EDGE RECORDS (e3k_edge_records): erec_dst over the destination CSR (dst_perm, src), erec_src over the source CSR
+ * (src_perm, dst); each [E, 16] int32, 64-byte aligned. */
+int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_dst, const int32_t* dst_ptr,
+                      int64_t N, int64_t E, float* out, void* stream);
+int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* erec_src, const float* g_out, const int32_t* src_ptr,
+                        int64_t N, int64_t E, float* g_x, void* stream);
 /* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights
  * then depend on pos through the radius, nn/message_passing.py:93).  With F = <g, TP(x[src], sh, w(T, coef))>, linear in each
  * of (g, x, sh, T, coef), every first and second derivative is one of the walks below (plans with e3k_tp_table2_supported:
@@ -285,6 +285,14 @@ int64_t e3k_csr_workspace_ints(int64_t N, int64_t E);
 int e3k_csr_build(const int64_t* edge_index, int64_t N, int64_t E, int32_t* src, int32_t* dst, int32_t* dst_ptr,
                   int32_t* dst_perm, int32_t* src_ptr, int32_t* src_perm, int32_t* workspace, int32_t* bad_flag,
                   void* stream);
+
+/* Edge records: what a tensor-product kernel needs about the t-th edge of a CSR walk (perm [E]: the walk's edge ids, nbr [E]: the
+ * neighbour node of an edge -- src for the destination CSR, dst for the source CSR) as ONE 64-byte block per edge, in walk order:
+ *   rec[t] = { nbr[e], bin[e], coef[e, 0..3], sh[e, 0..8], e },  e = perm[t]        (bin / coef NULL: zeros; d_sh < 9: zero padded)
+ * replacing the chain perm[t] -> e -> {nbr, bin, coef, sh}[e] of dependent scalar loads in front of every edge's row loads
+ * (reference: what `x[edge_src]`, `edge_spherical[e]`, `weight[e]` index, nn/message_passing.py:96-109).  rec: 64-byte aligned. */
+int e3k_edge_records(const int32_t* perm, const int32_t* nbr, const int32_t* bin, const float* coef, const float* sh, int32_t d_sh,
+                     int64_t E, int32_t* rec, void* stream);
 
 /* Rows grouped by a small categorical key (the keyed self-connection groups nodes by species: node_attrs =
  * Linear(one_hot(species)), layer_configs.py:104-118 feeding nn/message_passing.py:81-87,100): perm [R] int32 = row ids
@@ -601,6 +609,8 @@ typedef struct {
   float* z[4];               /* [R, h] pre-activations (keep) */
   float* T;                  /* table: [R, W] out; without the table unused */
   float* w;                  /* [E, W] out */
+  const int32_t* erec_dst;   /* with P: the batch's edge records over the destination CSR (forward) and over the source CSR */
+  const int32_t* erec_src;   /* (input gradient), e3k_edge_records with this table's bin / coef */
   void* P;                   /* in_kernel only: the table packed for the tensor-product kernels [R, W, 3] dwords (e3k_rtable_pack),
                               * written behind T by the forward, read by tp_fwd / tp_bwd_x; NULL: they gather four rows of T */
 } e3k_layer_radial;

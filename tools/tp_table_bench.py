@@ -51,6 +51,18 @@ def timeit(fn, reps=20):
 
 
 print(f"N={n} E={e} W={tp.w_numel} d_in={tp.d_in} d_mid={tp.d_mid} bonds={bonds}")
+if "--ablate" in sys.argv:      # dbg library only (E3K_LIB=.../libe3k_dbg.so): timing-only masks of the packed forward
+    import ctypes
+    from e3_layers_amd.backend import lib as L
+    lib = ctypes.CDLL(os.environ["E3K_LIB"])
+    bins = radial_table.build_bins(r, 4.0, 512)
+    T = torch.randn(bins.knots + 1, tp.w_numel, device=dev) * 1e-3
+    P = radial_table.pack_raw(T, bins.knots)
+    for mask, what in ((0, "full"), (1, "no table loads"), (2, "no x loads"), (3, "no table, no x loads"), (4, "no CG arithmetic"), (7, "loop skeleton")):
+        assert lib.e3k_dbg_tp_ablate(mask) == 0
+        print(f"packed tp_fwd, {what:22s}: {timeit(lambda: conv_force._tp_fwd_ptable(x, sh, P, bins, topo, tp)):7.1f} us")
+    lib.e3k_dbg_tp_ablate(0)
+    sys.exit(0)
 print(f"streamed  tp_fwd {timeit(lambda: ops._tp_fwd_raw(x, sh, w, topo, tp)):7.1f} us   tp_bwd_x {timeit(lambda: ops._tp_bwd_x_raw(sh, w, g, topo, tp)):7.1f} us"
       f"   tp_bwd_w {timeit(lambda: ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)):7.1f} us")
 gw, _ = ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)
