@@ -51,6 +51,37 @@ def timeit(fn, reps=20):
 
 
 print(f"N={n} E={e} W={tp.w_numel} d_in={tp.d_in} d_mid={tp.d_mid} bonds={bonds}")
+if "--knot-order" in sys.argv:
+    # VERDICT r4 item 3 (the g_w[E, W] round trip): a kernel that forms g_w[e] in registers while walking the edges in KNOT order
+    # (so that the four stencil sums of a knot segment stay in registers) has to gather x[src] AND g_mid[dst] per edge with no
+    # destination locality.  Its dominant cost is emulated with the existing streamed tp_bwd_x kernel walking a fake CSR whose
+    # "nodes" are the <= 64-edge knot segments of the transposed interpolation: per edge it gathers the same g_mid[dst] rows
+    # (26 KB) plus one w row (7.7 KB, standing in for the x[src] gather of 4.6 KB) -- a LOWER bound of the fused kernel's gather
+    # traffic (results meaningless) -- to be compared with tp_bwd_w + the table transpose it would replace.
+    from e3_layers_amd.backend.graph import GraphTopo
+    bins = radial_table.build_bins(r, 4.0, 512)
+    seg_ptr = []
+    ptr = bins.ptr.cpu().tolist()
+    for b in range(len(ptr) - 1):
+        for s0 in range(ptr[b], ptr[b + 1], 64):
+            seg_ptr.append(s0)
+    seg_ptr.append(e)
+    seg_ptr = torch.tensor(seg_ptr, dtype=torch.int32, device=dev)
+    fake = GraphTopo(topo.src, topo.dst, topo.dst_ptr, topo.dst_perm, seg_ptr, bins.perm)
+    n_seg = seg_ptr.numel() - 1
+    gx = torch.zeros(n_seg, tp.d_in, device=dev)
+    from e3_layers_amd.backend import lib as L_
+    def knot_walk():
+        L_.check(L_.load().e3k_tp_bwd_x(tp.handle(dev), L_.ptr(sh), L_.ptr(w), L_.ptr(g), L_.ptr(fake.dst), L_.ptr(fake.src_ptr), L_.ptr(fake.src_perm),
+                                        n_seg, e, L_.ptr(gx), L_.stream_ptr()), "knot walk")
+    t_k = timeit(knot_walk)
+    t_w = timeit(lambda: ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True))
+    gw, _ = ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)
+    t_t = timeit(lambda: radial_table.interp_bwd_raw(gw, bins))
+    t_x = timeit(lambda: ops._tp_bwd_x_raw(sh, w, g, topo, tp))
+    print(f"knot-order walk ({n_seg} segments of <= 64 edges; gathers g_mid[dst] + one 7.7 KB row per edge): {t_k:7.1f} us")
+    print(f"what it would replace: tp_bwd_w {t_w:7.1f} us + table transpose {t_t:7.1f} us = {t_w + t_t:7.1f} us   (tp_bwd_x in source order, same gather volume: {t_x:7.1f} us)")
+    sys.exit(0)
 if "--ablate" in sys.argv:      # dbg library only (E3K_LIB=.../libe3k_dbg.so): timing-only masks of the packed forward
     import ctypes
     from e3_layers_amd.backend import lib as L
