@@ -49,15 +49,20 @@ constexpr int RT_SEG = 64;          // edges of one knot summed by one wave of t
 // one workgroup (4 waves) per chunk of RT_CHUNK consecutive edges; wave w ranks its quarter of the chunk against its own
 // (K + 1)-entry histogram in LDS (the serial part: one ballot round per distinct knot among 64 edges), then the quarters are
 // chained: a lane's rank += the edges of its knot in the waves before it
-__global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __restrict__ r, int64_t E, float h_inv, int32_t K,
-                                                               int32_t* __restrict__ bin, float* __restrict__ coef,
-                                                               int32_t* __restrict__ lrank,
+// KEYED tables (round 5): an edge embedding that is a function of the radius AND a small categorical key (a bond type, say) is
+// served by n_keys tables stacked into one -- block k holds the rows of key k --: KT + 1 = n_keys (K + 1) rows in all, an edge's
+// knot becomes key[e] (K + 1) + i, and every consumer (interpolation, its transpose, the tensor-product kernels) works on the
+// stacked table unchanged: the stencil i - 1 .. i + 2 never leaves a block (i in [1, K - 2]) and the first and the last two knots
+// of every block hold no edges, so nothing of one block's transposed sums reaches another's rows.
+__global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __restrict__ r, const int64_t* __restrict__ key, int64_t E,
+                                                               float h_inv, int32_t K, int32_t KT, int32_t* __restrict__ bin,
+                                                               float* __restrict__ coef, int32_t* __restrict__ lrank,
                                                                int32_t* __restrict__ chunk_hist) {
-  extern __shared__ int32_t hist_all[];                      // [4][K + 1]
+  extern __shared__ int32_t hist_all[];                      // [4][KT + 1]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  int32_t* hist = hist_all + wv * (K + 1);
+  int32_t* hist = hist_all + wv * (KT + 1);
   const int64_t chunk = blockIdx.x;
-  for (int b = threadIdx.x; b < 4 * (K + 1); b += 256) hist_all[b] = 0;
+  for (int b = threadIdx.x; b < 4 * (KT + 1); b += 256) hist_all[b] = 0;
   __syncthreads();
   constexpr int PER_WAVE = RT_CHUNK / 4 / 64;
   const int64_t base = chunk * RT_CHUNK + (int64_t)wv * (RT_CHUNK / 4);
@@ -79,6 +84,11 @@ __global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __re
       c.y = tp1 * tm1 * tm2 * 0.5f;
       c.z = -tp1 * t * tm2 * 0.5f;
       c.w = tp1 * t * tm1 * (1.f / 6.f);
+      if (key) {      // (a key outside [0, n_keys) would index past the stacked table: folded into block 0)
+        const int64_t kk = key[e];
+        const int nk = (KT + 1) / (K + 1);
+        i += (kk >= 0 && kk < nk) ? (int)kk * (K + 1) : 0;
+      }
       bin[e] = i;
       *reinterpret_cast<float4*>(coef + 4 * e) = c;
     }
@@ -102,11 +112,11 @@ __global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __re
   for (int it = 0; it < PER_WAVE; ++it) {
     if (my_bin[it] < 0) continue;
     int before = 0;
-    for (int w = 0; w < wv; ++w) before += hist_all[w * (K + 1) + my_bin[it]];
+    for (int w = 0; w < wv; ++w) before += hist_all[w * (KT + 1) + my_bin[it]];
     lrank[base + it * 64 + lane] = my_rank[it] + before;
   }
-  for (int b = threadIdx.x; b <= K; b += 256)
-    chunk_hist[chunk * (K + 1) + b] = hist_all[b] + hist_all[(K + 1) + b] + hist_all[2 * (K + 1) + b] + hist_all[3 * (K + 1) + b];
+  for (int b = threadIdx.x; b <= KT; b += 256)
+    chunk_hist[chunk * (KT + 1) + b] = hist_all[b] + hist_all[(KT + 1) + b] + hist_all[2 * (KT + 1) + b] + hist_all[3 * (KT + 1) + b];
 }
 
 // ---- pass 2: one workgroup.  chunk_hist[c][b] -> number of edges of knot b in the chunks before c (in place);
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256) void rtable_bwd_combine_kernel(const float* __
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int b = j + 1 - k;
-    if (b < 1 || b > K - 2) continue;       // only these knots hold edges
+    if (b < 1 || b > K - 2) continue;       // (K = the stacked table's last row: inside it, knots that hold no edges have no segments)
     const int s0 = seg[b], s1 = seg[b + 1];
     for (int s = s0; s < s1; ++s) {
       const float4 v = *reinterpret_cast<const float4*>(P + ((int64_t)s * 4 + k) * W + col);
@@ -527,12 +537,14 @@ extern "C" int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K) {
   return E + n_chunks * ((int64_t)K + 1);      // [rank inside (chunk, knot) | chunk x knot counts -> offsets]
 }
 
-extern "C" int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
-                               int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
+static int rtable_bins_impl(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K, int32_t* bin,
+                            float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
   // h_inv = 1 / knot spacing; a power of two makes x = r * h_inv and the offset t = x - floor(x) exact (the caller's choice:
   // backend/radial_table.py lays its tables out that way)
-  if (E < 0 || K < 4 || !(h_inv > 0.f)) return E3K_ERR_INVALID;
-  if (K > 4000 || E >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;       // 4 x (K + 1) int32 of LDS per workgroup
+  if (E < 0 || K < 4 || !(h_inv > 0.f) || n_keys < 1) return E3K_ERR_INVALID;
+  const int64_t KT64 = (int64_t)n_keys * (K + 1) - 1;      // last row of the stacked table
+  if (KT64 > 4000 || E >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;       // 4 x (KT + 1) int32 of LDS per workgroup
+  const int32_t KT = (int32_t)KT64;
   if (!bin_ptr || !bin_seg) return E3K_ERR_INVALID;
   if (E > 0 && (!r || !bin || !coef || !bin_perm || !workspace)) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -540,14 +552,28 @@ extern "C" int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K
   int32_t* lrank = workspace;
   int32_t* chunk_hist = workspace + E;
   if (E > 0)
-    hipLaunchKernelGGL(e3k::rtable_bins_rank_kernel, dim3((unsigned)n_chunks), dim3(256), sizeof(int32_t) * 4 * (K + 1), st, r, E,
-                       h_inv, K, bin, coef, lrank, chunk_hist);
-  hipLaunchKernelGGL(e3k::rtable_bins_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_hist, (int32_t)n_chunks, K, bin_ptr, bin_seg);
+    hipLaunchKernelGGL(e3k::rtable_bins_rank_kernel, dim3((unsigned)n_chunks), dim3(256), sizeof(int32_t) * 4 * (KT + 1), st, r, key, E,
+                       h_inv, K, KT, bin, coef, lrank, chunk_hist);
+  hipLaunchKernelGGL(e3k::rtable_bins_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_hist, (int32_t)n_chunks, KT, bin_ptr, bin_seg);
   if (E > 0)
     hipLaunchKernelGGL(e3k::rtable_bins_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, bin, lrank, chunk_hist,
-                       bin_ptr, E, K, bin_perm);
+                       bin_ptr, E, KT, bin_perm);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
+}
+
+extern "C" int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
+                               int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
+  return rtable_bins_impl(r, nullptr, 1, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, stream);
+}
+
+// n_keys tables of K + 1 rows stacked: bin[e] = key[e] (K + 1) + i; bin_ptr / bin_seg [n_keys (K + 1) + 1]; workspace:
+// e3k_rtable_bins_workspace_ints(E, n_keys (K + 1) - 1)
+extern "C" int e3k_rtable_bins_keyed(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K,
+                                     int32_t* bin, float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm,
+                                     int32_t* workspace, void* stream) {
+  if (E > 0 && !key) return E3K_ERR_INVALID;
+  return rtable_bins_impl(r, key, n_keys, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, stream);
 }
 
 extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E,

@@ -103,7 +103,7 @@ def _radial_branch(rows, plan: ConvBlockPlan, w_last, w_hidden, keep: bool, tabl
     with ops.timed_launch("radial_last_fwd", (h.shape[0], plan.last_spec.d_in, plan.last_spec.d_out)):
         ops._lin_fwd_raw(h, w_last, None, w, plan.last_spec, 1.0, False)
     if table is not None:      # w so far: the MLP on the knots; every edge interpolates between its three knots
-        radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, w)
+        radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, w, blocks=table.blocks)
         w = radial_table.interp_fwd_raw(w, table)
     return h, zs, w
 

@@ -308,6 +308,7 @@ class RadialStackFn(torch.autograd.Function):
         behind their tables T_l (``e3k_radial_slope_fwd``: forward-mode derivative of the hidden chains per knot in float64, last
         layers in fp32)."""
         L.require_cuda(rows)
+        blocks = int(getattr(rows, "_e3k_blocks", 1))      # (a keyed source's stacked knot basis: its tables are guarded block by block)
         rows = L.f32c(rows)
         dev = rows.device
         n = len(plans)
@@ -348,7 +349,7 @@ class RadialStackFn(torch.autograd.Function):
         STACK_STATS[0] += 1
         STACK_STATS[1] = n
         if use_table:      # one launch for the tables of all the layers (recorded with every build while a graph is captured)
-            radial_table.guard_many([(plan.guard_key if plan.guard_key is not None else weights[i * per], out, False)
+            radial_table.guard_many([(plan.guard_key if plan.guard_key is not None else weights[i * per], out, False, blocks)
                                      for i, (plan, out) in enumerate(zip(plans, outs))])
         hps, slopes = [], []
         if slope is not None:
@@ -686,7 +687,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             L.check(L.load().e3k_layer_fwd(layer, C.byref(a)), "e3k_layer_fwd")
         if own_table is not None:      # the a-posteriori error guard of the table just built (radial stream)
             with conv_block._on(side, main):
-                radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, own_table)
+                radial_table.guard(plan.guard_key if plan.guard_key is not None else w_last, own_table, blocks=table.blocks)
         if fork:      # what a stream other than the allocating one touched must not return to the allocator before that
             # stream is done with it.  record_stream costs ~5 us a call: only the pairs that need it -- the radial buffers
             # live on the radial stream (w is also read by the tensor product on this one), tensors every layer of a
@@ -716,7 +717,7 @@ class NativeConvBlockFn(torch.autograd.Function):
             rad_n, nbuf, ncarve, w_n, t_n, plan_n, w_last_n = nxt_keep
             if t_n is not None:
                 with conv_block._on(side, main):
-                    radial_table.guard(plan_n.guard_key if plan_n.guard_key is not None else w_last_n, t_n)
+                    radial_table.guard(plan_n.guard_key if plan_n.guard_key is not None else w_last_n, t_n, blocks=table.blocks)
             # (the rows and the table themselves are the key: held here, their identity cannot be reused by a later batch;
             #  in stack mode the key is the next layer's own rows, w_last_n stands for them)
             plan_n.prefetched = ((w_last_n if stack else edge_radial, table, keep, fork, mode), (nbuf, ncarve, w_n, t_n))

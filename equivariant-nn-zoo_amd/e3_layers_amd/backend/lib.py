@@ -218,6 +218,7 @@ SIGNATURES = {
     "e3k_group_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
     "e3k_rtable_bins_workspace_ints": (C.c_int64, [_I64, _I32]),
     "e3k_rtable_bins": (C.c_int, [_P, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "e3k_rtable_bins_keyed": (C.c_int, [_P, _P, _I32, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P]),
     "e3k_rtable_interp_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "e3k_rtable_interp_fwd2": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),

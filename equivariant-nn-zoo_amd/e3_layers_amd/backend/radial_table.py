@@ -43,6 +43,13 @@ ENABLED = _knob("E3K_RADIAL_TABLE")
 KNOTS = _knob("E3K_RADIAL_KNOTS")                  # r_max 4: 512 intervals of 2^-7 A; r_max 5: 640
 KNOTS_SLOPE = _knob("E3K_RADIAL_KNOTS_SLOPE")       # ... when the radii require grad (value + slope tables)
 MIN_EDGES_PER_KNOT = _knob("E3K_RADIAL_MIN_EDGES_PER_KNOT")      # below this the per-edge MLP is the cheaper one
+# Keyed tables (``KeyedRadialSource``: an edge embedding that is a function of the radius and a small categorical key -- config_diffusion's
+# bond type).  Built and pinned to the oracle in round 5 (score 2.4e-6, parameter gradients 3.1e-6), and OFF by default: the only shipped
+# model it serves has 32 channels, whose tensor-product plans have no in-kernel table form, so the weights are still materialised
+# [E, W] per layer, its radial MLP is 32 wide (2.6 GFLOP per layer per edge pass: not what the step waits for), and 42 k edges spread
+# over 4 x 733 knot rows are 14 edges per row -- the transposed interpolation's segments are nearly empty.  Measured, 128 molecules,
+# graph-replayed step: 3.52 ms with the tables against 3.32 ms per edge (profiles/r05_bench_lines.json).  1 switches it on.
+KEYED = _knob("E3K_RADIAL_TABLE_KEYED")
 
 
 def layout(r_max: float, target: int):
@@ -60,12 +67,13 @@ class KnotBins:
     i - 1 .. i + 2), ``coef`` [E, 4] (the four weights), the edges grouped by knot -- ``ptr`` [K + 2], ``perm`` [E] (ascending
     edge id inside a knot), ``seg`` [K + 2] (first <= 64-edge segment of every knot) -- and the knot count."""
 
-    __slots__ = ("bin", "coef", "ptr", "perm", "seg", "knots", "spacing", "_buf", "_rec", "__weakref__")
+    __slots__ = ("bin", "coef", "ptr", "perm", "seg", "knots", "spacing", "blocks", "_buf", "_rec", "__weakref__")
 
     def __init__(self, bin, coef, ptr, perm, seg, knots: int, spacing: float, buf=None):
         self.bin, self.coef, self.ptr, self.perm, self.seg, self.knots, self.spacing = bin, coef, ptr, perm, seg, int(knots), float(spacing)
         self._buf = buf
         self._rec = {}
+        self.blocks = 1      # > 1: ``blocks`` tables of (knots + 1) / blocks rows stacked (keyed tables, ``build_bins(key=...)``)
 
     def records(self, topo, sh: torch.Tensor, walk: str) -> torch.Tensor:
         """The batch's EDGE RECORDS [E, 16] int32 (``e3k_edge_records``) for the walk over the destination CSR (``walk="dst"``: the
@@ -95,20 +103,35 @@ class KnotBins:
         return iter(self.tensors())
 
 
-def build_bins(r: torch.Tensor, r_max: float, target: int) -> KnotBins:
-    """``target``: the knot count asked for over [0, r_max] (``layout`` turns it into a power-of-two spacing)."""
+def build_bins(r: torch.Tensor, r_max: float, target: int, key: Optional[torch.Tensor] = None, n_keys: int = 1) -> KnotBins:
+    """``target``: the knot count asked for over [0, r_max] (``layout`` turns it into a power-of-two spacing).
+    ``key`` [E] int64 in [0, n_keys): KEYED tables -- ``n_keys`` tables of ``knots + 1`` rows stacked into one, an edge's knot is
+    ``key[e] (knots + 1) + i``; the returned bins describe the stacked table (``.knots`` = its last row, ``.blocks`` = n_keys)."""
     knots, h = layout(r_max, target)
     r = L.f32c(r.detach().reshape(-1))
     L.require_cuda(r)
     e, dev = r.numel(), r.device
     lib = L.load()
-    sizes = [e, e, knots + 2, knots + 2, int(lib.e3k_rtable_bins_workspace_ints(e, knots))]
+    n_keys = int(n_keys) if key is not None else 1
+    last = n_keys * (knots + 1) - 1            # last row of the (stacked) table
+    sizes = [e, e, last + 2, last + 2, int(lib.e3k_rtable_bins_workspace_ints(e, last))]
     buf = torch.empty(sum(sizes), dtype=torch.int32, device=dev)      # one allocation: [bin | perm | ptr | seg | workspace]
     bin32, perm, ptr, seg, work = torch.split(buf, sizes)
     coef = torch.empty(e, 4, dtype=torch.float32, device=dev)
-    L.check(lib.e3k_rtable_bins(L.ptr(r), e, 1.0 / h, knots, L.ptr(bin32), L.ptr(coef), L.ptr(ptr), L.ptr(seg), L.ptr(perm),
-                                L.ptr(work), L.stream_ptr()), "e3k_rtable_bins")
-    return KnotBins(bin32, coef, ptr, perm, seg, knots, h, buf)
+    if key is None:
+        L.check(lib.e3k_rtable_bins(L.ptr(r), e, 1.0 / h, knots, L.ptr(bin32), L.ptr(coef), L.ptr(ptr), L.ptr(seg), L.ptr(perm),
+                                    L.ptr(work), L.stream_ptr()), "e3k_rtable_bins")
+    else:
+        key = key.detach().reshape(-1)
+        if key.dtype != torch.int64 or not key.is_contiguous():
+            key = key.long().contiguous()
+        if key.numel() != e:
+            raise ValueError(f"{key.numel()} keys for {e} radii")
+        L.check(lib.e3k_rtable_bins_keyed(L.ptr(r), L.ptr(key), n_keys, e, 1.0 / h, knots, L.ptr(bin32), L.ptr(coef), L.ptr(ptr),
+                                          L.ptr(seg), L.ptr(perm), L.ptr(work), L.stream_ptr()), "e3k_rtable_bins_keyed")
+    bins = KnotBins(bin32, coef, ptr, perm, seg, last, h, buf)
+    bins.blocks = n_keys
+    return bins
 
 
 class RadialSource:
@@ -160,6 +183,51 @@ def knot_radii(r_max: float, target: int, device) -> torch.Tensor:
     return k
 
 
+class KeyedRadialSource:
+    """An edge embedding that is a ROW-WISE function of (radius, small categorical key): ``Concat(one_hot(bond type), RadialBasisEncoding(
+    edge_length)) -> Linear`` in ``e3_layers/configs/config_diffusion.py:73-82``.  It is served by ``n_keys`` knot tables stacked into one:
+    the radial MLP of a layer runs on ``n_keys (knots + 1)`` rows -- the embedding of every (key, knot radius) pair, ``rows_fn`` applied
+    to the base source's knot basis -- and an edge interpolates inside the block of its key.  Same interface as ``RadialSource``."""
+
+    __slots__ = ("base", "key", "n_keys", "rows_fn", "version", "_bins", "_knot_basis", "_stack", "__weakref__")
+
+    def __init__(self, base: RadialSource, key: torch.Tensor, n_keys: int, rows_fn, version: int = 0):
+        self.base, self.key, self.n_keys, self.rows_fn, self.version = base, key, int(n_keys), rows_fn, int(version)
+        self._bins, self._knot_basis, self._stack = {}, {}, {}
+
+    @property
+    def r(self):
+        return self.base.r
+
+    @property
+    def blocks(self) -> int:
+        return self.n_keys
+
+    def module(self):
+        return self.base.module()
+
+    def bins(self, knots: Optional[int] = None) -> KnotBins:
+        knots = KNOTS if knots is None else int(knots)
+        hit = self._bins.get(knots)
+        if hit is None:
+            hit = self._bins[knots] = build_bins(self.base.r, float(self.module().basis.r_max), knots, self.key, self.n_keys)
+        return hit
+
+    def knot_basis(self, knots: Optional[int] = None):
+        """[n_keys (knots + 1), width]: the embedding of every (key, knot) pair, key-major; differentiable w.r.t. the parameters of
+        ``rows_fn`` (the Concat's Linear) and of the basis (the Bessel frequencies)."""
+        knots = KNOTS if knots is None else int(knots)
+        kb = self._knot_basis.get(knots)
+        if kb is None or kb[1] != torch.is_grad_enabled():
+            base = self.base.knot_basis(knots)                               # [rows, n_basis]
+            rows = base.shape[0]
+            keys = torch.arange(self.n_keys, device=base.device).repeat_interleave(rows)
+            rows_all = self.rows_fn(keys, base.repeat(self.n_keys, 1))
+            rows_all._e3k_blocks = self.n_keys
+            kb = self._knot_basis[knots] = (rows_all, torch.is_grad_enabled())
+        return kb[0]
+
+
 def source_of(edge_radial) -> Optional[RadialSource]:
     return getattr(edge_radial, "_e3k_radial_src", None)
 
@@ -174,6 +242,8 @@ def knots_for(edge_radial, w_last=None, allow_grad: bool = False) -> int:
     src = source_of(edge_radial)
     if src is None or src.module() is None:
         return 0
+    if isinstance(src, KeyedRadialSource) and not KEYED:
+        return 0
     grad = bool(src.r.requires_grad)
     if grad and not allow_grad:
         return 0
@@ -182,7 +252,9 @@ def knots_for(edge_radial, w_last=None, allow_grad: bool = False) -> int:
     if w_last is not None and not guard_ok(w_last, slope=grad):
         return 0
     knots = KNOTS_SLOPE if grad else KNOTS
-    rows = layout(float(src.module().basis.r_max), knots)[0] + 1
+    rows = (layout(float(src.module().basis.r_max), knots)[0] + 1) * getattr(src, "blocks", 1)
+    if rows > 4000:                        # (the stacked table of a keyed source: the bins kernel's LDS histogram)
+        return 0
     return knots if edge_radial.shape[0] >= MIN_EDGES_PER_KNOT * rows else 0
 
 
@@ -245,13 +317,13 @@ _GUARDS: dict = {}      # (id(weight), slope) -> (weak reference to the weight, 
 
 
 def _guard_of(w_last, slope: bool = False, create: bool = False):
-    key = (id(w_last), bool(slope))
+    key = (id(w_last), slope if isinstance(slope, tuple) else bool(slope))      # (slope, block) for the blocks > 0 of a stacked table
     hit = _GUARDS.get(key)
     if hit is not None and hit[0]() is w_last:
         return hit[1]
     if not create:
         return None
-    g = _Guard("slope" if slope else "value")
+    g = _Guard("slope" if (slope[0] if isinstance(slope, tuple) else slope) else "value")
     _GUARDS[key] = (weakref.ref(w_last, lambda _r, key=key: _GUARDS.pop(key, None)), g)
     return g
 
@@ -285,13 +357,17 @@ def drain_guards() -> None:
 
 
 def guard_ok(w_last, slope: bool = False) -> bool:
-    """The value table's guard, and -- ``slope`` -- the slope table's too."""
+    """The value table's guard (all its blocks, for a stacked keyed table), and -- ``slope`` -- the slope table's too."""
     ok = True
-    for kind in ((False, True) if slope else (False,)):
-        g = _guard_of(w_last, kind)
-        if g is not None:
-            _poll(g)
-            ok = ok and g.ok
+    wid = id(w_last)
+    for (kid, kind), (ref, g) in list(_GUARDS.items()):
+        if kid != wid or ref() is not w_last:
+            continue
+        is_slope = kind[0] if isinstance(kind, tuple) else kind
+        if is_slope and not slope:
+            continue
+        _poll(g)
+        ok = ok and g.ok
     return ok
 
 
@@ -335,8 +411,17 @@ def guard_many(items) -> None:
     while a stream captures: the kernel is recorded with EVERY build (each replay then updates the persistent maxima)."""
     capturing = torch.cuda.is_current_stream_capturing()
     todo = []
-    for w_last, table, slope in items:
-        g = _guard_of(w_last, slope, create=True)
+    flat = []
+    for it in items:      # a stacked (keyed) table is guarded block by block: differences must not straddle two keys' tables
+        w_last, table, slope = it[:3]
+        blocks = int(it[3]) if len(it) > 3 else 1
+        if blocks > 1 and table.shape[0] % blocks == 0:
+            per = table.shape[0] // blocks
+            flat += [(w_last, table[b * per:(b + 1) * per], slope, b) for b in range(blocks)]
+        else:
+            flat.append((w_last, table, slope, 0))
+    for w_last, table, slope, block in flat:
+        g = _guard_of(w_last, (slope, block) if block else slope, create=True)
         g.calls += 1
         _poll(g)
         if table.shape[0] < 5 or not table.is_cuda:
@@ -373,9 +458,9 @@ def guard_many(items) -> None:
             _send(g, 1, reset=False)
 
 
-def guard(w_last, table: torch.Tensor, slope: bool = False) -> None:
-    """Call with the table just computed (on the stream that computed it)."""
-    guard_many([(w_last, table, slope)])
+def guard(w_last, table: torch.Tensor, slope: bool = False, blocks: int = 1) -> None:
+    """Call with the table just computed (on the stream that computed it); ``blocks`` > 1: a stacked table of that many keys."""
+    guard_many([(w_last, table, slope, blocks)])
 
 
 CAPTURE_LOG = None      # while a CapturedStep records: the guards whose kernel went into the graph
@@ -465,5 +550,5 @@ def table_weights(fc, edge_radial) -> torch.Tensor:
     """``fc(edge_radial)`` through the knot table (call only when ``applicable(edge_radial, last_weight(fc))``)."""
     src = source_of(edge_radial)
     table = fc(src.knot_basis())            # the MLP on KNOTS + 1 rows: its forward AND backward shrink with it
-    guard(last_weight(fc), table)
+    guard(last_weight(fc), table, blocks=getattr(src, "blocks", 1))
     return RadialTableFn.apply(table, src.bins())

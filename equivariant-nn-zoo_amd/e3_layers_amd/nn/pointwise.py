@@ -89,4 +89,49 @@ class Concat(Module):
         key = combine_row_keys([data[k] for k in keys])
         if key is not None:
             set_row_key(out, *key)
+        self._tag_keyed_radial(data, keys, out)
         return {"output": out}, {"output": (attrs[keys[0]][0], self.irreps_out["output"])}
+
+    KEYED_RADIAL_MAX_KEYS = 8
+
+    def _tag_keyed_radial(self, data, keys, out) -> None:
+        """``Concat(one_hot(small key), RadialBasisEncoding(edge_length))`` (``e3_layers/configs/config_diffusion.py:73-82``: the 4-way
+        bond type beside the Bessel basis) is a row-wise function of (radius, key): the convolution layers' radial MLPs can then run
+        on one knot table per key instead of per edge (``backend/radial_table.KeyedRadialSource``).  Applies when exactly one input
+        carries a radial source that still describes it, and every other input is a one-hot of ONE small key."""
+        from ..backend import radial_table
+
+        if not out.is_cuda:
+            return
+        radial = [k for k in keys if radial_table.source_of(data[k]) is not None]
+        others = [k for k in keys if k not in radial]
+        if len(radial) != 1 or not others:
+            return
+        src = radial_table.source_of(data[radial[0]])
+        if not isinstance(src, radial_table.RadialSource) or data[radial[0]]._version != src.version:
+            return
+        okey = combine_row_keys([data[k] for k in others])
+        if okey is None or not (1 < okey[1] <= self.KEYED_RADIAL_MAX_KEYS):
+            return
+        if any(data[k].shape[1] != get_row_key(data[k])[1] for k in others):      # (plain one-hot rows: rebuilt from the key below)
+            return
+        order = list(keys)
+        widths = {k: data[k].shape[1] for k in keys}
+        nkeys = {k: get_row_key(data[k])[1] for k in others}
+        linear = self.linear
+
+        def rows_fn(kidx, basis_rows):
+            # the Concat's own arithmetic on synthetic rows: for every (key, knot) the one-hot blocks of the key and the basis row
+            cols, rest = [], kidx
+            parts = {}
+            for k in reversed(others):                 # (combine_row_keys: index = ((k0) n1 + k1) n2 + k2 ...)
+                parts[k] = rest % nkeys[k]
+                rest = rest // nkeys[k]
+            for k in order:
+                if k in parts:
+                    cols.append(torch.nn.functional.one_hot(parts[k], num_classes=widths[k]).to(basis_rows.dtype))
+                else:
+                    cols.append(basis_rows)
+            return linear(torch.cat(cols, dim=1))
+
+        out._e3k_radial_src = radial_table.KeyedRadialSource(src, okey[0], okey[1], rows_fn, out._version)

@@ -324,6 +324,12 @@ int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t* perm, int3
 int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K);
 int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
                     int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream);
+/* KEYED tables: the edge embedding is a function of the radius and of a small categorical key per edge (config_diffusion.py:73-82:
+ * the Bessel basis concatenated with a 4-way bond-type one-hot) -- n_keys tables of K + 1 rows stacked into one of n_keys (K + 1)
+ * rows, bin[e] = key[e] (K + 1) + i.  bin_ptr / bin_seg [n_keys (K + 1) + 1]; workspace e3k_rtable_bins_workspace_ints(E,
+ * n_keys (K + 1) - 1).  Every consumer takes the stacked table with K := n_keys (K + 1) - 1. */
+int e3k_rtable_bins_keyed(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K, int32_t* bin,
+                          float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream);
 int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
                           int32_t W, float* w, void* stream);
 /* two tables of one shape through the same weights in one pass (force training: w from T and dw/dr from the slope table) */
