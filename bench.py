@@ -44,7 +44,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (the clock an MFMA loop sustains is lower)
 # rocprofv3 --pmc passes over this command at the two l_max values (tools/collect_profiles_r04.sh, tools/summarize_profiles_r04.py)
-TRAFFIC_FILES = {2: "profiles/r04_tp_traffic.json", 3: "profiles/r04_lmax3_tp_traffic.json"}
+TRAFFIC_FILES = {2: "profiles/r05_tp_traffic.json", 3: "profiles/r05_lmax3_tp_traffic.json"}
 
 
 def parse():
@@ -71,6 +71,12 @@ def parse():
     ap.add_argument("--graph", action="store_true",
                     help="capture the whole step (fwd+loss+bwd+all-reduce+Adam) on ONE resident batch in a HIP graph and "
                          "replay it (no per-batch work in the replayed step: disclosed in config.launch)")
+    ap.add_argument("--launch", default="fixed", choices=["fixed", "auto"],
+                    help="fixed (default): ONE launch mode per workload, decided by the workload alone -- the eager multi-stream step for "
+                         "config_energy (the metric's workload) and config_diffusion_CA, the HIP-graph replay of padded fresh batches for "
+                         "config_energy_force and config_diffusion (the batch sizes the reference ships for them are launch-bound); "
+                         "auto: time the eager layouts (and the replay when the host is the limit) on this box and keep the fastest "
+                         "(rounds 3-4's default; reported under config.launch_auto)")
     ap.add_argument("--cpu-budget", type=float, default=30.0, help="seconds of CPU work for the baseline leg")
     return ap.parse_args()
 
@@ -454,6 +460,8 @@ def main():
 
         return bucket_, run_, n_cap, e_cap
 
+    if args.launch == "fixed" and cfg_kind in ("energy_force", "diffusion") and world == 1 and not (args.loader or args.graph):
+        args.graph_fresh = True      # the fixed mode of these workloads (no run-time choice in the default line)
     if args.graph_fresh:
         if cfg_kind not in ("energy", "energy_force", "diffusion") or args.loader or args.graph:
             raise SystemExit("--graph-fresh replays the config_energy / config_energy_force / config_diffusion step on padded resident "
@@ -488,8 +496,8 @@ def main():
     # by the host, capture the bucketed step, time it, and keep whichever is faster for the timed region.  One rank; the
     # config_energy, config_energy_force and config_diffusion workloads (the ones the bucketed replay serves);
     # E3K_BENCH_AUTO=0 pins the eager step.
-    if (cfg_kind in ("energy", "energy_force", "diffusion") and not (args.loader or args.graph or args.graph_fresh) and n_ref
-            and os.environ.get("E3K_BENCH_AUTO", "1") != "0"):
+    if (args.launch == "auto" and cfg_kind in ("energy", "energy_force", "diffusion") and not (args.loader or args.graph or args.graph_fresh)
+            and n_ref and os.environ.get("E3K_BENCH_AUTO", "1") != "0"):
         # (several ranks: only the choice between the two eager layouts -- they issue the same collectives, so the ranks cannot
         #  diverge; the times compared are the maxima over the ranks, so every rank takes the same decision)
         auto = {"eager_ms_per_step": round(1e3 * ref_step, 3), "eager_host_busy_ms_per_step": round(1e3 * host_ref / n_ref, 3),

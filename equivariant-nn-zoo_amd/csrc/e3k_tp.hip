@@ -992,18 +992,19 @@ __global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
 }
-// table-form edge backward (g_sh, g_coef, optionally g_w) and the dual weight gradient: channel-complete, un-split plans
-template <int MAXL, int L3MAX, bool STREAM>
+// table-form edge backward (g_sh, g_coef, optionally g_w) and the dual weight gradient: channel-complete plans (SPLIT: the l_max 3
+// plans walked by two waves per group -- streamed weights only; g_sh / g_r of the two parts meet in the same atomics)
+template <int MAXL, int L3MAX, bool STREAM, bool SPLIT = false>
 __global__ __launch_bounds__(256) void tp_bwd_e_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
-  constexpr bool FULL = true, SPLIT = false;
+  constexpr bool FULL = true;
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX, STREAM)
 }
-template <int MAXL, int L3MAX>
+template <int MAXL, int L3MAX, bool SPLIT = false>
 __global__ __launch_bounds__(256) void tp_bwd_w_dual_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                             const int2* __restrict__ gc, int n_gc) {
-  constexpr bool FULL = true, SPLIT = false;
+  constexpr bool FULL = true;
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_w_dual_body, L3MAX)
 }
@@ -1212,10 +1213,29 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
   if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL) {
-    // second-order forms of force training: channel-complete plans walked by one wave per group (the l_max <= 2 models)
-    if (!p->full64 || p->split) return E3K_ERR_UNSUPPORTED;
+    // second-order forms of force training: channel-complete plans; walked by one wave per group (the l_max <= 2 models), or by two
+    // (SPLIT: l_max 3) with the weights STREAMED (w[e], dw/dr[e] materialised -- what the force block does by default)
+    if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1;
     const bool streamed = args.bin == nullptr;      // w[e] / dw[e] rows in a.w / a.w2 instead of the tables + per-edge knots
+    if (p->split) {
+      if (!streamed) return E3K_ERR_UNSUPPORTED;
+#define E3K_TP_LAUNCH_2S(ML)                                                                                                            \
+  switch (kind) {                                                                                                                       \
+    case TP_FWD_JVP: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;      \
+    case TP_BWD_X_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_E: hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, 3, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;         \
+    default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, 3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                \
+  }
+      switch (p->max_l1) {
+        case 1: E3K_TP_LAUNCH_2S(1) break;
+        case 2: E3K_TP_LAUNCH_2S(2) break;
+        default: E3K_TP_LAUNCH_2S(3) break;
+      }
+#undef E3K_TP_LAUNCH_2S
+      E3K_CHECK_LAUNCH();
+      return E3K_OK;
+    }
 #define E3K_TP_LAUNCH_2(ML, L3)                                                                                                         \
   switch (kind) {                                                                                                                       \
     case TP_FWD_JVP:                                                                                                                    \
@@ -1346,6 +1366,10 @@ extern "C" int e3k_tp_table_supported(const e3k_tp_plan* p) {
 }
 extern "C" int e3k_tp_table2_supported(const e3k_tp_plan* p) {
   return (p && p->full64 && !p->split) ? 1 : 0;
+}
+/* the second-order forms with w[e] / dw/dr[e] MATERIALISED (bin = coef = NULL): also the split (l_max 3) plans */
+extern "C" int e3k_tp_second_order_streamed_supported(const e3k_tp_plan* p) {
+  return (p && p->full64) ? 1 : 0;
 }
 
 extern "C" int e3k_tp_fwd_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const int32_t* bin,

@@ -64,13 +64,17 @@ class declined:
 
 
 def supported(plan: ConvBlockPlan, dev) -> bool:
-    """Layers the force block serves: keyed self-connection inside the block, a tensor-product plan with the table's
-    second-order kernels (channel-complete, one wave per group: the l_max <= 2 models)."""
+    """Layers the force block serves: keyed self-connection inside the block, a tensor-product plan with the second-order kernels
+    (channel-complete: the 64-channel models, l_max <= 3)."""
     if not ENABLED or _DECLINE[0] or plan is None or plan.addend or plan.sc_spec is None:
         return False
     hit = plan.__dict__.get("_force_ok")
     if hit is None:
-        hit = plan.__dict__["_force_ok"] = bool(L.load().e3k_tp_table2_supported(plan.tp_plan.handle(dev)))
+        h = plan.tp_plan.handle(dev)
+        # (with the weights materialised -- the default -- the second-order kernels also exist for the l_max 3 plans that are walked
+        #  by two waves per group)
+        hit = plan.__dict__["_force_ok"] = bool(L.load().e3k_tp_table2_supported(h)
+                                                or (MATERIALIZE and L.load().e3k_tp_second_order_streamed_supported(h)))
     return hit
 
 

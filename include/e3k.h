@@ -256,6 +256,9 @@ int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* e
  * With bin = coef = NULL the first three take w and dw/dr MATERIALISED: T = w [E, W], D = dw/dr [E, W] (e3k_rtable_interp_fwd of
  * either table): five or six kernels per layer read them, and one 7.7 KB row per edge is a quarter of four table rows. */
 int e3k_tp_table2_supported(const e3k_tp_plan* plan);
+/* ... and with the weights and their slope passed MATERIALISED (bin = coef = NULL): every channel-complete plan, the l_max 3 ones
+ * (two waves per group) included */
+int e3k_tp_second_order_streamed_supported(const e3k_tp_plan* plan);
 int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
                        const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
                        const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream);

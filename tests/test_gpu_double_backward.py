@@ -279,11 +279,11 @@ def test_force_training_step_matches_oracle(dev):
     assert checked >= 10
 
 
-def _force_net(dev, n_layers=3, r_max=4.0, seed=0):
+def _force_net(dev, n_layers=3, r_max=4.0, seed=0, l_max=2):
     from e3_layers_amd.configs.layer_configs import addEnergyOutput, addForceOutput, featureModel
     from e3_layers_amd.utils import build
 
-    cfg = featureModel(n_dim=64, l_max=2, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
+    cfg = featureModel(n_dim=64, l_max=l_max, edge_spherical="1x0e+1x1o+1x2e", node_attrs="16x0e", edge_radial="8x0e",
                        num_types=10, num_layers=n_layers, r_max=r_max)
     cfg = addForceOutput(addEnergyOutput(cfg, None, output_key="energy_total"), y="energy_total")
     torch.manual_seed(seed)
@@ -319,24 +319,31 @@ def _force_losses(prod, orc, batch, dev, plain_backward=False):
     return out, loss, ref
 
 
-@pytest.mark.parametrize("n_layers", [3, 4])
-def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch, n_layers):
+@pytest.mark.parametrize("n_layers,l_max", [(3, 2), (4, 2), (3, 3)])
+def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch, n_layers, l_max):
     """force training on the knot table.  Energy + force model (64 channels: the table's second-order kernels
     take channel-complete plans) in TRAINING mode on the force block (backend/conv_force.py: value table T and slope table D on
     the table's knots, three autograd nodes per layer): forces within 1e-5 and every parameter gradient within 5e-5 of the float64
-    oracle -- d/dtheta of dE/dpos, the double backward through every kernel, WITH the table on."""
+    oracle -- d/dtheta of dE/dpos, the double backward through every kernel, WITH the table on.
+    ``l_max=3`` (round 5): the features carry l = 3 irreps, the tensor-product plans are walked by two waves per
+    group -- the second-order kernels' SPLIT instantiations, with the weights and their slope materialised."""
     from e3_layers_amd.backend import conv_force, radial_table
     from e3_layers_amd.data.synthetic import synth_qm9
 
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)      # (a 20-molecule batch -- the keyed self-connection wants 256 nodes --: the float64 oracle's double backward is the slow part)
-    prod, orc = _force_net(dev, n_layers)
+    prod, orc = _force_net(dev, n_layers, l_max=l_max)
+    if l_max == 3:
+        from e3_layers_amd.backend import lib as _lib
+
+        h = prod.func.layer2.conv.tp.tp.plan.handle(dev)
+        assert not _lib.load().e3k_tp_table2_supported(h) and _lib.load().e3k_tp_second_order_streamed_supported(h)
     batch = synth_qm9(7, 20)
     assert batch["edge_index"].shape[1] >= radial_table.layout(4.0, radial_table.KNOTS_SLOPE)[0] + 1
     before = list(conv_force.STATS)
     out, loss, (o, loss_r) = _force_losses(prod, orc, batch, dev)
     assert [a - b for a, b in zip(conv_force.STATS, before)] == [n_layers, n_layers, n_layers]      # every layer ran as a force block
     err_f, err_e = rel_err(out["forces"], o["forces"]), rel_err(out["energy_total"], o["energy_total"])
-    record_measured("force_block_table", layers=n_layers, forces=err_f, energy=err_e)
+    record_measured("force_block_table", layers=n_layers, l_max=l_max, forces=err_f, energy=err_e)
     assert err_e < 1e-5 and err_f < 1e-5, (err_e, err_f)
     assert abs(float(loss.detach()) - float(loss_r.detach())) < 1e-5 * abs(float(loss_r.detach()))
     ref_params = dict(orc.named_parameters())
@@ -350,7 +357,7 @@ def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch,
         worst = max(worst, err)
         assert err < 5e-5, (name, err)
         checked += 1
-    record_measured("force_block_table_grads", layers=n_layers, worst_parameter_gradient=worst, checked=checked)
+    record_measured("force_block_table_grads", layers=n_layers, l_max=l_max, worst_parameter_gradient=worst, checked=checked)
     assert checked >= 10
     # a plain loss.backward() (the reference's trainer) gives the same parameter gradients (d loss / d pos is not formed: warned once)
     grads = {n: p.grad.clone() for n, p in prod.named_parameters() if p.grad is not None}

@@ -1,14 +1,12 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root: the rocprofv3 evidence of round 4 into gpurun_out/r04/
+# Run on the GPU box (via gpurun) from the repo root: the rocprofv3 evidence of round 5 into gpurun_out/r05/
 # (kernel-trace stats; separate --pmc passes, no trace domains beside --pmc), then
-#   python3 tools/summarize_profiles_r04.py        (runs anywhere)
+#   python3 tools/summarize_profiles_r05.py        (runs anywhere)
 cd /tmp && export TMPDIR=/tmp
 cd "$GRAFT_REPO_ROOT" || exit 1
-OUT=gpurun_out/r04
+OUT=gpurun_out/r05
 rm -rf $OUT; mkdir -p $OUT
 B="python3 bench.py --no-cpu-baseline"
-export E3K_BENCH_AUTO=0      # the profiler passes describe the eager four-stream step (a profiler makes the host slow: the bench
-                             # would otherwise switch to the graph replay); section 5 runs the default line with the choice on
 # 1. default workload: kernel stats + one step's launch sequence, PMC traffic, calibration probe
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o s -- $B --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 python3 tools/step_kernels.py $(ls -t $OUT/stats/*kernel_trace.csv | head -1) $OUT/step_kernels.txt
@@ -18,8 +16,6 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/probe_fetc
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/probe_write -o p -- python3 tools/pmc_probe.py > /dev/null 2>&1
 # 1b. L2 hit rates of the edge kernels inside the step (TCC hit rate of tp_fwd / tp_bwd_x) and in isolation vs knot count
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace --output-format csv -d $OUT/pmc_l2 -o p -- $B --steps 3 --warmup 1 > /dev/null 2>&1
-python3 tools/tp_table_bench.py 128 256 512 1024 2048 > $OUT/tp_table_bench.txt 2>&1
-python3 tools/tp_table_bench.py --clustered 512 2048 >> $OUT/tp_table_bench.txt 2>&1
 # 2. config_energy as shipped (l_max 3): kernel stats + PMC traffic
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/l3_stats -o s -- $B --lmax 3 --steps 10 --warmup 3 > $OUT/l3_bench_under_rocprof.json 2> $OUT/l3.err
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/l3_pmc_fetch -o p -- $B --lmax 3 --steps 3 --warmup 1 > /dev/null 2>&1
@@ -35,21 +31,15 @@ TRACE_ARGS="--graph-fresh --config energy_force" bash tools/trace_graph.sh > $OU
 TRACE_ARGS="--graph-fresh --batch 256" bash tools/trace_graph.sh > $OUT/trace_graph_energy.txt 2>&1
 cd "$GRAFT_REPO_ROOT"
 # 5. the lines themselves (no profiler; launch mode chosen by the bench unless the line's name says otherwise)
-unset E3K_BENCH_AUTO
-bash tools/collect_lines_r04.sh > $OUT/lines.log 2>&1
+bash tools/collect_lines_r05.sh > $OUT/lines.log 2>&1
 # 6. measured errors of the model-level parity tests (tests/util.py: record_measured)
 rm -f $OUT/parity_measured.jsonl
-E3K_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl python3 -m pytest tests/test_gpu_model.py tests/test_gpu_double_backward.py -q -m gpu -k "protein or diffusion or bench_path or guard or backbone or force_block or threshold" > $OUT/parity_tests.log 2>&1
-# 7. the GEMM kernels in isolation (layer-3 trailing Linear of config_energy, 4 608 nodes): times, and the timing-only ablations
-#    of the dbg library (no MFMA / no loads / no stores) that show the phases of the LDS-tiled kernels adding up; the persistent
-#    and LDS-direct experiment kernels beside the shipped ones
-python3 tools/postlin_bench.py 256 > $OUT/gemm_postlin_bench.txt 2>&1
-D=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so
-{
-  for a in 0 16 32 48; do echo "== gemm_kernel  E3K_GEMM_ABLATE=$a (16: no MFMA, 32: no stores)"; E3K_LIB=$D E3K_GEMM_ABLATE=$a python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear fwd\|post-linear dgrad"; done
-  for a in 0 16 32 48; do echo "== gemm_wgrad2_kernel  E3K_WGRAD2_ABLATE=$a (16: no MFMA, 32: no loads)"; E3K_LIB=$D E3K_WGRAD2_ABLATE=$a python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"; done
-  echo "== the round-3 weight-gradient kernel (E3K_WGRAD2=0)"; E3K_LIB=$D E3K_WGRAD2=0 python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"
-  for c in 0 1 2; do echo "== LDS-direct ring weight gradient (E3K_WGRAD2=2, configuration $c)"; E3K_LIB=$D E3K_WGRAD2=2 E3K_WGRAD3_CFG=$c python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear wgrad"; done
-  for w in 1 2 3; do echo "== persistent forward / dgrad (E3K_GEMM_PERSIST=1, $w workgroups per CU)"; E3K_LIB=$D E3K_GEMM_PERSIST=1 E3K_GEMM_PERSIST_MIN_TILES=1 E3K_GEMM_PERSIST_WG_PER_CU=$w python3 tools/postlin_bench.py 256 2>&1 | grep "post-linear fwd\|post-linear dgrad\|K  1024"; done
-} > $OUT/gemm_phase_ablation.txt 2>&1
+E3K_PARITY_LOG=$PWD/$OUT/parity_measured.jsonl python3 -m pytest tests/test_gpu_model.py tests/test_gpu_double_backward.py -q -m gpu -k "protein or diffusion or bench_path or guard or backbone or force_block or threshold or shipped_config or position_gradient" > $OUT/parity_tests.log 2>&1
+# 7. round-5 probes: the packed-table kernels in isolation (+ the debug library's timing-only ablation of the packed forward), the
+#    knot-order walk that would replace the g_w round trip (emulated), the guard's ratios at random init, the host's share of a step
+python3 tools/tp_table_bench.py 512 > $OUT/tp_table_bench.txt 2>&1
+E3K_LIB=$PWD/equivariant-nn-zoo_amd/csrc/libe3k_dbg.so python3 tools/tp_table_bench.py --ablate >> $OUT/tp_table_bench.txt 2>&1
+python3 tools/tp_table_bench.py --knot-order > $OUT/knot_order_walk.txt 2>&1
+python3 tools/guard_probe.py > $OUT/guard_probe.txt 2>&1
+E3K_HOST_TIMING=1 python3 tools/host_split.py 256 --layer-timing > $OUT/host_split.txt 2>&1
 ls $OUT; tail -c 600 $OUT/bench_default.json

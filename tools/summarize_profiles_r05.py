@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
-"""gpurun_out/r04/* (tools/collect_profiles_r04.sh) -> the committed summaries under profiles/r04_*:
+"""gpurun_out/r05/* (tools/collect_profiles_r05.sh) -> the committed summaries under profiles/r05_*:
 kernel stats (default workload, l_max 3, the other BASELINE configurations), one step's launch census, HBM traffic per
 launch of the three edge kernels from the FETCH_SIZE / WRITE_SIZE counters (separate passes, calibrated on a known
 1 GiB stream in the same session: FETCH_SIZE reads 1/2 on gfx950) for l_max 2 and l_max 3, MFMA-busy fractions of the
 GEMM kernels, and the bench lines of the session."""
 import collections, csv, glob, json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r04")
+SRC = os.path.join(ROOT, "gpurun_out", "r05")
 DST = os.path.join(ROOT, "profiles")
 KERNELS = {"tp_fwd": "tp_fwd_kernel", "tp_bwd_x": "tp_bwd_x_kernel", "tp_bwd_w": "tp_bwd_w_kernel"}
 
@@ -37,7 +37,7 @@ cal_w = 2 ** 20 / (sum(pw["calibration_act_fwd"]) / len(pw["calibration_act_fwd"
 
 def traffic(tag, stats_dir, fetch_dir, write_dir, under_json, out_name):
     stats = newest(f"{stats_dir}/**/*kernel_stats.csv")
-    shutil.copy(stats, os.path.join(DST, f"r04_{tag}kernel_stats.csv"))
+    shutil.copy(stats, os.path.join(DST, f"r05_{tag}kernel_stats.csv"))
     rows = list(csv.DictReader(open(stats)))
     bf, bw = counters(fetch_dir, "FETCH_SIZE", KERNELS), counters(write_dir, "WRITE_SIZE", KERNELS)
     under = last_json(os.path.join(SRC, under_json))
@@ -63,18 +63,18 @@ def traffic(tag, stats_dir, fetch_dir, write_dir, under_json, out_name):
     return out
 
 
-t2 = traffic("bench_", "stats", "pmc_fetch", "pmc_write", "bench_under_rocprof.json", "r04_tp_traffic.json")
-t3 = traffic("lmax3_", "l3_stats", "l3_pmc_fetch", "l3_pmc_write", "l3_bench_under_rocprof.json", "r04_lmax3_tp_traffic.json")
-shutil.copy(os.path.join(SRC, "step_kernels.txt"), os.path.join(DST, "r04_step_kernels.txt"))
+t2 = traffic("bench_", "stats", "pmc_fetch", "pmc_write", "bench_under_rocprof.json", "r05_tp_traffic.json")
+t3 = traffic("lmax3_", "l3_stats", "l3_pmc_fetch", "l3_pmc_write", "l3_bench_under_rocprof.json", "r05_lmax3_tp_traffic.json")
+shutil.copy(os.path.join(SRC, "step_kernels.txt"), os.path.join(DST, "r05_step_kernels.txt"))
 for name, tag in (("cfg_energy_force", "config3"), ("cfg_diffusion", "config4"), ("cfg_diffusion_CA", "config5")):
-    shutil.copy(newest(f"{name}/**/*kernel_stats.csv"), os.path.join(DST, f"r04_{tag}_kernel_stats.csv"))
+    shutil.copy(newest(f"{name}/**/*kernel_stats.csv"), os.path.join(DST, f"r05_{tag}_kernel_stats.csv"))
 # ---- L2 hit rates of the edge kernels inside the step
 l2 = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(newest("pmc_l2/**/*counter_collection.csv"))):
     kn = r["Kernel_Name"]
     if "tp_" in kn or "rtable" in kn:
         l2[kn.split("(")[0].replace("void e3k::", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
-with open(os.path.join(DST, "r04_tp_l2_hit.txt"), "w") as f:
+with open(os.path.join(DST, "r05_tp_l2_hit.txt"), "w") as f:
     f.write("# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 (default workload, MI355X)\n"
             "# per kernel: launches, mean L2 hits / misses per launch (millions of requests), hit rate\n")
     for k, cs in sorted(l2.items()):
@@ -82,9 +82,9 @@ with open(os.path.join(DST, "r04_tp_l2_hit.txt"), "w") as f:
         if h and m:
             hm, mm = sum(h) / len(h), sum(m) / len(m)
             f.write(f"{k}: launches {len(h)} hits {hm / 1e6:.2f} M misses {mm / 1e6:.2f} M hit rate {hm / max(hm + mm, 1):.3f}\n")
-for name in ("tp_table_bench.txt", "trace_graph_energy_force.txt", "trace_graph_energy.txt", "gemm_postlin_bench.txt", "gemm_phase_ablation.txt"):
+for name in ("tp_table_bench.txt", "trace_graph_energy_force.txt", "trace_graph_energy.txt", "knot_order_walk.txt", "guard_probe.txt", "host_split.txt"):
     if os.path.exists(os.path.join(SRC, name)):
-        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r04_" + name))
+        shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r05_" + name))
 # ---- MFMA busy of the GEMM kernels
 agg = collections.defaultdict(lambda: collections.defaultdict(float))
 cnt = collections.Counter()
@@ -109,7 +109,7 @@ for name, c in sorted(agg.items(), key=lambda kv: -dur[kv[0]]):
     gui = c.get("GRBM_GUI_ACTIVE", 0.0)
     mfma["kernels"][name] = {"launches": cnt[name], "total_us": round(dur[name], 1),
                              "mfma_busy_fraction": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (gui / 8 * 1024), 4) if gui else None}
-json.dump(mfma, open(os.path.join(DST, "r04_gemm_mfma_util.json"), "w"), indent=1)
+json.dump(mfma, open(os.path.join(DST, "r05_gemm_mfma_util.json"), "w"), indent=1)
 # ---- bench lines
 lines = {}
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
@@ -120,9 +120,9 @@ for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))):
             lines[os.path.basename(f)[:-5]]["cpu_baseline"] = d["cpu_baseline"]
     except Exception as exc:
         lines[os.path.basename(f)[:-5]] = {"error": str(exc)}
-json.dump(lines, open(os.path.join(DST, "r04_bench_lines.json"), "w"), indent=1)
-shutil.copy(os.path.join(SRC, "bench_default.json"), os.path.join(DST, "r04_bench_default.json"))
-shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, "r04_bench_under_rocprof.json"))
+json.dump(lines, open(os.path.join(DST, "r05_bench_lines.json"), "w"), indent=1)
+shutil.copy(os.path.join(SRC, "bench_default.json"), os.path.join(DST, "r05_bench_default.json"))
+shutil.copy(os.path.join(SRC, "bench_under_rocprof.json"), os.path.join(DST, "r05_bench_under_rocprof.json"))
 for key in ("tp_fwd", "tp_bwd_x", "tp_bwd_w"):
     for tag, t in (("l_max 2", t2), ("l_max 3", t3)):
         if key in t:
@@ -133,4 +133,4 @@ print(json.dumps(mfma["kernels"], indent=1)[:1500])
 
 pm = os.path.join(SRC, "parity_measured.jsonl")
 if os.path.exists(pm) and sum(1 for _ in open(pm)) > 1:
-    shutil.copy(pm, os.path.join(DST, "r04_parity_measured.jsonl"))
+    shutil.copy(pm, os.path.join(DST, "r05_parity_measured.jsonl"))
