@@ -560,7 +560,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         x, edge_radial, sh = L.f32c(x), L.f32c(edge_radial), L.f32c(sh)
         dev = x.device
         layer = native_layer(plan).handle(dev)
-        main = torch.cuda.current_stream(dev)
+        main = ops.current_stream(dev)
         fork = bool(fork) and not torch.cuda.is_current_stream_capturing()
         side = ops.side_stream(dev, 0) if fork else main
         side2 = ops.side_stream(dev, 1) if fork else main
@@ -766,7 +766,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         has_sc = plan.sc_spec is not None
         dev = gy.device
         layer = native_layer(plan).handle(dev)
-        main = torch.cuda.current_stream(dev)
+        main = ops.current_stream(dev)
         fork = fork and not torch.cuda.is_current_stream_capturing()
         side = ops.side_stream(dev, 0) if fork else main
         side2 = ops.side_stream(dev, 1) if fork else main

@@ -156,7 +156,7 @@ class FactorizedConvolution(Module):
             # the radial MLP (edge side: one big GEMM) and the node side (relayout, self-connection, linear_1: small
             # launches that leave most CUs idle) are independent until the tensor product: run them on two streams
             with ops.IN_FORK:
-                main = torch.cuda.current_stream(x.device)
+                main = ops.current_stream(x.device)
                 side = ops.side_stream(x.device)
                 radial = data["edge_radial"]
                 # (issuing the NEXT convolution's radial MLP here, one layer early -- rounds 1-4's E3K_RADIAL_AHEAD -- measured no gain
@@ -336,7 +336,7 @@ class MessagePassing(Module):
             weights.extend(mod.weight for mod in fc[:-1])
         plans = [pl for _, pl, _ in chain]
         if fork:
-            main = torch.cuda.current_stream(rows.device)
+            main = ops.current_stream(rows.device)
             side = ops.side_stream(rows.device)
             side.wait_stream(main)              # (the knot basis was evaluated on this stream)
             with ops.on_stream(side, main):     # forward AND backward of the stack live on the radial stream
@@ -379,7 +379,7 @@ class MessagePassing(Module):
         plans = [pl for _, pl in chain]
         weights = [m.conv.sc.weight for m, _ in chain]
         if fork:
-            main = torch.cuda.current_stream(attrs.device)
+            main = ops.current_stream(attrs.device)
             side2 = ops.side_stream(attrs.device, 1)
             side2.wait_stream(main)             # (the attributes were produced on this stream)
             with ops.on_stream(side2, main):    # forward AND backward of the stack live on the self-connection stream
@@ -463,7 +463,7 @@ class MessagePassing(Module):
         fork = bool(FWD_FORK and conv._fork_pays(n_edges, table is not None)
                     and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         if fork:      # gradient contributions of the shared inputs are summed on the streams that produce them
-            main = torch.cuda.current_stream(x.device)
+            main = ops.current_stream(x.device)
             side = ops.side_stream(x.device)
             with ops.on_stream(side, main):          # (the alias's autograd node lives on the stream current NOW)
                 radial = _stream_alias(radial, side)
@@ -530,7 +530,7 @@ class MessagePassing(Module):
         fork = bool(ADDEND_FORK and FWD_FORK and conv._fork_pays(data["edge_radial"].shape[0], table is not None)
                     and (ops.FORK_IN_CAPTURE or not torch.cuda.is_current_stream_capturing()))
         if fork:
-            main = torch.cuda.current_stream(x.device)
+            main = ops.current_stream(x.device)
             side = ops.side_stream(x.device)
             with ops.on_stream(side, main):
                 radial = _stream_alias(radial, side)
