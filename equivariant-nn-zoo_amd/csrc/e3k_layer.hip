@@ -452,12 +452,18 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (want_sc) E3K_TRY(keyed_weight_grads());
   }
   // tensor product
+  // packed table + both gradients wanted: ONE walk of the source CSR forms g_x1 and g_w [E, W] (csrc/e3k_tp.hip, MODE 5): the
+  // weight-gradient pass re-gathered sh, x[src] and g_mid[dst] of every edge for a dot product with sums the input gradient
+  // already holds (layer 3 of config_energy at 256 molecules: 213 + 104 us -> 258 us isolated, 217 + 169 -> see DESIGN section 5 in the step)
+  const bool fused_xw = a->fuse_xw && need_x1 && in_kernel_table(d, r) && r.P && need_radial_side && a->E > 0 && a->g_w && a->x1 && !(ABLATE & 32);
   if (need_x1) {
     if (!a->g_x1) return E3K_ERR_INVALID;
     if (!d.tp_bwd_x_overwrites && e3k::zero_fill(a->g_x1, sizeof(float) * a->N * d.d_x1, (hipStream_t)main))
       return E3K_ERR_LAUNCH;
     Timed t(L, E3K_PROF_TP_BWD_X, main, a->N, a->E);
     if (ABLATE & 32) {
+    } else if (fused_xw) {      // ... and the per-edge weight gradient in the same walk: no tp_bwd_w pass below
+      E3K_TRY(e3k_tp_bwd_xw_ptable(d.tp, a->x1, r.P, r.erec_src, a->g_mid, a->src_ptr, a->N, a->E, a->g_x1, a->g_w, main));
     } else if (in_kernel_table(d, r) && r.P) {
       E3K_TRY(e3k_tp_bwd_x_ptable(d.tp, r.P, r.erec_src, a->g_mid, a->src_ptr, a->N, a->E, a->g_x1, main));
     } else if (in_kernel_table(d, r)) {
@@ -478,9 +484,9 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     // the weight-gradient pass: on the radial stream BEHIND tp_bwd_x (both are memory streams: side by side they only
     // stretch each other), where it runs beside the GEMMs that follow on the main stream (this layer's linear_1 dgrad, the
     // previous layer's gate' and post-TP dgrad) -- nothing on the main stream waits for it
-    void* wst = (BWDW_SIDE && side != main) ? side : main;
+    void* wst = (BWDW_SIDE && side != main && !fused_xw) ? side : main;
     if (wst != main) E3K_TRY(edge(L, 2, main, side));
-    {
+    if (!fused_xw) {
       Timed t(L, E3K_PROF_TP_BWD_W, wst, a->N, a->E);
       E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, wst));
     }

@@ -61,6 +61,9 @@ __device__ __forceinline__ float buf_ld(__amdgpu_buffer_rsrc_t r, int voff, int 
 __device__ __forceinline__ float buf_ld_stream(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, E3K_STREAM_AUX));
 }
+__device__ __forceinline__ void buf_st_stream(float v, __amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, E3K_STREAM_AUX);
+}
 __device__ __forceinline__ void load_y_full(YRegs& y, const float* __restrict__ yr) {
   y.y0[0] = yr[0];
 #pragma unroll
@@ -698,7 +701,12 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE == 2 || MODE == 3;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
-  constexpr bool PACKED = MODE == 4;                                                // MODE 4: w from the packed table (see tp_fwd_body_full)
+  constexpr bool PACKED = MODE == 4 || MODE == 5;                                   // MODE 4: w from the packed table (see tp_fwd_body_full)
+  // MODE 5: ... and the WEIGHT gradient of every edge beside it.  Both gradients contract the same sums t[m1] = sum CG sh[m2] g[m3]
+  // of an edge and a path: g_x[src] += w t, g_w[e] = <x[src], t> -- with the source's own rows resident (2 l1 + 1 registers) the
+  // second costs 2 l1 + 1 FMAs and one 256-byte store per path, against a whole second walk of the edges (tp_bwd_w_kernel: the
+  // sh, x[src] and g[dst] gathers again) -- and the 0.5 GB of g_w [E, W] leave through HBM while this kernel waits on its L2 gathers
+  constexpr bool GW = MODE == 5;
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -711,9 +719,14 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     cf[Q] = g.coeff[Q];
   });
   const int row_g = a.d_mid * 4, row_w = a.W * 4;
-  float gx[D1];
+  float gx[D1], xs[GW ? D1 : 1];
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
+  if constexpr (GW) {
+    const float* __restrict__ xr = a.x + (int64_t)node * a.d_in + g.x_off;      // wave-uniform
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xs[i] = (xr + i * mul)[u];
+  }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   EdgeRec cur{};
   if constexpr (PACKED) {
@@ -735,6 +748,7 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     }
     if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
+    const __amdgpu_buffer_rsrc_t rgw = row_rsrc(GW ? a.g_w + (int64_t)e * a.W : nullptr, GW ? row_w : 0);
     float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
     if constexpr (PACKED) {
       const KnotPacked kp = knot_packed_rec(a, cur, row_w * 3);
@@ -809,6 +823,17 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
       if constexpr (DUAL) {
         CG<L1, L2, L3>::yg(yref<L2>(y2), gk, wn[Q] * cf[Q], gx);
         CG<L1, L2, L3>::yg(yref<L2>(yc), gk, w2[Q] * cf[Q], gx);
+      } else if constexpr (GW) {
+        float tq[D1];
+        CG<L1, L2, L3>::yt(yref<L2>(yc), gk, tq);
+        const float sw = wn[Q] * cf[Q];
+        float dot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          gx[i] = fmaf(sw, tq[i], gx[i]);      // (the bits of CG::yg: MODE 4 and MODE 5 give the same g_x)
+          dot = fmaf(xs[i], tq[i], dot);
+        }
+        buf_st_stream(dot * cf[Q], rgw, u4, woff4[Q]);
       } else {
         CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
       }
@@ -986,8 +1011,16 @@ __global__ __launch_bounds__(256) void tp_bwd_w_kernel(TpArgs a, const e3k_tp_gr
   E3K_TP_DISPATCH(tp_bwd_w_body, WITH_SH, L3MAX)
 }
 
+#ifndef E3K_TP_XW_WAVES
+#define E3K_TP_XW_WAVES 8
+#endif
+#ifdef E3K_DEBUG_KNOBS
+#define E3K_TP_BWDX_WAVES(MODE, MAXL, L3MAX) 1
+#else
+#define E3K_TP_BWDX_WAVES(MODE, MAXL, L3MAX) ((MODE == 5 && MAXL <= 2 && L3MAX <= 2) ? E3K_TP_XW_WAVES : 1)
+#endif
 template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
-__global__ __launch_bounds__(256) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
+__global__ __launch_bounds__(256, E3K_TP_BWDX_WAVES(MODE, MAXL, L3MAX)) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
   E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
@@ -1193,7 +1226,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 
 namespace {
 enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL,
-              TP_FWD_PACKED, TP_BWD_X_PACKED };
+              TP_FWD_PACKED, TP_BWD_X_PACKED, TP_BWD_XW_PACKED };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -1205,7 +1238,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   // (packed table, layer 3 of config_energy at 256 molecules, isolated: forward 163 -> 151 us, input gradient 221 -> 215; inside the
   //  step 124 -> 118 and 194 -> 187; the four-row form, whose 3.9 MB table stays in L2 either way, gains nothing: 187 / 188 us)
   E3K_KNOB_INT(tp_order, "E3K_TP_ORDER", 1);
-  args.order = (tp_order && (kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED) && N >= 64) ? 1 : 0;
+  args.order = (tp_order && (kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED || kind == TP_BWD_XW_PACKED) && N >= 64) ? 1 : 0;
 #ifdef E3K_DEBUG_KNOBS
   args.ablate = e3k::g_tp_ablate_host;
 #endif
@@ -1262,7 +1295,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     E3K_CHECK_LAUNCH();
     return E3K_OK;
   }
-  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE || kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED) {      // channel-complete (FULL) plans, split or not
+  if (kind == TP_FWD_TABLE || kind == TP_BWD_X_TABLE || kind == TP_FWD_PACKED || kind == TP_BWD_X_PACKED || kind == TP_BWD_XW_PACKED) {      // channel-complete (FULL) plans, split or not
     if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1, spl = p->split != 0;
 #define E3K_TP_LAUNCH_T(ML, L3, SP)                                                                                                     \
@@ -1273,6 +1306,8 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
       hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, true, 4>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);              \
     else if (kind == TP_BWD_X_PACKED)                                                                                                   \
       hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 4>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
+    else if (kind == TP_BWD_XW_PACKED)                                                                                                  \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 5>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
     else                                                                                                                                \
       hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 1>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);            \
   }
@@ -1422,6 +1457,21 @@ extern "C" int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_PACKED, a, plan, N, (hipStream_t)stream);
+}
+
+// ... and, in the same walk, the weight gradient of every edge: g_w [E, W] row e = dF/dw[e] (what e3k_tp_bwd_w writes; x = the
+// layer's input rows [N, d_in], channel-fastest).  Every (edge, path, channel) is written exactly once: no zero-fill needed.
+extern "C" int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_src, const float* g_out,
+                                    const int32_t* src_ptr, int64_t N, int64_t E, float* g_x, float* g_w, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !g_out || !g_x || !src_ptr || (E > 0 && (!P || !erec_src || !g_w))) return E3K_ERR_INVALID;
+  if (reinterpret_cast<uintptr_t>(erec_src) & 63) return E3K_ERR_UNSUPPORTED;
+  e3k::TpArgs a{};
+  a.x = x; a.w = static_cast<const float*>(P); a.erec = erec_src; a.g_out = g_out; a.g_x = g_x; a.g_w = g_w; a.ptr = src_ptr;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_XW_PACKED, a, plan, N, (hipStream_t)stream);
 }
 
 // ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------

@@ -114,6 +114,17 @@ def _tp_bwd_x_ptable(sh, packed, bins, g_mid, topo, tp):
     return gx
 
 
+def _tp_bwd_xw_ptable(x1, sh, packed, bins, g_mid, topo, tp):
+    """(g_x1 [N, d_in], g_w [E, W]): the input gradient and every edge's weight gradient in ONE walk of the source CSR"""
+    n, e = g_mid.shape[0], sh.shape[0]
+    gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
+    gw = torch.empty(e, tp.w_numel, device=sh.device, dtype=torch.float32)
+    L.check(L.load().e3k_tp_bwd_xw_ptable(tp.handle(sh.device), L.ptr(x1), L.ptr(packed), L.ptr(bins.records(topo, sh, "src")),
+                                          L.ptr(g_mid), L.ptr(topo.src_ptr), n, e, L.ptr(gx), L.ptr(gw), L.stream_ptr()),
+            "e3k_tp_bwd_xw_ptable")
+    return gx, gw
+
+
 def _b(bins):
     """(knot, weights) pointers of the table form, or (None, None): T / D are then the materialised rows w / dw [E, W]"""
     return (None, None) if bins is None else (L.ptr(bins.bin), L.ptr(bins.coef))

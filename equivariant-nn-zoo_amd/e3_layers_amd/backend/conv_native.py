@@ -209,6 +209,7 @@ ADDEND_INPLACE = _knob("E3K_ADDEND_INPLACE")
 # middle of the knot interval, the two small ones in fp16): one dwordx3 load per path slot instead of four dword loads out of four
 # rows; 0: the four-row form of round 4
 TP_TABLE_PACKED = _knob("E3K_TP_TABLE_PACKED")
+TP_BWD_FUSED = _knob("E3K_TP_BWD_FUSED")
 
 
 def _packed_buffer(rows: int, width: int, dev) -> torch.Tensor:
@@ -779,6 +780,7 @@ class NativeConvBlockFn(torch.autograd.Function):
         a.N, a.E = n, e
         a.in_cf, a.out_cf, a.fork = int(in_cf), int(out_cf), int(fork)
         a.need_x, a.need_attrs, a.need_radial = int(need_x), int(bool(need_attrs and has_sc)), int(need_radial)
+        a.fuse_xw = int(TP_BWD_FUSED)
         a.main, a.side, a.side2, a.side3 = main.cuda_stream, side.cuda_stream, side2.cuda_stream, side3.cuda_stream
         a.x_cf = _ptr(buf, off["x_cf"]) if need_relayout else x_in.data_ptr()
         a.sh, a.x1, a.mid = sh.data_ptr(), _ptr(buf, off["x1"]), _ptr(buf, off["mid"])

@@ -129,7 +129,7 @@ class LayerFwdArgs(C.Structure):
 class LayerBwdArgs(C.Structure):
     _fields_ = ([("N", C.c_int64), ("E", C.c_int64)]
                 + [(k, C.c_int32) for k in ("in_cf", "out_cf", "fork", "n_keys", "need_x", "need_attrs", "need_radial", "acc_sc",
-                                            "have_m", "_pad")]
+                                            "have_m", "fuse_xw")]
                 + [(k, C.c_void_p) for k in ("main", "side", "side2", "side3", "x_cf", "sh", "x1", "mid", "conv", "a_rep", "m",
                                              "src", "dst", "dst_ptr", "dst_perm", "src_ptr", "src_perm", "perm", "bounds", "reps",
                                              "w_lin1", "w_post", "w_sc")]
@@ -206,6 +206,7 @@ SIGNATURES = {
     "e3k_tp_bwd_x_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_fwd_ptable": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x_ptable": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
+    "e3k_tp_bwd_xw_ptable": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "e3k_edge_records": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _P, _P]),
     "e3k_tp_table2_supported": (C.c_int, [_P]),
     "e3k_tp_second_order_streamed_supported": (C.c_int, [_P]),

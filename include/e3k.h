@@ -241,6 +241,11 @@ int e3k_tp_fwd_ptable(const e3k_tp_plan* plan, const float* x, const void* P, co
                       int64_t N, int64_t E, float* out, void* stream);
 int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* erec_src, const float* g_out, const int32_t* src_ptr,
                         int64_t N, int64_t E, float* g_x, void* stream);
+/* ... the input gradient AND every edge's weight gradient in the one walk (replaces e3k_tp_bwd_x_ptable + e3k_tp_bwd_w of a layer's
+ * backward, nn/message_passing.py:93,104-109 under autograd): x [N, d_in] channel-fastest = the layer's tensor-product input rows,
+ * g_w [E, W] row e = d F / d w[e] (written once each: no zero-fill).  g_x carries the bits of e3k_tp_bwd_x_ptable. */
+int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_src, const float* g_out,
+                         const int32_t* src_ptr, int64_t N, int64_t E, float* g_x, float* g_w, void* stream);
 /* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights
  * then depend on pos through the radius, nn/message_passing.py:93).  With F = <g, TP(x[src], sh, w(T, coef))>, linear in each
  * of (g, x, sh, T, coef), every first and second derivative is one of the walks below (plans with e3k_tp_table2_supported:
@@ -644,8 +649,10 @@ int e3k_layer_fwd(const e3k_layer* layer, const e3k_layer_fwd_args* a);
 typedef struct {
   int64_t N, E;
   int32_t in_cf, out_cf, fork, n_keys, need_x, need_attrs, need_radial, acc_sc;
-  int32_t have_m, _pad;              /* have_m: `gm` (gradient of the per-key weights) is an OUTPUT handed to e3k_kw_stack_bwd;
-                                        no weight / attribute gradient of the self-connection is formed here */
+  int32_t have_m, fuse_xw;           /* have_m: `gm` (gradient of the per-key weights) is an OUTPUT handed to e3k_kw_stack_bwd;
+                                        no weight / attribute gradient of the self-connection is formed here.
+                                        fuse_xw: with rad.P, the per-edge weight gradient g_w is formed by the input-gradient
+                                        walk (e3k_tp_bwd_xw_ptable) instead of a pass of its own (e3k_tp_bwd_w) */
   void *main, *side, *side2, *side3;
   /* saved by the forward */
   const float *x_cf, *sh, *x1, *mid, *conv, *a_rep, *m;

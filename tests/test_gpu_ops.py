@@ -685,6 +685,18 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
     assert float((w_p.cpu().double() - ws_ref).abs().max()) < 2e-6 * float(s64.abs().max())
     # the gradient of the table: tp_bwd_w -> g_w[E, W] -> transposed interpolation, against an index_add in float64; twice: same bits
     g_w, _ = ops._tp_bwd_w_raw(x, sh, None, g_out, topo, plan, False, True)
+    # the FUSED input + weight gradient (e3k_tp_bwd_xw_ptable: what a packed-table layer's backward runs): g_x with the bits of
+    # e3k_tp_bwd_x_ptable, g_w == tp_bwd_w's up to the order of the sums (<x, sum CG sh g> here, <sum CG x sh, g> there);
+    # twice: same bits (no atomics on g_w)
+    gx_f, gw_f = conv_force._tp_bwd_xw_ptable(x, sh, packed, bins, g_out, topo, plan)
+    gx_f2, gw_f2 = conv_force._tp_bwd_xw_ptable(x, sh, packed, bins, g_out, topo, plan)
+    torch.cuda.synchronize()
+    assert torch.equal(gw_f, gw_f2)
+    if plan.bwd_x_overwrites(dev):
+        assert torch.equal(gx_f, gx_p) and torch.equal(gx_f, gx_f2)
+    else:
+        assert rel_err(gx_f, gx_p) < 1e-6
+    assert rel_err(gw_f, g_w) < 1e-6      # (tp_bwd_w itself against the float64 oracle: test_tp_fused_against_unfused_oracle)
     gt_a = radial_table.interp_bwd_raw(g_w, bins)
     gt_b = radial_table.interp_bwd_raw(g_w, bins)
     assert torch.equal(gt_a, gt_b)

@@ -108,6 +108,13 @@ for target in targets:
     t_p = timeit(lambda: radial_table.pack_raw(T, bins.knots))
     t_fp = timeit(lambda: conv_force._tp_fwd_ptable(x, sh, P, bins, topo, tp))
     t_xp = timeit(lambda: conv_force._tp_bwd_x_ptable(sh, P, bins, g, topo, tp))
+    t_xw = timeit(lambda: conv_force._tp_bwd_xw_ptable(x, sh, P, bins, g, topo, tp))
+    gx_a = conv_force._tp_bwd_x_ptable(sh, P, bins, g, topo, tp)
+    gx_b, gw_b = conv_force._tp_bwd_xw_ptable(x, sh, P, bins, g, topo, tp)
+    gx_c = conv_force._tp_bwd_x_ptable(sh, P, bins, g, topo, tp)
+    print(f"  (two runs of the unfused kernel bit-equal {bool(torch.equal(gx_a, gx_c))}; fused vs unfused max |d| {float((gx_a - gx_b).abs().max()):.2e} of {float(gx_a.abs().max()):.2e})")
+    print(f"  fused input + weight gradient {t_xw:7.1f} us: g_x bit-equal {bool(torch.equal(gx_a, gx_b))}, "
+          f"g_w vs tp_bwd_w max |d| {float((gw_b - gw).abs().max()):.2e} of {float(gw.abs().max()):.2e}")
     t_i = timeit(lambda: radial_table.interp_fwd_raw(T, bins))
     t_t = timeit(lambda: radial_table.interp_bwd_raw(gw, bins))
     print(f"knots {bins.knots:5d} (table {4e-6 * (bins.knots + 1) * tp.w_numel:5.1f} MB, edges/knot mean {float(cnt[cnt > 0].mean()):6.1f} max {int(cnt.max()):5d}): "
