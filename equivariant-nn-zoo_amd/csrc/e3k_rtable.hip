@@ -409,6 +409,7 @@ __device__ __forceinline__ void atomic_max_pos(float* p, float v) {      // v >=
   atomicMax(reinterpret_cast<unsigned int*>(p), __float_as_uint(v));
 }
 
+constexpr int RT_GUARD_PARTS = 8;      // row ranges per table column = 4 waves x this many workgroups (e3k.h: scratch size)
 __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   __shared__ float s_col[4][64], s_d4[4][64];
   __shared__ int s_last;
@@ -420,10 +421,13 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   const int col = blockIdx.x * 64 + lane;
   const int rows = a.rows;
-  // row quarter q covers fourth differences starting at rows [lo, hi): reads rows lo .. hi + 3
+  // row range (blockIdx.z, q) of 4 RT_GUARD_PARTS covers fourth differences starting at rows [lo, hi): reads rows lo .. hi + 3
+  // (a wave's walk down its rows is a chain of dependent loads: with four ranges per table column it lasted 52 us -- every replay
+  //  of a captured step pays it -- with 32 it takes 9)
   const int n_d4 = rows - 4;
-  const int per = (n_d4 + 3) / 4;
-  const int lo = q * per, hi = (lo + per < n_d4) ? lo + per : n_d4;
+  const int per = (n_d4 + 4 * RT_GUARD_PARTS - 1) / (4 * RT_GUARD_PARTS);
+  const int rq = blockIdx.z * 4 + q;
+  const int lo = rq * per < n_d4 ? rq * per : n_d4, hi = (lo + per < n_d4) ? lo + per : n_d4;
   float cmax = 0.f, dmax = 0.f;
   bool bad = false;
   if (col < W && lo < hi) {
@@ -446,19 +450,31 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   s_col[q][lane] = bad ? INFINITY : cmax;
   s_d4[q][lane] = bad ? INFINITY : dmax;
   __syncthreads();
-  float* __restrict__ scratch = a.scratch[tb];
+  float* __restrict__ scratch = a.scratch[tb];      // [RT_GUARD_PARTS][2][W]
   if (q == 0 && col < W) {
-    scratch[col] = fmaxf(fmaxf(s_col[0][lane], s_col[1][lane]), fmaxf(s_col[2][lane], s_col[3][lane]));
-    scratch[W + col] = fmaxf(fmaxf(s_d4[0][lane], s_d4[1][lane]), fmaxf(s_d4[2][lane], s_d4[3][lane]));
+    float* __restrict__ mine = scratch + (int64_t)blockIdx.z * 2 * W;
+    mine[col] = fmaxf(fmaxf(s_col[0][lane], s_col[1][lane]), fmaxf(s_col[2][lane], s_col[3][lane]));
+    mine[W + col] = fmaxf(fmaxf(s_d4[0][lane], s_d4[1][lane]), fmaxf(s_d4[2][lane], s_d4[3][lane]));
   }
   __threadfence();
   __syncthreads();
   int* counter = reinterpret_cast<int*>(a.state[tb] + 2);
-  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == n_chunks - 1) ? 1 : 0;
+  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == n_chunks * RT_GUARD_PARTS - 1) ? 1 : 0;
   __syncthreads();
   if (!s_last) return;
   __threadfence();
-  // the table's last workgroup: global maximum, then the worst column
+  // the table's last workgroup: fold the row ranges per column, global maximum, then the worst column
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float cm = 0.f, dm = 0.f;
+    for (int z = 0; z < RT_GUARD_PARTS; ++z) {
+      cm = fmaxf(cm, __builtin_nontemporal_load(scratch + (int64_t)z * 2 * W + c));
+      dm = fmaxf(dm, __builtin_nontemporal_load(scratch + (int64_t)z * 2 * W + W + c));
+    }
+    scratch[c] = cm;
+    scratch[W + c] = dm;
+  }
+  __threadfence();
+  __syncthreads();
   float g = 0.f;
   for (int c = threadIdx.x; c < W; c += 256) g = fmaxf(g, __builtin_nontemporal_load(scratch + c));
   g = wave_max_f(g);
@@ -506,7 +522,8 @@ extern "C" int e3k_rtable_guard(const float* const* tables, float* const* states
     wmax = widths[i] > wmax ? widths[i] : wmax;
   }
   a.rows = rows; a.floor_rel = floor_rel; a.c4 = 3.0f / 128.0f; a.col_weight = col_weight; a.pack_weight = packed ? 1.f : 0.f;
-  hipLaunchKernelGGL(e3k::rtable_guard_kernel, dim3((unsigned)((wmax + 63) / 64), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(e3k::rtable_guard_kernel, dim3((unsigned)((wmax + 63) / 64), (unsigned)n, e3k::RT_GUARD_PARTS), dim3(256), 0,
+                     (hipStream_t)stream, a);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -740,6 +740,9 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
       nxt = load_rec(a.erec, t + 1 < end ? t + 1 : t);
       e = cur.e;
       d = cur.nbr;
+#ifdef E3K_DEBUG_KNOBS
+      if (a.ablate & 8) d = node;      // timing only: every edge reads the walker's own gradient rows (an L1 hit) instead of g[dst]
+#endif
       rec_y(yc, cur);
     } else {
       e = uniform(a.perm[t]);
@@ -759,7 +762,7 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k)
           gn[OFF + k] = buf_ld(rg, u4, goff4[Q] + k * gstr4[Q]);
-        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2);
+        rec[Q] = buf_ld_rec(kp.r, u4, woff4[Q], row_w * 2, a.ablate);
       });
       __builtin_amdgcn_sched_barrier(0);
       slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {

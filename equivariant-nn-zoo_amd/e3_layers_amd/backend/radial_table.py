@@ -304,11 +304,11 @@ class _Guard:
 
     def device_state(self, device, width: int):
         """Allocated OUTSIDE any capture (persistent across replays); None while capturing if it does not exist yet."""
-        if self.dev is None or self.dev.device != device or self.scratch.numel() < 2 * width:
+        if self.dev is None or self.dev.device != device or self.scratch.numel() < 16 * width:
             if torch.cuda.is_current_stream_capturing():
                 return None
             self.dev = torch.zeros(4, dtype=torch.float32, device=device)
-            self.scratch = torch.empty(2 * width, dtype=torch.float32, device=device)
+            self.scratch = torch.empty(16 * width, dtype=torch.float32, device=device)      # (e3k.h: 8 row ranges x 2 x W)
         return self.dev
 
 

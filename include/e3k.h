@@ -371,7 +371,7 @@ int e3k_rtable_interp_packed(const void* P, const int32_t* bin_perm, const int32
  * for up to 16 tables of `rows` rows in ONE launch (the layers of a radial stack).  states[t] float [4]: [0] running maximum of
  * est since the caller last zeroed it (atomic max: survives HIP-graph replays, which never re-enter the host code that would
  * read a per-launch value), [1] est of this launch, [2] internal ticket counter (zero it once at allocation), [3] est_c of this
- * launch.  scratch[t] float [2 * widths[t]].  A non-finite table entry gives est = +inf.  rows < 5: nothing to do. */
+ * launch.  scratch[t] float [16 * widths[t]].  A non-finite table entry gives est = +inf.  rows < 5: nothing to do. */
 int e3k_rtable_guard(const float* const* tables, float* const* states, float* const* scratch, const int32_t* widths, int32_t n,
                      int32_t rows, float floor_rel, float col_weight, int32_t packed, void* stream);
 

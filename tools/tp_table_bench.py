@@ -92,6 +92,10 @@ if "--ablate" in sys.argv:      # dbg library only (E3K_LIB=.../libe3k_dbg.so): 
     for mask, what in ((0, "full"), (1, "no table loads"), (2, "no x loads"), (3, "no table, no x loads"), (4, "no CG arithmetic"), (7, "loop skeleton")):
         assert lib.e3k_dbg_tp_ablate(mask) == 0
         print(f"packed tp_fwd, {what:22s}: {timeit(lambda: conv_force._tp_fwd_ptable(x, sh, P, bins, topo, tp)):7.1f} us")
+    for mask, what in ((0, "full"), (8, "g[dst] rows from the walker's own node (L1 hits)"), (1, "no table loads"), (9, "neither")):
+        assert lib.e3k_dbg_tp_ablate(mask) == 0
+        print(f"packed tp_bwd_x, {what:50s}: {timeit(lambda: conv_force._tp_bwd_x_ptable(sh, P, bins, g, topo, tp)):7.1f} us   "
+              f"with g_w: {timeit(lambda: conv_force._tp_bwd_xw_ptable(x, sh, P, bins, g, topo, tp)):7.1f} us")
     lib.e3k_dbg_tp_ablate(0)
     sys.exit(0)
 print(f"streamed  tp_fwd {timeit(lambda: ops._tp_fwd_raw(x, sh, w, topo, tp)):7.1f} us   tp_bwd_x {timeit(lambda: ops._tp_bwd_x_raw(sh, w, g, topo, tp)):7.1f} us"
