@@ -683,6 +683,10 @@ def main():
         return bool(conv_native.TP_TABLE and radial_table.ENABLED and getattr(plan, "_e3k_table_form", False)
                     and e >= radial_table.MIN_EDGES_PER_KNOT * table_rows)
 
+    def fused_bwd(e, plan):
+        """This input-gradient launch also wrote the per-edge weight gradient (csrc/e3k_tp.hip MODE 5: packed-table layers)."""
+        return bool(in_kernel(e, plan) and conv_native.TP_TABLE_PACKED and conv_native.TP_BWD_FUSED and conv_native.ENABLED)
+
     def tp_bytes(kind, n, e, plan, variant="A"):
         """Algorithmic bytes of one launch.  Variant A = the module-API operation
         tp(x[src], sh, w) + scatter with the per-edge weights supplied (E x W streamed); variant B = the radial-fused
@@ -697,7 +701,8 @@ def main():
         if kind == "tp_bwd_w":      # x[src] gather + sh + g_w stream + g_mid rows
             return e * (4 * plan.d_in + 4 * plan.d_sh + 4 * plan.w_numel + 16) + n * 4 * plan.d_mid
         if kind == "tp_bwd_x":      # compulsory: w + sh + g_mid once + g_x rows (the g_mid[dst] gather is not counted)
-            return e * (4 * plan.d_sh + w_term + 16) + n * 4 * (plan.d_mid + plan.d_in) + extra
+            fused = e * 4 * plan.w_numel + n * 4 * plan.d_in if (variant == "B" and fused_bwd(e, plan)) else 0      # + g_w [E, W] out, x rows in
+            return e * (4 * plan.d_sh + w_term + 16) + n * 4 * (plan.d_mid + plan.d_in) + extra + fused
         raise KeyError(kind)
 
     def summarise(kind):
@@ -752,6 +757,13 @@ def main():
     kernels = []
     for kind in ("tp_bwd_x", "tp_bwd_w"):
         k = summarise(kind)
+        if kind == "tp_bwd_w" and not k["launches"]:
+            continue      # (every layer formed its weight gradient inside the input-gradient walk)
+        if kind == "tp_bwd_x":
+            n_f = sum(1 for _, _, (nn, e, plan) in (records or {}).get(kind, []) if fused_bwd(e, plan))
+            if n_f:
+                k["launches_with_fused_weight_gradient"] = n_f
+                k["kernel"] += " (MODE 5: the per-edge weight gradient g_w [E, W] written in the same walk -- its bytes are in the model)"
         t_k = traffic.get(kind, {}).get("traffic_bytes_per_launch")
         k["traffic"] = round(t_k) if t_k else None
         if t_k and k["avg_launch_us"] > 0:

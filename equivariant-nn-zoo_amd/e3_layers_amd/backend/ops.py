@@ -503,6 +503,7 @@ class StridedLinearFn(torch.autograd.Function):
             ctx.save_for_backward(x, weight)
         ctx.act, ctx.act_cst = act, act_cst
         ctx.spec, ctx.scale, ctx.has_bias, ctx.has_base = spec, scale, bias is not None, base is not None
+        ctx.bias_param = bias      # (a parameter: looked up in the gradient sink by the backward)
         ctx.in_fork = bool(IN_FORK)
         return y
 
@@ -558,10 +559,14 @@ class StridedLinearFn(torch.autograd.Function):
             gw = None   # already accumulated into the flat gradient buffer
         if ctx.has_bias and need[2]:
             nb = sum(m for _, m, _ in spec.bias_blocks)
-            gb = torch.zeros(nb, device=x.device, dtype=torch.float32)
+            # (the column sums are accumulated with atomics: straight into the flat gradient buffer when the bias has a slot there --
+            #  no zero-filled temporary, no add by autograd)
+            gb_out = _sink_for(ctx.bias_param) if ctx.bias_param.numel() == nb else None
+            if gb_out is None:
+                gb = gb_out = torch.zeros(nb, device=x.device, dtype=torch.float32)
             lib = L.load()
             for off, mul, boff in spec.bias_blocks:
-                L.check(lib.e3k_colsum(_addr(gy, off), rows, mul, spec.d_out, _addr(gb, boff), L.stream_ptr()), "e3k_colsum")
+                L.check(lib.e3k_colsum(_addr(gy, off), rows, mul, spec.d_out, _addr(gb_out, boff), L.stream_ptr()), "e3k_colsum")
         gbase = gy if (ctx.has_base and need[3]) else None
         return gx, gw, gb, gbase, None, None, None, None
 
