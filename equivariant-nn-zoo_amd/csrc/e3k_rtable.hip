@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256) void rtable_interp_packed_kernel(const uint32_
 // radial stack's layers): a workgroup = 64 columns x 4 row quarters; the LAST workgroup of a table (ticket counter in the
 // table's state) reduces the per-column maxima to the estimate.  state [4]: [0] running maximum of the estimate since the host
 // last reset it (what a replayed HIP graph leaves behind: the captured step never re-enters Python), [1] the estimate of this
-// launch, [2] ticket counter (self-resetting), [3] the per-column ratio of this launch (un-weighted).  A non-finite table entry
+// launch, [2] unused, [3] the per-column ratio of this launch (un-weighted).  A non-finite table entry
 // gives +inf.
 struct GuardArgs {
   const float* T[16];
@@ -410,9 +410,12 @@ __device__ __forceinline__ void atomic_max_pos(float* p, float v) {      // v >=
 }
 
 constexpr int RT_GUARD_PARTS = 8;      // row ranges per table column = 4 waves x this many workgroups (e3k.h: scratch size)
+// pass 1: per (table, 64-column chunk, row range) the column maxima of |T| and of the error bound -> scratch [PARTS][2][W].
+// (Round 5 first had ONE kernel whose last workgroup per table -- found with a ticket counter behind __threadfence() -- did pass 2:
+//  97 us for five tables of 641 x 1 920.  A device-scope fence on this multi-XCD part writes an L2's dirty lines back, and the tables
+//  had just been written: 1 200 workgroups each paid for it.  Two launches, no fence: the kernel boundary publishes the scratch.)
 __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   __shared__ float s_col[4][64], s_d4[4][64];
-  __shared__ int s_last;
   const int tb = blockIdx.y;
   const int W = a.W[tb];
   const int n_chunks = (W + 63) / 64;
@@ -422,8 +425,6 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   const int col = blockIdx.x * 64 + lane;
   const int rows = a.rows;
   // row range (blockIdx.z, q) of 4 RT_GUARD_PARTS covers fourth differences starting at rows [lo, hi): reads rows lo .. hi + 3
-  // (a wave's walk down its rows is a chain of dependent loads: with four ranges per table column it lasted 52 us -- every replay
-  //  of a captured step pays it -- with 32 it takes 9)
   const int n_d4 = rows - 4;
   const int per = (n_d4 + 4 * RT_GUARD_PARTS - 1) / (4 * RT_GUARD_PARTS);
   const int rq = blockIdx.z * 4 + q;
@@ -450,49 +451,49 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
   s_col[q][lane] = bad ? INFINITY : cmax;
   s_d4[q][lane] = bad ? INFINITY : dmax;
   __syncthreads();
-  float* __restrict__ scratch = a.scratch[tb];      // [RT_GUARD_PARTS][2][W]
   if (q == 0 && col < W) {
-    float* __restrict__ mine = scratch + (int64_t)blockIdx.z * 2 * W;
+    float* __restrict__ mine = a.scratch[tb] + (int64_t)blockIdx.z * 2 * W;      // [RT_GUARD_PARTS][2][W]
     mine[col] = fmaxf(fmaxf(s_col[0][lane], s_col[1][lane]), fmaxf(s_col[2][lane], s_col[3][lane]));
     mine[W + col] = fmaxf(fmaxf(s_d4[0][lane], s_d4[1][lane]), fmaxf(s_d4[2][lane], s_d4[3][lane]));
   }
-  __threadfence();
-  __syncthreads();
-  int* counter = reinterpret_cast<int*>(a.state[tb] + 2);
-  if (threadIdx.x == 0) s_last = (atomicAdd(counter, 1) == n_chunks * RT_GUARD_PARTS - 1) ? 1 : 0;
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  // the table's last workgroup: fold the row ranges per column, global maximum, then the worst column
-  for (int c = threadIdx.x; c < W; c += 256) {
-    float cm = 0.f, dm = 0.f;
-    for (int z = 0; z < RT_GUARD_PARTS; ++z) {
-      cm = fmaxf(cm, __builtin_nontemporal_load(scratch + (int64_t)z * 2 * W + c));
-      dm = fmaxf(dm, __builtin_nontemporal_load(scratch + (int64_t)z * 2 * W + W + c));
-    }
-    scratch[c] = cm;
-    scratch[W + c] = dm;
-  }
-  __threadfence();
-  __syncthreads();
+}
+
+// pass 2: one workgroup per table: fold the row ranges per column, the table's largest entry, then the worst column
+__global__ __launch_bounds__(256) void rtable_guard_reduce_kernel(GuardArgs a) {
+  __shared__ float s_red[4], s_red2[4];
+  const int tb = blockIdx.x;
+  const int W = a.W[tb];
+  const float* __restrict__ scratch = a.scratch[tb];
+  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
   float g = 0.f;
-  for (int c = threadIdx.x; c < W; c += 256) g = fmaxf(g, __builtin_nontemporal_load(scratch + c));
+  auto fold = [&](int c, float& cm, float& dm) {
+    cm = 0.f, dm = 0.f;
+#pragma unroll
+    for (int z = 0; z < RT_GUARD_PARTS; ++z) {
+      cm = fmaxf(cm, scratch[(int64_t)z * 2 * W + c]);
+      dm = fmaxf(dm, scratch[(int64_t)z * 2 * W + W + c]);
+    }
+  };
+  for (int c = threadIdx.x; c < W; c += 256) {
+    float cm, dm;
+    fold(c, cm, dm);
+    g = fmaxf(g, cm);
+  }
   g = wave_max_f(g);
-  __shared__ float s_red[4];
   if (lane == 0) s_red[q] = g;
   __syncthreads();
   g = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   const float fl = fmaxf(a.floor_rel * g, 1e-30f), gs = fmaxf(g, 1e-30f);
   float est_c = 0.f, est_g = 0.f;
-  for (int c = threadIdx.x; c < W; c += 256) {
-    const float cm = __builtin_nontemporal_load(scratch + c), dm = __builtin_nontemporal_load(scratch + W + c);
+  for (int c = threadIdx.x; c < W; c += 256) {      // (folded again rather than kept: no limit on the width, the scratch is an L2 hit)
+    float cm, dm;
+    fold(c, cm, dm);
     const bool fin = dm < INFINITY && cm < INFINITY;
     est_c = fmaxf(est_c, fin ? dm / fmaxf(cm, fl) : INFINITY);
     est_g = fmaxf(est_g, fin ? dm / gs : INFINITY);
   }
   est_c = wave_max_f(est_c);
   est_g = wave_max_f(est_g);
-  __shared__ float s_red2[4];
   __syncthreads();
   if (lane == 0) s_red[q] = est_c, s_red2[q] = est_g;
   __syncthreads();
@@ -503,7 +504,6 @@ __global__ __launch_bounds__(256) void rtable_guard_kernel(GuardArgs a) {
     a.state[tb][1] = est;
     a.state[tb][3] = est_c;
     atomic_max_pos(a.state[tb], est);
-    *counter = 0;
   }
 }
 
@@ -524,6 +524,7 @@ extern "C" int e3k_rtable_guard(const float* const* tables, float* const* states
   a.rows = rows; a.floor_rel = floor_rel; a.c4 = 3.0f / 128.0f; a.col_weight = col_weight; a.pack_weight = packed ? 1.f : 0.f;
   hipLaunchKernelGGL(e3k::rtable_guard_kernel, dim3((unsigned)((wmax + 63) / 64), (unsigned)n, e3k::RT_GUARD_PARTS), dim3(256), 0,
                      (hipStream_t)stream, a);
+  hipLaunchKernelGGL(e3k::rtable_guard_reduce_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, a);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -9,8 +9,12 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # last 10 steps = timed region: find adam kernels
 adam = [i for i, r in enumerate(rows) if "adam_ema_kernel" in r["Kernel_Name"]]
-lo, hi = adam[-6], adam[-1]          # five whole steps
+# five whole REPLAYED steps from the middle of the run (the last steps of a bench run are the eager host-time measurement: several
+# queues; a replayed step runs on one)
+mid = len(adam) // 2
+lo, hi = adam[mid - 3], adam[mid + 2]
 sel = rows[lo + 1: hi + 1]
+print("queues in the selection:", sorted({r["Queue_Id"] for r in sel}))
 agg = collections.Counter(); cnt = collections.Counter()
 for r in sel:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("e3k::", "")
