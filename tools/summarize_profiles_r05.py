@@ -45,7 +45,7 @@ def traffic(tag, stats_dir, fetch_dir, write_dir, under_json, out_name):
                      "1 GiB dword-per-lane stream in tools/pmc_probe.py (FETCH_SIZE reads 1/2 on gfx950)",
            "workload": under["config"]["workload"], "calibration": {"fetch_factor": cal_f, "write_factor": cal_w}}
     by_name = {"tp_fwd": under["roofline"]}
-    by_name.update({k["kernel"].split("::")[1].replace("_kernel", ""): k for k in under["roofline"].get("kernels", []) if "::tp_" in k["kernel"]})
+    by_name.update({k["kernel"].split("::")[1].split(" ")[0].replace("_kernel", ""): k for k in under["roofline"].get("kernels", []) if "::tp_" in k["kernel"]})
     for key, pat in KERNELS.items():
         if not bf.get(key):
             continue
