@@ -298,13 +298,13 @@ def main():
     def loss_of(batch):
         if cfg_kind == "energy":
             target = batch["total_energy"]          # the model writes its prediction under the same key of the same Batch
-            return 1e3 * torch.nn.functional.mse_loss(model(batch)["total_energy"], target)
+            return ops.sq_error(model(batch)["total_energy"], target, None, 1e3)      # (= 1e3 * mse_loss: loss + gradient in one launch)
         if cfg_kind == "energy_force":                  # config_energy_force.py:18 loss_coeffs
             # (the model writes its graph energy under "energy", config_energy_force.py:73; the synthetic target travels as
             #  "total_energy" -- until round 5 this line compared the target with itself: the energy term was identically zero)
             e_t, f_t = batch["total_energy"], batch["forces_target"]
             out = model(batch)
-            return 1e3 * ((out["energy"] - e_t) ** 2).mean() + 3e4 * ((out["forces"] - f_t) ** 2).mean()
+            return ops.sq_error(out["energy"], e_t, None, 1e3) + ops.sq_error(out["forces"], f_t, None, 3e4)
         return sde_loss(sde, model, batch, generator=gen)[0]
 
     # setup, not a step of the workload: libe3k.so is loaded, the TP plans are created and the code objects of every
@@ -421,14 +421,13 @@ def main():
                 return loss
             target, weight = batch["total_energy"], batch["_graph_weight"]      # weight: 1 / G for the real graphs, 0 for the ghost
             if cfg_kind == "energy":
-                loss = 1e3 * (((model(batch)["total_energy"] - target) ** 2) * weight).sum()
+                loss = ops.sq_error(model(batch)["total_energy"], target, weight, 1e3)
                 flat.zero()
                 loss.backward()
             else:      # config_energy_force.py:18 loss_coeffs; the force term is a mean over the REAL nodes' components
                 f_t, wn = batch["forces_target"], batch["_node_weight"]
                 out = model(batch)
-                loss = (1e3 * (((out["energy"] - target) ** 2) * weight).sum()
-                        + 3e4 * (((out["forces"] - f_t) ** 2) * (wn / 3.0)).sum())
+                loss = ops.sq_error(out["energy"], target, weight, 1e3) + ops.sq_error(out["forces"], f_t, wn, 3e4 / 3.0)
                 flat.zero()
                 backward_parameters(loss, opt.params)
             return loss

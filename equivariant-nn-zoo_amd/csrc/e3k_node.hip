@@ -752,6 +752,39 @@ __global__ __launch_bounds__(256) void segment_sum_kernel(const float* __restric
   }
 }
 
+// segment sizes -> row pointers: ptr[0] = 0, ptr[s + 1] = n[0] + .. + n[s]  (one workgroup: chunks of 256 counts, a running carry;
+// replaces zeros + cumsum + a dtype conversion + a slice copy in front of every Pooling)
+__global__ __launch_bounds__(256) void counts_to_ptr_kernel(const int64_t* __restrict__ n, int G, int32_t* __restrict__ ptr) {
+  __shared__ int part[256];
+  __shared__ int carry;
+  const int t = threadIdx.x;
+  if (t == 0) carry = 0, ptr[0] = 0;
+  __syncthreads();
+  for (int base = 0; base < G; base += 256) {
+    const int v = base + t < G ? (int)n[base + t] : 0;
+    part[t] = v;
+    __syncthreads();
+    for (int off = 1; off < 256; off <<= 1) {      // inclusive Hillis-Steele scan of the chunk
+      const int add = t >= off ? part[t - off] : 0;
+      __syncthreads();
+      part[t] += add;
+      __syncthreads();
+    }
+    if (base + t < G) ptr[base + t + 1] = carry + part[t];
+    __syncthreads();
+    if (t == 255) carry += part[255];
+    __syncthreads();
+  }
+}
+
+// one-hot rows of a type index: out[r, t] = (idx[r] == t) -- replaces zeros + scatter + a dtype conversion (OneHotEncoding)
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ idx, int64_t total, int T, float* __restrict__ out) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t r = i / T;
+    out[i] = idx[r] == (int64_t)(i - r * T) ? 1.f : 0.f;
+  }
+}
+
 // column-fixed kernels: grid.x covers the columns, grid.y strides the rows (about 8 k workgroups in all)
 inline dim3 grid_cols(int cols, int64_t rows) {
   const int gx = (cols + 255) / 256;
@@ -1207,6 +1240,23 @@ extern "C" int e3k_layernorm_bwd2(const float* x, const float* g_y, const float*
   if (lblocks > 512) lblocks = 512;
   hipLaunchKernelGGL(e3k::layernorm_bwd2_kernel, dim3((unsigned)lblocks), dim3(256), 0, (hipStream_t)stream, x, g_y, h, h_std,
                      inv_norm, rows, row_dim, ba, std, g_gy, g_x, g_std);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_counts_to_ptr(const int64_t* counts, int32_t n_seg, int32_t* ptr, void* stream) {
+  if (n_seg < 0 || !ptr || (n_seg > 0 && !counts)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::counts_to_ptr_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, counts, n_seg, ptr);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, void* stream) {
+  if (rows < 0 || num_types <= 0) return E3K_ERR_INVALID;
+  if (rows == 0) return E3K_OK;
+  if (!idx || !out) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::onehot_kernel, dim3(e3k::grid_for(rows * num_types)), dim3(256), 0, (hipStream_t)stream, idx,
+                     rows * num_types, num_types, out);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

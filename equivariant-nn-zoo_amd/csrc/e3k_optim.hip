@@ -132,6 +132,42 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
 
 }  // namespace e3k
 
+// loss = scale * sum_i w_i (pred_i - target_i)^2 and its gradient 2 scale w_i (pred_i - target_i) in ONE launch (w == NULL: 1 / n, a
+// mean): the step's loss on a few hundred graph energies (or a few thousand force components) is launch latency, not arithmetic --
+// as torch ops it is a subtraction, a power, one or two products, a reduction and their five or six backward kernels.  One
+// workgroup, a fixed summation order (bit-reproducible).
+namespace e3k {
+__global__ __launch_bounds__(1024) void sq_error_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                                        const float* __restrict__ w, int w_group, int64_t n, float scale,
+                                                        float* __restrict__ loss, float* __restrict__ grad) {
+  __shared__ float part[16];
+  const float wu = 1.0f / (float)n;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float d = pred[i] - target[i], wi = w ? w[i / w_group] : wu;
+    acc = fmaf(wi * d, d, acc);
+    grad[i] = 2.0f * scale * wi * d;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int k = 0; k < 16; ++k) s += part[k];
+    loss[0] = scale * s;
+  }
+}
+}  // namespace e3k
+
+extern "C" int e3k_sq_error(const float* pred, const float* target, const float* weight, int32_t w_group, int64_t n, float scale,
+                            float* loss, float* grad, void* stream) {
+  if (n <= 0 || !pred || !target || !loss || !grad || (weight && w_group < 1)) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::sq_error_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, pred, target, weight, weight ? w_group : 1, n,
+                     scale, loss, grad);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
 extern "C" int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema,
                                  int64_t n, float lr, float beta1, float beta2, float eps, float weight_decay,
                                  float ema_decay, int32_t ema_use_num_updates, float max_grad_norm,

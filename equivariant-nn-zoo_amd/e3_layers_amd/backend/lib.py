@@ -179,6 +179,9 @@ SIGNATURES = {
     "e3k_layer_profile_mask": (C.c_int, [_P, _I32, C.c_uint32]),
     "e3k_layer_profile_read": (C.c_int, [_P, _I32, C.POINTER(C.c_float), C.POINTER(C.c_int64), C.POINTER(C.c_int64), _I32]),
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
+    "e3k_counts_to_ptr": (C.c_int, [_P, _I32, _P, _P]),
+    "e3k_sq_error": (C.c_int, [_P, _P, _P, _I32, _I64, C.c_float, _P, _P, _P]),
+    "e3k_onehot": (C.c_int, [_P, _I64, _I32, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "e3k_edge_vector_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),

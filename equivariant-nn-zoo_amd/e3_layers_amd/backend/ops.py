@@ -1851,6 +1851,35 @@ class SegmentSumFn(torch.autograd.Function):
         return g.index_select(0, seg_index), None, None, None
 
 
+class SqErrorFn(torch.autograd.Function):
+    """scale * sum_i w_i (pred_i - target_i)^2 (w = 1 / n without weights: scale * mse_loss) -- loss and gradient in one launch."""
+
+    @staticmethod
+    def forward(ctx, pred, target, weight, scale: float):
+        L.require_cuda(pred, target)
+        p, t = L.f32c(pred).reshape(-1), L.f32c(target).reshape(-1)
+        w = None if weight is None else L.f32c(weight).reshape(-1)
+        assert p.numel() == t.numel() and (w is None or (w.numel() > 0 and p.numel() % w.numel() == 0))
+        loss = torch.empty((), device=p.device, dtype=torch.float32)
+        grad = torch.empty_like(p)
+        L.check(L.load().e3k_sq_error(L.ptr(p), L.ptr(t), L.ptr(w), 1 if w is None else p.numel() // w.numel(), p.numel(), float(scale),
+                                      L.ptr(loss), L.ptr(grad), L.stream_ptr()), "e3k_sq_error")
+        ctx.save_for_backward(grad)
+        ctx.shape = pred.shape
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (grad * g).view(ctx.shape), None, None, None
+
+
+def sq_error(pred, target, weight=None, scale: float = 1.0):
+    """``scale * (weight * (pred - target) ** 2).sum()`` (``weight`` per entry, or per ROW of ``pred``), or
+    ``scale * mse_loss(pred, target)`` without weights (first order only: a loss term is differentiated once)."""
+    return SqErrorFn.apply(pred, target, weight, float(scale))
+
+
 def segment_sum(x, ptr, seg_index, mean=False):
     return SegmentSumFn.apply(_c(x), ptr, seg_index, bool(mean))
 

@@ -141,7 +141,13 @@ class OneHotEncoding(Module):
             # cycle through the C++ reference counts that nothing ever collects
             idx = src.squeeze(-1).clone()
             src._e3k_flat_index = (src._version, idx)
-        one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
+        if idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 1:      # one launch instead of zeros + scatter + conversion
+            from ..backend import lib as L
+
+            one_hot = torch.empty(idx.shape[0], self.num_types, device=idx.device, dtype=torch.float32)
+            L.check(L.load().e3k_onehot(L.ptr(idx), idx.shape[0], self.num_types, L.ptr(one_hot), L.stream_ptr()), "e3k_onehot")
+        else:
+            one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
         set_row_key(one_hot, idx, self.num_types)   # rows are a function of the type index only
         return {"one_hot": one_hot}, {"one_hot": (attrs["input"][0], self.irreps_out["one_hot"])}
 

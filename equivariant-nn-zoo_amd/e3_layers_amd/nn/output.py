@@ -60,7 +60,13 @@ class Pooling(Module):
     def forward(self, data, attrs):
         x = data["input"]
         n = data["_n_nodes"].view(-1).to(x.device)
-        ptr = torch.zeros(n.numel() + 1, dtype=torch.int32, device=x.device)
-        ptr[1:] = torch.cumsum(n, 0).to(torch.int32)
+        ptr = torch.empty(n.numel() + 1, dtype=torch.int32, device=x.device)
+        if x.is_cuda and n.dtype == torch.int64 and n.is_contiguous():
+            from ..backend import lib as L
+
+            L.check(L.load().e3k_counts_to_ptr(L.ptr(n), n.numel(), L.ptr(ptr), L.stream_ptr()), "e3k_counts_to_ptr")
+        else:
+            ptr[0] = 0
+            ptr[1:] = torch.cumsum(n, 0).to(torch.int32)
         out = ops.segment_sum(x, ptr, data["_node_segment"].to(x.device), self.reduce == "mean")
         return {"output": out}, {"output": ("graph", self.irreps_out["output"])}

@@ -226,11 +226,19 @@ class BucketedStep:
         self.captured = CapturedStep(captured_fn, warmup=warmup, generators=generators)
 
     def __call__(self, padded):
+        by_dtype = {}
         for k in self.keys:
             dst, src = self.static[k], padded[k]
             if dst.shape != src.shape:
                 raise ValueError(f"{k}: {tuple(src.shape)} does not fit the captured {tuple(dst.shape)} (another bucket?)")
-            dst.copy_(src, non_blocking=True)
+            if src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous():
+                pair = by_dtype.setdefault(dst.dtype, ([], []))
+                pair[0].append(dst)
+                pair[1].append(src)
+            else:
+                dst.copy_(src, non_blocking=True)
+        for dsts, srcs in by_dtype.values():      # one multi-tensor launch per dtype instead of one copy per field (eleven fields:
+            torch._foreach_copy_(dsts, srcs)      # 53 us in front of every replay)
         out = self.captured()
         if self.tail is not None:
             self.tail()

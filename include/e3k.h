@@ -448,6 +448,12 @@ int e3k_layernorm_bwd2(const float* x, const float* g_y, const float* h, const f
                        int64_t rows, int32_t row_dim, const e3k_block* blocks, int32_t n_blocks, const float* std,
                        float* g_gy, float* g_x, float* g_std, void* stream);
 
+/* segment sizes -> row pointers (what Pooling derives from the batch's per-graph node counts, nn/output.py:66-74):
+ * ptr[0] = 0, ptr[s + 1] = counts[0] + .. + counts[s]; ptr has n_seg + 1 entries */
+int e3k_counts_to_ptr(const int64_t* counts, int32_t n_seg, int32_t* ptr, void* stream);
+/* one-hot rows of a type index (OneHotEncoding, nn/embedding.py:271-281: torch.nn.functional.one_hot(...).to(float)):
+ * out [rows, num_types], out[r, t] = (idx[r] == t); an index outside [0, num_types) gives a zero row */
+int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, void* stream);
 /* sorted-segment sum (Pooling, nn/output.py:66-74): out[s, :] = sum_{r in [ptr[s], ptr[s+1])} x[r, :] (* 1/count if mean) */
 int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t dim, int32_t mean, float* out,
                     void* stream);
@@ -549,6 +555,13 @@ int e3k_radius_graph_fill(const float* pos, const int32_t* graph_start, const in
  *   state: DEVICE float[16], zero-initialised once by the caller; holds the step count, bias corrections, clip
  *   coefficient, skip flag, gradient norm ([7]) and the EMA update count — so a captured HIP graph replays
  *   correctly. */
+/* A squared-error loss term and its gradient in one launch (a trainer's coefficient x MSELoss term, e3_layers/run/loss.py:186-288
+ * with torch.nn.MSELoss; weight != NULL: a weighted sum instead of the mean -- padded batches give their ghost entries weight 0):
+ *   loss[0] = scale * sum_i w_i (pred_i - target_i)^2,   grad[i] = 2 scale w_i (pred_i - target_i),   w_i = weight[i / w_group] (one
+ * weight per w_group consecutive entries: per node for its three force components), or 1 / n when weight == NULL.
+ * One workgroup, fixed summation order. */
+int e3k_sq_error(const float* pred, const float* target, const float* weight, int32_t w_group, int64_t n, float scale, float* loss,
+                 float* grad, void* stream);
 int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, float* ema, int64_t n,
                       float lr, float beta1, float beta2, float eps, float weight_decay, float ema_decay,
                       int32_t ema_use_num_updates, float max_grad_norm, int32_t skip_nonfinite, float* state,

@@ -1206,3 +1206,38 @@ def test_unkeyed_self_connection_shapes(dev, in1, v, out, rows):
     gx, ga, gw = _grads(y, [xin, ain, tp.weight], to_cf(seed, out).float().to(dev))
     assert rel_err(from_cf(gx.cpu(), in1), rx) < GTOL
     assert rel_err(ga, ra) < GTOL and rel_err(gw, rw) < GTOL
+
+
+@pytest.mark.gpu
+def test_small_step_plumbing_kernels_match_torch(dev):
+    """Round 5's launch-count work: the one-launch forms of OneHotEncoding's rows, Pooling's row pointers and a squared-error loss
+    term (value AND gradient) against the torch ops they replace (`nn/embedding.py:271-281`, `nn/output.py:66-74`,
+    `run/loss.py` with MSELoss)."""
+    from e3_layers_amd.backend import lib as L
+    from e3_layers_amd.backend import ops
+
+    lib = L.load()
+    gen = torch.Generator().manual_seed(3)
+    idx = torch.randint(0, 7, (1234,), generator=gen).to(dev)
+    one = torch.empty(1234, 7, device=dev)
+    L.check(lib.e3k_onehot(L.ptr(idx), 1234, 7, L.ptr(one), L.stream_ptr()), "e3k_onehot")
+    assert torch.equal(one, torch.nn.functional.one_hot(idx, 7).float())
+    for g in (1, 255, 256, 257, 1000):
+        counts = torch.randint(0, 40, (g,), generator=gen).to(dev)
+        ptr = torch.empty(g + 1, dtype=torch.int32, device=dev)
+        L.check(lib.e3k_counts_to_ptr(L.ptr(counts), g, L.ptr(ptr), L.stream_ptr()), "e3k_counts_to_ptr")
+        ref = torch.zeros(g + 1, dtype=torch.int64, device=dev)
+        ref[1:] = torch.cumsum(counts, 0)
+        assert torch.equal(ptr.long(), ref)
+    for n, rows_w in ((257, None), (257, 1), (3 * 1500, 3)):      # mean; per-entry weights; one weight per row of three components
+        pred = torch.randn(n, generator=gen).to(dev).requires_grad_(True)
+        target = torch.randn(n, generator=gen).to(dev)
+        w = None if rows_w is None else torch.rand(n // rows_w, generator=gen).to(dev)
+        loss = ops.sq_error(pred.view(-1, rows_w or 1), target.view(-1, rows_w or 1), None if w is None else w.view(-1, 1), 1e3)
+        (g_k,) = torch.autograd.grad(2.0 * loss, pred)
+        p64 = pred.detach().double().requires_grad_(True)
+        d2 = (p64 - target.double()) ** 2
+        ref = 1e3 * (d2.mean() if w is None else (d2.view(-1, rows_w) * w.double().view(-1, 1)).sum())
+        (g_r,) = torch.autograd.grad(2.0 * ref, p64)
+        assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
+        assert rel_err(g_k, g_r) < 1e-6
