@@ -700,13 +700,16 @@ template <int L1, int L3MAX, int MODE, int PART>
 __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
-  constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE == 2 || MODE == 3;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
+  constexpr bool TABLE = MODE == 1 || MODE == 2, DUAL = MODE == 2 || MODE == 3 || MODE == 7;     // MODE 3: the DUAL form on STREAMED w[e], dw/dr[e] rows
+  // MODE 7: MODE 3 + the weight gradients that share its sums -- the DUAL one, g_w[e] = <x2, t(sh)> + <x, t(sh2)> (what tp_bwd_w_dual
+  // forms in a walk of its own), and optionally the plain one, g_w2[e] = <x, t(sh)> (tp_bwd_w): the u-sweep of force training wants all three
+  constexpr bool GW2 = MODE == 7;
   constexpr bool PACKED = MODE == 4 || MODE == 5;                                   // MODE 4: w from the packed table (see tp_fwd_body_full)
   // MODE 5: ... and the WEIGHT gradient of every edge beside it.  Both gradients contract the same sums t[m1] = sum CG sh[m2] g[m3]
   // of an edge and a path: g_x[src] += w t, g_w[e] = <x[src], t> -- with the source's own rows resident (2 l1 + 1 registers) the
   // second costs 2 l1 + 1 FMAs and one 256-byte store per path, against a whole second walk of the edges (tp_bwd_w_kernel: the
   // sh, x[src] and g[dst] gathers again) -- and the 0.5 GB of g_w [E, W] leave through HBM while this kernel waits on its L2 gathers
-  constexpr bool GW = MODE == 5;
+  constexpr bool GW = MODE == 5 || MODE == 6;      // (MODE 6: the same with the weights STREAMED from w[E, W] -- force training's rows)
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -719,13 +722,18 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     cf[Q] = g.coeff[Q];
   });
   const int row_g = a.d_mid * 4, row_w = a.W * 4;
-  float gx[D1], xs[GW ? D1 : 1];
+  float gx[D1], xs[(GW || GW2) ? D1 : 1], xs2[GW2 ? D1 : 1];
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
-  if constexpr (GW) {
+  if constexpr (GW || GW2) {
     const float* __restrict__ xr = a.x + (int64_t)node * a.d_in + g.x_off;      // wave-uniform
 #pragma unroll
     for (int i = 0; i < D1; ++i) xs[i] = (xr + i * mul)[u];
+  }
+  if constexpr (GW2) {
+    const float* __restrict__ xr2 = a.x2 + (int64_t)node * a.d_in + g.x_off;
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xs2[i] = (xr2 + i * mul)[u];
   }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   EdgeRec cur{};
@@ -751,7 +759,9 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     }
     if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
-    const __amdgpu_buffer_rsrc_t rgw = row_rsrc(GW ? a.g_w + (int64_t)e * a.W : nullptr, GW ? row_w : 0);
+    const __amdgpu_buffer_rsrc_t rgw = row_rsrc((GW || GW2) ? a.g_w + (int64_t)e * a.W : nullptr, (GW || GW2) ? row_w : 0);
+    const bool plain2 = GW2 && a.g_w2 != nullptr;
+    const __amdgpu_buffer_rsrc_t rgw2 = row_rsrc(plain2 ? a.g_w2 + (int64_t)e * a.W : nullptr, plain2 ? row_w : 0);
     float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
     if constexpr (PACKED) {
       const KnotPacked kp = knot_packed_rec(a, cur, row_w * 3);
@@ -823,7 +833,24 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
       float gk[2 * L3 + 1];
 #pragma unroll
       for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
-      if constexpr (DUAL) {
+      if constexpr (GW2) {
+        float ta[D1], tb[D1];
+        CG<L1, L2, L3>::yt(yref<L2>(y2), gk, ta);
+        CG<L1, L2, L3>::yt(yref<L2>(yc), gk, tb);
+        const float sa = wn[Q] * cf[Q], sb = w2[Q] * cf[Q];
+        float dd = 0.0f, dp = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) gx[i] = fmaf(sa, ta[i], gx[i]);      // (the order and the bits of the two CG::yg calls of MODE 3)
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          gx[i] = fmaf(sb, tb[i], gx[i]);
+          dd = fmaf(xs2[i], tb[i], dd);
+          dd = fmaf(xs[i], ta[i], dd);
+          dp = fmaf(xs[i], tb[i], dp);
+        }
+        buf_st_stream(dd * cf[Q], rgw, u4, woff4[Q]);
+        if (plain2) buf_st_stream(dp * cf[Q], rgw2, u4, woff4[Q]);
+      } else if constexpr (DUAL) {
         CG<L1, L2, L3>::yg(yref<L2>(y2), gk, wn[Q] * cf[Q], gx);
         CG<L1, L2, L3>::yg(yref<L2>(yc), gk, w2[Q] * cf[Q], gx);
       } else if constexpr (GW) {
@@ -1229,7 +1256,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 
 namespace {
 enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL,
-              TP_FWD_PACKED, TP_BWD_X_PACKED, TP_BWD_XW_PACKED };
+              TP_FWD_PACKED, TP_BWD_X_PACKED, TP_BWD_XW_PACKED, TP_BWD_XW, TP_BWD_XW_DUAL };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -1248,18 +1275,20 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   if (args.order) blocks = 8 * ((((N + 7) / 8) * n_gc + 3) / 4);      // eight equal sub-grids, one per XCD (blocks b, b + 8, .. share one)
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-  if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL) {
+  if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL || kind == TP_BWD_XW_DUAL) {
     // second-order forms of force training: channel-complete plans; walked by one wave per group (the l_max <= 2 models), or by two
     // (SPLIT: l_max 3) with the weights STREAMED (w[e], dw/dr[e] materialised -- what the force block does by default)
     if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1;
     const bool streamed = args.bin == nullptr;      // w[e] / dw[e] rows in a.w / a.w2 instead of the tables + per-edge knots
+    if (kind == TP_BWD_XW_DUAL && !streamed) return E3K_ERR_UNSUPPORTED;
     if (p->split) {
       if (!streamed) return E3K_ERR_UNSUPPORTED;
 #define E3K_TP_LAUNCH_2S(ML)                                                                                                            \
   switch (kind) {                                                                                                                       \
     case TP_FWD_JVP: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;      \
     case TP_BWD_X_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_XW_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 7>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_E: hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, 3, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;         \
     default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, 3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                \
   }
@@ -1281,6 +1310,9 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     case TP_BWD_X_DUAL:                                                                                                                 \
       if (streamed) hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); \
       else hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 2>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);          \
+      break;                                                                                                                            \
+    case TP_BWD_XW_DUAL:                                                                                                                \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 7>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);         \
       break;                                                                                                                            \
     case TP_BWD_E:                                                                                                                      \
       if (streamed) hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);           \
@@ -1326,6 +1358,9 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   }
 #define E3K_TP_LAUNCH_F(ML, L3, SP, FU)                                                                                      \
   switch (kind) {                                                                                                   \
+    case TP_BWD_XW:                                                                                                 \
+      if constexpr (FU) hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 6>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); \
+      break;                                                                                                        \
     case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_W:                                                                                                  \
       hipLaunchKernelGGL((e3k::tp_bwd_w_kernel<false, ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);  \
@@ -1341,6 +1376,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   else { E3K_TP_LAUNCH_F(ML, L3, SP, false) }
   // instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3, the latter
   // also in the split form (two waves per group)
+  if (kind == TP_BWD_XW && !p->full64) return E3K_ERR_UNSUPPORTED;      // (channel-complete plans only, like the table forms)
   const bool low = p->max_l3 <= p->max_l1;
   const bool sp = p->split != 0;
   switch (p->max_l1) {
@@ -1477,6 +1513,21 @@ extern "C" int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, con
   return launch_all(TP_BWD_XW_PACKED, a, plan, N, (hipStream_t)stream);
 }
 
+// ... and with the weights streamed from w [E, W] (what force training materialises per layer): g_x AND g_w in the one walk of the
+// source CSR; plans with e3k_tp_table_supported (channel-complete groups)
+extern "C" int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out,
+                             const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x,
+                             float* g_w, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !g_out || !g_x || !src_ptr || (E > 0 && (!sh || !w || !dst || !src_perm || !g_w))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = w; a.g_out = g_out; a.g_x = g_x; a.g_w = g_w; a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_XW, a, plan, N, (hipStream_t)stream);
+}
+
 // ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------
 // With F = <g, TP(x[src], sh, w(T, coef))> (linear in each of g, x, sh, T, coef):
 // (w[e] = sum_k coef[e,k] T[bin[e]-1+k], dw/dr[e] = sum_k coef[e,k] D[bin[e]-1+k] with D the slope table; with bin = coef = NULL
@@ -1528,6 +1579,26 @@ extern "C" int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh,
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_DUAL, a, plan, N, (hipStream_t)stream);
+}
+
+// e3k_tp_bwd_x_dual_table on STREAMED rows (w, dw [E, W]) that also writes the weight gradients sharing its sums:
+//   g_w [E, W]  = dF/dw at (x2, sh) + dF/dw at (x, sh2)      (e3k_tp_bwd_w_dual)
+//   g_w_plain   = dF/dw at (x, sh)                            (e3k_tp_bwd_w; may be NULL)
+// one walk of the source CSR instead of three walks
+extern "C" int e3k_tp_bwd_xw_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
+                                  const float* w, const float* dw, const float* s2, const float* g_out, const int32_t* dst,
+                                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_w,
+                                  float* g_w_plain, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !x2 || !g_out || !g_x || !src_ptr || (E > 0 && (!sh || !sh2 || !w || !dw || !s2 || !dst || !src_perm || !g_w)))
+    return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.x2 = x2; a.sh = sh; a.sh2 = sh2; a.w = w; a.w2 = dw; a.s2 = s2; a.g_out = g_out; a.g_x = g_x; a.g_w = g_w; a.g_w2 = g_w_plain;
+  a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_XW_DUAL, a, plan, N, (hipStream_t)stream);
 }
 
 extern "C" int e3k_tp_bwd_w_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,

@@ -38,6 +38,7 @@ struct TpArgs {
   const float* g_out;  // [N, d_mid] cf (backward)
   float* out;          // [N, d_mid] cf (forward)
   float* g_w;          // [E, W]
+  float* g_w2;         // [E, W], optional second weight-gradient output (tp_bwd_x MODE 7: the plain one beside the dual one)
   float* g_sh;         // [E, d_sh]
   float* g_x;          // [N, d_in]
   const int32_t* nbr;  // src[e] (fwd, bwd_w) or dst[e] (bwd_x)

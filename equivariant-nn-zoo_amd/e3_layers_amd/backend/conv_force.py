@@ -45,6 +45,7 @@ ENABLED = _knob("E3K_FORCE_BLOCK")
 # tensor-product kernel of the three passes streams those rows; 0: every kernel gathers four rows per table and edge itself (the
 # in-kernel form of the energy step).  Five or six kernels per layer read them: 64 molecules 7.03 -> see DESIGN.md ms per step.
 MATERIALIZE = _knob("E3K_FORCE_MATERIALIZE")
+FUSE_XW = _knob("E3K_TP_BWD_FUSED")      # the input and the weight gradient of the tensor product in one walk (as conv_native)
 STATS = [0, 0, 0]      # forwards, first backwards (create_graph), u-sweeps (tests)
 _WARNED = [False]
 _DECLINE = [0]
@@ -156,6 +157,18 @@ def _tp_bwd_x_dual(sh, sh2, T, D, bins, s2, g_mid, topo, tp):
     L.check(L.load().e3k_tp_bwd_x_dual_table(tp.handle(sh.device), L.ptr(sh), L.ptr(sh2), L.ptr(T), L.ptr(D), *_b(bins), L.ptr(s2), L.ptr(g_mid), L.ptr(topo.dst), L.ptr(topo.src_ptr),
                                              L.ptr(topo.src_perm), n, e, L.ptr(gx), L.stream_ptr()), "e3k_tp_bwd_x_dual_table")
     return gx
+
+
+def _tp_bwd_xw_dual(x1, x2, sh, sh2, w, dw, s2, g_mid, topo, tp, want_plain: bool):
+    """(cot_x1, g_w dual, g_w plain or None): ``_tp_bwd_x_dual`` + ``_tp_bwd_w_dual`` (+ ``tp_bwd_w``) in one walk (streamed rows)"""
+    n, e = g_mid.shape[0], sh.shape[0]
+    gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
+    gw = torch.empty(e, tp.w_numel, device=sh.device, dtype=torch.float32)
+    gwp = torch.empty(e, tp.w_numel, device=sh.device, dtype=torch.float32) if want_plain else None
+    L.check(L.load().e3k_tp_bwd_xw_dual(tp.handle(sh.device), L.ptr(x1), L.ptr(x2), L.ptr(sh), L.ptr(sh2), L.ptr(w), L.ptr(dw), L.ptr(s2),
+                                        L.ptr(g_mid), L.ptr(topo.dst), L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.ptr(gw),
+                                        L.ptr(gwp), L.stream_ptr()), "e3k_tp_bwd_xw_dual")
+    return gx, gw, gwp
 
 
 def _tp_bwd_w_dual(x1, x2, sh, sh2, g_mid, topo, tp):
@@ -277,8 +290,12 @@ class ForceBlockFn(torch.autograd.Function):
             g_xcf = (torch.empty if plan.sc_spec.in_covered else torch.zeros)(n, plan.sc_spec.d_in, device=dev, dtype=torch.float32)
             ops._run_segments([ops._lin_dgrad_segs(g_conv, w_post, g_mid, plan.post_spec, plan.scale, False),
                                ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off)])
+            g_w = None
             if MATERIALIZE:
-                g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
+                if params and need[2] and FUSE_XW:      # both gradients of the product in one walk (csrc/e3k_tp.hip MODE 6)
+                    g_x1, g_w = ops._tp_bwd_xw_raw(x1, sh, cfg.weights(T), g_mid, topo, tp)
+                else:
+                    g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
                 if want_e:
                     g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
             else:
@@ -286,7 +303,8 @@ class ForceBlockFn(torch.autograd.Function):
                 if want_e:
                     g_sh, g_r = _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp)
             if params and need[2]:
-                g_w, _ = ops._tp_bwd_w_raw(x1, sh, None, g_mid, topo, tp, False, True)
+                if g_w is None:
+                    g_w, _ = ops._tp_bwd_w_raw(x1, sh, None, g_mid, topo, tp, False, True)
                 g_T = radial_table.interp_bwd_raw(g_w, bins)
         if g_x1_in is not None:
             g_x1 = L.f32c(g_x1_in) if g_x1 is None else g_x1.add_(g_x1_in)
@@ -392,13 +410,19 @@ class ForceBlockBwdFn(torch.autograd.Function):
         else:
             wv, dwv, kb = T, D, bins
         cot_gmid = _tp_fwd_jvp(x1, u_gx1, sh, u_sh, wv, dwv, kb, u_r, topo, tp)
-        cot_x1 = _tp_bwd_x_dual(sh, u_sh, wv, dwv, kb, u_r, g_mid, topo, tp) if need[1] else None
         g_T = g_D = None
-        if need[4]:
-            g_T = radial_table.interp_bwd_raw(_tp_bwd_w_dual(x1, u_gx1, sh, u_sh, g_mid, topo, tp), bins)
-        if need[5]:
-            g_w, _ = ops._tp_bwd_w_raw(x1, sh, None, g_mid, topo, tp, False, True)
-            g_D = radial_table.interp_bwd_raw(g_w, bins, scale=u_r)
+        if MATERIALIZE and FUSE_XW and need[1] and need[4]:      # the three walks below as one (csrc/e3k_tp.hip MODE 7)
+            cot_x1, gw_dual, gw_plain = _tp_bwd_xw_dual(x1, u_gx1, sh, u_sh, wv, dwv, u_r, g_mid, topo, tp, bool(need[5]))
+            g_T = radial_table.interp_bwd_raw(gw_dual, bins)
+            if need[5]:
+                g_D = radial_table.interp_bwd_raw(gw_plain, bins, scale=u_r)
+        else:
+            cot_x1 = _tp_bwd_x_dual(sh, u_sh, wv, dwv, kb, u_r, g_mid, topo, tp) if need[1] else None
+            if need[4]:
+                g_T = radial_table.interp_bwd_raw(_tp_bwd_w_dual(x1, u_gx1, sh, u_sh, g_mid, topo, tp), bins)
+            if need[5]:
+                g_w, _ = ops._tp_bwd_w_raw(x1, sh, None, g_mid, topo, tp, False, True)
+                g_D = radial_table.interp_bwd_raw(g_w, bins, scale=u_r)
         # trailing Linear: g_mid = scale * Linear^T(g_conv)
         if cot_gconv is None:
             cot_gconv = (torch.empty if plan.post_spec.out_covered else torch.zeros)(n, plan.post_spec.d_out, device=dev, dtype=torch.float32)

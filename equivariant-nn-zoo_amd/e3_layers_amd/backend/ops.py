@@ -1380,6 +1380,18 @@ def _tp_bwd_x_raw(sh, w, g_out, topo: GraphTopo, plan: TpPlan):
     return gx
 
 
+def _tp_bwd_xw_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan):
+    """(g_x [N, d_in], g_w [E, W]) in ONE walk of the source CSR (channel-complete plans: ``e3k_tp_table_supported``)"""
+    n, e = topo.num_nodes, topo.num_edges
+    gx = (torch.empty if plan.bwd_x_overwrites(sh.device) else torch.zeros)(n, plan.d_in, device=sh.device, dtype=torch.float32)
+    gw = torch.empty(e, plan.w_numel, device=sh.device, dtype=torch.float32)
+    with timed_launch("tp_bwd_x", (n, e, plan)):
+        L.check(L.load().e3k_tp_bwd_xw(plan.handle(sh.device), L.ptr(x), L.ptr(sh), L.ptr(w), L.ptr(g_out), L.ptr(topo.dst),
+                                       L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.ptr(gw), L.stream_ptr()),
+                "e3k_tp_bwd_xw")
+    return gx, gw
+
+
 def _tp_bwd_w_raw(x, sh, w, g_out, topo: GraphTopo, plan: TpPlan, want_sh: bool, want_w: bool = True):
     n, e = topo.num_nodes, topo.num_edges
     assert want_w or want_sh

@@ -246,6 +246,10 @@ int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* e
  * g_w [E, W] row e = d F / d w[e] (written once each: no zero-fill).  g_x carries the bits of e3k_tp_bwd_x_ptable. */
 int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_src, const float* g_out,
                          const int32_t* src_ptr, int64_t N, int64_t E, float* g_x, float* g_w, void* stream);
+/* ... the same pair of gradients with the weights streamed from w [E, W] (plans with e3k_tp_table_supported: channel-complete
+ * groups): replaces e3k_tp_bwd_x + e3k_tp_bwd_w where both are wanted (force training's materialised rows). */
+int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out, const int32_t* dst,
+                  const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_w, void* stream);
 /* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights
  * then depend on pos through the radius, nn/message_passing.py:93).  With F = <g, TP(x[src], sh, w(T, coef))>, linear in each
  * of (g, x, sh, T, coef), every first and second derivative is one of the walks below (plans with e3k_tp_table2_supported:
@@ -274,6 +278,12 @@ int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x
 int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh, const float* sh2, const float* T, const float* D,
                             const int32_t* bin, const float* coef, const float* s2, const float* g_out, const int32_t* dst,
                             const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
+/* e3k_tp_bwd_x_dual_table on streamed rows (w, dw [E, W]; bin = coef = NULL there) that ALSO writes the weight gradients sharing its
+ * per-edge sums: g_w = e3k_tp_bwd_w_dual's, g_w_plain (may be NULL) = e3k_tp_bwd_w's -- one walk instead of three (the u-sweep of
+ * force training: the adjoint of nn/output.py:42-50's first backward) */
+int e3k_tp_bwd_xw_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2, const float* w,
+                       const float* dw, const float* s2, const float* g_out, const int32_t* dst, const int32_t* src_ptr,
+                       const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_w, float* g_w_plain, void* stream);
 int e3k_tp_bwd_w_dual(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
                       const float* g_out, const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E,
                       float* g_w, void* stream);

@@ -697,6 +697,14 @@ def test_tp_with_in_kernel_knot_table_is_interpolate_then_tp(dev, left, out):
     else:
         assert rel_err(gx_f, gx_p) < 1e-6
     assert rel_err(gw_f, g_w) < 1e-6      # (tp_bwd_w itself against the float64 oracle: test_tp_fused_against_unfused_oracle)
+    # ... and with the weights streamed from w [E, W] (e3k_tp_bwd_xw: force training's materialised rows)
+    gx_s, gw_s = ops._tp_bwd_xw_raw(x, sh, w_p, g_out, topo, plan)
+    ref_gx_s = ops._tp_bwd_x_raw(sh, w_p, g_out, topo, plan)
+    if plan.bwd_x_overwrites(dev):
+        assert torch.equal(gx_s, ref_gx_s)
+    else:
+        assert rel_err(gx_s, ref_gx_s) < 1e-6
+    assert torch.equal(gw_s, gw_f)      # (the same sums in the same order: the weights do not enter g_w)
     gt_a = radial_table.interp_bwd_raw(g_w, bins)
     gt_b = radial_table.interp_bwd_raw(g_w, bins)
     assert torch.equal(gt_a, gt_b)
@@ -764,6 +772,18 @@ def test_tp_table_second_order_forms_are_sums_of_first_order_kernels(dev, left, 
     ref = (ops._tp_bwd_w_raw(x2, sh, None, g, topo, tp, False, True)[0].double()
            + ops._tp_bwd_w_raw(x, sh2, None, g, topo, tp, False, True)[0].double())
     assert rel_err(gw, ref) < 1e-5
+    # the three walks of the u-sweep as one (e3k_tp_bwd_xw_dual, streamed rows): the input gradient with the bits of the streamed
+    # dual kernel, the dual and the plain weight gradient against the kernels they replace
+    gx_s = conv_force._tp_bwd_x_dual(sh, sh2, w, dw, None, s2, g, topo, tp)
+    gx_f, gw_f, gwp_f = conv_force._tp_bwd_xw_dual(x, x2, sh, sh2, w, dw, s2, g, topo, tp, True)
+    if tp.bwd_x_overwrites(dev):
+        assert torch.equal(gx_f, gx_s)
+    else:
+        assert rel_err(gx_f, gx_s) < 1e-6
+    assert rel_err(gw_f, gw) < 1e-6
+    assert rel_err(gwp_f, ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)[0]) < 1e-6
+    gx_n, gw_n, none = conv_force._tp_bwd_xw_dual(x, x2, sh, sh2, w, dw, s2, g, topo, tp, False)
+    assert none is None and torch.equal(gw_n, gw_f)
 
 
 @pytest.mark.parametrize("n_basis", [8, 48])
