@@ -456,6 +456,11 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // weight-gradient pass re-gathered sh, x[src] and g_mid[dst] of every edge for a dot product with sums the input gradient
   // already holds (layer 3 of config_energy at 256 molecules: 213 + 104 us -> 258 us isolated, 217 + 169 -> see DESIGN section 5 in the step)
   const bool fused_xw = a->fuse_xw && need_x1 && in_kernel_table(d, r) && r.P && need_radial_side && a->E > 0 && a->g_w && a->x1 && !(ABLATE & 32);
+  // ... the same for layers whose weights are streamed from w [E, W] (per-edge radial MLP, 32-channel plans), where the replayed /
+  // one-stream step gains what the packed layers gain; with the backward forked over streams the separate weight-gradient pass
+  // already runs beside the main stream's GEMMs, and stays
+  const bool fused_xw_s = a->fuse_xw && !fused_xw && need_x1 && !in_kernel_table(d, r) && need_radial_side && a->E > 0 && a->g_w && a->x1 &&
+                          r.w && side == main && !(ABLATE & 32);
   if (need_x1) {
     if (!a->g_x1) return E3K_ERR_INVALID;
     if (!d.tp_bwd_x_overwrites && e3k::zero_fill(a->g_x1, sizeof(float) * a->N * d.d_x1, (hipStream_t)main))
@@ -464,6 +469,8 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     if (ABLATE & 32) {
     } else if (fused_xw) {      // ... and the per-edge weight gradient in the same walk: no tp_bwd_w pass below
       E3K_TRY(e3k_tp_bwd_xw_ptable(d.tp, a->x1, r.P, r.erec_src, a->g_mid, a->src_ptr, a->N, a->E, a->g_x1, a->g_w, main));
+    } else if (fused_xw_s) {
+      E3K_TRY(e3k_tp_bwd_xw(d.tp, a->x1, a->sh, r.w, a->g_mid, a->dst, a->src_ptr, a->src_perm, a->N, a->E, a->g_x1, a->g_w, main));
     } else if (in_kernel_table(d, r) && r.P) {
       E3K_TRY(e3k_tp_bwd_x_ptable(d.tp, r.P, r.erec_src, a->g_mid, a->src_ptr, a->N, a->E, a->g_x1, main));
     } else if (in_kernel_table(d, r)) {
@@ -486,7 +493,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     // previous layer's gate' and post-TP dgrad) -- nothing on the main stream waits for it
     void* wst = (BWDW_SIDE && side != main && !fused_xw) ? side : main;
     if (wst != main) E3K_TRY(edge(L, 2, main, side));
-    if (!fused_xw) {
+    if (!fused_xw && !fused_xw_s) {
       Timed t(L, E3K_PROF_TP_BWD_W, wst, a->N, a->E);
       E3K_TRY(e3k_tp_bwd_w(d.tp, a->x1, a->sh, r.w, a->g_mid, a->src, a->dst_ptr, a->dst_perm, a->N, a->E, a->g_w, nullptr, wst));
     }

@@ -880,11 +880,12 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
 
 template <int L1, int L3MAX, int MODE, int PART, bool FULL, bool HALF = false>
 __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_group& g, const int node, const int u) {
-  static_assert(FULL || MODE == 0, "the table forms exist for FULL plans only");
+  static_assert(FULL || MODE == 0 || MODE == 6, "the table forms exist for FULL plans only");
   if constexpr (FULL) {
     tp_bwd_x_body_full<L1, L3MAX, MODE, PART>(a, g, node, u);
     return;
   }
+  constexpr bool GW = MODE == 6;      // ... with the per-edge weight gradient in the same walk (see tp_bwd_x_body_full)
   using S = Slots<L1>;
   constexpr int D1 = 2 * L1 + 1;
   const int mul = g.mul;
@@ -900,9 +901,14 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
   const bool lane_on = FULL || uu < mul;
   const unsigned mask = g.mask;
 
-  float gx[D1];
+  float gx[D1], xs[GW ? D1 : 1];
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
+  if constexpr (GW) {
+    const float* __restrict__ xr = a.x + (int64_t)node * a.d_in + g.x_off;      // wave-uniform: both lane halves walk edges of this node
+#pragma unroll
+    for (int i = 0; i < D1; ++i) xs[i] = lane_on ? (xr + i * mul)[uu] : 0.0f;
+  }
   const int beg = uniform(a.ptr[node]), end = uniform(a.ptr[node + 1]);
   // (a one-deep software pipeline measured the same: 495 vs 498 us at l_max 2)
   for (int t = beg; t < end; t += HALF ? 2 : 1) {
@@ -941,7 +947,20 @@ __device__ __forceinline__ void tp_bwd_x_body(const TpArgs& a, const e3k_tp_grou
         float gk[2 * L3 + 1];
 #pragma unroll
         for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
-        CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * g.coeff[Q], gx);
+        if constexpr (GW) {
+          float tq[D1];
+          CG<L1, L2, L3>::yt(yref<L2>(yc), gk, tq);
+          const float sw = wn[Q] * g.coeff[Q];
+          float dot = 0.0f;
+#pragma unroll
+          for (int i = 0; i < D1; ++i) {
+            gx[i] = fmaf(sw, tq[i], gx[i]);
+            dot = fmaf(xs[i], tq[i], dot);
+          }
+          if (active) E3K_STREAM_STORE(dot * g.coeff[Q], (a.g_w + (int64_t)e * a.W + g.w_off[Q]) + uu);
+        } else {
+          CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * g.coeff[Q], gx);
+        }
       }
     });
   }
@@ -1359,7 +1378,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
 #define E3K_TP_LAUNCH_F(ML, L3, SP, FU)                                                                                      \
   switch (kind) {                                                                                                   \
     case TP_BWD_XW:                                                                                                 \
-      if constexpr (FU) hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, true, 6>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, SP, FU, 6>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); \
       break;                                                                                                        \
     case TP_FWD: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, L3, SP, FU>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_W:                                                                                                  \
@@ -1376,7 +1395,6 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   else { E3K_TP_LAUNCH_F(ML, L3, SP, false) }
   // instantiations per input degree: outputs up to the same degree (l_max-limited models) or up to 3, the latter
   // also in the split form (two waves per group)
-  if (kind == TP_BWD_XW && !p->full64) return E3K_ERR_UNSUPPORTED;      // (channel-complete plans only, like the table forms)
   const bool low = p->max_l3 <= p->max_l1;
   const bool sp = p->split != 0;
   switch (p->max_l1) {
@@ -1513,8 +1531,8 @@ extern "C" int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, con
   return launch_all(TP_BWD_XW_PACKED, a, plan, N, (hipStream_t)stream);
 }
 
-// ... and with the weights streamed from w [E, W] (what force training materialises per layer): g_x AND g_w in the one walk of the
-// source CSR; plans with e3k_tp_table_supported (channel-complete groups)
+// ... and with the weights streamed from w [E, W] (the per-edge radial MLP's layers; force training's materialised rows): g_x AND g_w
+// in the one walk of the source CSR; every plan
 extern "C" int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out,
                              const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x,
                              float* g_w, void* stream) {

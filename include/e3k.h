@@ -246,8 +246,8 @@ int e3k_tp_bwd_x_ptable(const e3k_tp_plan* plan, const void* P, const int32_t* e
  * g_w [E, W] row e = d F / d w[e] (written once each: no zero-fill).  g_x carries the bits of e3k_tp_bwd_x_ptable. */
 int e3k_tp_bwd_xw_ptable(const e3k_tp_plan* plan, const float* x, const void* P, const int32_t* erec_src, const float* g_out,
                          const int32_t* src_ptr, int64_t N, int64_t E, float* g_x, float* g_w, void* stream);
-/* ... the same pair of gradients with the weights streamed from w [E, W] (plans with e3k_tp_table_supported: channel-complete
- * groups): replaces e3k_tp_bwd_x + e3k_tp_bwd_w where both are wanted (force training's materialised rows). */
+/* ... the same pair of gradients with the weights streamed from w [E, W] (every plan): replaces e3k_tp_bwd_x + e3k_tp_bwd_w where
+ * both are wanted (layers whose radial MLP runs per edge; force training's materialised rows). */
 int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* g_out, const int32_t* dst,
                   const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_w, void* stream);
 /* Force training on the table (GradientOutput: nn/output.py:31-53 with create_graph = self.training; the per-edge weights

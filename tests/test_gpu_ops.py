@@ -1261,3 +1261,42 @@ def test_small_step_plumbing_kernels_match_torch(dev):
         (g_r,) = torch.autograd.grad(2.0 * ref, p64)
         assert abs(float(loss) - float(ref)) < 1e-5 * abs(float(ref))
         assert rel_err(g_k, g_r) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("left,out", [
+    ("32x0e+32x1o+32x2e", "32x0e+32x1o+32x2e"),                                          # two edges per wave (HALF)
+    ("16x0e+16x1o", "16x0e+16x1o+16x2e"),
+    ("64x0e+64x1o+64x2e", "64x0e+64x1o"),                                                # 64 channels, not every slot present
+    ("48x0e+48x1e+48x1o", "48x0e+48x0o+48x1e+48x1o+48x2e"),                               # idle lanes in the last chunk
+    ("64x0e+64x0o+64x1e+64x1o+64x2e+64x2o", "64x0e+64x0o+64x1e+64x1o+64x2e+64x2o"),       # channel-complete
+])
+def test_tp_input_and_weight_gradient_in_one_walk_streamed(dev, left, out):
+    """e3k_tp_bwd_xw (weights streamed from w [E, W]; every plan shape) == e3k_tp_bwd_x + e3k_tp_bwd_w: the input gradient bit for bit
+    where that kernel stores (no atomics), the weight gradient up to the order of its sums; twice: the same bits."""
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.nn import TensorProductExpansion
+
+    torch.manual_seed(31)
+    n = 190
+    ei = _random_graph(n, 8, 5)
+    e = ei.shape[1]
+    mod = TensorProductExpansion(left, ("1x0e+1x1o+1x2e", "edge_spherical"), (out, "edge_features"), "uvu", internal_weight=False).to(dev)
+    plan = mod.tp.plan
+    topo = build_topology(ei.to(dev), n)
+    x = torch.randn(n, plan.d_in, device=dev)
+    sh = torch.randn(e, 9, device=dev)
+    w = torch.randn(e, plan.w_numel, device=dev)
+    g = torch.randn(n, plan.d_mid, device=dev)
+    gx_ref = ops._tp_bwd_x_raw(sh, w, g, topo, plan)
+    gw_ref, _ = ops._tp_bwd_w_raw(x, sh, None, g, topo, plan, False, True)
+    gx, gw = ops._tp_bwd_xw_raw(x, sh, w, g, topo, plan)
+    gx2, gw2 = ops._tp_bwd_xw_raw(x, sh, w, g, topo, plan)
+    torch.cuda.synchronize()
+    assert torch.equal(gw, gw2)
+    if plan.bwd_x_overwrites(dev):
+        assert torch.equal(gx, gx_ref) and torch.equal(gx, gx2)
+    else:
+        assert rel_err(gx, gx_ref) < 1e-6
+    assert rel_err(gw, gw_ref) < 1e-6
