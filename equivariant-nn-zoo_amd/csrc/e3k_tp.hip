@@ -710,6 +710,10 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
   // second costs 2 l1 + 1 FMAs and one 256-byte store per path, against a whole second walk of the edges (tp_bwd_w_kernel: the
   // sh, x[src] and g[dst] gathers again) -- and the 0.5 GB of g_w [E, W] leave through HBM while this kernel waits on its L2 gathers
   constexpr bool GW = MODE == 5 || MODE == 6;      // (MODE 6: the same with the weights STREAMED from w[E, W] -- force training's rows)
+  // MODE 8 (streamed rows w, dw/dr [E, W]; force training's first backward): MODE 6 + the EDGE gradients of tp_bwd_e in the same walk --
+  // g_sh[e] += xg(x[src], g[dst], w) (nine values: butterfly + one atomic per wave), g_r[e] += <g_w[e], dw/dr[e]> (one value) -- every
+  // operand of both is already in this walk's registers; g_w is stored only when asked for
+  constexpr bool GE = MODE == 8;
   const int mul = g.mul;
   const int u4 = u * 4;
   int goff4[S::NQ], gstr4[S::NQ], woff4[S::NQ];
@@ -722,10 +726,10 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     cf[Q] = g.coeff[Q];
   });
   const int row_g = a.d_mid * 4, row_w = a.W * 4;
-  float gx[D1], xs[(GW || GW2) ? D1 : 1], xs2[GW2 ? D1 : 1];
+  float gx[D1], xs[(GW || GW2 || GE) ? D1 : 1], xs2[GW2 ? D1 : 1];
 #pragma unroll
   for (int i = 0; i < D1; ++i) gx[i] = 0.0f;
-  if constexpr (GW || GW2) {
+  if constexpr (GW || GW2 || GE) {
     const float* __restrict__ xr = a.x + (int64_t)node * a.d_in + g.x_off;      // wave-uniform
 #pragma unroll
     for (int i = 0; i < D1; ++i) xs[i] = (xr + i * mul)[u];
@@ -759,10 +763,20 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
     }
     if constexpr (DUAL) load_y_full(y2, a.sh2 + (int64_t)e * a.d_sh);
     const __amdgpu_buffer_rsrc_t rg = row_rsrc(a.g_out + (int64_t)d * a.d_mid, row_g);
-    const __amdgpu_buffer_rsrc_t rgw = row_rsrc((GW || GW2) ? a.g_w + (int64_t)e * a.W : nullptr, (GW || GW2) ? row_w : 0);
+    const bool gw_out = GW || GW2 || (GE && a.g_w != nullptr);
+    const __amdgpu_buffer_rsrc_t rgw = row_rsrc(gw_out ? a.g_w + (int64_t)e * a.W : nullptr, gw_out ? row_w : 0);
     const bool plain2 = GW2 && a.g_w2 != nullptr;
     const __amdgpu_buffer_rsrc_t rgw2 = row_rsrc(plain2 ? a.g_w2 + (int64_t)e * a.W : nullptr, plain2 ? row_w : 0);
-    float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1];
+    float gn[S::TOTAL], wn[S::NQ], w2[DUAL ? S::NQ : 1], dvv[GE ? S::NQ : 1];
+    YRegs gy;
+    float gr = 0.f;
+    if constexpr (GE) {
+      gy.y0[0] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 3; ++j) gy.y1[j] = 0.0f;
+#pragma unroll
+      for (int j = 0; j < 5; ++j) gy.y2[j] = 0.0f;
+    }
     if constexpr (PACKED) {
       const KnotPacked kp = knot_packed_rec(a, cur, row_w * 3);
       PackedRec rec[S::NQ];
@@ -825,6 +839,13 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
           w2[Q] = sc * buf_ld(rd, u4, woff4[Q]);
         });
       }
+      if constexpr (GE) {
+        const __amdgpu_buffer_rsrc_t rd = row_rsrc(a.w2 + (int64_t)e * a.W, row_w);
+        slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
+          constexpr int Q = decltype(qc)::value;
+          dvv[Q] = buf_ld(rd, u4, woff4[Q]);
+        });
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     slot_for_part<S, L1, L3MAX, PART>([&](auto qc) {
@@ -833,7 +854,21 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
       float gk[2 * L3 + 1];
 #pragma unroll
       for (int k = 0; k < 2 * L3 + 1; ++k) gk[k] = gn[OFF + k];
-      if constexpr (GW2) {
+      if constexpr (GE) {
+        float tq[D1];
+        CG<L1, L2, L3>::yt(yref<L2>(yc), gk, tq);
+        const float sw = wn[Q] * cf[Q];
+        float dot = 0.0f;
+#pragma unroll
+        for (int i = 0; i < D1; ++i) {
+          gx[i] = fmaf(sw, tq[i], gx[i]);
+          dot = fmaf(xs[i], tq[i], dot);
+        }
+        const float gwv = dot * cf[Q];
+        if (gw_out) buf_st_stream(gwv, rgw, u4, woff4[Q]);
+        gr = fmaf(gwv, dvv[Q], gr);
+        CG<L1, L2, L3>::xg(xs, gk, sw, yref<L2>(gy));
+      } else if constexpr (GW2) {
         float ta[D1], tb[D1];
         CG<L1, L2, L3>::yt(yref<L2>(y2), gk, ta);
         CG<L1, L2, L3>::yt(yref<L2>(yc), gk, tb);
@@ -868,6 +903,22 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
         CG<L1, L2, L3>::yg(yref<L2>(yc), gk, wn[Q] * cf[Q], gx);
       }
     });
+    if constexpr (GE) {
+      const int y_off[3] = {0, 1, 4};
+      if (a.g_sh) {
+        float v9[9];
+        v9[0] = gy.y0[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
+#pragma unroll
+        for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
+        wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off);
+      }
+      if (a.g_r) {
+        gr = wave_sum(gr);
+        if ((threadIdx.x & 63) == 0) atomicAdd(a.g_r + e, gr);
+      }
+    }
     if constexpr (PACKED) cur = nxt;
   }
   float* __restrict__ gxr = a.g_x + (int64_t)node * a.d_in + g.x_off;
@@ -1275,7 +1326,7 @@ extern "C" void e3k_tp_plan_destroy(e3k_tp_plan* p) {
 
 namespace {
 enum TpKind { TP_FWD, TP_BWD_W, TP_BWD_W_SH, TP_BWD_X, TP_FWD_TABLE, TP_BWD_X_TABLE, TP_FWD_JVP, TP_BWD_X_DUAL, TP_BWD_E, TP_BWD_W_DUAL,
-              TP_FWD_PACKED, TP_BWD_X_PACKED, TP_BWD_XW_PACKED, TP_BWD_XW, TP_BWD_XW_DUAL };
+              TP_FWD_PACKED, TP_BWD_X_PACKED, TP_BWD_XW_PACKED, TP_BWD_XW, TP_BWD_XW_DUAL, TP_BWD_XE };
 
 int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t N, hipStream_t st) {
   static_assert(E3K_L1MAX == 3, "extend the degree switch in the kernels when the CG tables grow");
@@ -1294,13 +1345,13 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
   if (args.order) blocks = 8 * ((((N + 7) / 8) * n_gc + 3) / 4);      // eight equal sub-grids, one per XCD (blocks b, b + 8, .. share one)
   if (blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
   dim3 grid((unsigned)blocks), block(256);
-  if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL || kind == TP_BWD_XW_DUAL) {
+  if (kind == TP_FWD_JVP || kind == TP_BWD_X_DUAL || kind == TP_BWD_E || kind == TP_BWD_W_DUAL || kind == TP_BWD_XW_DUAL || kind == TP_BWD_XE) {
     // second-order forms of force training: channel-complete plans; walked by one wave per group (the l_max <= 2 models), or by two
     // (SPLIT: l_max 3) with the weights STREAMED (w[e], dw/dr[e] materialised -- what the force block does by default)
     if (!p->full64) return E3K_ERR_UNSUPPORTED;
     const bool lo = p->max_l3 <= p->max_l1;
     const bool streamed = args.bin == nullptr;      // w[e] / dw[e] rows in a.w / a.w2 instead of the tables + per-edge knots
-    if (kind == TP_BWD_XW_DUAL && !streamed) return E3K_ERR_UNSUPPORTED;
+    if ((kind == TP_BWD_XW_DUAL || kind == TP_BWD_XE) && !streamed) return E3K_ERR_UNSUPPORTED;
     if (p->split) {
       if (!streamed) return E3K_ERR_UNSUPPORTED;
 #define E3K_TP_LAUNCH_2S(ML)                                                                                                            \
@@ -1308,6 +1359,7 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
     case TP_FWD_JVP: hipLaunchKernelGGL((e3k::tp_fwd_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;      \
     case TP_BWD_X_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 3>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_XW_DUAL: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 7>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
+    case TP_BWD_XE: hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, 3, true, true, 8>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break; \
     case TP_BWD_E: hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, 3, true, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;         \
     default: hipLaunchKernelGGL((e3k::tp_bwd_w_dual_kernel<ML, 3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc); break;                \
   }
@@ -1332,6 +1384,9 @@ int launch_all(TpKind kind, const e3k::TpArgs& a, const e3k_tp_plan* p, int64_t 
       break;                                                                                                                            \
     case TP_BWD_XW_DUAL:                                                                                                                \
       hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 7>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);         \
+      break;                                                                                                                            \
+    case TP_BWD_XE:                                                                                                                     \
+      hipLaunchKernelGGL((e3k::tp_bwd_x_kernel<ML, L3, false, true, 8>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);         \
       break;                                                                                                                            \
     case TP_BWD_E:                                                                                                                      \
       if (streamed) hipLaunchKernelGGL((e3k::tp_bwd_e_kernel<ML, L3, true>), grid, block, 0, st, args, p->d_groups, p->d_gc, n_gc);           \
@@ -1597,6 +1652,22 @@ extern "C" int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh,
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
   return launch_all(TP_BWD_X_DUAL, a, plan, N, (hipStream_t)stream);
+}
+
+// the first backward of a force evaluation in ONE walk of the source CSR (streamed rows w, dw [E, W]): g_x (e3k_tp_bwd_x), g_sh and g_r
+// (e3k_tp_bwd_e_table: ACCUMULATED with atomics, zero-fill them) and, when g_w != NULL, the per-edge weight gradient (e3k_tp_bwd_w)
+extern "C" int e3k_tp_bwd_xe(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* dw,
+                             const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E,
+                             float* g_x, float* g_sh, float* g_r, float* g_w, void* stream) {
+  if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
+  if (N == 0) return E3K_OK;
+  if (!x || !g_out || !g_x || !src_ptr || (E > 0 && (!sh || !w || !dw || !dst || !src_perm || (!g_sh && !g_r)))) return E3K_ERR_INVALID;
+  e3k::TpArgs a{};
+  a.x = x; a.sh = sh; a.w = w; a.w2 = dw; a.g_out = g_out; a.g_x = g_x; a.g_sh = g_sh; a.g_r = g_r; a.g_w = g_w;
+  a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
+  a.x_shared = plan->x_shared;
+  a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
+  return launch_all(TP_BWD_XE, a, plan, N, (hipStream_t)stream);
 }
 
 // e3k_tp_bwd_x_dual_table on STREAMED rows (w, dw [E, W]) that also writes the weight gradients sharing its sums:

@@ -159,6 +159,19 @@ def _tp_bwd_x_dual(sh, sh2, T, D, bins, s2, g_mid, topo, tp):
     return gx
 
 
+def _tp_bwd_xe(x1, sh, w, dw, g_mid, topo, tp, want_w: bool):
+    """(g_x1, g_sh, g_r, g_w or None): ``tp_bwd_x`` + ``_tp_bwd_e_table`` (+ ``tp_bwd_w``) in one walk (streamed rows w, dw [E, W])"""
+    n, e = g_mid.shape[0], sh.shape[0]
+    gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
+    buf = torch.zeros(e * (tp.d_sh + 1), device=sh.device, dtype=torch.float32)      # one fill for both (atomics accumulate)
+    g_sh, g_r = buf[:e * tp.d_sh].view(e, tp.d_sh), buf[e * tp.d_sh:]
+    gw = torch.empty(e, tp.w_numel, device=sh.device, dtype=torch.float32) if want_w else None
+    L.check(L.load().e3k_tp_bwd_xe(tp.handle(sh.device), L.ptr(x1), L.ptr(sh), L.ptr(w), L.ptr(dw), L.ptr(g_mid), L.ptr(topo.dst),
+                                   L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.ptr(g_sh), L.ptr(g_r), L.ptr(gw),
+                                   L.stream_ptr()), "e3k_tp_bwd_xe")
+    return gx, g_sh, g_r, gw
+
+
 def _tp_bwd_xw_dual(x1, x2, sh, sh2, w, dw, s2, g_mid, topo, tp, want_plain: bool):
     """(cot_x1, g_w dual, g_w plain or None): ``_tp_bwd_x_dual`` + ``_tp_bwd_w_dual`` (+ ``tp_bwd_w``) in one walk (streamed rows)"""
     n, e = g_mid.shape[0], sh.shape[0]
@@ -292,12 +305,14 @@ class ForceBlockFn(torch.autograd.Function):
                                ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off)])
             g_w = None
             if MATERIALIZE:
-                if params and need[2] and FUSE_XW:      # both gradients of the product in one walk (csrc/e3k_tp.hip MODE 6)
+                if want_e and FUSE_XW:                    # input, edge (and weight) gradients in one walk (csrc/e3k_tp.hip MODE 8)
+                    g_x1, g_sh, g_r, g_w = _tp_bwd_xe(x1, sh, cfg.weights(T), cfg.slopes(D), g_mid, topo, tp, bool(params and need[2]))
+                elif params and need[2] and FUSE_XW:      # both gradients of the product in one walk (MODE 6)
                     g_x1, g_w = ops._tp_bwd_xw_raw(x1, sh, cfg.weights(T), g_mid, topo, tp)
                 else:
                     g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
-                if want_e:
-                    g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
+                    if want_e:
+                        g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
             else:
                 g_x1 = _tp_bwd_x_table(sh, T, bins, g_mid, topo, tp)
                 if want_e:
@@ -344,7 +359,9 @@ class ForceBlockBwdFn(torch.autograd.Function):
         g_xcf = (torch.empty if plan.sc_spec.in_covered else torch.zeros)(n, plan.sc_spec.d_in, device=dev, dtype=torch.float32)
         ops._run_segments([ops._lin_dgrad_segs(g_conv, w_post, g_mid, plan.post_spec, plan.scale, False),
                            ops._grp_segs("dgrad", g_conv, m, g_xcf, groups, plan.sc_spec, plan.sc_m_off)])
-        if MATERIALIZE:
+        if MATERIALIZE and FUSE_XW:
+            g_x1, g_sh, g_r, _ = _tp_bwd_xe(x1, sh, cfg.weights(T), cfg.slopes(D), g_mid, topo, tp, False)
+        elif MATERIALIZE:
             g_x1 = ops._tp_bwd_x_raw(sh, cfg.weights(T), g_mid, topo, tp)
             g_sh, g_r = _tp_bwd_e_table(x1, sh, cfg.weights(T), cfg.slopes(D), None, g_mid, topo, tp)
         else:

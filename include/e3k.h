@@ -278,6 +278,12 @@ int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x
 int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh, const float* sh2, const float* T, const float* D,
                             const int32_t* bin, const float* coef, const float* s2, const float* g_out, const int32_t* dst,
                             const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
+/* The first backward of a force evaluation w.r.t. everything an edge touches, in ONE walk of the source CSR (streamed rows w,
+ * dw [E, W]): g_x (e3k_tp_bwd_x), g_sh [E, d_sh] and g_r [E] (e3k_tp_bwd_e_table: accumulated with atomics -- zero-fill them; either
+ * may be NULL, not both) and, when g_w != NULL, the per-edge weight gradient (e3k_tp_bwd_w).  Channel-complete plans. */
+int e3k_tp_bwd_xe(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* dw, const float* g_out,
+                  const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_sh,
+                  float* g_r, float* g_w, void* stream);
 /* e3k_tp_bwd_x_dual_table on streamed rows (w, dw [E, W]; bin = coef = NULL there) that ALSO writes the weight gradients sharing its
  * per-edge sums: g_w = e3k_tp_bwd_w_dual's, g_w_plain (may be NULL) = e3k_tp_bwd_w's -- one walk instead of three (the u-sweep of
  * force training: the adjoint of nn/output.py:42-50's first backward) */

@@ -784,6 +784,18 @@ def test_tp_table_second_order_forms_are_sums_of_first_order_kernels(dev, left, 
     assert rel_err(gwp_f, ops._tp_bwd_w_raw(x, sh, None, g, topo, tp, False, True)[0]) < 1e-6
     gx_n, gw_n, none = conv_force._tp_bwd_xw_dual(x, x2, sh, sh2, w, dw, s2, g, topo, tp, False)
     assert none is None and torch.equal(gw_n, gw_f)
+    # the first backward's three walks as one (e3k_tp_bwd_xe, streamed rows): g_x bit for bit, g_w likewise the fused kernel's, the
+    # edge gradients (atomics across the groups: order-free sums) against e3k_tp_bwd_e_table
+    gx_e, gsh_e, gr_e, gw_e = conv_force._tp_bwd_xe(x, sh, w, dw, g, topo, tp, True)
+    gx_ref = ops._tp_bwd_x_raw(sh, w, g, topo, tp)
+    if tp.bwd_x_overwrites(dev):
+        assert torch.equal(gx_e, gx_ref)
+    else:
+        assert rel_err(gx_e, gx_ref) < 1e-6
+    assert rel_err(gw_e, g_w_ref) < 1e-6
+    assert rel_err(gsh_e, g_sh_ref) < 1e-5
+    assert rel_err(gr_e, (g_w_ref.double() * dw.double()).sum(1)) < 1e-5
+    assert conv_force._tp_bwd_xe(x, sh, w, dw, g, topo, tp, False)[3] is None
 
 
 @pytest.mark.parametrize("n_basis", [8, 48])
