@@ -454,7 +454,7 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
   // tensor product
   // packed table + both gradients wanted: ONE walk of the source CSR forms g_x1 and g_w [E, W] (csrc/e3k_tp.hip, MODE 5): the
   // weight-gradient pass re-gathered sh, x[src] and g_mid[dst] of every edge for a dot product with sums the input gradient
-  // already holds (layer 3 of config_energy at 256 molecules: 213 + 104 us -> 258 us isolated, 217 + 169 -> see DESIGN section 5 in the step)
+  // already holds (layer 3 of config_energy at 256 molecules: 213 + 104 us -> 258 us isolated; 217 + 169 -> 261 in the replayed step)
   const bool fused_xw = a->fuse_xw && need_x1 && in_kernel_table(d, r) && r.P && need_radial_side && a->E > 0 && a->g_w && a->x1 && !(ABLATE & 32);
   // ... the same for layers whose weights are streamed from w [E, W] (per-edge radial MLP, 32-channel plans), where the replayed /
   // one-stream step gains what the packed layers gain; with the backward forked over streams the separate weight-gradient pass
