@@ -36,7 +36,7 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_KW_STACK": (1, "path", "the per-key self-connection weights of all layers formed as one batch"),
     "E3K_TP_TABLE": (1, "path", "table layers interpolate their path weights inside the tensor-product kernels (no w[E, W]); 0: interpolation pass"),
     "E3K_TP_TABLE_PACKED": (1, "accuracy", "... from the table packed into 12-byte Taylor records (two small coefficients in fp16: bounded by the guard); 0: four fp32 rows"),
-    "E3K_TP_BWD_FUSED": (1, "path", "packed-table layers form the per-edge weight gradient inside the input-gradient walk (one kernel, csrc/e3k_tp.hip MODE 5); 0: tp_bwd_x + tp_bwd_w"),
+    "E3K_TP_BWD_FUSED": (1, "path", "the input-gradient walk of the tensor product also writes what shares its per-edge sums: the weight gradient (packed-table layers, one-stream layers with streamed weights), force training's edge gradients and dual weight gradients (csrc/e3k_tp.hip MODE 5-8); 0: one kernel per gradient"),
     # ---- streams ----
     "E3K_FWD_FORK": (1, "path", "0: one stream; 1: radial / self-connection / weight-gradient branches on side streams above the edge thresholds; 2: also inside a graph capture"),
     "E3K_FWD_FORK_SC": (1, "path", "composed path: the self-connection on a third stream"),
