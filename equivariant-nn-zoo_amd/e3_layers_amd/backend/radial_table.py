@@ -270,7 +270,7 @@ def applicable(edge_radial, w_last=None) -> bool:
 # stack).  Two ratios: TABLE-WIDE, max_c err_c / max|T| <= GUARD_TOL (1e-6: what the forward's parity feels -- a column's error
 # against the scale of the weights it is summed with; 1.1-1.8e-7 for the shipped models at random init on 512 knots, mostly the
 # fp32 rounding of the rows, whose fourth difference carries 16 eps), and PER COLUMN (round 5), err_c relative to the column's
-# own largest entry, floored at GUARD_COL_FLOOR (2^-7) of the table's largest, <= GUARD_TOL_COL (2e-5) -- until round 5 only the
+# own largest entry, floored at GUARD_COL_FLOOR (2^-7) of the table's largest, <= GUARD_TOL_COL (1e-5 since round 6; 2e-5 in round 5) -- until round 5 only the
 # table-wide ratio existed and a column a thousand times smaller than the largest could be off by 1e-3 relative and pass.  The
 # per-column ratio has its own, wider tolerance because random combinations of the hidden units that cancel their smooth part
 # have 20-40 x the typical relative curvature: 1-4e-6 at random init over 2-3 k columns (``tools/guard_probe.py``,

@@ -56,7 +56,9 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_RADIAL_MIN_EDGES_PER_KNOT": (4.0, "threshold", "the table applies from this many edges per table row"),
     "E3K_RADIAL_TABLE_TOL": (1e-6, "accuracy", "a-posteriori interpolation-error bound above which an MLP's table is switched off"),
     "E3K_RADIAL_TABLE_CHECK_EVERY": (64, "debug", "eager: the guard is evaluated every this-many table builds; replayed graphs: its running maximum is read every this-many replays"),
-    "E3K_RADIAL_TABLE_TOL_COL": (2e-5, "accuracy", "... and the bound of a weight column's error relative to the column's own scale"),
+    "E3K_RADIAL_TABLE_TOL_COL": (1e-5, "accuracy", "... and the bound of a weight column's error relative to the column's own scale "
+                                 "(round 6: 2e-5 -> 1e-5, the forward bound it protects; measured 1.1-2.5e-6 at random init, <= 4.1e-6 after "
+                                 "200 Adam steps at lr 1e-2: profiles/r06_parity_measured.jsonl)"),
     "E3K_RADIAL_TABLE_COL_FLOOR": (2.0 ** -7, "accuracy", "the guard's bound is relative to each weight column's own scale, floored at this fraction of the table's largest entry"),
     # ---- debug ----
     "E3K_HOST_TIMING": (0, "debug", "host seconds inside the layer functions (tools/host_split.py)"),
