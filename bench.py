@@ -408,7 +408,7 @@ def main():
     auto = None
 
     def make_bucket():
-        from e3_layers_amd.run.graph_step import BucketedStep, bucket_capacity, pad_batch
+        from e3_layers_amd.run.graph_step import BucketedStep, PipelinedBucketedStep, bucket_capacity, pad_batch
 
         # the bucket: here the capacity of the resident batches (a training run takes it from the dataset's statistics and
         # steps a batch that does not fit eagerly)
@@ -450,7 +450,10 @@ def main():
                 finish()
                 return loss
 
-            bucket_ = BucketedStep(train_on, padded[0], warmup=3, generators=gens)
+            if pipelined_prep:
+                bucket_ = PipelinedBucketedStep(prep_fn, train_on, padded[0], warmup=3, generators=gens)
+            else:
+                bucket_ = BucketedStep(train_on, padded[0], warmup=3, generators=gens)
         else:
             # several ranks: forward + backward are the graph, the flat all-reduce (the same fixed sequence of slices as in the
             # eager step, issued in one go) and the fused optimizer launch follow it eagerly -- RCCL stays outside the capture
@@ -460,16 +463,26 @@ def main():
                 return loss
 
             flat.early_start = False
-            bucket_ = BucketedStep(backward_on, padded[0], warmup=3, generators=gens, tail=finish)
+            if pipelined_prep:
+                bucket_ = PipelinedBucketedStep(prep_fn, backward_on, padded[0], warmup=3, generators=gens, tail=finish)
+            else:
+                bucket_ = BucketedStep(backward_on, padded[0], warmup=3, generators=gens, tail=finish)
 
         def run_():
             b = padded[counter[0] % n_res]
             counter[0] += 1
+            if pipelined_prep:      # ... and the NEXT batch is handed to the preparation stream (what a prefetching loader does)
+                return bucket_(b, nxt=padded[counter[0] % n_res])
             return bucket_(b)
 
         return bucket_, run_, n_cap, e_cap
 
     replay_error = None
+    # batch preparation (device copy, CSR views, edge geometry, species groups, knot bins, edge records) as its own graph on a second
+    # stream beside the previous step (run/graph_step.PipelinedBucketedStep); E3K_BENCH_PREP_PIPELINE=0: inside the step's graph
+    pipelined_prep = bool(args.graph_fresh and hasattr(model, "prepare_data") and os.environ.get("E3K_BENCH_PREP_PIPELINE", "1") != "0")
+    # (the denoising loss noises ``pos`` on a clone of the batch: nothing that reads the positions may be computed ahead of it)
+    prep_fn = (lambda b: model.prepare_data(b, exclude=("pos",))) if cfg_kind == "diffusion" else getattr(model, "prepare_data", None)
     if args.graph_fresh:
         if cfg_kind not in ("energy", "energy_force", "diffusion") or args.loader or args.graph:
             raise SystemExit("--graph-fresh replays the config_energy / config_energy_force / config_diffusion step on padded resident "
@@ -886,7 +899,9 @@ def main():
                 "streams": ("one (captured)" if graph is not None else
                             "one" if (auto or {}).get("chosen") == "eager, one stream" else "per size: four from 60 000 edges (table layers)"),
                 "launch": ((f"hip-graph replay, a NEW batch every step: padded to the bucket ({n_cap} nodes, {e_cap} edges) with a ghost "
-                            "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins inside the graph"
+                            "graph of zero loss weight, copied into the captured tensors, CSR build / species groups / knot bins "
+                            + ("in a second graph on a preparation stream, beside the previous batch's step (two buffers)" if pipelined_prep
+                               else "inside the graph")
                             + ("; forward + backward replayed, the flat all-reduce and the optimizer launch follow eagerly" if world > 1 else ""))
                            if bucket is not None else
                            "hip-graph replay of ONE resident batch (no per-batch work in the replayed step)" if graph is not None else "eager"),

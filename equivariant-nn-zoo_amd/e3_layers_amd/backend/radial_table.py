@@ -141,9 +141,10 @@ class RadialSource:
 
     __slots__ = ("module", "r", "version", "_bins", "_knot_basis", "_stack", "__weakref__")
 
-    def __init__(self, module, r: torch.Tensor, version: int = 0):
+    def __init__(self, module, r: torch.Tensor, version: int = 0, prepared: Optional[dict] = None):
+        """``prepared``: {target knot count: KnotBins} built ahead of the step for exactly these radii (``prepare_bins``)."""
         self.module, self.r, self.version = weakref.ref(module), r, int(version)
-        self._bins = {}
+        self._bins = dict(prepared) if prepared else {}
         self._knot_basis = {}
         self._stack = {}      # id(MessagePassing) -> (its radial MLP's rows on the knots, mode): nn/message_passing.py:_stack_rows
 
@@ -166,6 +167,19 @@ class RadialSource:
                                      b.one_over_r, c.cutoff.kind)
             kb = self._knot_basis[knots] = (basis, torch.is_grad_enabled())
         return kb[0]
+
+
+def prepare_bins(r: torch.Tensor, r_max: float, target: int) -> KnotBins:
+    """Knot bins of the radii ``r`` built NOW and left on the tensor (``SequentialGraphNetwork.prepare_data``: the batch's radii are
+    known before the step that reads them); ``prepared_bins(r)`` hands them out while ``r`` has not been written to since."""
+    bins = build_bins(r, r_max, target)
+    r._e3k_bins = (r._version, float(r_max), {int(target): bins})
+    return bins
+
+
+def prepared_bins(r: torch.Tensor) -> Optional[dict]:
+    hit = getattr(r, "_e3k_bins", None)
+    return hit[2] if (hit is not None and hit[0] == r._version) else None
 
 
 _KNOT_CACHE = {}

@@ -51,6 +51,9 @@ def computeEdgeVector(data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]
     return data, attrs
 
 
+computeEdgeVector.data_only_inputs = ("pos", "edge_index")      # (SequentialGraphNetwork.prepare_data: parameter-free, reads these keys)
+
+
 def _all_pairs(n_nodes: Tensor, device) -> Tensor:
     """[2, sum n_g^2] candidate edges, graphs concatenated, (i, j) lexicographic inside a graph; built on ``device``
     (one host sync for the candidate count when the counts live on the GPU)."""

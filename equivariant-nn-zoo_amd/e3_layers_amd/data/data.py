@@ -158,6 +158,9 @@ class Data:
         out.attrs = copy.deepcopy(self.attrs)
         out.data = dict(self.data)
         out.device = self.device
+        done = getattr(self, "_e3k_done", None)      # (SequentialGraphNetwork.prepare_data: validated against the tensors at forward time)
+        if done:
+            out._e3k_done = done
         return out
 
     def __repr__(self):

@@ -57,6 +57,8 @@ class BesselBasis(nn.Module):
 
 
 class SphericalEncoding(Module):
+    data_only = True      # parameter-free: ``SequentialGraphNetwork.prepare_data`` may run it ahead of the step
+
     def __init__(self, irreps_out, edge_sh_normalization: str = "component", edge_sh_normalize: bool = True,
                  irreps_in="1x1o"):
         super().__init__()
@@ -97,9 +99,24 @@ class RadialBasisEncoding(Module):
         if per_row == 1 and c.cutoff.kind == 0 and b.r_min == 0.0:
             # a pure function of one radius per row, constant beyond r_max: the convolutions may evaluate their radial MLPs
             # on a knot table instead of per edge (backend/radial_table.py); any op that builds a new tensor drops the tag
-            out._e3k_radial_src = radial_table.RadialSource(self, x.reshape(-1), out._version)
+            out._e3k_radial_src = radial_table.RadialSource(self, x.reshape(-1), out._version, prepared=radial_table.prepared_bins(x))
         return ({"radial_embedding": out},
                 {"radial_embedding": (attrs["input"][0], self.irreps_out["radial_embedding"])})
+
+    def prepare_batch(self, network, data, avail) -> None:
+        """``SequentialGraphNetwork.prepare_data`` hook: the radii are batch data, so the knot bins of the radial table (which edge
+        interpolates between which rows, the edges grouped by knot: ``e3k_rtable_bins``, three launches) can be built before the
+        step; ``forward`` hands them to the ``RadialSource`` it tags its output with."""
+        key = next((g for g, loc in self.input_key_mapping.items() if loc == "input"), None)
+        x = data.get(key) if key in avail else None
+        b, c = self.basis, self.cutoff
+        if (x is None or not x.is_cuda or not radial_table.ENABLED or x.dim() > 1 and x.shape[1] != 1 or c.cutoff.kind != 0
+                or b.r_min != 0.0):
+            return
+        knots = radial_table.KNOTS
+        rows = radial_table.layout(float(b.r_max), knots)[0] + 1
+        if x.shape[0] >= radial_table.MIN_EDGES_PER_KNOT * rows:
+            radial_table.prepare_bins(x, float(b.r_max), knots)
 
 
 class Broadcast(Module):
@@ -122,6 +139,7 @@ class Broadcast(Module):
 
 class OneHotEncoding(Module):
     num_types: int
+    data_only = True      # parameter-free: ``SequentialGraphNetwork.prepare_data`` may run it ahead of the step
 
     def __init__(self, num_types: int, irreps_out, irreps_in="0x0e"):
         super().__init__()
@@ -150,6 +168,17 @@ class OneHotEncoding(Module):
             one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
         set_row_key(one_hot, idx, self.num_types)   # rows are a function of the type index only
         return {"one_hot": one_hot}, {"one_hot": (attrs["input"][0], self.irreps_out["one_hot"])}
+
+    def prepare_batch(self, network, data, avail) -> None:
+        """``prepare_data`` hook: the rows grouped by type (what the keyed self-connections of the convolutions sort their nodes
+        by; memoised on the index tensor, ``nn/core.row_groups``) -- only when some layer of the network has a self-connection."""
+        key = self.output_key_mapping.get("one_hot")
+        t = data.get(key) if key in avail else None
+        rk = getattr(t, "_e3k_key", None) if t is not None else None
+        if rk is not None and t.is_cuda and any(getattr(getattr(m, "conv", None), "sc", None) is not None for _, m in network.layers):
+            from .core import row_groups
+
+            row_groups(rk[0], rk[1])
 
 
 class RelativePositionEncoding(Module):

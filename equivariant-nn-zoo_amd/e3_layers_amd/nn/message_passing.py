@@ -538,6 +538,30 @@ class MessagePassing(Module):
                                      conv.linear_1.weight, conv.tp.linear.weight, None,
                                      fc[-1].weight, [m.weight for m in fc[:-1]], table=table, m_pre=sc_out)
 
+    def prepare_batch(self, network, data, avail) -> None:
+        """``SequentialGraphNetwork.prepare_data`` hook: the EDGE RECORDS the packed-table tensor-product kernels walk (one 64-byte
+        block per edge and CSR direction: ``KnotBins.records``) depend on the batch alone -- topology, knot bins, spherical
+        harmonics -- and are shared by all layers: built here when all three are known before the step."""
+        from ..backend import conv_native
+        from ..backend.graph import GraphTopo
+
+        if not (conv_native.ENABLED and conv_native.TP_TABLE and conv_native.TP_TABLE_PACKED):
+            return
+        inv = {loc: g for g, loc in self.input_key_mapping.items()}
+        sh_key, rad_key = inv.get("edge_spherical"), inv.get("edge_radial")
+        sh = data.get(sh_key) if sh_key in avail else None
+        topo = GraphTopo.from_dict(data)
+        if sh is None or topo is None or not sh.is_cuda or sh.dim() != 2 or sh.shape[1] > 9 or sh.shape[0] != topo.num_edges:
+            return
+        for _, layer in network.layers:      # the layer that produces this convolution's edge embedding: its radii carry the bins
+            if rad_key in getattr(layer, "output_key_mapping", {}).values() and hasattr(layer, "basis"):
+                r_key = next((g for g, loc in layer.input_key_mapping.items() if loc == "input"), None)
+                bins = radial_table.prepared_bins(data[r_key]) if (r_key in avail and r_key in data) else None
+                for b in (bins or {}).values():
+                    b.records(topo, sh, "dst")
+                    if torch.is_grad_enabled() or self.training:
+                        b.records(topo, sh, "src")
+
     def forward(self, data: Dict[str, Tensor], attrs: Dict[str, Tuple[str, str]]):
         old_x = data["input_features"]
         blk = self._forward_block(data, bool(self._emit_cf))

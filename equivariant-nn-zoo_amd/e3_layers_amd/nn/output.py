@@ -24,6 +24,16 @@ class GradientOutput(Module):
             func = build(func, **kwargs)
         self.func = func
 
+    def prepare_data(self, batch) -> dict:
+        """``SequentialGraphNetwork.prepare_data`` of the wrapped network, minus everything that reads ``x``: the forward
+        differentiates w.r.t. it, so edge vectors, lengths and spherical harmonics belong to the autograd graph of the step (what is
+        left: topology, one-hot species, key groups)."""
+        inner = getattr(self.func, "prepare_data", None)
+        if inner is None:
+            return {}
+        x_key = next((g for g, loc in self.input_key_mapping.items() if loc == "x"), "x")
+        return inner(batch, exclude=(x_key,))
+
     def forward(self, data):
         wrt = self.inputKeyMap(data)["x"]
         old = wrt.requires_grad

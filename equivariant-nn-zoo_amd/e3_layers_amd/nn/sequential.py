@@ -105,8 +105,61 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         batch._e3k_prepared = done
         return done
 
+    # ---- batch preparation ahead of the step (round 6) -----------------------------------------------------------------
+    # Everything a forward derives from the batch ALONE -- CSR topology, edge vectors, spherical harmonics, one-hot species, the
+    # species groups of the keyed self-connection, the knot bins of the radial table and the edge records the packed tensor-product
+    # kernels walk -- is about 25 small dependent launches (0.2 ms of a 4.2 ms replayed step at 256 molecules) in front of the first
+    # convolution.  In the reference that work is the data loader's (``computeEdgeIndex`` in ``data.preprocess``,
+    # ``e3_layers/configs/config_energy.py:49``; ``Batch.from_data_list``'s segment loops): it runs in worker processes beside the
+    # previous step.  ``prepare_data(batch)`` is that split: it runs the parameter-free layers whose inputs are batch keys (or
+    # outputs of such layers) and the per-batch builds of the layers that declare a ``prepare_batch`` hook, leaves their results
+    # in the batch and records what they were computed FROM; ``forward`` skips a recorded layer only while its inputs are still
+    # the same tensor objects at the same version (a loss that perturbs ``pos`` before calling the model gets the layer run
+    # again).  ``run/graph_step.PipelinedBucketedStep`` replays it as its own HIP graph on a second stream while the previous
+    # batch's step runs.
+    @staticmethod
+    def _data_only_inputs(layer):
+        """Global batch keys a parameter-free layer reads, or None when the layer cannot be run ahead."""
+        if isinstance(layer, Module):
+            if not getattr(layer, "data_only", False) or any(True for _ in layer.parameters()):
+                return None
+            return tuple(layer.input_key_mapping.keys())
+        return getattr(layer, "data_only_inputs", None)
+
+    def prepare_data(self, batch, exclude=()) -> dict:
+        """``exclude``: keys that will require grad in the forward (``GradientOutput``'s ``x``): nothing that reads them is run ahead."""
+        from ..backend.graph import get_topology
+
+        data, attrs = batch.data, batch.attrs
+        avail = {k for k, v in data.items() if torch.is_tensor(v) and not v.requires_grad} - set(exclude)
+        done = {}
+        with torch.no_grad():
+            if "edge_index" in data and "pos" in data and data["edge_index"].is_cuda:
+                data.update(get_topology(data, data["pos"].shape[0]).as_dict())
+            for name, layer in self.layers:
+                ins = self._data_only_inputs(layer)
+                if ins is None or not all(k in avail for k in ins):
+                    continue
+                before = dict(data)
+                self._run_layer(layer, data, attrs)
+                avail |= {k for k, v in data.items() if before.get(k) is not v}
+                done[name] = tuple((k, data[k], data[k]._version) for k in ins)
+            for name, layer in self.layers:
+                hook = getattr(layer, "prepare_batch", None)
+                if hook is not None:
+                    hook(self, data, avail)
+        batch._e3k_done = done
+        return done
+
+    @staticmethod
+    def _still_valid(record, data) -> bool:
+        return all(data.get(k) is t and t._version == v for k, t, v in record)
+
     def forward(self, batch):
         data, attrs = batch.data, batch.attrs
+        done = getattr(batch, "_e3k_done", None)
+        if done:
+            batch._e3k_done = None      # (one forward: see ``prepare`` below)
         # layer names appear in a torch profile when one is running; otherwise the 2 x 14 record_function ops per forward
         # are 0.3 ms of pure host time
         profiling = torch.autograd._profiler_enabled()
@@ -116,6 +169,8 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         if start:
             batch._e3k_prepared = 0
         for key, layer in (self.layers[start:] if start else self.layers):
+            if done and key in done and self._still_valid(done[key], data):
+                continue                # run ahead by prepare_data() on exactly these input tensors: its outputs are in ``data``
             if profiling:
                 with record_function(key):
                     self._run_layer(layer, data, attrs)

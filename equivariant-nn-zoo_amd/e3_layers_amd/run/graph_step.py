@@ -16,6 +16,7 @@ static-edge mode does exactly that for the reverse-diffusion loop).
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Callable
 
 import torch
@@ -240,6 +241,140 @@ class BucketedStep:
         for dsts, srcs in by_dtype.values():      # one multi-tensor launch per dtype instead of one copy per field (eleven fields:
             torch._foreach_copy_(dsts, srcs)      # 53 us in front of every replay)
         out = self.captured()
+        if self.tail is not None:
+            self.tail()
+        return out
+
+
+def stream_beside(main, candidates: int = 6):
+    """A stream whose work demonstrably runs BESIDE ``main``'s.  HIP multiplexes the streams of a process over a few hardware queues
+    (four by default) in creation order, and two streams that share a queue execute in submission order: a preparation stream that
+    lands on the main stream's queue runs in front of the step instead of beside it (seen in the first trace of this class: every
+    kernel of both graphs on one queue, no gain).  A stream of another PRIORITY has a queue of its own, but mixing priority levels
+    makes the queues starve each other on this part (8.4 instead of 4.2 ms per step; DESIGN.md section 5, round 5 saw the same with a
+    high-priority main stream).  So: a few fresh streams are tried in turn -- a millisecond of kernels on ``main``, one tiny kernel
+    on the candidate -- and the first whose kernel finishes while ``main`` is still busy is kept."""
+    dev = main.device
+    busy = torch.empty(16 << 20, device=dev)
+    tiny = torch.zeros(64, device=dev)
+    pool = [torch.cuda.Stream(dev) for _ in range(candidates)]
+    for st in pool:
+        torch.cuda.synchronize(dev)
+        with torch.cuda.stream(main):
+            for _ in range(40):
+                busy.mul_(1.0)
+            main_done = torch.cuda.Event()
+            main_done.record(main)
+        with torch.cuda.stream(st):
+            tiny.add_(1.0)
+            mine = torch.cuda.Event()
+            mine.record(st)
+        mine.synchronize()
+        beside = not main_done.query()
+        torch.cuda.synchronize(dev)
+        if beside:
+            return st
+    return pool[0]
+
+
+class PipelinedBucketedStep:
+    """``BucketedStep`` with the batch-only part of the step taken OFF the step's critical path (round 6).
+
+    A replayed step is one in-order queue: whatever the forward derives from the batch alone -- the device copy of the batch, both
+    CSR views, edge vectors, spherical harmonics, one-hot species, species groups, knot bins, edge records: about 25 small dependent
+    launches, 0.2 ms of 4.2 at 256 molecules -- runs in front of the first convolution with the chip idle.  In the reference that
+    work belongs to the data loader's worker processes (``e3_layers/data/dataloader.py:30-118``: collate; ``computeEdgeIndex`` as a
+    ``preprocess`` step) and overlaps the previous step.  Here it is a second HIP graph per buffer:
+
+        P[b]  = copy of the padded batch into the static tensors of buffer b + ``model.prepare_data(static[b])``   (prep stream)
+        M[b]  = ``fn(static[b].view())``: the step itself, captured with P[b]'s results in place                    (main stream)
+
+    and two buffers, so that P of batch t + 1 runs BESIDE M of batch t:
+
+        step(batch_t, nxt=batch_t+1):   main: wait P(batch_t) -> M[b];   prep: wait M[1 - b] of step t - 1 -> P[1 - b](batch_t+1)
+
+    Both graphs are single-stream chains (the HIP graph executor launches those from pre-built packets: no host work to speak of);
+    the only cross-stream edges are two events per step.  A batch that was not announced with ``nxt`` is prepared on the main
+    stream in front of its step (the first call, or a caller that does not look ahead): same result, no overlap.  Results are
+    bit-identical to ``BucketedStep`` (same kernels on the same inputs; ``tests/test_gpu_model.py``)."""
+
+    def __init__(self, prepare: Callable[[Any], Any], fn: Callable[[Any], Any], example, warmup: int = 3, generators=(),
+                 tail: Callable[[], Any] = None):
+        from ..backend.graph import capture_flag
+
+        self.tail = tail
+        self.dev = example["pos"].device
+        self.prep_stream = stream_beside(torch.cuda.current_stream(self.dev))
+        self.static, self.prep_graphs, self.steps = [], [], []
+        self.ev_prep = [torch.cuda.Event() for _ in range(2)]
+        self.ev_step = [torch.cuda.Event() for _ in range(2)]
+        self._holds = [None, None]          # which padded batch (by identity) buffer b has been prepared for
+        self._step_ran = [False, False]
+        self.keys = None
+        capture_flag(self.dev)              # (the persistent index-check flag captured builds fold into: before any recording)
+        for b in range(2):
+            static = example.clone()        # (fresh tensors: no per-batch memo of the framework knows them yet)
+            if self.keys is None:
+                self.keys = [k for k in static.keys() if torch.is_tensor(static[k])]
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                prepare(static)
+            g.replay()                      # (a capture records, it does not run: the step's warm-up below reads these results)
+            torch.cuda.synchronize(self.dev)
+            self.static.append(static)
+            self.prep_graphs.append(g)
+            # warm-up steps only for the first buffer's capture (lazy initialisation is process-wide); they take optimizer steps
+            # like BucketedStep's do
+            self.steps.append(CapturedStep((lambda s=static: fn(s.view())), warmup=warmup if b == 0 else 1, generators=generators))
+        self.captured = self.steps[0]       # (bench.py / tests: .graph, .recaptures of the first buffer's step)
+
+    @property
+    def recaptures(self) -> int:
+        return sum(s.recaptures for s in self.steps)
+
+    def _enqueue_prepare(self, b: int, padded) -> None:
+        """On the CURRENT stream: the padded batch into buffer b's static tensors, then its preparation graph."""
+        static = self.static[b]
+        by_dtype = {}
+        for k in self.keys:
+            dst, src = static[k], padded[k]
+            if dst.shape != src.shape:
+                raise ValueError(f"{k}: {tuple(src.shape)} does not fit the captured {tuple(dst.shape)} (another bucket?)")
+            if src.device == dst.device and src.dtype == dst.dtype and src.is_contiguous() and dst.is_contiguous():
+                pair = by_dtype.setdefault(dst.dtype, ([], []))
+                pair[0].append(dst)
+                pair[1].append(src)
+            else:
+                dst.copy_(src, non_blocking=True)
+        for dsts, srcs in by_dtype.values():
+            torch._foreach_copy_(dsts, srcs)
+        self.prep_graphs[b].replay()
+        self._holds[b] = padded
+
+    def __call__(self, padded, nxt=None):
+        main = torch.cuda.current_stream(self.dev)
+        b = next((i for i in range(2) if self._holds[i] is padded), None)
+        if b is None:                       # not announced: prepared here, in front of its step
+            b = 0 if self._holds[0] is None else (1 if self._holds[1] is None else 0)
+            if self._holds[b] is not None:  # (an announced batch that is not coming after all: its preparation may still be running)
+                main.wait_event(self.ev_prep[b])
+            self._enqueue_prepare(b, padded)
+        else:
+            main.wait_event(self.ev_prep[b])
+        out = self.steps[b]()
+        self.ev_step[b].record(main)
+        self._step_ran[b] = True
+        self._holds[b] = None
+        if nxt is not None:
+            o = 1 - b
+            if self._step_ran[o]:
+                self.prep_stream.wait_event(self.ev_step[o])      # the last step that read buffer o
+            else:
+                self.prep_stream.wait_stream(main)
+            with torch.cuda.stream(self.prep_stream):
+                self._enqueue_prepare(o, nxt)
+                self.ev_prep[o].record(self.prep_stream)
         if self.tail is not None:
             self.tail()
         return out
