@@ -1520,7 +1520,12 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       E3K_KNOB_INT(kTarget, "E3K_WGRAD_TARGET", 1024);
       E3K_KNOB_INT(kChunks, "E3K_WGRAD_CHUNKS", 4);
       int64_t splits = (kTarget + tiles - 1) / tiles;
-      const int64_t max_splits = (M + kChunks * e3k::WR - 1) / (kChunks * e3k::WR);
+      // rows per workgroup: kChunks chunks of WR rows -- unless that leaves most of the chip idle (round 6: the one-hot embeddings'
+      // and the energy head's weight gradients are ONE tile over 4 600 rows: 18 workgroups walking four chunks each took 17-22 us
+      // apiece in the replayed step; a chunk per workgroup, 73 workgroups, is one load latency long)
+      int chunks = kChunks;
+      while (chunks > 1 && tiles * ((M + (int64_t)chunks * e3k::WR - 1) / ((int64_t)chunks * e3k::WR)) < n_cu) chunks >>= 1;
+      const int64_t max_splits = (M + chunks * e3k::WR - 1) / (chunks * e3k::WR);
       if (splits > max_splits) splits = max_splits;
       if (splits < 1) splits = 1;
       e3k::GemmBatch& gb = b.gb;

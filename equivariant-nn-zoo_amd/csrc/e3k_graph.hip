@@ -166,6 +166,7 @@ __global__ __launch_bounds__(1024) void group_rows_kernel(const int64_t* __restr
   __shared__ int32_t hist[16][GR_MAXK];
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   if (t < GR_MAXK) count[t] = 0, running[t] = 0;
+  if (t == 0) *bad = 0;      // (one workgroup: cleared here, in front of the barrier, instead of by a fill launch of its own)
   __syncthreads();
   for (int i = t; i < R; i += 1024) {
     const int64_t k = key[i];
@@ -273,7 +274,6 @@ extern "C" int e3k_group_rows(const int64_t* key, int64_t R, int32_t K, int32_t*
   if (K > e3k::GR_MAXK || R >= 0x7fffffffLL) return E3K_ERR_UNSUPPORTED;
   if (!bounds || !reps || !bad_flag || (R > 0 && (!key || !perm))) return E3K_ERR_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  if (e3k::zero_fill(bad_flag, sizeof(int32_t), st)) return E3K_ERR_LAUNCH;
   hipLaunchKernelGGL(e3k::group_rows_kernel, dim3(1), dim3(1024), 0, st, key, (int32_t)R, K, perm, bounds, reps, bad_flag);
   E3K_CHECK_LAUNCH();
   return E3K_OK;

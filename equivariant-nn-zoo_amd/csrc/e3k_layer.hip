@@ -171,7 +171,7 @@ int edge(const e3k_layer* L, int slot, void* producer, void* consumer) {
 
 // the in-kernel table in its packed form (12-byte records, e3k_rtable_pack): behind whatever wrote T, on the radial stream
 int pack_table(const e3k_layer* L, const e3k_layer_radial& r, void* st) {
-  if (!in_kernel_table(L->d, r) || !r.P) return E3K_OK;
+  if (!in_kernel_table(L->d, r) || !r.P || r.packed) return E3K_OK;      // (packed: e3k_radial_stack_fwd did it for all its layers at once)
   return e3k_rtable_pack(r.T, r.knots, L->d.W, r.P, st);
 }
 
@@ -434,7 +434,8 @@ extern "C" int e3k_layer_bwd(const e3k_layer* L, const e3k_layer_bwd_args* a) {
     Seg g;
     if (with_g_conv && need_post) g.add(L, POST_WGRAD, a->mid, a->gb_post, const_cast<float*>(a->g_conv), a->N);
     if (with_g_conv && want_sc) {
-      if (e3k::zero_fill(a->gm, sizeof(float) * a->n_keys * d.ld_m, (hipStream_t)st)) return E3K_ERR_LAUNCH;
+      // (have_m == 2: gm arrives zero-filled -- e3k_kw_stack's caller fills the gM of all its layers with one launch)
+      if (a->have_m != 2 && e3k::zero_fill(a->gm, sizeof(float) * a->n_keys * d.ld_m, (hipStream_t)st)) return E3K_ERR_LAUNCH;
       g.add_keyed(L, SC_WGRAD, a->x_cf, a->gm, const_cast<float*>(a->g_conv), a->N, a->perm, a->bounds, a->n_keys);
     }
     if (with_lin1 && need_lin1) g.add(L, LIN1_WGRAD, a->x_cf, a->gb_lin1, a->g_x1, a->N);
@@ -577,6 +578,19 @@ extern "C" int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_la
       Timed t(layers[base], E3K_PROF_RADIAL_LAST_FWD, stream, rads[0].R, rads[0].E);
       E3K_TRY(g.run(0, stream));
     }
+    // the tables the tensor-product kernels will read packed (rads with in_kernel and P): all of them in one launch, behind the
+    // last layers (round 6: five launches of 5-8 us in front of the five layers' forward otherwise)
+    const float* tabs[16];
+    void* packs[16];
+    int32_t widths[16];
+    int np = 0;
+    for (int i = 0; i < n; ++i)
+      if (rads[i].use_table && rads[i].in_kernel && rads[i].P && rads[i].T) {
+        tabs[np] = rads[i].T;
+        packs[np] = rads[i].P;
+        widths[np++] = layers[i]->d.W;
+      }
+    if (np) E3K_TRY(e3k_rtable_pack_multi(tabs, (int32_t)(rads[0].R - 1), widths, packs, np, stream));
   }
   if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
   return E3K_OK;

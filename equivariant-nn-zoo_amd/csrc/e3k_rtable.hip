@@ -355,6 +355,38 @@ __global__ __launch_bounds__(256) void rtable_pack_kernel(const float* __restric
   row[2 * W + col] = __builtin_bit_cast(uint32_t, h);
 }
 
+// the tables of a radial stack (one row count, up to 16 widths) packed by ONE launch: blockIdx.y = table
+struct PackMulti {
+  const float* T[16];
+  uint32_t* P[16];
+  int32_t W[16];
+};
+__global__ __launch_bounds__(256) void rtable_pack_multi_kernel(PackMulti a, int32_t K) {
+  const int tb = blockIdx.y;
+  const int32_t W = a.W[tb];
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= (int64_t)(K + 1) * W) return;
+  const float* __restrict__ T = a.T[tb];
+  const int i = (int)(q / W), col = (int)(q - (int64_t)i * W);
+  uint32_t* row = a.P[tb] + 3 * (int64_t)i * W;
+  if (i < 1 || i > K - 2) {
+    row[2 * col] = row[2 * col + 1] = row[2 * W + col] = 0u;
+    return;
+  }
+  // (the arithmetic of rtable_pack_kernel, line for line: the two must produce the same bits)
+  const double ta = T[q - W], b = T[q], c = T[q + W], d = T[q + 2 * (int64_t)W];
+  const double c1 = -ta / 3.0 - b / 2.0 + c - d / 6.0, c2 = ta / 2.0 - b + c / 2.0, c3 = -ta / 6.0 + b / 2.0 - c / 2.0 + d / 6.0;
+  const double e2 = c2 + 1.5 * c3;
+  f16x2 h;
+  h.x = (_Float16)(float)(e2 * (double)PK_S2);
+  h.y = (_Float16)(float)(c3 * (double)PK_S3);
+  const double r2 = e2 - (double)(float)h.x / (double)PK_S2, r3 = c3 - (double)(float)h.y / (double)PK_S3;
+  const float d0 = (float)(b + c1 / 2.0 + c2 / 4.0 + c3 / 8.0 + r2 / 8.0), d1 = (float)(c1 + c2 + 0.75 * c3 + 3.0 * r3 / 16.0);
+  row[2 * col] = __float_as_uint(d0);
+  row[2 * col + 1] = __float_as_uint(d1);
+  row[2 * W + col] = __builtin_bit_cast(uint32_t, h);
+}
+
 __device__ __forceinline__ float packed_eval(float s, float s2, float s3, float d0, float d1, uint32_t pk) {
   const f16x2 h = __builtin_bit_cast(f16x2, pk);
   return fmaf(s, fmaf(s2, fmaf(s3, (float)h.y, (float)h.x), d1), d0);
@@ -535,6 +567,25 @@ extern "C" int e3k_rtable_pack(const float* T, int32_t K, int32_t W, void* P, vo
   const int64_t q = (int64_t)(K + 1) * W;
   hipLaunchKernelGGL(e3k::rtable_pack_kernel, dim3((unsigned)((q + 255) / 256)), dim3(256), 0, (hipStream_t)stream, T, K, W,
                      static_cast<uint32_t*>(P));
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_rtable_pack_multi(const float* const* T, int32_t K, const int32_t* W, void* const* P, int32_t n, void* stream) {
+  if (K < 4 || n < 0 || n > 16) return E3K_ERR_INVALID;
+  if (n == 0) return E3K_OK;
+  if (!T || !W || !P) return E3K_ERR_INVALID;
+  e3k::PackMulti a{};
+  int32_t wmax = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!T[i] || !P[i] || W[i] <= 0) return E3K_ERR_INVALID;
+    a.T[i] = T[i];
+    a.P[i] = static_cast<uint32_t*>(P[i]);
+    a.W[i] = W[i];
+    wmax = W[i] > wmax ? W[i] : wmax;
+  }
+  const int64_t q = (int64_t)(K + 1) * wmax;
+  hipLaunchKernelGGL(e3k::rtable_pack_multi_kernel, dim3((unsigned)((q + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, a, K);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

@@ -112,6 +112,20 @@ class NativeLayer:
             d.post_out_covered = 1      # (no zero fill: the buffer holds the addend)
         d.sc_in_covered = int(sc.in_covered) if has_sc else 1
         d.sc_out_covered = int(sc.out_covered) if has_sc else 1
+        if has_sc and not sc.out_covered and not plan.addend:
+            # The self-connection does not reach every column of the pre-gate buffer (layer 0: scalars in, so only the 0e blocks; the
+            # trailing Linear fills 1o and 2e) and the executor zero-filled the buffer for the Linear to accumulate on: a fill launch
+            # per layer in front of the first GEMM.  Instead the FIRST writer of a block nobody wrote yet overwrites -- when the two
+            # together reach every column (checked here: the widths of the distinct blocks add up to the row).
+            widths = {ins.out_off: ins.mul_out * ins.dim for ins in list(sc.instr) + list(post.instr)}
+            if sum(widths.values()) == post.d_out:
+                written = {ins.out_off for ins in sc.instr}
+                for i in range(d.post_fwd.n):
+                    off = (d.post_fwd.p[i].C or 0) // 4
+                    if off not in written:
+                        d.post_fwd.p[i].accumulate = 0
+                        written.add(off)
+                d.sc_out_covered = 1
         if plan.gate_spec.in_dim != post.d_out or (has_sc and (sc.d_out != post.d_out or sc.d_in != lin1.d_in)):
             raise NotImplementedError("layer dims")
         return d
@@ -253,10 +267,11 @@ def _radial_struct(rad: L.LayerRadial, plan, edge_radial, table, n_edges: int, k
     rad.P = p_tab.data_ptr() if (p_tab is not None and w is None) else None
 
 
-def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w, p_tab=None):
+def _stack_radial_struct(rad: L.LayerRadial, plan, pre, table, n_edges: int, w, p_tab=None, packed: bool = False):
     """Radial argument block of a layer whose MLP rows ``pre`` came from the stack: with the table the layer interpolates
-    ``pre`` (= T) into ``w``; without, ``pre`` is ``w``."""
+    ``pre`` (= T) into ``w``; without, ``pre`` is ``w``.  ``packed``: ``p_tab`` was filled by the stack (one launch for all layers)."""
     rad.R, rad.E, rad.keep, rad.have_rows = pre.shape[0], n_edges, 0, 1
+    rad.packed = int(bool(packed and p_tab is not None))
     rad.use_table = int(table is not None)
     if table is not None:
         _table_fields(rad, table)
@@ -341,6 +356,10 @@ class RadialStackFn(torch.autograd.Function):
             rad.h = _ptr(buf, carve.off["h"])
             if use_table:
                 rad.T = out.data_ptr()
+                if TP_TABLE_PACKED and slope is None and blocks == 1 and in_kernel_table(plan, True, dev):
+                    # the in-kernel form's packed table: written by the stack's own launch for all layers (e3k_rtable_pack_multi)
+                    out._e3k_packed = _packed_buffer(r, plan.last_spec.d_out, dev)
+                    rad.in_kernel, rad.P = 1, out._e3k_packed.data_ptr()
             else:
                 rad.w = out.data_ptr()
             outs.append(out)
@@ -470,6 +489,13 @@ class KwStackFn(torch.autograd.Function):
         n, n_keys, v = len(plans), groups.n_keys, plans[0].sc_spec.v
         a_rep = torch.empty(n_keys, v, device=dev, dtype=torch.float32)
         ms = [torch.empty(n_keys, p.sc_ld_m, device=dev, dtype=torch.float32) for p in plans]
+        if any(ctx.needs_input_grad):
+            # the layers' keyed weight-gradient GEMMs ADD into gM_l: zero-filled here for all layers by ONE launch (each layer's
+            # backward takes its slice exactly once -- a second backward through the same graph allocates and fills its own)
+            sizes = [n_keys * p.sc_ld_m for p in plans]
+            gm_all = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+            for m, g in zip(ms, torch.split(gm_all, sizes)):
+                m._e3k_gm = [g.view(n_keys, -1)]
         handles = (C.c_void_p * n)(*[native_layer(p).handle(dev) for p in plans])
         items = (L.KwStackItem * n)()
         for it, w, m in zip(items, w_sc, ms):
@@ -593,10 +619,14 @@ class NativeConvBlockFn(torch.autograd.Function):
         inker = in_kernel_table(plan, table, dev)
         if stack and inker:
             w = None                                 # the tensor-product kernels read the table rows themselves
+            p_ready = False
             if TP_TABLE_PACKED:
-                with conv_block._on(side, main):     # (packed behind the stack's rows, on the radial stream)
-                    p_tab = _packed_buffer(pre.shape[0], plan.last_spec.d_out, dev)
-            _stack_radial_struct(a.rad, plan, pre, table, e, None, p_tab)
+                p_tab = getattr(pre, "_e3k_packed", None)      # packed by the stack, with the tables of the other layers
+                p_ready = p_tab is not None
+                if p_tab is None:
+                    with conv_block._on(side, main):     # (packed behind the stack's rows, on the radial stream)
+                        p_tab = _packed_buffer(pre.shape[0], plan.last_spec.d_out, dev)
+            _stack_radial_struct(a.rad, plan, pre, table, e, None, p_tab, packed=p_ready)
         elif stack and table is None:
             w = pre                                  # per-edge weights straight from the stack
             _stack_radial_struct(a.rad, plan, pre, None, e, None)
@@ -836,8 +866,15 @@ class NativeConvBlockFn(torch.autograd.Function):
         g_pre = g_m = None
         if has_sc and have_m and need_m:      # gM: written by the keyed weight-gradient GEMM (weight-gradient stream), read by
             # KwStackFn's backward on the self-connection stream (the executor orders the two)
-            with conv_block._on(side3, main):
-                g_m = torch.empty(groups.n_keys, plan.sc_ld_m, device=dev, dtype=torch.float32)
+            ready = getattr(m_pre, "_e3k_gm", None)
+            if ready:                           # zero-filled by KwStackFn's forward with the other layers' (taken once)
+                g_m = ready.pop()
+                a.have_m = 2
+                if fork:
+                    g_m.record_stream(side3)
+            else:
+                with conv_block._on(side3, main):
+                    g_m = torch.empty(groups.n_keys, plan.sc_ld_m, device=dev, dtype=torch.float32)
             a.gm = g_m.data_ptr()
         # ---- scratch: one allocation
         sc_ = _Carve()

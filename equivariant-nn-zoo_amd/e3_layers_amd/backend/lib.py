@@ -88,7 +88,7 @@ class LayerDesc(C.Structure):
 
 class LayerRadial(C.Structure):
     _fields_ = [("R", C.c_int64), ("E", C.c_int64), ("use_table", C.c_int32), ("keep", C.c_int32), ("knots", C.c_int32),
-                ("have_rows", C.c_int32), ("in_kernel", C.c_int32), ("_pad", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
+                ("have_rows", C.c_int32), ("in_kernel", C.c_int32), ("packed", C.c_int32), ("radial", C.c_void_p), ("bin", C.c_void_p), ("bin_ptr", C.c_void_p), ("bin_perm", C.c_void_p),
                 ("bin_coef", C.c_void_p), ("bin_seg", C.c_void_p), ("w_last", C.c_void_p), ("w_hidden", C.c_void_p * 4), ("h", C.c_void_p),
                 ("z", C.c_void_p * 4), ("T", C.c_void_p), ("w", C.c_void_p), ("erec_dst", C.c_void_p), ("erec_src", C.c_void_p), ("P", C.c_void_p)]
 
@@ -232,6 +232,7 @@ SIGNATURES = {
     "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),
     "e3k_rtable_interp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _I32, _P]),
     "e3k_rtable_pack": (C.c_int, [_P, _I32, _I32, _P, _P]),
+    "e3k_rtable_pack_multi": (C.c_int, [_P, _I32, _P, _P, _I32, _P]),
     "e3k_rtable_interp_packed": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "e3k_rtable_guard": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _F, _F, _I32, _P]),
     "e3k_act_fwd": (C.c_int, [_P, _I64, _I32, _F, _P, _P]),

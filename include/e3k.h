@@ -374,6 +374,8 @@ int e3k_rtable_interp_bwd(const float* g_w, const float* coef, const float* scal
  * 512 knots).
  * e3k_rtable_interp_packed materialises w[e, :] from P with the kernels' own arithmetic (bit-identical; tests). */
 int e3k_rtable_pack(const float* T, int32_t K, int32_t W, void* P, void* stream);
+/* ... n <= 16 tables of one row count (the layers of a radial stack) in ONE launch; the same bits as n e3k_rtable_pack calls */
+int e3k_rtable_pack_multi(const float* const* T, int32_t K, const int32_t* W, void* const* P, int32_t n, void* stream);
 int e3k_rtable_interp_packed(const void* P, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
                              int32_t W, float* w, void* stream);
 
@@ -639,7 +641,8 @@ typedef struct {
   int32_t in_kernel;         /* table only, plans with e3k_tp_table_supported: the tensor-product kernels interpolate the
                                 path weights from T themselves (e3k_tp_fwd_table / e3k_tp_bwd_x_table): no interpolation
                                 pass, w unused (may be null); the backward needs T */
-  int32_t _pad;
+  int32_t packed;            /* P already holds the packed form of T (e3k_radial_stack_fwd packs the tables of all its layers
+                                in one launch when their rads carry in_kernel and P): the layer does not pack again */
   const float* radial;       /* [R, k0] */
   const int32_t* bin;        /* table: knot per edge, */
   const int32_t* bin_ptr;    /*        edges grouped by knot (backward), */
@@ -679,7 +682,8 @@ typedef struct {
   int64_t N, E;
   int32_t in_cf, out_cf, fork, n_keys, need_x, need_attrs, need_radial, acc_sc;
   int32_t have_m, fuse_xw;           /* have_m: `gm` (gradient of the per-key weights) is an OUTPUT handed to e3k_kw_stack_bwd;
-                                        no weight / attribute gradient of the self-connection is formed here.
+                                        no weight / attribute gradient of the self-connection is formed here (2: gm arrives
+                                        zero-filled, 1: it is zero-filled here).
                                         fuse_xw: with rad.P, the per-edge weight gradient g_w is formed by the input-gradient
                                         walk (e3k_tp_bwd_xw_ptable) instead of a pass of its own (e3k_tp_bwd_w) */
   void *main, *side, *side2, *side3;
