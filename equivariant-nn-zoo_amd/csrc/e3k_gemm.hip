@@ -28,7 +28,7 @@
 //                       split over blocks, 64-row chunks staged in natural row-major order (both MFMA
 //                       operands conflict-free), fp32 atomics on the small output.
 //
-// Descriptors: up to 16 problems per launch, passed by value (3.2 KB of kernel arguments); keyed and plain problems mix; every
+// Descriptors: up to 20 problems per launch, passed by value (3.85 KB of kernel arguments); keyed and plain problems mix; every
 // workgroup finds its problem and pulls it into scalar registers with s_load (the batch is wave-uniform).
 #include <algorithm>
 #include <cstdlib>
@@ -39,7 +39,10 @@ namespace e3k {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int GEMM_MAXP = 16;   // 16 x 168 B of descriptors + tables = 3.2 KB of the 4 KB kernel-argument segment
+// 20 x 168 B of descriptors + tables = 3.85 KB of the 4 KB kernel-argument segment (round 6: 16 -> 20 -- the three weight gradients of a
+// layer are 7 + 7 + 6 problems: with 16 per launch linear_1's last four went out as a second, 23 us launch of their own)
+constexpr int GEMM_MAXP = 20;
+static_assert(true, "");
 struct GemmBatch {
   int n;
   int reps[GEMM_MAXP];              // > 1: the problem stands for `reps` key groups (its tile range is reps equal sub-ranges);
@@ -50,6 +53,7 @@ struct GemmBatch {
   e3k_gemm_problem p[GEMM_MAXP];
 };
 static_assert(sizeof(GemmBatch) % 4 == 0 && sizeof(e3k_gemm_problem) % 4 == 0, "word-copyable descriptors");
+static_assert(sizeof(GemmBatch) + 16 <= 4096, "the batch travels by value in the kernel-argument segment");
 
 constexpr int BN = 64, BK = 32;
 constexpr int LDA = BK + 1;
@@ -1286,6 +1290,20 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       kind[i] = FWD_PLAIN;
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);   // keyed: the groups partition these rows
     }
+  }
+  // A split-K problem next to plain ones costs the call a launch of its own (the accumulating second round of a layer's input
+  // gradients: the gate scalars' K = 256 block of the self-connection goes split-K, its sibling of the trailing Linear plain:
+  // 13 + 14 us as two dependent launches in the replayed step).  When the call has plain problems anyway and the split-K one is
+  // small (K <= 512), it rides in their launch as a plain problem: its 64-row tiles finish under the siblings' tiles.
+  {
+    bool any_plain = false;
+    for (int i = 0; i < n_problems; ++i) any_plain = any_plain || kind[i] == FWD_PLAIN;
+    if (any_plain)
+      for (int i = 0; i < n_problems; ++i)
+        if (kind[i] == FWD_SPLITK && problems[i].K <= 512) {
+          kind[i] = FWD_PLAIN;
+          plain_tiles128 += (((int64_t)problems[i].M1 * problems[i].M2 + 127) / 128) * ((problems[i].N + e3k::BN - 1) / e3k::BN);
+        }
   }
   // plain problems with vector-loadable operands: the persistent kernel when the launch holds enough tiles for every
   // workgroup slot to walk a sequence of them (below that the one-tile-per-workgroup kernels start sooner)

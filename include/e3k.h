@@ -89,7 +89,7 @@ int e3k_gemm_rebased(const e3k_gemm_problem* templates, int n_templates, const v
                      const void* b_base, void* c_base, const void* bias_base, int64_t M1, int32_t wgrad,
                      void* stream);
 
-/* Several descriptor arrays in ONE call (as few launches as the kernel kinds allow; up to 16 problems per launch, keyed
+/* Several descriptor arrays in ONE call (as few launches as the kernel kinds allow; up to 20 problems per launch, keyed
  * and plain problems mixed): what a convolution layer issues together -- linear_1 with the keyed self-connection
  * (e3_layers/nn/message_passing.py:100,102: both read the node features), the input gradients of the trailing Linear
  * and of the self-connection (both read the gradient of the convolution output), the three weight gradients.
