@@ -857,11 +857,25 @@ __global__ __launch_bounds__(256) void counts_to_ptr_kernel(const int64_t* __res
 }
 
 // one-hot rows of a type index: out[r, t] = (idx[r] == t) -- replaces zeros + scatter + a dtype conversion (OneHotEncoding)
-__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ idx, int64_t total, int T, float* __restrict__ out) {
+// (an index outside [0, T) leaves an all-zero row -- the reference's torch one_hot raises on it: here bit 2 of the caller's error
+//  flag is set, ORed in and never cleared by this kernel, so the flag may be a persistent one that several checks share)
+__global__ __launch_bounds__(256) void onehot_kernel(const int64_t* __restrict__ idx, int64_t total, int T, float* __restrict__ out,
+                                                     int32_t* __restrict__ bad) {
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int64_t r = i / T;
-    out[i] = idx[r] == (int64_t)(i - r * T) ? 1.f : 0.f;
+    const int64_t v = idx[r];
+    const int t = (int)(i - r * T);
+    out[i] = v == (int64_t)t ? 1.f : 0.f;
+    if (bad && t == 0 && (v < 0 || v >= T)) atomicOr(bad, 4);
   }
+}
+
+// the value of a device error flag to (pinned, device-visible) host memory and the flag cleared, in ONE launch and in stream
+// order: a flag that several replays fold their index checks into is handed over exactly once per bad batch -- a copy followed
+// by a clear issued when the HOST gets round to reading the copy loses whatever was flagged in between
+__global__ void flag_fetch_clear_kernel(int32_t* __restrict__ flag, int32_t* __restrict__ host) {
+  const int32_t v = atomicExch(flag, 0);
+  __hip_atomic_store(host, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // column-fixed kernels: grid.x covers the columns, grid.y strides the rows (about 8 k workgroups in all)
@@ -1345,12 +1359,19 @@ extern "C" int e3k_counts_to_ptr(const int64_t* counts, int32_t n_seg, int32_t* 
   return E3K_OK;
 }
 
-extern "C" int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, void* stream) {
+extern "C" int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, int32_t* bad_flag, void* stream) {
   if (rows < 0 || num_types <= 0) return E3K_ERR_INVALID;
   if (rows == 0) return E3K_OK;
   if (!idx || !out) return E3K_ERR_INVALID;
   hipLaunchKernelGGL(e3k::onehot_kernel, dim3(e3k::grid_for(rows * num_types)), dim3(256), 0, (hipStream_t)stream, idx,
-                     rows * num_types, num_types, out);
+                     rows * num_types, num_types, out, bad_flag);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+
+extern "C" int e3k_flag_fetch_clear(int32_t* flag, int32_t* host_out, void* stream) {
+  if (!flag || !host_out) return E3K_ERR_INVALID;
+  hipLaunchKernelGGL(e3k::flag_fetch_clear_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, host_out);
   E3K_CHECK_LAUNCH();
   return E3K_OK;
 }

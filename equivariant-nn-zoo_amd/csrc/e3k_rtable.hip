@@ -57,7 +57,7 @@ constexpr int RT_SEG = 64;          // edges of one knot summed by one wave of t
 __global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __restrict__ r, const int64_t* __restrict__ key, int64_t E,
                                                                float h_inv, int32_t K, int32_t KT, int32_t* __restrict__ bin,
                                                                float* __restrict__ coef, int32_t* __restrict__ lrank,
-                                                               int32_t* __restrict__ chunk_hist) {
+                                                               int32_t* __restrict__ chunk_hist, int32_t* __restrict__ bad) {
   extern __shared__ int32_t hist_all[];                      // [4][KT + 1]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   int32_t* hist = hist_all + wv * (KT + 1);
@@ -84,10 +84,12 @@ __global__ __launch_bounds__(256) void rtable_bins_rank_kernel(const float* __re
       c.y = tp1 * tm1 * tm2 * 0.5f;
       c.z = -tp1 * t * tm2 * 0.5f;
       c.w = tp1 * t * tm1 * (1.f / 6.f);
-      if (key) {      // (a key outside [0, n_keys) would index past the stacked table: folded into block 0)
+      if (key) {      // (a key outside [0, n_keys) would index past the stacked table: folded into block 0 -- and FLAGGED, bit 3)
         const int64_t kk = key[e];
         const int nk = (KT + 1) / (K + 1);
-        i += (kk >= 0 && kk < nk) ? (int)kk * (K + 1) : 0;
+        const bool in_range = kk >= 0 && kk < nk;
+        i += in_range ? (int)kk * (K + 1) : 0;
+        if (!in_range && bad) atomicOr(bad, 8);
       }
       bin[e] = i;
       *reinterpret_cast<float4*>(coef + 4 * e) = c;
@@ -607,7 +609,8 @@ extern "C" int64_t e3k_rtable_bins_workspace_ints(int64_t E, int32_t K) {
 }
 
 static int rtable_bins_impl(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K, int32_t* bin,
-                            float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
+                            float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, int32_t* bad_flag,
+                            void* stream) {
   // h_inv = 1 / knot spacing; a power of two makes x = r * h_inv and the offset t = x - floor(x) exact (the caller's choice:
   // backend/radial_table.py lays its tables out that way)
   if (E < 0 || K < 4 || !(h_inv > 0.f) || n_keys < 1) return E3K_ERR_INVALID;
@@ -622,7 +625,7 @@ static int rtable_bins_impl(const float* r, const int64_t* key, int32_t n_keys, 
   int32_t* chunk_hist = workspace + E;
   if (E > 0)
     hipLaunchKernelGGL(e3k::rtable_bins_rank_kernel, dim3((unsigned)n_chunks), dim3(256), sizeof(int32_t) * 4 * (KT + 1), st, r, key, E,
-                       h_inv, K, KT, bin, coef, lrank, chunk_hist);
+                       h_inv, K, KT, bin, coef, lrank, chunk_hist, bad_flag);
   hipLaunchKernelGGL(e3k::rtable_bins_scan_kernel, dim3(1), dim3(1024), 0, st, chunk_hist, (int32_t)n_chunks, KT, bin_ptr, bin_seg);
   if (E > 0)
     hipLaunchKernelGGL(e3k::rtable_bins_place_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, st, bin, lrank, chunk_hist,
@@ -633,16 +636,16 @@ static int rtable_bins_impl(const float* r, const int64_t* key, int32_t n_keys, 
 
 extern "C" int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* bin, float* coef,
                                int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream) {
-  return rtable_bins_impl(r, nullptr, 1, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, stream);
+  return rtable_bins_impl(r, nullptr, 1, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, nullptr, stream);
 }
 
 // n_keys tables of K + 1 rows stacked: bin[e] = key[e] (K + 1) + i; bin_ptr / bin_seg [n_keys (K + 1) + 1]; workspace:
 // e3k_rtable_bins_workspace_ints(E, n_keys (K + 1) - 1)
 extern "C" int e3k_rtable_bins_keyed(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K,
                                      int32_t* bin, float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm,
-                                     int32_t* workspace, void* stream) {
+                                     int32_t* workspace, int32_t* bad_flag, void* stream) {
   if (E > 0 && !key) return E3K_ERR_INVALID;
-  return rtable_bins_impl(r, key, n_keys, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, stream);
+  return rtable_bins_impl(r, key, n_keys, E, h_inv, K, bin, coef, bin_ptr, bin_seg, bin_perm, workspace, bad_flag, stream);
 }
 
 extern "C" int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E,

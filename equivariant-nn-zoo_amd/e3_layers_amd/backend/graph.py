@@ -75,12 +75,10 @@ def _check_pending_flags() -> None:
     while _pending_flags and _pending_flags[0][0].query():
         _, host, msg, sticky = _pending_flags.pop(0)
         if int(host[0]) != 0:
-            if sticky is not None:
-                # a persistent (captured-step) flag: reported ONCE, then cleared -- a caller that catches the error and skips the
-                # batch must not see it again on every later, valid batch.  Copies of the same flag already in flight
-                # are dropped with it.
-                sticky.zero_()
-                _pending_flags[:] = [p for p in _pending_flags if p[3] is not sticky]
+            # (a persistent flag -- ``sticky`` -- was cleared on the device by the same launch that sent this value home
+            #  (``e3k_flag_fetch_clear``, in stream order): every flagged batch is reported exactly once, nothing that was flagged
+            #  between this copy and a later host-side clear can be lost, and a caller that catches the error and skips
+            #  the batch does not see it again on later, valid batches)
             raise ValueError(msg)
 
 
@@ -120,9 +118,27 @@ def poll_capture_flags(device=None) -> None:
     f = _capture_flags.get(idx)
     if f is not None:
         with torch.cuda.device(idx):
-            defer_flag(f, "a batch fed through a captured (graph-replayed) step held node ids outside [0, num_nodes) in its edge_index "
-                          "(such edges were attached to node 0) or row keys outside [0, n_keys) (such rows were dropped from the keyed "
-                          "self-connection)", sticky=f)
+            defer_flag(f, _PERSISTENT_MSG, sticky=f)
+
+
+_PERSISTENT_MSG = ("a batch held node ids outside [0, num_nodes) in its edge_index (such edges were attached to node 0), row keys "
+                   "outside [0, n_keys) (such rows were dropped from the keyed self-connection), a type index outside [0, num_types) "
+                   "(OneHotEncoding: an all-zero row where the reference's one_hot raises) or an edge key outside the keyed radial tables")
+
+
+def persistent_flag(device) -> torch.Tensor:
+    """The device's persistent error flag for kernels that only ever OR bits into it (``e3k_onehot``, ``e3k_rtable_bins_keyed``,
+    captured index checks); allocated on first use -- OUTSIDE a capture (``CapturedStep`` does that before it records)."""
+    return capture_flag(device)
+
+
+def report_persistent(device) -> None:
+    """Eager callers of the OR-only kernels: send the device's persistent flag home behind what was just enqueued (one launch, no
+    sync; read by the next build / optimizer step / ``check_indices()``).  While a stream captures nothing is recorded here:
+    ``CapturedStep`` fetches the flag after every replay."""
+    if torch.cuda.is_current_stream_capturing():
+        return
+    poll_capture_flags(device)
 
 
 def defer_flag(flag: torch.Tensor, message: str, sticky: Optional[torch.Tensor] = None) -> None:
@@ -144,7 +160,12 @@ def defer_flag(flag: torch.Tensor, message: str, sticky: Optional[torch.Tensor] 
         _flag_ring = torch.zeros(_FLAG_RING, dtype=torch.int32).pin_memory()
     host = _flag_ring[_flag_next:_flag_next + 1]
     _flag_next = (_flag_next + 1) % _FLAG_RING
-    host.copy_(flag, non_blocking=True)
+    if sticky is not None and sticky is flag:
+        from . import lib as L
+
+        L.check(L.load().e3k_flag_fetch_clear(L.ptr(flag), host.data_ptr(), L.stream_ptr()), "e3k_flag_fetch_clear")
+    else:
+        host.copy_(flag, non_blocking=True)
     ev = torch.cuda.Event()
     ev.record()
     _pending_flags.append((ev, host, message, sticky))

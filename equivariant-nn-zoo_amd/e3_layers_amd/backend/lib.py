@@ -181,7 +181,8 @@ SIGNATURES = {
     "e3k_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "e3k_counts_to_ptr": (C.c_int, [_P, _I32, _P, _P]),
     "e3k_sq_error": (C.c_int, [_P, _P, _P, _I32, _I64, C.c_float, _P, _P, _P]),
-    "e3k_onehot": (C.c_int, [_P, _I64, _I32, _P, _P]),
+    "e3k_onehot": (C.c_int, [_P, _I64, _I32, _P, _P, _P]),
+    "e3k_flag_fetch_clear": (C.c_int, [_P, _P, _P]),
     "e3k_fctp_reduce_bwd": (C.c_int, [_P, _P, _P, _I32, _I32, _I32, _I32, _I64, _I64, _I64, _P, _I32, _P, _P]),
     "e3k_edge_vector_fwd": (C.c_int, [_P, _P, _P, _I64, _P, _P, _P]),
     "e3k_edge_vector_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _P, _P]),
@@ -226,7 +227,7 @@ SIGNATURES = {
     "e3k_group_rows": (C.c_int, [_P, _I64, _I32, _P, _P, _P, _P, _P]),
     "e3k_rtable_bins_workspace_ints": (C.c_int64, [_I64, _I32]),
     "e3k_rtable_bins": (C.c_int, [_P, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P]),
-    "e3k_rtable_bins_keyed": (C.c_int, [_P, _P, _I32, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P]),
+    "e3k_rtable_bins_keyed": (C.c_int, [_P, _P, _I32, _I64, _F, _I32, _P, _P, _P, _P, _P, _P, _P, _P]),
     "e3k_rtable_interp_fwd": (C.c_int, [_P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "e3k_rtable_interp_fwd2": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "e3k_rtable_bwd_workspace_floats": (C.c_int64, [_I64, _I32, _I32]),

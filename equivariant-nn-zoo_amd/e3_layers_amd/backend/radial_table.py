@@ -127,8 +127,14 @@ def build_bins(r: torch.Tensor, r_max: float, target: int, key: Optional[torch.T
             key = key.long().contiguous()
         if key.numel() != e:
             raise ValueError(f"{key.numel()} keys for {e} radii")
+        from . import graph as _graph
+
+        capturing = torch.cuda.is_current_stream_capturing()
+        flag = _graph._capture_flags.get(dev.index) if capturing else _graph.persistent_flag(dev)
         L.check(lib.e3k_rtable_bins_keyed(L.ptr(r), L.ptr(key), n_keys, e, 1.0 / h, knots, L.ptr(bin32), L.ptr(coef), L.ptr(ptr),
-                                          L.ptr(seg), L.ptr(perm), L.ptr(work), L.stream_ptr()), "e3k_rtable_bins_keyed")
+                                          L.ptr(seg), L.ptr(perm), L.ptr(work), L.ptr(flag), L.stream_ptr()), "e3k_rtable_bins_keyed")
+        if flag is not None:      # (a key outside [0, n_keys) interpolates in another bond type's table: reported like a bad edge endpoint)
+            _graph.report_persistent(dev)
     bins = KnotBins(bin32, coef, ptr, perm, seg, last, h, buf)
     bins.blocks = n_keys
     return bins
@@ -397,15 +403,26 @@ def guard_error(w_last, slope: bool = False):
 _HOST_RING = None      # pinned float slots for the read-backs, allocated once (a pinned allocation synchronises the device)
 _HOST_NEXT = 0
 _HOST_SLOTS = 512
+_HOST_BUSY = {}        # slot index -> event of the read-back that last took it (a slot is not handed out again while
+                       # that read-back has not landed and been looked at -- 512 outstanding read-backs mean nobody polls)
 
 
 def _host_slot() -> torch.Tensor:
     global _HOST_RING, _HOST_NEXT
     if _HOST_RING is None:
         _HOST_RING = torch.zeros(_HOST_SLOTS, dtype=torch.float32).pin_memory()
-    slot = _HOST_RING[_HOST_NEXT:_HOST_NEXT + 1]
-    _HOST_NEXT = (_HOST_NEXT + 1) % _HOST_SLOTS
-    return slot
+    for _ in range(_HOST_SLOTS):
+        i = _HOST_NEXT
+        _HOST_NEXT = (_HOST_NEXT + 1) % _HOST_SLOTS
+        ev = _HOST_BUSY.get(i)
+        if ev is None or ev.query():
+            _HOST_BUSY.pop(i, None)
+            _HOST_SLOT_TAKEN[0] = i
+            return _HOST_RING[i:i + 1]
+    raise RuntimeError("radial table guard: 512 read-backs outstanding -- nothing polls the guards (drain_guards() after a sync)")
+
+
+_HOST_SLOT_TAKEN = [0]
 
 
 def _send(g: _Guard, index: int, reset: bool) -> None:
@@ -416,6 +433,7 @@ def _send(g: _Guard, index: int, reset: bool) -> None:
         g.dev[0:1].zero_()
     ev = torch.cuda.Event()
     ev.record()
+    _HOST_BUSY[_HOST_SLOT_TAKEN[0]] = ev
     g.pending.append((ev, host))
 
 

@@ -162,8 +162,16 @@ class OneHotEncoding(Module):
         if idx.is_cuda and idx.dtype == torch.int64 and idx.dim() == 1:      # one launch instead of zeros + scatter + conversion
             from ..backend import lib as L
 
+            from ..backend import graph as _graph
+
             one_hot = torch.empty(idx.shape[0], self.num_types, device=idx.device, dtype=torch.float32)
-            L.check(L.load().e3k_onehot(L.ptr(idx), idx.shape[0], self.num_types, L.ptr(one_hot), L.stream_ptr()), "e3k_onehot")
+            # an index outside [0, num_types) leaves a zero row and a bit in the device's persistent error flag: raised by the next
+            # topology build / optimizer step / check_indices(), as a bad edge endpoint is (the reference's one_hot raises at once)
+            capturing = torch.cuda.is_current_stream_capturing()
+            flag = _graph._capture_flags.get(idx.device.index) if capturing else _graph.persistent_flag(idx.device)
+            L.check(L.load().e3k_onehot(L.ptr(idx), idx.shape[0], self.num_types, L.ptr(one_hot), L.ptr(flag), L.stream_ptr()), "e3k_onehot")
+            if flag is not None:
+                _graph.report_persistent(idx.device)
         else:
             one_hot = torch.nn.functional.one_hot(idx, num_classes=self.num_types).to(dtype=torch.float)
         set_row_key(one_hot, idx, self.num_types)   # rows are a function of the type index only

@@ -96,7 +96,8 @@ def _stream_alias(t: Tensor, stream) -> Tensor:
         # cyclic collector frees -- 0.3 MB of device memory per step piled up between its runs.  The consumers' autograd
         # graphs keep the alias alive for as long as it matters.
         cache[key] = weakref.ref(alias)
-        for attr in ("_e3k_key", "_e3k_data_only", "_e3k_param_only"):      # row keys / provenance marks ride along
+        for attr in ("_e3k_key", "_e3k_data_only", "_e3k_param_only", "_e3k_blocks"):      # row keys / provenance marks / the block count
+            # of a keyed source's stacked knot basis (without it the guard differenced across the tables' seams) ride along
             if hasattr(t, attr):
                 setattr(alias, attr, getattr(t, attr))
     return alias

@@ -38,7 +38,12 @@ class GradientOutput(Module):
         wrt = self.inputKeyMap(data)["x"]
         old = wrt.requires_grad
         wrt.requires_grad_(True)
-        if old and self.training:
+        #  edge vectors the CALLER supplied and that require grad hang on some other leaf (a cell, a strain): the force
+        # block's second pass hands back parameter gradients only, so the force-loss share of that leaf's gradient would be
+        # missing -- such a call takes the composed path too
+        pre = data.get("edge_vector") if "edge_vector" in data else None
+        foreign = pre is not None and bool(pre.requires_grad)
+        if (old and self.training) or foreign:
             # the caller differentiates w.r.t. ``x`` itself (it required grad before this call) and the graph of the gradient is
             # kept: d loss / d x of a loss on the gradients needs third derivatives of the layers -- the force block
             # (backend/conv_force.py) does not form them, the composed per-kernel path does

@@ -351,9 +351,12 @@ int e3k_rtable_bins(const float* r, int64_t E, float h_inv, int32_t K, int32_t* 
 /* KEYED tables: the edge embedding is a function of the radius and of a small categorical key per edge (config_diffusion.py:73-82:
  * the Bessel basis concatenated with a 4-way bond-type one-hot) -- n_keys tables of K + 1 rows stacked into one of n_keys (K + 1)
  * rows, bin[e] = key[e] (K + 1) + i.  bin_ptr / bin_seg [n_keys (K + 1) + 1]; workspace e3k_rtable_bins_workspace_ints(E,
- * n_keys (K + 1) - 1).  Every consumer takes the stacked table with K := n_keys (K + 1) - 1. */
+ * n_keys (K + 1) - 1).  Every consumer takes the stacked table with K := n_keys (K + 1) - 1.
+ * bad_flag (may be NULL): bit 3 is ORed in when a key lies outside [0, n_keys) (such an edge interpolates in block 0); the flag is
+ * never cleared here, so it may be a persistent one shared with other checks (e3k_flag_fetch_clear hands it to the host). */
 int e3k_rtable_bins_keyed(const float* r, const int64_t* key, int32_t n_keys, int64_t E, float h_inv, int32_t K, int32_t* bin,
-                          float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, void* stream);
+                          float* coef, int32_t* bin_ptr, int32_t* bin_seg, int32_t* bin_perm, int32_t* workspace, int32_t* bad_flag,
+                          void* stream);
 int e3k_rtable_interp_fwd(const float* T, const int32_t* bin_perm, const int32_t* bin, const float* coef, int64_t E, int32_t K,
                           int32_t W, float* w, void* stream);
 /* two tables of one shape through the same weights in one pass (force training: w from T and dw/dr from the slope table) */
@@ -470,8 +473,13 @@ int e3k_layernorm_bwd2(const float* x, const float* g_y, const float* h, const f
  * ptr[0] = 0, ptr[s + 1] = counts[0] + .. + counts[s]; ptr has n_seg + 1 entries */
 int e3k_counts_to_ptr(const int64_t* counts, int32_t n_seg, int32_t* ptr, void* stream);
 /* one-hot rows of a type index (OneHotEncoding, nn/embedding.py:271-281: torch.nn.functional.one_hot(...).to(float)):
- * out [rows, num_types], out[r, t] = (idx[r] == t); an index outside [0, num_types) gives a zero row */
-int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, void* stream);
+ * out [rows, num_types], out[r, t] = (idx[r] == t); an index outside [0, num_types) gives a zero row AND ORs bit 2 into
+ * *bad_flag (may be NULL; never cleared here: the reference's one_hot raises on such an index) */
+int e3k_onehot(const int64_t* idx, int64_t rows, int32_t num_types, float* out, int32_t* bad_flag, void* stream);
+/* *host_out = *flag; *flag = 0 -- one launch, in stream order (host_out: pinned, device-visible host memory).  How a persistent
+ * device error flag that kernels only ever OR into (captured index checks, the two above) reaches the host exactly once per
+ * flagged batch. */
+int e3k_flag_fetch_clear(int32_t* flag, int32_t* host_out, void* stream);
 /* sorted-segment sum (Pooling, nn/output.py:66-74): out[s, :] = sum_{r in [ptr[s], ptr[s+1])} x[r, :] (* 1/count if mean) */
 int e3k_segment_sum(const float* x, const int32_t* ptr, int64_t n_seg, int32_t dim, int32_t mean, float* out,
                     void* stream);

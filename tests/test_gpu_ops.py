@@ -1252,7 +1252,18 @@ def test_small_step_plumbing_kernels_match_torch(dev):
     gen = torch.Generator().manual_seed(3)
     idx = torch.randint(0, 7, (1234,), generator=gen).to(dev)
     one = torch.empty(1234, 7, device=dev)
-    L.check(lib.e3k_onehot(L.ptr(idx), 1234, 7, L.ptr(one), L.stream_ptr()), "e3k_onehot")
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.e3k_onehot(L.ptr(idx), 1234, 7, L.ptr(one), L.ptr(flag), L.stream_ptr()), "e3k_onehot")
+    assert int(flag) == 0
+    bad = idx.clone()
+    bad[17] = 7                                   # one index outside [0, 7): a zero row and bit 2 of the flag
+    one_bad = torch.empty(1234, 7, device=dev)
+    L.check(lib.e3k_onehot(L.ptr(bad), 1234, 7, L.ptr(one_bad), L.ptr(flag), L.stream_ptr()), "e3k_onehot")
+    assert int(flag) == 4 and float(one_bad[17].abs().sum()) == 0.0
+    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+    L.check(lib.e3k_flag_fetch_clear(L.ptr(flag), host.data_ptr(), L.stream_ptr()), "e3k_flag_fetch_clear")
+    torch.cuda.synchronize()
+    assert int(host[0]) == 4 and int(flag) == 0   # handed over and cleared by one launch
     assert torch.equal(one, torch.nn.functional.one_hot(idx, 7).float())
     for g in (1, 255, 256, 257, 1000):
         counts = torch.randint(0, 40, (g,), generator=gen).to(dev)
@@ -1312,3 +1323,27 @@ def test_tp_input_and_weight_gradient_in_one_walk_streamed(dev, left, out):
     else:
         assert rel_err(gx, gx_ref) < 1e-6
     assert rel_err(gw, gw_ref) < 1e-6
+
+
+@pytest.mark.gpu
+def test_type_index_outside_the_one_hot_range_is_reported(dev):
+    """ADVICE r5: ``torch.nn.functional.one_hot`` raises on an index outside [0, num_types) (``e3_layers/nn/embedding.py:271-281``);
+    the one-launch kernel wrote a zero row and said nothing.  Now it ORs a bit into the device's persistent error flag, which
+    reaches the host without a sync and is raised by ``check_indices()`` (or the next build / optimizer step) -- once."""
+    from e3_layers_amd.backend import graph as G
+    from e3_layers_amd.nn import OneHotEncoding
+
+    G.check_indices()
+    enc = OneHotEncoding(num_types=5, irreps_out=("5x0e", "one_hot"), irreps_in=("1x0e", "input"))
+    good = torch.randint(0, 5, (300, 1)).to(dev)
+    out, _ = enc({"input": good}, {"input": ("node", "1x0e")})
+    G.check_indices()                                             # nothing to report
+    assert torch.equal(out["one_hot"].argmax(1), good.view(-1))
+    bad = good.clone()
+    bad[7, 0] = 5
+    out, _ = enc({"input": bad}, {"input": ("node", "1x0e")})
+    assert float(out["one_hot"][7].abs().sum()) == 0.0
+    with pytest.raises(ValueError, match="type index outside"):
+        G.check_indices()
+    enc({"input": good.clone()}, {"input": ("node", "1x0e")})      # reported once: a later, valid batch is clean
+    G.check_indices()
