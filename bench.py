@@ -705,9 +705,20 @@ def main():
     ops.PROFILE = {}
     for nl in conv_native._LAYERS:
         nl.profile(16)
-    for _ in range(min(args.steps, 5)):
+    from e3_layers_amd.nn import message_passing as _mp_
+
+    forked_ = (_mp_.FORK_MIN_EDGES, _mp_.FORK_MIN_EDGES_TABLE)
+    if graph is not None:
+        # A replayed step is ONE in-order queue.  Event pairs cannot bracket a kernel inside a graph on this runtime (the HIP 7.0
+        # runtime torch ships rejects hipEventRecordWithFlags(hipEventRecordExternal) under a capture -- tools/micro/ext_event_torch.py;
+        # ROCm 7.2's own accepts it: tools/micro/ext_event.hip), so the kernels' durations are taken from eager steps laid out like
+        # the replay: one stream, every kernel alone on the chip.  profiles/r06_bench_kernel_stats.csv (rocprofv3 over this very
+        # command: it does see the replayed kernels) carries the in-graph durations to compare with.
+        _mp_.FORK_MIN_EDGES = _mp_.FORK_MIN_EDGES_TABLE = 10 ** 12
+    for _ in range(min(args.steps, 5) + (2 if graph is not None else 0)):
         step()
     torch.cuda.synchronize()
+    _mp_.FORK_MIN_EDGES, _mp_.FORK_MIN_EDGES_TABLE = forked_
     records, ops.PROFILE = ops.PROFILE, None
     records = native_records(records)
     records.update(live)
