@@ -44,7 +44,7 @@ import torch.distributed as dist
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 at 2.4 GHz (the clock an MFMA loop sustains is lower)
 # rocprofv3 --pmc passes over this command at the two l_max values (tools/collect_profiles_r04.sh, tools/summarize_profiles_r04.py)
-TRAFFIC_FILES = {2: "profiles/r05_tp_traffic.json", 3: "profiles/r05_lmax3_tp_traffic.json"}
+TRAFFIC_FILES = {2: "profiles/r06_tp_traffic.json", 3: "profiles/r06_lmax3_tp_traffic.json"}
 
 
 def parse():

@@ -63,6 +63,29 @@ __global__ void tick_kernel(float* __restrict__ state, float beta1, float beta2,
   state[4] = scale;
 }
 
+// both ticks in ONE launch (round 6: a step without a gradient norm).  Folding them into the update kernel itself was built and
+// measured: every workgroup has to have read the old state before anybody writes the new one, i.e. a ticket -- 2 048 atomics on
+// one address took the update from 24 to 43-46 us (profiles/r06_trace_graph_energy.txt of that build); one tiny launch it is.
+__global__ void tick_both_kernel(float* __restrict__ state, float beta1, float beta2, float ema_decay, int use_num_updates) {
+  const float t = state[0] + 1.f;
+  state[6] = 0.f;
+  state[5] = 0.f;
+  state[0] = t;
+  state[1] = (float)(1.0 - pow((double)beta1, (double)fmaxf(t, 1.f)));
+  state[2] = (float)(1.0 - pow((double)beta2, (double)fmaxf(t, 1.f)));
+  state[7] = 0.f;
+  state[4] = 1.f;
+  float* ema_state = state + 8;
+  const float k = ema_state[0] + 1.f;
+  ema_state[0] = k;
+  float d = ema_decay;
+  if (use_num_updates) {
+    const float alt = (1.f + k) / (10.f + k);
+    d = alt < d ? alt : d;
+  }
+  ema_state[1] = d;
+}
+
 __global__ void ema_tick_kernel(float* __restrict__ ema_state, float ema_decay, int use_num_updates) {
   // ema_state[0] number of updates so far, [1] effective decay of THIS update
   const float k = ema_state[0] + 1.f;
@@ -75,40 +98,17 @@ __global__ void ema_tick_kernel(float* __restrict__ ema_state, float ema_decay, 
   ema_state[1] = d;
 }
 
-// TICK (round 6; steps without a gradient norm -- no clipping, no non-finite skip): the two one-thread tick launches are folded in.
-// Every thread derives the step's scalars from the step count it finds (the arithmetic of tick_kernel / ema_tick_kernel, so the
-// same bits), and the LAST workgroup to finish (a ticket in state[10]; by then every workgroup has read the old state) writes the
-// new state.  Two dependent launches of ~5 us less in front of the update of every replayed step.
-template <bool EMA, bool TICK = false>
+template <bool EMA>
 __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                         float* __restrict__ m, float* __restrict__ v,
                                                         float* __restrict__ ema, int64_t n, float lr, float beta1,
                                                         float beta2, float eps, float wd,
-                                                        float* __restrict__ state,
-                                                        float* __restrict__ ema_state, float ema_decay, int use_num_updates) {
-  float bc1, bc2, gscale, t_new = 0.f, k_new = 0.f, decay = 0.f;
-  bool skip;
-  if constexpr (TICK) {
-    t_new = state[0] + 1.f;
-    bc1 = (float)(1.0 - pow((double)beta1, (double)fmaxf(t_new, 1.f)));
-    bc2 = (float)(1.0 - pow((double)beta2, (double)fmaxf(t_new, 1.f)));
-    gscale = 1.f;
-    skip = false;
-    if constexpr (EMA) {
-      k_new = ema_state[0] + 1.f;
-      decay = ema_decay;
-      if (use_num_updates) {
-        const float alt = (1.f + k_new) / (10.f + k_new);
-        decay = alt < decay ? alt : decay;
-      }
-    }
-  } else {
-    bc1 = state[1], bc2 = state[2], gscale = state[4];
-    skip = state[6] != 0.f;
-    if constexpr (EMA) decay = ema_state[1];
-  }
+                                                        const float* __restrict__ state,
+                                                        const float* __restrict__ ema_state) {
+  const float bc1 = state[1], bc2 = state[2], gscale = state[4];
+  const bool skip = state[6] != 0.f;
   const float step_size = lr / bc1, inv_sqrt_bc2 = rsqrtf(bc2);
-  const float one_minus_decay = EMA ? 1.0f - decay : 0.f;
+  const float one_minus_decay = EMA ? 1.0f - ema_state[1] : 0.f;
   auto upd = [&](float& pv, float gv, float& mv, float& vv, float& ev) {
     if (!skip) {
       gv *= gscale;
@@ -150,29 +150,6 @@ __global__ __launch_bounds__(256) void adam_ema_kernel(float* __restrict__ p, co
       v[i] = vv;
     }
     if constexpr (EMA) ema[i] = ev;
-  }
-  if constexpr (TICK) {
-    __syncthreads();      // (this workgroup's reads of the old state are done)
-    if (threadIdx.x == 0) {
-      // (no __threadfence(): the only ordering needed is "this workgroup's READS of the state precede the last workgroup's writes",
-      //  and the values read have been consumed above; a device-scope fence on this multi-XCD part writes the L2's dirty lines back --
-      //  the parameters just stored -- once per workgroup: round 5's guard kernel paid 97 us for exactly that)
-      const unsigned done = atomicAdd(reinterpret_cast<unsigned*>(state + 10), 1u);
-      if (done == gridDim.x - 1) {      // the last workgroup: what tick_kernel / ema_tick_kernel leave behind
-        state[0] = t_new;
-        state[1] = bc1;
-        state[2] = bc2;
-        state[4] = 1.f;
-        state[5] = 0.f;
-        state[6] = 0.f;
-        state[7] = 0.f;
-        if constexpr (EMA) {
-          ema_state[0] = k_new;
-          ema_state[1] = decay;
-        }
-        *reinterpret_cast<unsigned*>(state + 10) = 0u;
-      }
-    }
   }
 }
 
@@ -235,28 +212,24 @@ extern "C" int e3k_adam_ema_step(float* param, const float* grad, float* exp_avg
     hipLaunchKernelGGL(e3k::sumsq_kernel, dim3((unsigned)(blocks < 512 ? blocks : 512)), dim3(256), 0, st, grad, n, state);
     E3K_CHECK_LAUNCH();
   }
-  if (!have_norm) {      // no gradient norm to wait for: the ticks ride in the update kernel (one launch instead of three)
-    if (ema)
-      hipLaunchKernelGGL((e3k::adam_ema_kernel<true, true>), dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq,
-                         ema, n, lr, beta1, beta2, eps, weight_decay, state, state + 8, ema_decay, ema_use_num_updates);
-    else
-      hipLaunchKernelGGL((e3k::adam_ema_kernel<false, true>), dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg, exp_avg_sq,
-                         (float*)nullptr, n, lr, beta1, beta2, eps, weight_decay, state, (float*)nullptr, 0.f, 0);
+  if (ema && !have_norm) {      // (the same values tick_kernel + ema_tick_kernel leave behind, one launch)
+    hipLaunchKernelGGL(e3k::tick_both_kernel, dim3(1), dim3(1), 0, st, state, beta1, beta2, ema_decay, ema_use_num_updates);
     E3K_CHECK_LAUNCH();
-    return E3K_OK;
-  }
-  hipLaunchKernelGGL(e3k::tick_kernel, dim3(1), dim3(1), 0, st, state, beta1, beta2, max_grad_norm,
-                     have_norm, skip_nonfinite);
-  E3K_CHECK_LAUNCH();
-  if (ema) {
-    hipLaunchKernelGGL(e3k::ema_tick_kernel, dim3(1), dim3(1), 0, st, state + 8, ema_decay, ema_use_num_updates);
-    E3K_CHECK_LAUNCH();
-    hipLaunchKernelGGL((e3k::adam_ema_kernel<true, false>), dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg,
-                       exp_avg_sq, ema, n, lr, beta1, beta2, eps, weight_decay, state, state + 8, 0.f, 0);
   } else {
-    hipLaunchKernelGGL((e3k::adam_ema_kernel<false, false>), dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg,
+    hipLaunchKernelGGL(e3k::tick_kernel, dim3(1), dim3(1), 0, st, state, beta1, beta2, max_grad_norm, have_norm, skip_nonfinite);
+    E3K_CHECK_LAUNCH();
+    if (ema) {
+      hipLaunchKernelGGL(e3k::ema_tick_kernel, dim3(1), dim3(1), 0, st, state + 8, ema_decay, ema_use_num_updates);
+      E3K_CHECK_LAUNCH();
+    }
+  }
+  if (ema) {
+    hipLaunchKernelGGL(e3k::adam_ema_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg,
+                       exp_avg_sq, ema, n, lr, beta1, beta2, eps, weight_decay, state, state + 8);
+  } else {
+    hipLaunchKernelGGL(e3k::adam_ema_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, param, grad, exp_avg,
                        exp_avg_sq, (float*)nullptr, n, lr, beta1, beta2, eps, weight_decay, state,
-                       (float*)nullptr, 0.f, 0);
+                       (const float*)nullptr);
   }
   E3K_CHECK_LAUNCH();
   return E3K_OK;
