@@ -312,6 +312,10 @@ class PipelinedBucketedStep:
         self._step_ran = [False, False]
         self.keys = None
         capture_flag(self.dev)              # (the persistent index-check flag captured builds fold into: before any recording)
+        warm = example.clone()              # one eager preparation first: nothing a capture records may be a kernel's first launch
+        prepare(warm)                       # in the process (lazy initialisation inside a capture is not something to rely on)
+        torch.cuda.synchronize(self.dev)
+        del warm
         for b in range(2):
             static = example.clone()        # (fresh tensors: no per-batch memo of the framework knows them yet)
             if self.keys is None:
