@@ -423,7 +423,7 @@ __device__ __forceinline__ void tp_fwd_body(const TpArgs& a, const e3k_tp_group&
 // 5+3+2+1+1+1 = 13 cross-lane moves for nine values instead of 9 x 6, and leaves value `idx` on the lanes whose upper bits
 // spell idx.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void wave_add9(const float (&v9)[9], float* __restrict__ row, const int32_t* y_off) {
+__device__ __forceinline__ void wave_add9(const float (&v9)[9], float* __restrict__ row, const int32_t* y_off, const bool store = false) {
   const int lane = threadIdx.x & 63;
   int idx = 0;
   const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4;
@@ -468,7 +468,10 @@ __device__ __forceinline__ void wave_add9(const float (&v9)[9], float* __restric
     if (idx == 0) off = y_off[0];
     else if (idx < 4) off = y_off[1] >= 0 ? y_off[1] + (idx - 1) : -1;
     else off = y_off[2] >= 0 ? y_off[2] + (idx - 4) : -1;
-    if (off >= 0) atomicAdd(row + off, tot);
+    if (off >= 0) {
+      if (store) row[off] = tot;      // (e_store: this work item's own slice -- no other wave writes it)
+      else atomicAdd(row + off, tot);
+    }
   }
 }
 // ------------------------------------------------------------------------------------------
@@ -676,11 +679,14 @@ __device__ __forceinline__ void tp_bwd_e_body_full(const TpArgs& a, const e3k_tp
       for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
 #pragma unroll
       for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
-      wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off);
+      wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off, a.e_store != 0);
     }
     if (a.g_r) {
       gr = wave_sum(gr);
-      if ((threadIdx.x & 63) == 0) atomicAdd(a.g_r + e, gr);
+      if ((threadIdx.x & 63) == 0) {
+        if (a.e_store) a.g_r[e] = gr;
+        else atomicAdd(a.g_r + e, gr);
+      }
     }
   }
 }
@@ -912,11 +918,14 @@ __device__ __forceinline__ void tp_bwd_x_body_full(const TpArgs& a, const e3k_tp
         for (int j = 0; j < 3; ++j) v9[1 + j] = gy.y1[j];
 #pragma unroll
         for (int j = 0; j < 5; ++j) v9[4 + j] = gy.y2[j];
-        wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off);
+        wave_add9(v9, a.g_sh + (int64_t)e * a.d_sh, y_off, a.e_store != 0);
       }
       if (a.g_r) {
         gr = wave_sum(gr);
-        if ((threadIdx.x & 63) == 0) atomicAdd(a.g_r + e, gr);
+        if ((threadIdx.x & 63) == 0) {
+          if (a.e_store) a.g_r[e] = gr;
+          else atomicAdd(a.g_r + e, gr);
+        }
       }
     }
     if constexpr (PACKED) cur = nxt;
@@ -1123,7 +1132,19 @@ template <int MAXL, int L3MAX, bool SPLIT, bool FULL, int MODE = 0>
 __global__ __launch_bounds__(256, E3K_TP_BWDX_WAVES(MODE, MAXL, L3MAX)) void tp_bwd_x_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
                                                        const int2* __restrict__ gc, int n_gc) {
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
+  if constexpr (MODE == 8) {      // (e_store: this work item's slices of the edge-gradient partials)
+    TpArgs ap = a;
+    if (a.e_store) {
+      if (a.g_sh) ap.g_sh = a.g_sh + (int64_t)gci * a.e_edges * a.d_sh;
+      if (a.g_r) ap.g_r = a.g_r + (int64_t)gci * a.e_edges;
+    }
+    {
+      const TpArgs& a = ap;
+      E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
+    }
+  } else {
+    E3K_TP_DISPATCH(tp_bwd_x_body, L3MAX, MODE)
+  }
 }
 // table-form edge backward (g_sh, g_coef, optionally g_w) and the dual weight gradient: channel-complete plans (SPLIT: the l_max 3
 // plans walked by two waves per group -- streamed weights only; g_sh / g_r of the two parts meet in the same atomics)
@@ -1132,7 +1153,36 @@ __global__ __launch_bounds__(256) void tp_bwd_e_kernel(TpArgs a, const e3k_tp_gr
                                                        const int2* __restrict__ gc, int n_gc) {
   constexpr bool FULL = true;
   E3K_TP_PROLOGUE
-  E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX, STREAM)
+  TpArgs ap = a;
+  if (a.e_store) {
+    if (a.g_sh) ap.g_sh = a.g_sh + (int64_t)gci * a.e_edges * a.d_sh;
+    if (a.g_r) ap.g_r = a.g_r + (int64_t)gci * a.e_edges;
+  }
+  {
+    const TpArgs& a = ap;
+    E3K_TP_DISPATCH(tp_bwd_e_body, L3MAX, STREAM)
+  }
+}
+
+// g_sh[e, :] = sum over the work items (in item order) of their stored shares; g_r likewise: the ordered combine behind an e_store launch
+__global__ __launch_bounds__(256) void edge_partials_combine_kernel(const float* __restrict__ part_sh, const float* __restrict__ part_r,
+                                                                    int n_items, int64_t E, int d_sh, float* __restrict__ g_sh,
+                                                                    float* __restrict__ g_r) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int width = d_sh + 1;
+  if (q >= E * width) return;
+  const int64_t e = q / width;
+  const int j = (int)(q - e * width);
+  float acc = 0.f;
+  if (j < d_sh) {
+    if (!g_sh) return;
+    for (int i = 0; i < n_items; ++i) acc += part_sh[((int64_t)i * E + e) * d_sh + j];
+    g_sh[e * d_sh + j] = acc;
+  } else {
+    if (!g_r) return;
+    for (int i = 0; i < n_items; ++i) acc += part_r[(int64_t)i * E + e];
+    g_r[e] = acc;
+  }
 }
 template <int MAXL, int L3MAX, bool SPLIT = false>
 __global__ __launch_bounds__(256) void tp_bwd_w_dual_kernel(TpArgs a, const e3k_tp_group* __restrict__ groups,
@@ -1601,6 +1651,27 @@ extern "C" int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const floa
   return launch_all(TP_BWD_XW, a, plan, N, (hipStream_t)stream);
 }
 
+// ---- deterministic edge gradients: per-work-item partials [n_gc, E, d_sh] + [n_gc, E], combined in item order -------------------------
+extern "C" int64_t e3k_tp_edge_partials_floats(const e3k_tp_plan* plan, int64_t E) {
+  if (!plan || E < 0) return 0;
+  return (int64_t)plan->n_gc * E * (plan->d_sh + 1);
+}
+namespace {
+void edge_partials_args(e3k::TpArgs& a, const e3k_tp_plan* plan, int64_t E, float* partials) {
+  a.e_store = 1;
+  a.e_edges = E;
+  if (a.g_sh) a.g_sh = partials;
+  if (a.g_r) a.g_r = partials + (int64_t)plan->n_gc * E * plan->d_sh;
+}
+int edge_partials_combine(const e3k_tp_plan* plan, int64_t E, const float* partials, float* g_sh, float* g_r, hipStream_t st) {
+  const int64_t total = E * (plan->d_sh + 1);
+  hipLaunchKernelGGL(e3k::edge_partials_combine_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, partials,
+                     partials + (int64_t)plan->n_gc * E * plan->d_sh, plan->n_gc, E, plan->d_sh, g_sh, g_r);
+  E3K_CHECK_LAUNCH();
+  return E3K_OK;
+}
+}  // namespace
+
 // ---- force training on the table (plans with e3k_tp_table2_supported) ------------------------------------------------------
 // With F = <g, TP(x[src], sh, w(T, coef))> (linear in each of g, x, sh, T, coef):
 // (w[e] = sum_k coef[e,k] T[bin[e]-1+k], dw/dr[e] = sum_k coef[e,k] D[bin[e]-1+k] with D the slope table; with bin = coef = NULL
@@ -1612,7 +1683,8 @@ extern "C" int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const floa
 //   e3k_tp_bwd_w_dual    g_w[e] = dF/dw at (x2, sh) + dF/dw at (x, sh2)       (no table involved: w is the open slot)
 extern "C" int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
                                   const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
-                                  const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream) {
+                                  const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, float* e_partials,
+                                  void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0 || E == 0) return E3K_OK;
   if (!x || !sh || !T || !D || (bin != nullptr) != (coef != nullptr) || !g_out || !src || !dst_ptr || !dst_perm || (!g_sh && !g_r && !g_w))
@@ -1621,7 +1693,11 @@ extern "C" int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const
   a.x = x; a.sh = sh; a.w = T; a.w2 = D; a.bin = bin; a.coef = coef; a.g_out = g_out; a.g_sh = g_sh; a.g_r = g_r; a.g_w = g_w;
   a.nbr = src; a.ptr = dst_ptr; a.perm = dst_perm;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
-  return launch_all(TP_BWD_E, a, plan, N, (hipStream_t)stream);
+  const bool part = e_partials && (g_sh || g_r);
+  if (part) edge_partials_args(a, plan, E, e_partials);
+  const int rc = launch_all(TP_BWD_E, a, plan, N, (hipStream_t)stream);
+  if (rc != E3K_OK || !part) return rc;
+  return edge_partials_combine(plan, E, e_partials, g_sh, g_r, (hipStream_t)stream);
 }
 
 extern "C" int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
@@ -1658,7 +1734,7 @@ extern "C" int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh,
 // (e3k_tp_bwd_e_table: ACCUMULATED with atomics, zero-fill them) and, when g_w != NULL, the per-edge weight gradient (e3k_tp_bwd_w)
 extern "C" int e3k_tp_bwd_xe(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* dw,
                              const float* g_out, const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E,
-                             float* g_x, float* g_sh, float* g_r, float* g_w, void* stream) {
+                             float* g_x, float* g_sh, float* g_r, float* g_w, float* e_partials, void* stream) {
   if (!plan || N < 0 || E < 0) return E3K_ERR_INVALID;
   if (N == 0) return E3K_OK;
   if (!x || !g_out || !g_x || !src_ptr || (E > 0 && (!sh || !w || !dw || !dst || !src_perm || (!g_sh && !g_r)))) return E3K_ERR_INVALID;
@@ -1667,7 +1743,11 @@ extern "C" int e3k_tp_bwd_xe(const e3k_tp_plan* plan, const float* x, const floa
   a.nbr = dst; a.ptr = src_ptr; a.perm = src_perm;
   a.x_shared = plan->x_shared;
   a.d_in = plan->d_in; a.d_sh = plan->d_sh; a.W = plan->w_numel; a.d_mid = plan->d_mid;
-  return launch_all(TP_BWD_XE, a, plan, N, (hipStream_t)stream);
+  const bool part = e_partials && E > 0;
+  if (part) edge_partials_args(a, plan, E, e_partials);
+  const int rc = launch_all(TP_BWD_XE, a, plan, N, (hipStream_t)stream);
+  if (rc != E3K_OK || !part) return rc;
+  return edge_partials_combine(plan, E, e_partials, g_sh, g_r, (hipStream_t)stream);
 }
 
 // e3k_tp_bwd_x_dual_table on STREAMED rows (w, dw [E, W]) that also writes the weight gradients sharing its sums:

@@ -59,6 +59,9 @@ struct TpArgs {
   int32_t x_shared;    // bwd_x: some input block is read by more than one group => accumulate g_x with atomics
   int32_t ablate;      // debug build only: timing-only ablation mask (0 in the product library)
   int32_t order;       // work order of the launch (E3K_TP_PROLOGUE): 0 node-major, 1 group-major inside an XCD's node slice
+  int32_t e_store;     // edge gradients (g_sh, g_r): 0 = float atomics into [E, .]; 1 = every work item STORES its share into its own
+                       // slice of [n_gc, E, .] (g_sh / g_r point at the slices' base, e_edges = E): summed in a fixed order afterwards
+  int64_t e_edges;
   int64_t n_items;
 };
 

@@ -45,6 +45,7 @@ ENABLED = _knob("E3K_FORCE_BLOCK")
 # tensor-product kernel of the three passes streams those rows; 0: every kernel gathers four rows per table and edge itself (the
 # in-kernel form of the energy step).  Five or six kernels per layer read them: 64 molecules 7.03 -> see DESIGN.md ms per step.
 MATERIALIZE = _knob("E3K_FORCE_MATERIALIZE")
+EDGE_ATOMICS = _knob("E3K_FORCE_EDGE_ATOMICS")      # 1: rounds 4-5's atomics on g_sh / g_r (not reproducible run to run)
 FUSE_XW = _knob("E3K_TP_BWD_FUSED")      # the input and the weight gradient of the tensor product in one walk (as conv_native)
 STATS = [0, 0, 0]      # forwards, first backwards (create_graph), u-sweeps (tests)
 _WARNED = [False]
@@ -126,6 +127,19 @@ def _tp_bwd_xw_ptable(x1, sh, packed, bins, g_mid, topo, tp):
     return gx, gw
 
 
+def _edge_grad_buffers(tp, e: int, dev):
+    """(g_sh [E, d_sh], g_r [E], per-item partials or None).  DETERMINISTIC (default): every (node, group) work item stores its
+    share of an edge's sums into its own slice and the library adds the slices in item order -- forces are bit-reproducible run to
+    run and no zero fill is needed; ``E3K_FORCE_EDGE_ATOMICS=1`` restores rounds 4-5's float atomics onto a zero-filled pair."""
+    if EDGE_ATOMICS:
+        buf = torch.zeros(e * (tp.d_sh + 1), device=dev, dtype=torch.float32)      # one fill for both (atomics accumulate)
+        part = None
+    else:
+        buf = torch.empty(e * (tp.d_sh + 1), device=dev, dtype=torch.float32)
+        part = torch.empty(max(int(L.load().e3k_tp_edge_partials_floats(tp.handle(dev), e)), 1), device=dev, dtype=torch.float32)
+    return buf[:e * tp.d_sh].view(e, tp.d_sh), buf[e * tp.d_sh:], part
+
+
 def _b(bins):
     """(knot, weights) pointers of the table form, or (None, None): T / D are then the materialised rows w / dw [E, W]"""
     return (None, None) if bins is None else (L.ptr(bins.bin), L.ptr(bins.coef))
@@ -134,11 +148,10 @@ def _b(bins):
 def _tp_bwd_e_table(x1, sh, T, D, bins, g_mid, topo, tp):
     """(g_sh [E, d_sh], g_r [E]): the gradient w.r.t. the spherical harmonics and the radius"""
     n, e = x1.shape[0], sh.shape[0]
-    buf = torch.zeros(e * (tp.d_sh + 1), device=x1.device, dtype=torch.float32)      # one fill for both (atomics accumulate)
-    g_sh, g_r = buf[:e * tp.d_sh].view(e, tp.d_sh), buf[e * tp.d_sh:]
+    g_sh, g_r, part = _edge_grad_buffers(tp, e, x1.device)
     L.check(L.load().e3k_tp_bwd_e_table(tp.handle(x1.device), L.ptr(x1), L.ptr(sh), L.ptr(T), L.ptr(D), *_b(bins),
                                         L.ptr(g_mid), L.ptr(topo.src), L.ptr(topo.dst_ptr), L.ptr(topo.dst_perm), n, e, L.ptr(g_sh),
-                                        L.ptr(g_r), None, L.stream_ptr()), "e3k_tp_bwd_e_table")
+                                        L.ptr(g_r), None, L.ptr(part), L.stream_ptr()), "e3k_tp_bwd_e_table")
     return g_sh, g_r
 
 
@@ -163,12 +176,11 @@ def _tp_bwd_xe(x1, sh, w, dw, g_mid, topo, tp, want_w: bool):
     """(g_x1, g_sh, g_r, g_w or None): ``tp_bwd_x`` + ``_tp_bwd_e_table`` (+ ``tp_bwd_w``) in one walk (streamed rows w, dw [E, W])"""
     n, e = g_mid.shape[0], sh.shape[0]
     gx = (torch.empty if tp.bwd_x_overwrites(sh.device) else torch.zeros)(n, tp.d_in, device=sh.device, dtype=torch.float32)
-    buf = torch.zeros(e * (tp.d_sh + 1), device=sh.device, dtype=torch.float32)      # one fill for both (atomics accumulate)
-    g_sh, g_r = buf[:e * tp.d_sh].view(e, tp.d_sh), buf[e * tp.d_sh:]
+    g_sh, g_r, part = _edge_grad_buffers(tp, e, sh.device)
     gw = torch.empty(e, tp.w_numel, device=sh.device, dtype=torch.float32) if want_w else None
     L.check(L.load().e3k_tp_bwd_xe(tp.handle(sh.device), L.ptr(x1), L.ptr(sh), L.ptr(w), L.ptr(dw), L.ptr(g_mid), L.ptr(topo.dst),
                                    L.ptr(topo.src_ptr), L.ptr(topo.src_perm), n, e, L.ptr(gx), L.ptr(g_sh), L.ptr(g_r), L.ptr(gw),
-                                   L.stream_ptr()), "e3k_tp_bwd_xe")
+                                   L.ptr(part), L.stream_ptr()), "e3k_tp_bwd_xe")
     return gx, g_sh, g_r, gw
 
 

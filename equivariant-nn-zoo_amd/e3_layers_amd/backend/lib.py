@@ -212,12 +212,13 @@ SIGNATURES = {
     "e3k_tp_bwd_x_ptable": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_xw_ptable": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
     "e3k_tp_bwd_xw": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P]),
-    "e3k_tp_bwd_xe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
+    "e3k_tp_bwd_xe": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P, _P]),
+    "e3k_tp_edge_partials_floats": (C.c_int64, [_P, _I64]),
     "e3k_tp_bwd_xw_dual": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
     "e3k_edge_records": (C.c_int, [_P, _P, _P, _P, _P, _I32, _I64, _P, _P]),
     "e3k_tp_table2_supported": (C.c_int, [_P]),
     "e3k_tp_second_order_streamed_supported": (C.c_int, [_P]),
-    "e3k_tp_bwd_e_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P]),
+    "e3k_tp_bwd_e_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P, _P, _P]),
     "e3k_tp_fwd_jvp_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_x_dual_table": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),
     "e3k_tp_bwd_w_dual": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P]),

@@ -257,8 +257,12 @@ int e3k_tp_bwd_xw(const e3k_tp_plan* plan, const float* x, const float* sh, cons
  * D [K + 1, W] is the SLOPE table dT/dr on the knots (e3k_radial_slope_fwd), interpolated with the same weights:
  * dw/dr[e] = sum_k coef[e,k] D[bin[e] - 1 + k]  (differentiating the weights instead would amplify the table's fp32 rounding by
  * 1 / knot spacing: measured 7e-6 .. 4e-5 relative slope error at any knot count, against 5e-8 this way).
- *   e3k_tp_bwd_e_table      g_sh [E, d_sh] += dF/dsh, g_r [E] += <dF/dw, dw/dr> (atomics: the caller zero-fills; either may be
- *                           NULL), g_w [E, W] = dF/dw written when non-null -- the first backward of a force evaluation
+ *   e3k_tp_bwd_e_table      g_sh [E, d_sh] = dF/dsh, g_r [E] = <dF/dw, dw/dr> (either may be NULL), g_w [E, W] = dF/dw written when
+ *                           non-null -- the first backward of a force evaluation.  A work item (node, group) holds only its group's
+ *                           share of an edge's sum: with e_partials (e3k_tp_edge_partials_floats(plan, E) floats of scratch) every
+ *                           item STORES its share into its own slice and a second launch adds the slices in item order into g_sh /
+ *                           g_r (overwritten: no zero fill, bit-reproducible -- round 6); with e_partials = NULL the shares are
+ *                           float atomics onto g_sh / g_r, which the caller zero-fills (not reproducible run to run)
  *   e3k_tp_fwd_jvp_table    out = TP(x2, sh, w) + TP(x, sh2, w) + TP(x, sh, s2 * dw/dr)          (s2 [E]: the radius' partner)
  *   e3k_tp_bwd_x_dual_table g_x = dF/dx at (sh2, w) + dF/dx at (sh, s2 * dw/dr)
  *   e3k_tp_bwd_w_dual       g_w = dF/dw at (x2, sh) + dF/dw at (x, sh2)           (w is the open slot: no table involved)
@@ -270,7 +274,9 @@ int e3k_tp_table2_supported(const e3k_tp_plan* plan);
 int e3k_tp_second_order_streamed_supported(const e3k_tp_plan* plan);
 int e3k_tp_bwd_e_table(const e3k_tp_plan* plan, const float* x, const float* sh, const float* T, const float* D,
                        const int32_t* bin, const float* coef, const float* g_out, const int32_t* src, const int32_t* dst_ptr,
-                       const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, void* stream);
+                       const int32_t* dst_perm, int64_t N, int64_t E, float* g_sh, float* g_r, float* g_w, float* e_partials,
+                       void* stream);
+int64_t e3k_tp_edge_partials_floats(const e3k_tp_plan* plan, int64_t E);
 int e3k_tp_fwd_jvp_table(const e3k_tp_plan* plan, const float* x, const float* x2, const float* sh, const float* sh2,
                          const float* T, const float* D, const int32_t* bin, const float* coef, const float* s2,
                          const int32_t* src, const int32_t* dst_ptr, const int32_t* dst_perm, int64_t N, int64_t E, float* out,
@@ -279,11 +285,11 @@ int e3k_tp_bwd_x_dual_table(const e3k_tp_plan* plan, const float* sh, const floa
                             const int32_t* bin, const float* coef, const float* s2, const float* g_out, const int32_t* dst,
                             const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, void* stream);
 /* The first backward of a force evaluation w.r.t. everything an edge touches, in ONE walk of the source CSR (streamed rows w,
- * dw [E, W]): g_x (e3k_tp_bwd_x), g_sh [E, d_sh] and g_r [E] (e3k_tp_bwd_e_table: accumulated with atomics -- zero-fill them; either
- * may be NULL, not both) and, when g_w != NULL, the per-edge weight gradient (e3k_tp_bwd_w).  Channel-complete plans. */
+ * dw [E, W]): g_x (e3k_tp_bwd_x), g_sh [E, d_sh] and g_r [E] (as e3k_tp_bwd_e_table, e_partials included; either may be NULL, not
+ * both) and, when g_w != NULL, the per-edge weight gradient (e3k_tp_bwd_w).  Channel-complete plans. */
 int e3k_tp_bwd_xe(const e3k_tp_plan* plan, const float* x, const float* sh, const float* w, const float* dw, const float* g_out,
                   const int32_t* dst, const int32_t* src_ptr, const int32_t* src_perm, int64_t N, int64_t E, float* g_x, float* g_sh,
-                  float* g_r, float* g_w, void* stream);
+                  float* g_r, float* g_w, float* e_partials, void* stream);
 /* e3k_tp_bwd_x_dual_table on streamed rows (w, dw [E, W]; bin = coef = NULL there) that ALSO writes the weight gradients sharing its
  * per-edge sums: g_w = e3k_tp_bwd_w_dual's, g_w_plain (may be NULL) = e3k_tp_bwd_w's -- one walk instead of three (the u-sweep of
  * force training: the adjoint of nn/output.py:42-50's first backward) */

@@ -531,3 +531,29 @@ def test_position_gradient_of_a_force_loss_takes_the_composed_path(dev, monkeypa
     out2 = prod(batch.clone().to(dev))
     assert conv_force.STATS[0] - before[0] == 3
     assert rel_err(out2["forces"], out["forces"]) < 2e-5
+
+
+def test_forces_are_bit_reproducible(dev, monkeypatch):
+    """VERDICT r5 item 6 (second half): a force evaluation summed an edge's `g_sh` / `g_r` over the groups of a plan with float
+    atomics -- forces differed in the last bits from run to run.  Round 6: every (node, group) work item stores its share, a second
+    launch adds the shares in item order (`e3k_tp_bwd_xe / e3k_tp_bwd_e_table` with `e_partials`): forces of the force block are
+    bit-identical over repeated evaluations, in training mode (create_graph) and in evaluation mode."""
+    from e3_layers_amd.backend import conv_force, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+
+    monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
+    prod, _ = _force_net(dev, 3)
+    batch = synth_qm9(23, 20)
+    assert batch["pos"].shape[0] >= 256
+    for training in (True, False):
+        prod.train(training)
+        before = list(conv_force.STATS)
+        runs = []
+        for _ in range(4):
+            out = prod(batch.clone().to(dev))
+            runs.append(out["forces"].detach().clone())
+        assert conv_force.STATS[0] - before[0] == 12                  # 4 evaluations x 3 layers on the force block
+        torch.cuda.synchronize()
+        for f in runs[1:]:
+            assert torch.equal(f, runs[0]), training
+    prod.train(True)

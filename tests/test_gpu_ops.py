@@ -796,6 +796,22 @@ def test_tp_table_second_order_forms_are_sums_of_first_order_kernels(dev, left, 
     assert rel_err(gsh_e, g_sh_ref) < 1e-5
     assert rel_err(gr_e, (g_w_ref.double() * dw.double()).sum(1)) < 1e-5
     assert conv_force._tp_bwd_xe(x, sh, w, dw, g, topo, tp, False)[3] is None
+    # round 6: the edge gradients are per-item partials combined in a fixed order -- bit-identical run to run, and equal (up to the
+    # order of six additions) to the atomic form of rounds 4-5
+    for _ in range(3):
+        again = conv_force._tp_bwd_xe(x, sh, w, dw, g, topo, tp, False)
+        assert torch.equal(again[1], gsh_e) and torch.equal(again[2], gr_e)
+        a_sh, a_r = conv_force._tp_bwd_e_table(x, sh, T, D, bins, g, topo, tp)
+        assert torch.equal(a_sh, g_sh) and torch.equal(a_r, g_r)
+    monkey_atomics = conv_force.EDGE_ATOMICS
+    conv_force.EDGE_ATOMICS = 1
+    try:
+        at = conv_force._tp_bwd_xe(x, sh, w, dw, g, topo, tp, False)
+        assert rel_err(at[1], gsh_e) < 1e-6 and rel_err(at[2], gr_e) < 1e-6
+        at_sh, at_r = conv_force._tp_bwd_e_table(x, sh, T, D, bins, g, topo, tp)
+        assert rel_err(at_sh, g_sh) < 1e-6 and rel_err(at_r, g_r) < 1e-6
+    finally:
+        conv_force.EDGE_ATOMICS = monkey_atomics
 
 
 @pytest.mark.parametrize("n_basis", [8, 48])
