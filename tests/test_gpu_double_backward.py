@@ -366,9 +366,12 @@ def test_force_block_training_step_matches_oracle_on_the_table(dev, monkeypatch,
     with warnings.catch_warnings():
         warnings.simplefilter("ignore")
         _force_losses(prod, None, batch, dev, plain_backward=True)
+    # (two evaluations of the same fp32 sums whose order differs -- the weight-gradient GEMMs and the bias column sums add with float
+    #  atomics: a ONE-element gradient such as the energy head's bias, a sum over all nodes, moved by 1.0-1.15e-6 in 2 of 12 runs
+    #  of this test under a 1e-6 bound (round 6, gpurun_out of the loop); the bound is on reordering noise, not on the path)
     for n, p in prod.named_parameters():
         if n in grads:
-            assert rel_err(p.grad, grads[n]) < 1e-6, n
+            assert rel_err(p.grad, grads[n]) < 5e-6, n
 
 
 def test_force_training_shipped_config_matches_oracle(dev):

@@ -13,7 +13,7 @@ import pytest
 import torch
 
 from oracle import e3ref
-from tests.util import batch_to_oracle, oracle_like, record_measured, rel_err
+from tests.util import batch_to_oracle, oracle_like, record_measured, rel_err, zero_shifts as _zero_shifts
 
 pytestmark = pytest.mark.gpu
 
@@ -48,15 +48,6 @@ def _guard_ratios(model, r_max, knots, dev):
             out.append({"layer": name, "table_wide": wide, "per_column": col, "kernel_estimate": radial_table.guard_error(key),
                         "ok": bool(radial_table.guard_ok(key)), "max_abs": float(top)})
     return out
-
-
-def _zero_shifts(*models):
-    for model in models:
-        for m in model.modules():
-            s = getattr(m, "shifts", None)
-            if isinstance(s, torch.Tensor):
-                with torch.no_grad():
-                    s.zero_()
 
 
 def _train_replayed(model, opt, padded, loss_of, steps, generators=()):

@@ -52,6 +52,18 @@ def _rename(sd, orc):
     return out
 
 
+def zero_shifts(*models) -> None:
+    """Zeroes the per-species energy shifts of ``PerTypeScaleShift`` layers.  The QM9 shifts are about -1e4 eV per molecule: with them
+    in, a NORMWISE relative bound of 1e-5 on ``total_energy`` allows 0.1 eV of absolute error on a learned part of O(1) (VERDICT r5,
+    weak item 3).  Tests that compare energies with the oracle zero them in both models first: the bound is then on the network."""
+    for model in models:
+        for m in model.modules():
+            s = getattr(m, "shifts", None)
+            if isinstance(s, torch.Tensor):
+                with torch.no_grad():
+                    s.zero_()
+
+
 def batch_to_oracle(batch, dtype=torch.float64):
     data = {k: (v.detach().cpu().to(dtype) if v.is_floating_point() else v.detach().cpu())
             for k, v in batch.data.items() if not k.startswith("_e3k_")}
