@@ -351,7 +351,7 @@ def main():
         loss = loss_of(batch)
         flat.zero()
         if cfg_kind == "energy":
-            loss.backward()
+            loss.backward(gradient=ops.unit_gradient(loss))      # (a persistent 1.0: no ones_like fill, no multiplication by it)
         else:
             backward_parameters(loss, opt.params)
         flat.all_reduce_mean()
@@ -433,7 +433,7 @@ def main():
             if cfg_kind == "energy":
                 loss = ops.sq_error(model(batch)["total_energy"], target, weight, 1e3)
                 flat.zero()
-                loss.backward()
+                loss.backward(gradient=ops.unit_gradient(loss))
             else:      # config_energy_force.py:18 loss_coeffs; the force term is a mean over the REAL nodes' components
                 f_t, wn = batch["forces_target"], batch["_node_weight"]
                 out = model(batch)

@@ -121,10 +121,13 @@ enum SetId { LIN1_FWD, LIN1_DGRAD, LIN1_DGRAD_ACC, LIN1_WGRAD, POST_FWD, POST_DG
   } while (0)
 
 // template sets that go out together: round r of every set in one e3k_gemm_multi call, the rounds in order
+// (eight sets per call since round 6: the last layers of ALL five radial MLPs of a stack in one call -- with four the fifth layer's
+//  went out as launches of its own: 2 x 20 us of split-K for what rides in the first launch for 5)
+constexpr int SEG_MAX = 8;
 struct Seg {
-  e3k_gemm_segment s[4];
-  const e3k_layer* layer[4];
-  int id[4];
+  e3k_gemm_segment s[SEG_MAX];
+  const e3k_layer* layer[SEG_MAX];
+  int id[SEG_MAX];
   int n = 0;
   void add(const e3k_layer* L, SetId set, const void* a, const void* b, void* c, int64_t rows) {
     e3k_gemm_segment sg{};
@@ -142,7 +145,7 @@ struct Seg {
   }
   int run(int wgrad, void* st) {
     for (int r = 0;; ++r) {
-      e3k_gemm_segment round[4];
+      e3k_gemm_segment round[SEG_MAX];
       int m = 0;
       for (int i = 0; i < n; ++i) {
         const e3k_layer* L = layer[i];
@@ -569,9 +572,9 @@ extern "C" int e3k_radial_stack_fwd(const e3k_layer* const* layers, const e3k_la
   if (rads[0].R == 0) return E3K_OK;
   if (!(ABLATE & 16)) {
     E3K_TRY(e3k_mlp_hidden_fwd_multi(nets, n, rads[0].radial, rads[0].R, d0.k0, d0.h, d0.n_hidden, d0.alphas, d0.act, d0.cst, stream));
-    for (int base = 0; base < n; base += 4) {      // last layers: one e3k_gemm_multi call per four layers
+    for (int base = 0; base < n; base += SEG_MAX) {      // last layers: one e3k_gemm_multi call per SEG_MAX layers
       Seg g;
-      for (int i = base; i < n && i < base + 4; ++i) {
+      for (int i = base; i < n && i < base + SEG_MAX; ++i) {
         const e3k_layer_radial& r = rads[i];
         g.add(layers[i], LAST_FWD, r.h, r.w_last, r.use_table ? r.T : r.w, r.R);
       }
@@ -614,9 +617,9 @@ extern "C" int e3k_radial_slope_fwd(const e3k_layer* const* layers, const e3k_la
   }
   E3K_TRY(e3k_slope_tangent_fwd(wh, n, d0.n_hidden, d0.alphas, sl->knots, R, sl->bessel_w, d0.k0, d0.h, sl->r_max, sl->r_min, sl->p,
                                 sl->one_over_r, sl->cutoff_kind, d0.act, d0.cst, hp, stream));
-  for (int base = 0; base < n; base += 4) {      // D_l = H'_l W_last_l: the layers' last-layer GEMMs, four per call
+  for (int base = 0; base < n; base += SEG_MAX) {      // D_l = H'_l W_last_l: the layers' last-layer GEMMs, SEG_MAX per call
     Seg g;
-    for (int i = base; i < n && i < base + 4; ++i) g.add(layers[i], LAST_FWD, hp[i], rads[i].w_last, D[i], R);
+    for (int i = base; i < n && i < base + SEG_MAX; ++i) g.add(layers[i], LAST_FWD, hp[i], rads[i].w_last, D[i], R);
     E3K_TRY(g.run(0, stream));
   }
   if (hipGetLastError() != hipSuccess) return E3K_ERR_LAUNCH;
@@ -632,14 +635,14 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
   if (ABLATE & 16) return E3K_OK;
   e3k_mlp_net nets[16];
   int n_nets = 0;
-  for (int base = 0; base < n; base += 4) {        // weight gradients of the last layers
+  for (int base = 0; base < n; base += SEG_MAX) {        // weight gradients of the last layers
     Seg g;
-    for (int i = base; i < n && i < base + 4; ++i)
+    for (int i = base; i < n && i < base + SEG_MAX; ++i)
       if (items[i].gb_last && items[i].g_rows)
         g.add(layers[i], LAST_WGRAD, items[i].rad.h, items[i].gb_last, const_cast<float*>(items[i].g_rows), R);
     E3K_TRY(g.run(1, stream));
     Seg gs;                                        // ... and through the slope table: gb_last += H'^T g_D
-    for (int i = base; i < n && i < base + 4; ++i)
+    for (int i = base; i < n && i < base + SEG_MAX; ++i)
       if (items[i].gb_last && items[i].g_slope && items[i].hp)
         gs.add(layers[i], LAST_WGRAD, items[i].hp, items[i].gb_last, const_cast<float*>(items[i].g_slope), R);
     E3K_TRY(gs.run(1, stream));
@@ -648,9 +651,9 @@ extern "C" int e3k_radial_stack_bwd(const e3k_layer* const* layers, const e3k_ra
   float* sl_g[16 * 4] = {nullptr};
   const float* sl_ghp[16];
   int n_adj = 0;
-  for (int base = 0; base < n; base += 4) {        // their input gradients, then the hidden chains
+  for (int base = 0; base < n; base += SEG_MAX) {        // their input gradients, then the hidden chains
     Seg g, gsl;
-    for (int i = base; i < n && i < base + 4; ++i) {
+    for (int i = base; i < n && i < base + SEG_MAX; ++i) {
       const e3k_radial_stack_item& it = items[i];
       bool need_hidden = it.g_radial != nullptr;
       for (int l = 0; l < d0.n_hidden; ++l) need_hidden = need_hidden || it.gb_hidden[l];
@@ -733,10 +736,12 @@ extern "C" int e3k_kw_stack_bwd(const e3k_layer* const* layers, const e3k_kw_sta
     mi[i] = e3k_kw_multi_item{layers[i]->kwa, items[i].w_sc, items[i].m, items[i].gb_sc, items[i].acc_sc, 0};
   }
   hipStream_t st = (hipStream_t)stream;
-  if (ga && e3k::zero_fill(ga, sizeof(float) * n_keys * V, st)) return E3K_ERR_LAUNCH;
+  // (ga directly in front of g_attrs in one allocation -- what the Python side hands over --: ONE fill for both)
+  const bool together = ga && g_attrs == ga + (int64_t)n_keys * V;
+  if (ga && e3k::zero_fill(ga, sizeof(float) * ((int64_t)n_keys * V + (together ? N * V : 0)), st)) return E3K_ERR_LAUNCH;
   if (!(ABLATE & 1)) E3K_TRY(e3k_keyed_weights_bwd_multi(mi, n, a_rep, n_keys, ga, workspace, stream));
   if (g_attrs) {
-    if (e3k::zero_fill(g_attrs, sizeof(float) * N * V, st)) return E3K_ERR_LAUNCH;
+    if (!together && e3k::zero_fill(g_attrs, sizeof(float) * N * V, st)) return E3K_ERR_LAUNCH;
     const int tot = n_keys * V;
     hipLaunchKernelGGL(e3k::scatter_rows_kernel, dim3((tot + 255) / 256), dim3(256), 0, st, ga, reps, bounds, n_keys, V, g_attrs);
   }

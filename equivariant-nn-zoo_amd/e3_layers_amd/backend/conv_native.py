@@ -539,8 +539,8 @@ class KwStackFn(torch.autograd.Function):
                         it.gb_sc, it.acc_sc = rets[i].data_ptr(), 0
             ga = ws = None
             if need[0]:
-                ga = torch.empty(n_keys, v, device=dev, dtype=torch.float32)
-                g_attrs = torch.empty(attrs_shape, device=dev, dtype=torch.float32)
+                both = torch.empty(n_keys * v + attrs_shape[0] * attrs_shape[1], device=dev, dtype=torch.float32)      # adjacent: one zero fill
+                ga, g_attrs = both[:n_keys * v].view(n_keys, v), both[n_keys * v:].view(attrs_shape)
                 ws = torch.empty(max(int(L.load().e3k_kw_stack_bwd_workspace(handles, n, n_keys)), 1), device=dev, dtype=torch.float32)
             L.check(L.load().e3k_kw_stack_bwd(handles, items, n, a_rep.data_ptr(), groups.reps.data_ptr(), groups.bounds.data_ptr(),
                                               attrs_shape[0], n_keys, _ptr(ga), _ptr(g_attrs), _ptr(ws), L.stream_ptr()),

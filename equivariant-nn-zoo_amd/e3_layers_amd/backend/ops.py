@@ -1883,7 +1883,27 @@ class SqErrorFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
+        unit = _UNIT.get(g.device.index)
+        if unit is not None and g.data_ptr() == unit.data_ptr():
+            return grad.view(ctx.shape), None, None, None      # (the loss's own upstream gradient, the constant 1: nothing to multiply)
         return (grad * g).view(ctx.shape), None, None, None
+
+
+_UNIT: Dict[int, torch.Tensor] = {}
+
+
+def unit_gradient(loss: torch.Tensor) -> torch.Tensor:
+    """A persistent scalar 1.0 on ``loss``'s device for ``loss.backward(gradient=ops.unit_gradient(loss))``: autograd otherwise makes
+    a ``ones_like(loss)`` per backward (a fill launch) and the loss nodes multiply by it (another): two launch-sized kernels per
+    step that a replayed graph pays for every time.  ``SqErrorFn`` recognises this tensor and skips the multiplication.  Allocated
+    on first use -- outside a capture (``CapturedStep``'s eager warm-up sees to that)."""
+    idx = loss.device.index if loss.device.index is not None else torch.cuda.current_device()
+    unit = _UNIT.get(idx)
+    if unit is None:
+        if torch.cuda.is_current_stream_capturing():
+            return torch.ones((), device=loss.device, dtype=loss.dtype)
+        unit = _UNIT[idx] = torch.ones((), device=loss.device, dtype=torch.float32)
+    return unit if loss.dtype == torch.float32 and loss.dim() == 0 else torch.ones_like(loss)
 
 
 def sq_error(pred, target, weight=None, scale: float = 1.0):

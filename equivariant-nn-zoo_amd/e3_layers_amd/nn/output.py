@@ -72,16 +72,32 @@ class Pooling(Module):
         assert reduce in ("sum", "mean")
         self.reduce = reduce
 
-    def forward(self, data, attrs):
-        x = data["input"]
-        n = data["_n_nodes"].view(-1).to(x.device)
-        ptr = torch.empty(n.numel() + 1, dtype=torch.int32, device=x.device)
-        if x.is_cuda and n.dtype == torch.int64 and n.is_contiguous():
+    @staticmethod
+    def _row_pointers(counts, device):
+        """int32 [G + 1] row pointers of the per-graph node counts; memoised on the counts tensor (``prepare_batch`` builds them
+        ahead of the step: they are batch data)."""
+        hit = getattr(counts, "_e3k_ptr", None)
+        if hit is not None and hit[0] == counts._version and hit[1].device == device:
+            return hit[1]
+        n = counts.view(-1).to(device)
+        ptr = torch.empty(n.numel() + 1, dtype=torch.int32, device=device)
+        if n.is_cuda and n.dtype == torch.int64 and n.is_contiguous():
             from ..backend import lib as L
 
             L.check(L.load().e3k_counts_to_ptr(L.ptr(n), n.numel(), L.ptr(ptr), L.stream_ptr()), "e3k_counts_to_ptr")
         else:
             ptr[0] = 0
             ptr[1:] = torch.cumsum(n, 0).to(torch.int32)
+        counts._e3k_ptr = (counts._version, ptr)
+        return ptr
+
+    def prepare_batch(self, network, data, avail) -> None:
+        """``SequentialGraphNetwork.prepare_data`` hook: the segment pointers depend on ``_n_nodes`` alone."""
+        if "_n_nodes" in avail and "_n_nodes" in data and data["_n_nodes"].is_cuda:
+            self._row_pointers(data["_n_nodes"], data["_n_nodes"].device)
+
+    def forward(self, data, attrs):
+        x = data["input"]
+        ptr = self._row_pointers(data["_n_nodes"], x.device)
         out = ops.segment_sum(x, ptr, data["_node_segment"].to(x.device), self.reduce == "mean")
         return {"output": out}, {"output": ("graph", self.irreps_out["output"])}

@@ -71,7 +71,7 @@ def backward_parameters(loss: torch.Tensor, params: Iterable[torch.nn.Parameter]
     from ..backend import ops
 
     with ops.params_only_backward():
-        loss.backward(inputs=[p for p in params if p.requires_grad])
+        loss.backward(gradient=ops.unit_gradient(loss) if loss.is_cuda else None, inputs=[p for p in params if p.requires_grad])
 
 
 def _radial_mlp_params(mp) -> list:
