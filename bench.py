@@ -144,6 +144,12 @@ def cpu_baseline(budget_s):
     }
 
 
+def _knots_now():
+    from e3_layers_amd.backend import radial_table
+
+    return [int(radial_table.KNOTS), int(radial_table.KNOTS_SLOPE)]
+
+
 def launch_ranks(args) -> int:
     """``python bench.py --gpus N`` as given (no torchrun around it): this process touches no GPU -- it starts N FRESH rank
     processes through ``python -m torch.distributed.run`` (one per GPU, rendezvous on 127.0.0.1, the reference's
@@ -907,6 +913,8 @@ def main():
                           f"weight), a-posteriori guard {radial_table.GUARD_TOL:g} table-wide / {radial_table.GUARD_TOL_COL:g} per column "
                           "evaluated on the device with every replay; arithmetic fp32"),
                 "replay_error": replay_error,
+                "knot_table_recaptures": (getattr(bucket, "recaptures", None) if bucket is not None else None),      # the table guard's
+                "knot_table_knots": _knots_now(),      # refinements (the knot count doubles) and vetoes made the step record itself again
                 "streams": ("one (captured)" if graph is not None else
                             "one" if (auto or {}).get("chosen") == "eager, one stream" else "per size: four from 60 000 edges (table layers)"),
                 "launch": ((f"hip-graph replay, a NEW batch every step: padded to the bucket ({n_cap} nodes, {e_cap} edges) with a ghost "

@@ -43,6 +43,16 @@ ENABLED = _knob("E3K_RADIAL_TABLE")
 KNOTS = _knob("E3K_RADIAL_KNOTS")                  # r_max 4: 512 intervals of 2^-7 A; r_max 5: 640
 KNOTS_SLOPE = _knob("E3K_RADIAL_KNOTS_SLOPE")       # ... when the radii require grad (value + slope tables)
 MIN_EDGES_PER_KNOT = _knob("E3K_RADIAL_MIN_EDGES_PER_KNOT")      # below this the per-edge MLP is the cheaper one
+# Refinement (round 6).  When a guard's bound passes the tolerance (the weights sharpen under the optimizer: the bound grows like
+# scale^4) the first answer is a FINER table, not the per-edge MLP: both target counts double (the cubic's error drops 16 x; the
+# bound is re-measured on the new table at once), up to KNOTS_MAX; only a bound that 2048 knots cannot hold switches that MLP's
+# table off.  Measured on the headline step: 3.94 ms at 512 knots, 4.09 ms at 1024, 4.46 ms with ONE layer's MLP per edge
+# (``tools/soak.sh``: 5 000 Adam steps at lr 1e-2 on four batches trip layer 1's per-column bound).  One resolution for every
+# table in the process: the layers share the batch's bins and edge records.  Keyed tables (rows x keys against the bins kernel's
+# 4 000-row histogram) do not refine.
+KNOTS_MAX = _knob("E3K_RADIAL_KNOTS_MAX")
+REFINEMENTS = 0      # how many times the counts doubled in this process (CapturedStep compares it with its own: a graph recorded
+                     # before a refinement holds the coarse tables and records itself again)
 # Keyed tables (``KeyedRadialSource``: an edge embedding that is a function of the radius and a small categorical key -- config_diffusion's
 # bond type).  Built and pinned to the oracle in round 5 (score 2.4e-6, parameter gradients 3.1e-6), and OFF by default: the only shipped
 # model it serves has 32 channels, whose tensor-product plans have no in-kernel table form, so the weights are still materialised
@@ -145,18 +155,20 @@ class RadialSource:
     counter of the embedding tensor when it was tagged (an in-place op on the embedding bumps it: the tag then no longer
     describes the tensor's contents and the table is not used)."""
 
-    __slots__ = ("module", "r", "version", "_bins", "_knot_basis", "_stack", "__weakref__")
+    __slots__ = ("module", "r", "version", "knots", "knots_slope", "_bins", "_knot_basis", "_stack", "__weakref__")
 
     def __init__(self, module, r: torch.Tensor, version: int = 0, prepared: Optional[dict] = None):
         """``prepared``: {target knot count: KnotBins} built ahead of the step for exactly these radii (``prepare_bins``)."""
         self.module, self.r, self.version = weakref.ref(module), r, int(version)
+        self.knots, self.knots_slope = int(KNOTS), int(KNOTS_SLOPE)      # this forward's resolution: a refinement that happens while
+                                                                         # it runs (``_refine``) applies from the NEXT source on
         self._bins = dict(prepared) if prepared else {}
         self._knot_basis = {}
         self._stack = {}      # id(MessagePassing) -> (its radial MLP's rows on the knots, mode): nn/message_passing.py:_stack_rows
 
     def bins(self, knots: Optional[int] = None) -> KnotBins:
         """Once per batch and (target) knot count, shared by the layers."""
-        knots = KNOTS if knots is None else int(knots)
+        knots = self.knots if knots is None else int(knots)
         hit = self._bins.get(knots)
         if hit is None:
             hit = self._bins[knots] = build_bins(self.r, float(self.module().basis.r_max), knots)
@@ -164,7 +176,7 @@ class RadialSource:
 
     def knot_basis(self, knots: Optional[int] = None):
         """RadialBasisEncoding on the knots (differentiable w.r.t. the Bessel frequencies) -- once per forward."""
-        knots = KNOTS if knots is None else int(knots)
+        knots = self.knots if knots is None else int(knots)
         kb = self._knot_basis.get(knots)
         if kb is None or kb[1] != torch.is_grad_enabled():
             mod = self.module()
@@ -226,8 +238,16 @@ class KeyedRadialSource:
     def module(self):
         return self.base.module()
 
+    @property
+    def knots(self) -> int:
+        return self.base.knots
+
+    @property
+    def knots_slope(self) -> int:
+        return self.base.knots_slope
+
     def bins(self, knots: Optional[int] = None) -> KnotBins:
-        knots = KNOTS if knots is None else int(knots)
+        knots = self.base.knots if knots is None else int(knots)
         hit = self._bins.get(knots)
         if hit is None:
             hit = self._bins[knots] = build_bins(self.base.r, float(self.module().basis.r_max), knots, self.key, self.n_keys)
@@ -236,7 +256,7 @@ class KeyedRadialSource:
     def knot_basis(self, knots: Optional[int] = None):
         """[n_keys (knots + 1), width]: the embedding of every (key, knot) pair, key-major; differentiable w.r.t. the parameters of
         ``rows_fn`` (the Concat's Linear) and of the basis (the Bessel frequencies)."""
-        knots = KNOTS if knots is None else int(knots)
+        knots = self.base.knots if knots is None else int(knots)
         kb = self._knot_basis.get(knots)
         if kb is None or kb[1] != torch.is_grad_enabled():
             base = self.base.knot_basis(knots)                               # [rows, n_basis]
@@ -271,7 +291,7 @@ def knots_for(edge_radial, w_last=None, allow_grad: bool = False) -> int:
         return 0                           # modified in place since RadialBasisEncoding produced it
     if w_last is not None and not guard_ok(w_last, slope=grad):
         return 0
-    knots = KNOTS_SLOPE if grad else KNOTS
+    knots = src.knots_slope if grad else src.knots
     rows = (layout(float(src.module().basis.r_max), knots)[0] + 1) * getattr(src, "blocks", 1)
     if rows > 4000:                        # (the stacked table of a keyed source: the bins kernel's LDS histogram)
         return 0
@@ -359,10 +379,40 @@ def _poll(g: _Guard, what: str = None) -> None:
             if g.ok:
                 import warnings
 
+                bound = g.last
+                if _refine(g):
+                    warnings.warn(f"radial knot table ({g.what}): interpolation error bound {bound:.2e} exceeds {GUARD_TOL:.0e}: the "
+                                  f"tables are rebuilt on {KNOTS} (value) / {KNOTS_SLOPE} (value + slope) knots from the next step on")
+                    return                 # (every guard's read-backs described the coarse tables: dropped by _refine)
                 warnings.warn(f"radial knot table ({g.what}): interpolation error bound {g.last:.2e} exceeds {GUARD_TOL:.0e}: this "
-                              "radial MLP is evaluated per edge from now on (E3K_RADIAL_KNOTS / E3K_RADIAL_KNOTS_SLOPE raise the "
-                              "resolution)")
+                              "radial MLP is evaluated per edge from now on (E3K_RADIAL_KNOTS_MAX raises the finest resolution the "
+                              "tables may take)")
             g.ok = False
+
+
+def _refine(g: _Guard) -> bool:
+    """Doubles both target knot counts if the table behind ``g`` can still get finer (see KNOTS_MAX above); every guard then starts
+    over: what it has measured, on the device and on its way home, describes the coarse tables."""
+    global KNOTS, KNOTS_SLOPE, REFINEMENTS
+    if g.last != g.last:                    # NaN: not a matter of resolution
+        return False
+    if any(isinstance(kind, tuple) for (_, kind) in _GUARDS):
+        return False                        # a stacked (keyed) table lives in this process
+    if 2 * int(KNOTS_SLOPE if g.what == "slope" else KNOTS) > int(KNOTS_MAX):
+        return False
+    KNOTS = min(2 * int(KNOTS), max(int(KNOTS_MAX), int(KNOTS)))
+    KNOTS_SLOPE = min(2 * int(KNOTS_SLOPE), max(int(KNOTS_MAX), int(KNOTS_SLOPE)))
+    REFINEMENTS += 1
+    for _, (ref, other) in list(_GUARDS.items()):
+        if ref() is None:
+            continue
+        other.pending.clear()               # (_HOST_BUSY keeps the events: a slot is reused only after its copy has landed)
+        other.calls = 0                     # the next eager build measures the fine table at once
+        if other.ok:
+            other.last = None
+        if other.dev is not None:
+            other.dev.zero_()
+    return True
 
 
 def drain_guards() -> None:

@@ -53,6 +53,7 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_RADIAL_TABLE": (1, "accuracy", "radial MLP on a knot table + cubic interpolation per edge (bound by the guard below); 0: per edge"),
     "E3K_RADIAL_KNOTS": (512, "accuracy", "target knot count over [0, r_max] (the spacing is the power of two at or below r_max / knots)"),
     "E3K_RADIAL_KNOTS_SLOPE": (512, "accuracy", "... of the value + slope tables of force training"),
+    "E3K_RADIAL_KNOTS_MAX": (2048, "accuracy", "a guard whose bound passes the tolerance doubles both knot counts up to this; beyond it that MLP's table is switched off (= E3K_RADIAL_KNOTS: never refine)"),
     "E3K_RADIAL_TABLE_KEYED": (0, "path", "one knot table per value of a small categorical edge key beside the radius (config_diffusion's bond type); measured slower than the per-edge MLP for the 32-channel net it serves: off"),
     "E3K_RADIAL_MIN_EDGES_PER_KNOT": (4.0, "threshold", "the table applies from this many edges per table row"),
     "E3K_RADIAL_TABLE_TOL": (1e-6, "accuracy", "a-posteriori interpolation-error bound above which an MLP's table is switched off"),

@@ -135,15 +135,19 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         done = {}
         with torch.no_grad():
             if "edge_index" in data and "pos" in data and data["edge_index"].is_cuda:
+                before = dict(data)
                 data.update(get_topology(data, data["pos"].shape[0]).as_dict())
+                wrote = tuple(k for k, v in data.items() if before.get(k) is not v)
+                done["_topology"] = ((("edge_index", data["edge_index"], data["edge_index"]._version),), wrote)
             for name, layer in self.layers:
                 ins = self._data_only_inputs(layer)
                 if ins is None or not all(k in avail for k in ins):
                     continue
                 before = dict(data)
                 self._run_layer(layer, data, attrs)
-                avail |= {k for k, v in data.items() if before.get(k) is not v}
-                done[name] = tuple((k, data[k], data[k]._version) for k in ins)
+                wrote = tuple(k for k, v in data.items() if before.get(k) is not v)
+                avail |= set(wrote)
+                done[name] = (tuple((k, data[k], data[k]._version) for k in ins), wrote)
             for name, layer in self.layers:
                 hook = getattr(layer, "prepare_batch", None)
                 if hook is not None:
@@ -153,7 +157,15 @@ class SequentialGraphNetwork(torch.nn.Sequential):
 
     @staticmethod
     def _still_valid(record, data) -> bool:
-        return all(data.get(k) is t and t._version == v for k, t, v in record)
+        """``record``: (((input key, tensor, version), ...), (output keys)) of one layer run ahead."""
+        return all(data.get(k) is t and t._version == v for k, t, v in record[0])
+
+    @staticmethod
+    def _forget(record, data) -> None:
+        """The inputs of a layer run ahead were replaced or written to since: what it left in the batch is stale, and a layer that
+        finds its output present keeps it (``computeEdgeVector`` does, as the reference's: ``e3_layers/data/computeEdgeVector``)."""
+        for k in record[1]:
+            data.pop(k, None)
 
     def forward(self, batch):
         data, attrs = batch.data, batch.attrs
@@ -168,9 +180,13 @@ class SequentialGraphNetwork(torch.nn.Sequential):
         start = int(getattr(batch, "_e3k_prepared", 0))
         if start:
             batch._e3k_prepared = 0
+        if done and "_topology" in done and not self._still_valid(done["_topology"], data):
+            self._forget(done["_topology"], data)
         for key, layer in (self.layers[start:] if start else self.layers):
-            if done and key in done and self._still_valid(done[key], data):
-                continue                # run ahead by prepare_data() on exactly these input tensors: its outputs are in ``data``
+            if done and key in done:
+                if self._still_valid(done[key], data):
+                    continue            # run ahead by prepare_data() on exactly these input tensors: its outputs are in ``data``
+                self._forget(done[key], data)
             if profiling:
                 with record_function(key):
                     self._run_layer(layer, data, attrs)

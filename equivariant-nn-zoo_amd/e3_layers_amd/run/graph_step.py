@@ -49,16 +49,20 @@ class CapturedStep:
 
     def _capture(self, warmup: int, keep_last: bool = False):
         dev = self.dev
-        out = self._eager(warmup)
-        if not keep_last:
-            out = None
-        torch.cuda.synchronize(dev)
         from ..backend.graph import capture_flag, check_indices
-
-        check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
         from ..backend import radial_table
 
-        radial_table.drain_guards()      # ... and the knot-table guards' pending read-backs (no Event.query() inside a capture)
+        for _ in range(4):
+            level = radial_table.REFINEMENTS
+            out = self._eager(warmup)
+            torch.cuda.synchronize(dev)
+            check_indices()      # the warm-up batches' deferred index checks (none are recorded while capturing)
+            radial_table.drain_guards()      # ... and the knot-table guards' pending read-backs (no Event.query() inside a capture)
+            if radial_table.REFINEMENTS == level:
+                break            # (a bound read just now doubled the knot counts: warm up again, on the tables the graph will hold)
+            warmup = 1
+        if not keep_last:
+            out = None
         capture_flag(dev)                # the persistent flag the captured index checks fold into (a bad batch fed
                                          # through a replay must raise, as it does on the eager path)
         self.graph = torch.cuda.CUDAGraph()
@@ -73,17 +77,25 @@ class CapturedStep:
             radial_table.CAPTURE_LOG = None
         self._replays = 0
         self._vetoed = False
+        self._level = radial_table.REFINEMENTS
         return out
+
+    @property
+    def stale(self) -> bool:
+        """The next call records the step again instead of replaying it."""
+        from ..backend import radial_table
+
+        return bool(self._vetoed or (self._guards and self._level != radial_table.REFINEMENTS))
 
     def __call__(self):
         from ..backend import radial_table
         from ..backend.graph import poll_capture_flags
 
-        if self._vetoed:
-            # A knot table this graph interpolates from has been switched off (its error bound, which the captured step evaluates on
-            # the device with every replay, passed the tolerance: the weights moved under the optimizer).  The graph still holds the
-            # table kernels: this call runs the step EAGERLY once (the vetoed layer takes its per-edge path -- also the warm-up of
-            # that path) and records the step again; later calls replay the new graph.
+        if self.stale:
+            # A knot table this graph interpolates from has been refined or switched off (its error bound, which the captured step
+            # evaluates on the device with every replay, passed the tolerance: the weights moved under the optimizer).  The graph still
+            # holds the coarse table's kernels: this call runs the step EAGERLY once (on the finer tables, or with the vetoed layer on
+            # its per-edge path -- also the warm-up of those kernels) and records the step again; later calls replay the new graph.
             self.recaptures += 1
             out = self._capture(1, keep_last=True)
             return out
@@ -91,7 +103,7 @@ class CapturedStep:
         self._replays += 1
         poll_capture_flags(self.dev)     # (one 4-byte async copy: read by the next build / optimizer step / check_indices())
         if self._guards:                 # every N-th replay: the guards' running maxima travel home (no sync)
-            self._vetoed = radial_table.poll_replay(self._guards, self._replays)
+            self._vetoed = radial_table.poll_replay(self._guards, self._replays) or self._level != radial_table.REFINEMENTS
         return self.out
 
 
@@ -226,6 +238,10 @@ class BucketedStep:
 
         self.captured = CapturedStep(captured_fn, warmup=warmup, generators=generators)
 
+    @property
+    def recaptures(self) -> int:
+        return self.captured.recaptures
+
     def __call__(self, padded):
         by_dtype = {}
         for k in self.keys:
@@ -303,6 +319,7 @@ class PipelinedBucketedStep:
         from ..backend.graph import capture_flag
 
         self.tail = tail
+        self.prepare = prepare
         self.dev = example["pos"].device
         self.prep_stream = stream_beside(torch.cuda.current_stream(self.dev))
         self.static, self.prep_graphs, self.steps = [], [], []
@@ -320,6 +337,7 @@ class PipelinedBucketedStep:
             static = example.clone()        # (fresh tensors: no per-batch memo of the framework knows them yet)
             if self.keys is None:
                 self.keys = [k for k in static.keys() if torch.is_tensor(static[k])]
+                self._given = list(static.keys())      # (what the caller's batches carry: everything else is the preparation's)
             torch.cuda.synchronize(self.dev)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
@@ -336,6 +354,32 @@ class PipelinedBucketedStep:
     @property
     def recaptures(self) -> int:
         return sum(s.recaptures for s in self.steps)
+
+    def _record_again(self, b: int) -> None:
+        """Buffer b's step has to record itself again (a knot table was refined or switched off: ``CapturedStep.stale``).  Its
+        preparation graph is recorded again FIRST, on new tensors holding the buffer's present contents: the step's recording must
+        find the batch as the first one did -- prepared by a graph, inputs untouched since (the copies of ``_enqueue_prepare`` bump
+        the inputs' version counters: the record of what was prepared from what, and every per-tensor memo, would count as stale,
+        the eager warm-up would rebuild them outside any graph and the new recording would replay the batch it was recorded on) --
+        and after a refinement the preparation builds the finer resolution's bins and edge records."""
+        torch.cuda.synchronize(self.dev)
+        static = self.static[b]
+        fresh = {k: (static.data[k].clone() if torch.is_tensor(static.data[k]) else static.data[k]) for k in self._given}
+        static.data.clear()                 # (same container: the step's closure reads it when it records; the preparation's own keys are
+        static.data.update(fresh)           # gone -- a layer that finds its output present keeps it)
+        static._e3k_done = None
+        forget_batch_memos()
+        self.prep_graphs[b] = None          # (its pool holds the old bins)
+        warm = static.clone()
+        self.prepare(warm)                  # (eagerly first: see __init__)
+        torch.cuda.synchronize(self.dev)
+        del warm
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.prepare(static)
+        self.prep_graphs[b] = g
+        g.replay()
+        torch.cuda.synchronize(self.dev)
 
     def _enqueue_prepare(self, b: int, padded) -> None:
         """On the CURRENT stream: the padded batch into buffer b's static tensors, then its preparation graph."""
@@ -366,6 +410,8 @@ class PipelinedBucketedStep:
             self._enqueue_prepare(b, padded)
         else:
             main.wait_event(self.ev_prep[b])
+        if self.steps[b].stale:
+            self._record_again(b)
         out = self.steps[b]()
         self.ev_step[b].record(main)
         self._step_ran[b] = True

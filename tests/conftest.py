@@ -26,3 +26,16 @@ def dev():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _knot_resolution_is_per_test():
+    """A guard that trips doubles the knot counts of the PROCESS (``backend/radial_table._refine``); tests that scale weights to trip
+    one must not hand the finer tables to the tests after them."""
+    from e3_layers_amd.backend import radial_table as rt
+
+    saved = (rt.KNOTS, rt.KNOTS_SLOPE, rt.KNOTS_MAX, rt.REFINEMENTS)
+    for _, g in list(rt._GUARDS.values()):      # (read-backs of an earlier test's model that is still waiting for the collector)
+        g.pending.clear()
+    yield
+    rt.KNOTS, rt.KNOTS_SLOPE, rt.KNOTS_MAX, rt.REFINEMENTS = saved

@@ -483,6 +483,7 @@ def test_slope_table_guard_vetoes_and_the_per_edge_path_takes_over(dev, monkeypa
 
     monkeypatch.setattr(radial_table, "MIN_EDGES_PER_KNOT", 1)
     monkeypatch.setattr(radial_table, "GUARD_EVERY", 1)
+    monkeypatch.setattr(radial_table, "KNOTS_MAX", radial_table.KNOTS_SLOPE)      # (no finer table: the veto itself is tested here)
     prod, orc = _force_net(dev, 3, seed=1)
     with torch.no_grad():
         prod.func.layer1.conv.fc.layer0.weight.mul_(40.0)

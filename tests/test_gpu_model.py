@@ -1541,6 +1541,7 @@ def test_radial_table_guard_vetoes_a_table_that_would_miss_the_parity_budget(dev
     tree = _energy_tree(2, 64, 3)
     prod, _ = _build_pair(tree, dev)
     monkeypatch.setattr(radial_table, "GUARD_EVERY", 1)
+    monkeypatch.setattr(radial_table, "KNOTS_MAX", radial_table.KNOTS)      # (no finer table to fall back on: the veto itself is tested here)
     with torch.no_grad():
         list(prod.layer1.conv.fc.children())[0].weight.mul_(30.0)
         list(prod.layer1.conv.fc.children())[1].weight.mul_(3.0)
@@ -1629,6 +1630,7 @@ def test_knot_table_guard_runs_inside_replayed_graphs_and_recaptures_on_a_veto(d
 
     every = 4
     monkeypatch.setattr(radial_table, "GUARD_EVERY", every)
+    monkeypatch.setattr(radial_table, "KNOTS_MAX", radial_table.KNOTS)      # (refinement is the next test's)
     torch.manual_seed(0)
     tree = _energy_tree(2, 64, 3)
     model = build(tree).to(dev).train()
@@ -1673,6 +1675,73 @@ def test_knot_table_guard_runs_inside_replayed_graphs_and_recaptures_on_a_veto(d
     out_ref, _ = orc(*batch_to_oracle(batch))
     err = rel_err(out, out_ref["total_energy"])
     record_measured("replay_guard", bound_before=max(bounds), bound_scaled=radial_table.guard_error(keys[1]), replays_to_veto=n, energy=err)
+    assert err < TOL, err
+
+
+def test_a_tripped_guard_refines_the_knot_tables_before_it_switches_one_off(dev, monkeypatch):
+    """Round 6.  A bound that passes the tolerance first DOUBLES the knot counts (cubic interpolation: 16 x less error), for every
+    table of the process (the layers share the batch's bins and edge records); the captured step records itself again on the
+    finer tables and every layer keeps its table.  5 000 Adam steps at lr 1e-2 on the headline model trip layer 1's per-column
+    bound (``tools/soak.sh``): one layer per edge costs 0.52 ms of a 3.94 ms step, the finer tables 0.15 ms.  Here the first radial
+    layer of one MLP is scaled after the capture until the bound sits between 1 and 16 tolerances."""
+    import warnings
+
+    from e3_layers_amd.backend import ops, radial_table
+    from e3_layers_amd.backend.graph import build_topology
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import CapturedStep
+    from e3_layers_amd.utils import build
+
+    every = 4
+    monkeypatch.setattr(radial_table, "GUARD_EVERY", every)
+    knots0 = radial_table.KNOTS
+    torch.manual_seed(0)
+    tree = _energy_tree(2, 64, 3)
+    model = build(tree).to(dev).train()
+    batch = synth_qm9(1000, 128)
+    fixed = batch.clone().to(dev)
+    assert fixed["edge_index"].shape[1] >= radial_table.MIN_EDGES_PER_KNOT * (4 * knots0 + 1)
+    fixed.update(build_topology(fixed["edge_index"], fixed["pos"].shape[0]).as_dict())
+    target = fixed["total_energy"].clone()
+
+    def step():
+        out = model(fixed.view())["total_energy"]
+        for p in model.parameters():
+            p.grad = None
+        (out - target).square().mean().backward()
+        return out
+
+    keys = [radial_table.last_weight(getattr(model, f"layer{i}").conv.fc) for i in range(3)]
+    captured = CapturedStep(step, warmup=2)
+    for _ in range(every + 1):
+        captured()
+        torch.cuda.synchronize()
+    assert captured.recaptures == 0 and radial_table.REFINEMENTS == 0
+    first = list(model.layer1.conv.fc.children())[0].weight
+    scale, tripped = 1.0, None
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        while captured.recaptures == 0 and scale < 40.0:      # grow the weight until the bound trips (the bound grows like scale^2..4)
+            with torch.no_grad():
+                first.mul_(1.25)
+            scale *= 1.25
+            for _ in range(every + 1):
+                captured()
+                torch.cuda.synchronize()
+    assert captured.recaptures == 1 and radial_table.REFINEMENTS == 1, (captured.recaptures, radial_table.REFINEMENTS, scale)
+    assert radial_table.KNOTS == 2 * knots0
+    assert any("are rebuilt on" in str(w.message) for w in caught)
+    assert all(radial_table.guard_ok(k) for k in keys)          # nobody lost the table
+    for _ in range(2 * every + 1):                              # the finer tables' bounds arrive and hold
+        out = captured().detach().clone()
+        torch.cuda.synchronize()
+    ops.join_side_streams()
+    bounds = [radial_table.guard_error(k) for k in keys]
+    assert captured.recaptures == 1 and all(b is not None and b < radial_table.GUARD_TOL for b in bounds), bounds
+    orc = oracle_like(model, tree)
+    out_ref, _ = orc(*batch_to_oracle(batch))
+    err = rel_err(out, out_ref["total_energy"])
+    record_measured("replay_guard_refine", scale=scale, knots=radial_table.KNOTS, bounds_after=max(bounds), energy=err)
     assert err < TOL, err
 
 

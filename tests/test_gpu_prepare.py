@@ -131,3 +131,96 @@ def test_pipelined_preparation_follows_the_plain_replay(dev):
         assert abs(a - b) <= 2e-5 * abs(b), (l_p, l_b)
     assert rel_err(flat_p - start, flat_b - start) < 2e-3      # (Adam amplifies the rounding of tiny gradients: the updates' bulk)
     assert rel_err(ema_p, ema_b) < 1e-6
+
+
+@pytest.mark.parametrize("refine", [True, False])
+def test_pipelined_step_records_itself_again_after_a_guard_trips(dev, monkeypatch, refine):
+    """A guard that trips doubles the knot counts (``backend/radial_table._refine``) or, with no finer table left, switches that
+    MLP's table off.  Either way both buffers' steps record themselves again -- each AFTER its preparation graph was recorded again
+    on fresh tensors (``PipelinedBucketedStep._record_again``: the finer resolution's bins and edge records; and a step recorded
+    on a buffer whose inputs were written to since its preparation was recorded would rebuild the per-tensor memos eagerly in its
+    warm-up and replay the batch it was recorded on -- the first version of this did, found by this test).  The replayed losses
+    equal the eager model's on the same batches afterwards, whichever batch a buffer held when it was recorded."""
+    import warnings
+
+    from e3_layers_amd.backend import ops, radial_table
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import PipelinedBucketedStep, bucket_capacity, pad_batch
+
+    every = 2
+    monkeypatch.setattr(radial_table, "GUARD_EVERY", every)
+    knots0 = radial_table.KNOTS
+    if not refine:
+        monkeypatch.setattr(radial_table, "KNOTS_MAX", knots0)
+    model = _energy_model(dev)
+    host = [synth_qm9(61 + k, 128) for k in range(3)]
+    n_cap, e_cap = bucket_capacity([(b["pos"].shape[0], b["edge_index"].shape[1]) for b in host])
+    assert e_cap >= radial_table.MIN_EDGES_PER_KNOT * (2 * knots0 + 1)
+    padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host]
+
+    def loss_on(batch):
+        target, weight = batch["total_energy"], batch["_graph_weight"]
+        loss = ops.sq_error(model(batch)["total_energy"], target, weight, 1e3)
+        for p in model.parameters():
+            p.grad = None
+        loss.backward()
+        return loss
+
+    step = PipelinedBucketedStep(model.prepare_data, loss_on, padded[0], warmup=2)
+    for i in range(4):
+        step(padded[i % 3], nxt=padded[(i + 1) % 3])
+    torch.cuda.synchronize()
+    assert step.recaptures == 0 and radial_table.REFINEMENTS == 0
+    first = list(model.layer1.conv.fc.children())[0].weight
+    key = radial_table.last_weight(model.layer1.conv.fc)
+    scale, i = 1.0, 4
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        while step.recaptures == 0 and scale < 40.0:
+            with torch.no_grad():
+                first.mul_(1.25)
+            scale *= 1.25
+            for _ in range(2 * every + 2):
+                step(padded[i % 3], nxt=padded[(i + 1) % 3])
+                i += 1
+                torch.cuda.synchronize()
+    if refine:
+        assert radial_table.REFINEMENTS == 1 and radial_table.KNOTS == 2 * knots0 and radial_table.guard_ok(key), scale
+        assert any("are rebuilt on" in str(w.message) for w in caught)
+    else:
+        assert radial_table.REFINEMENTS == 0 and radial_table.KNOTS == knots0 and not radial_table.guard_ok(key), scale
+        assert any("per edge from now on" in str(w.message) for w in caught)
+    losses = []
+    for _ in range(7):                                          # both buffers have recorded themselves again by now, or do so here;
+        losses.append((i % 3, float(step(padded[i % 3], nxt=padded[(i + 1) % 3]).detach())))      # every batch meets every buffer
+        i += 1
+        torch.cuda.synchronize()
+    assert step.recaptures == 2                                 # one per buffer
+    for b in range(2):                                          # the new preparation graphs build the bins of the resolution in force
+        assert set(radial_table.prepared_bins(step.static[b]["edge_length"])) == {radial_table.KNOTS}
+    ops.join_side_streams()
+    want = [float(loss_on(padded[k].clone()).detach()) for k in range(3)]
+    for k, got in losses:
+        assert abs(got - want[k]) <= 2e-5 * abs(want[k]), (k, got, want, losses)
+
+
+def test_inputs_overwritten_in_place_after_the_preparation_are_prepared_again(dev):
+    """``prepare_data(batch)`` and then the batch's tensors are WRITTEN to (another batch copied in): the version counters say so, the
+    forward drops what the layers run ahead left in the batch (edge vectors -- which ``computeEdgeVector`` would otherwise keep, as
+    the reference's does --, spherical harmonics, one-hot, the CSR views) and runs them again."""
+    from e3_layers_amd.data.synthetic import synth_qm9
+    from e3_layers_amd.run.graph_step import bucket_capacity, pad_batch
+
+    model = _energy_model(dev)
+    host = [synth_qm9(61 + k, 64) for k in range(2)]
+    n_cap, e_cap = bucket_capacity([(b["pos"].shape[0], b["edge_index"].shape[1]) for b in host])
+    padded = [pad_batch(b, n_cap, e_cap).to(dev) for b in host]
+    a = padded[0].clone()
+    model.prepare_data(a)
+    for k in padded[1].keys():
+        if torch.is_tensor(padded[1][k]):
+            a[k].copy_(padded[1][k])
+    with torch.no_grad():
+        got = model(a.view())["total_energy"]
+        want = model(padded[1].clone())["total_energy"]
+    assert torch.equal(got, want)
