@@ -48,9 +48,10 @@ MIN_EDGES_PER_KNOT = _knob("E3K_RADIAL_MIN_EDGES_PER_KNOT")      # below this th
 # bound is re-measured on the new table at once), up to KNOTS_MAX; only a bound that 2048 knots cannot hold switches that MLP's
 # table off.  Measured on the headline step: 3.94 ms at 512 knots, 4.09 ms at 1024, 4.46 ms with ONE layer's MLP per edge
 # (``tools/soak.sh``: 5 000 Adam steps at lr 1e-2 on four batches trip layer 1's per-column bound).  One resolution for every
-# table in the process: the layers share the batch's bins and edge records.  Keyed tables (rows x keys against the bins kernel's
-# 4 000-row histogram) do not refine.
+# table in the process: the layers share the batch's bins and edge records.  A keyed table's guard (rows x keys against the bins
+# kernel's 4 000-row histogram) does not refine, and a keyed source follows a refinement only as far as its stack still fits.
 KNOTS_MAX = _knob("E3K_RADIAL_KNOTS_MAX")
+_KNOTS_AT_START = (int(KNOTS), int(KNOTS_SLOPE))
 REFINEMENTS = 0      # how many times the counts doubled in this process (CapturedStep compares it with its own: a graph recorded
                      # before a refinement holds the coarse tables and records itself again)
 # Keyed tables (``KeyedRadialSource``: an edge embedding that is a function of the radius and a small categorical key -- config_diffusion's
@@ -238,16 +239,23 @@ class KeyedRadialSource:
     def module(self):
         return self.base.module()
 
+    def _fit(self, knots: int, floor: int) -> int:
+        """A refined resolution (``_refine``) only as far as the stacked table still fits the bins kernel's 4 000-row histogram."""
+        r_max = float(self.module().basis.r_max)
+        while knots > floor and (layout(r_max, knots)[0] + 1) * self.n_keys > 4000:
+            knots //= 2
+        return knots
+
     @property
     def knots(self) -> int:
-        return self.base.knots
+        return self._fit(self.base.knots, _KNOTS_AT_START[0])
 
     @property
     def knots_slope(self) -> int:
-        return self.base.knots_slope
+        return self._fit(self.base.knots_slope, _KNOTS_AT_START[1])
 
     def bins(self, knots: Optional[int] = None) -> KnotBins:
-        knots = self.base.knots if knots is None else int(knots)
+        knots = self.knots if knots is None else int(knots)
         hit = self._bins.get(knots)
         if hit is None:
             hit = self._bins[knots] = build_bins(self.base.r, float(self.module().basis.r_max), knots, self.key, self.n_keys)
@@ -256,7 +264,7 @@ class KeyedRadialSource:
     def knot_basis(self, knots: Optional[int] = None):
         """[n_keys (knots + 1), width]: the embedding of every (key, knot) pair, key-major; differentiable w.r.t. the parameters of
         ``rows_fn`` (the Concat's Linear) and of the basis (the Bessel frequencies)."""
-        knots = self.base.knots if knots is None else int(knots)
+        knots = self.knots if knots is None else int(knots)
         kb = self._knot_basis.get(knots)
         if kb is None or kb[1] != torch.is_grad_enabled():
             base = self.base.knot_basis(knots)                               # [rows, n_basis]
@@ -336,10 +344,10 @@ GUARD_TOL_COL = _knob("E3K_RADIAL_TABLE_TOL_COL")
 
 
 class _Guard:
-    __slots__ = ("calls", "pending", "ok", "last", "dev", "scratch", "what", "__weakref__")
+    __slots__ = ("calls", "pending", "ok", "last", "dev", "scratch", "what", "keyed", "__weakref__")
 
     def __init__(self, what: str):
-        self.calls, self.pending, self.ok, self.last, self.what = 0, [], True, None, what
+        self.calls, self.pending, self.ok, self.last, self.what, self.keyed = 0, [], True, None, what, False
         self.dev = self.scratch = None      # device state [4] (running max, last estimate, ticket, -) and the kernel's column scratch
 
     def device_state(self, device, width: int):
@@ -396,8 +404,8 @@ def _refine(g: _Guard) -> bool:
     global KNOTS, KNOTS_SLOPE, REFINEMENTS
     if g.last != g.last:                    # NaN: not a matter of resolution
         return False
-    if any(isinstance(kind, tuple) for (_, kind) in _GUARDS):
-        return False                        # a stacked (keyed) table lives in this process
+    if g.keyed:
+        return False                        # a stacked (keyed) table: its rows x keys are bounded by the bins kernel's histogram
     if 2 * int(KNOTS_SLOPE if g.what == "slope" else KNOTS) > int(KNOTS_MAX):
         return False
     KNOTS = min(2 * int(KNOTS), max(int(KNOTS_MAX), int(KNOTS)))
@@ -499,11 +507,12 @@ def guard_many(items) -> None:
         blocks = int(it[3]) if len(it) > 3 else 1
         if blocks > 1 and table.shape[0] % blocks == 0:
             per = table.shape[0] // blocks
-            flat += [(w_last, table[b * per:(b + 1) * per], slope, b) for b in range(blocks)]
+            flat += [(w_last, table[b * per:(b + 1) * per], slope, b, True) for b in range(blocks)]
         else:
-            flat.append((w_last, table, slope, 0))
-    for w_last, table, slope, block in flat:
+            flat.append((w_last, table, slope, 0, False))
+    for w_last, table, slope, block, keyed in flat:
         g = _guard_of(w_last, (slope, block) if block else slope, create=True)
+        g.keyed = keyed
         g.calls += 1
         _poll(g)
         if table.shape[0] < 5 or not table.is_cuda:

@@ -185,7 +185,8 @@ def test_pipelined_step_records_itself_again_after_a_guard_trips(dev, monkeypatc
                 i += 1
                 torch.cuda.synchronize()
     if refine:
-        assert radial_table.REFINEMENTS == 1 and radial_table.KNOTS == 2 * knots0 and radial_table.guard_ok(key), scale
+        assert radial_table.REFINEMENTS == 1 and radial_table.KNOTS == 2 * knots0 and radial_table.guard_ok(key), \
+            (scale, [str(w.message)[:160] for w in caught])
         assert any("are rebuilt on" in str(w.message) for w in caught)
     else:
         assert radial_table.REFINEMENTS == 0 and radial_table.KNOTS == knots0 and not radial_table.guard_ok(key), scale

@@ -1,6 +1,6 @@
 #!/bin/bash
 # full GPU suite + the default bench line + the ordered trace of a replayed step
-timeout 2300 python3 -m pytest tests -q -m gpu -x 2>&1 | tail -6 > gpurun_out/gpu_suite.log
+timeout 2300 python3 -m pytest tests -q -m gpu -x 2>&1 | tail -60 > gpurun_out/gpu_suite.log
 cat gpurun_out/gpu_suite.log | tail -3
 mkdir -p gpurun_out/e6
 B="python3 bench.py --no-cpu-baseline --steps 20 --warmup 5"
