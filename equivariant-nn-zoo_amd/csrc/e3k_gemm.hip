@@ -92,6 +92,7 @@ __device__ unsigned long long e3k_dbg_buf[1 << 20];
 struct BlockProblem {
   e3k_gemm_problem P;
   int flags, aux, local;
+  int pi, key;      // index of the problem in the batch; key group of a keyed problem (0 otherwise): what a K-chain's followers reuse
 };
 
 __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
@@ -108,6 +109,8 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
   out.flags = gb.flags[pi];
   out.aux = gb.aux[pi];
   out.P = gb.p[pi];
+  out.pi = pi;
+  out.key = 0;
   const int reps = gb.reps[pi];
   if (reps > 1) {  // keyed problem: which key group this workgroup belongs to
     const int per_key = (gb.tile_start[pi + 1] - gb.tile_start[pi]) / reps;
@@ -115,6 +118,7 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
     out.local -= key * per_key;
     out.P.B += (int64_t)key * gb.key_stride[pi];
     out.P.group_dev += 2 * key;
+    out.key = key;
   }
   if (out.P.row_index && out.P.group_dev) {  // device-side {start, count} of this key group
     const int start = uniform(out.P.group_dev[0]), count = uniform(out.P.group_dev[1]);
@@ -122,6 +126,25 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
     out.P.M1 = count < out.P.M1 ? count : out.P.M1;
   }
   return out;
+}
+
+// K-chain (round 6): problem pi + j, j = 1 .. P.chain of the head, continues the head's K loop into the SAME accumulators -- another A
+// block times another B block summed into the same C tile (the input gradient of an irrep that feeds two outputs of a Linear:
+// `64x0e` and the gates' `256x0e` both read `0e`; until now the second one was an accumulating second launch, 21 us of a
+// layer's backward for 0.4 GFLOP).  A follower has its head's rows, columns, C and key groups; it brings A, B, K, their strides
+// and alpha.  Zero tiles of its own: no workgroup ever finds it through tile_start.
+__device__ __forceinline__ void fetch_follower(const GemmBatch& gb, int idx, const BlockProblem& head, BlockProblem& out) {
+  out.P = gb.p[idx];
+  out.flags = gb.flags[idx];
+  if (gb.reps[idx] > 1) {
+    out.P.B += (int64_t)head.key * gb.key_stride[idx];
+    out.P.group_dev += 2 * head.key;
+  }
+  if (out.P.row_index && out.P.group_dev) {
+    const int start = uniform(out.P.group_dev[0]), count = uniform(out.P.group_dev[1]);
+    out.P.row_index += start;
+    out.P.M1 = count < out.P.M1 ? count : out.P.M1;
+  }
 }
 
 __device__ __forceinline__ float epilogue_act(const e3k_gemm_problem& P, float v) {
@@ -298,15 +321,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  const BlockProblem bp_ = fetch_problem(gb);
+  const BlockProblem head_ = fetch_problem(gb);
+  BlockProblem bp_ = head_;
   const e3k_gemm_problem& P = bp_.P;
-  const int flags = bp_.flags, local = bp_.local;
+  const int local = bp_.local;
   const int M = P.M1 * P.M2;
   const int tiles_n = (P.N + BN - 1) / BN;
   const int row0 = (local / tiles_n) * BM_, n0 = (local % tiles_n) * BN;
   if (row0 >= M) return;  // block-uniform: surplus workgroup of a device-sized group
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w % WM, wn = w / WM;
+  const int chain = head_.P.chain;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -314,9 +339,11 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[j][i] = 0.f;
 
+  for (int link = 0;; ++link) {      // (one trip unless the problem heads a K-chain)
   fill_row_tables<BM_>(P, row0, M, rowA, rowC);
   __syncthreads();
 
+  const int flags = bp_.flags;
   const bool avec = flags & 1;
   const int bmode = (flags >> 1) & 3;
   const float* ap = As + (wm * 32 + (lane & 31)) * LDA + (lane >> 5);
@@ -388,8 +415,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
       __syncthreads();
     }
   }
+  if (link == chain) break;
+  {      // the next link: acc holds sum / alpha of what is behind; alpha is applied once, in the epilogue, with the LAST link's value
+    const float behind = P.alpha;
+    fetch_follower(gb, head_.pi + link + 1, head_, bp_);
+    const float ratio = behind / P.alpha;
+    if (ratio != 1.0f) {
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[j][i] *= ratio;
+    }
+  }
+  }
 #ifdef E3K_DEBUG_KNOBS
-  if (flags & 32) return;      // timing only: no stores
+  if (bp_.flags & 32) return;      // timing only: no stores
 #endif
   store_acc<NT>(P, acc, rowC, wm * 32, n0 + wn * (BN / WN));
 }
@@ -1235,9 +1275,16 @@ int validate(const e3k_gemm_problem& P, bool wgrad) {
   if (!P.A || !P.B || !P.C) return E3K_ERR_INVALID;
   if (P.V < 0 || P.V > e3k::VMAX) return E3K_ERR_UNSUPPORTED;
   if (P.V > 0 && (!P.A2 || P.K % P.V != 0)) return E3K_ERR_INVALID;
-  if (wgrad && (P.bias || P.act)) return E3K_ERR_INVALID;
+  if (wgrad && (P.bias || P.act || P.chain)) return E3K_ERR_INVALID;
   if (P.act < 0 || P.act > 1) return E3K_ERR_INVALID;
+  if (P.chain < 0 || P.chain >= e3k::GEMM_MAXP) return E3K_ERR_INVALID;
   return E3K_OK;
+}
+
+// followers of a K-chain (e3k.h): the head's rows, columns, output and key groups
+bool follows(const e3k_gemm_problem& H, const e3k_gemm_problem& F) {
+  return F.chain == 0 && F.V == 0 && H.V == 0 && !F.bias && F.M1 == H.M1 && F.M2 == H.M2 && F.N == H.N && F.C == H.C && F.c_r1 == H.c_r1 &&
+         F.c_r2 == H.c_r2 && F.c_n == H.c_n && F.row_index == H.row_index && F.group_dev == H.group_dev && F.alpha != 0.f;
 }
 
 bool a_vec(const e3k_gemm_problem& P) {
@@ -1253,7 +1300,7 @@ int b_mode(const e3k_gemm_problem& P) {
   return 0;
 }
 
-enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_PERSIST, FWD_KINDS };
+enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_PERSIST, FWD_KINDS, FWD_FOLLOWER };      // (a follower rides with its head)
 
 struct Batcher {
   e3k::GemmBatch gb{};
@@ -1277,11 +1324,34 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
   int64_t plain_tiles128 = 0;
   E3K_KNOB_INT(sk_min_rows, "E3K_SK_MIN_ROWS", 1024);
   E3K_KNOB_INT(splitk_on, "E3K_SPLITK", 1);
+  int follower_of[MAX_CALL];
+  for (int i = 0; i < n_problems; ++i) follower_of[i] = -1;
   for (int i = 0; i < n_problems; ++i) {
     const e3k_gemm_problem& P = problems[i];
     const int rc = validate(P, false);
     if (rc != E3K_OK) return rc;
+    if (P.chain > 0) {      // a K-chain: head and followers on the plain kernel, in one batch
+      if (follower_of[i] >= 0 || i + P.chain >= n_problems) return E3K_ERR_INVALID;
+      for (int j = 1; j <= P.chain; ++j) {
+        if (!follows(P, problems[i + j]) || (reps && (reps[i + j] > 1) != (reps[i] > 1)) || (reps && reps[i + j] != reps[i])) return E3K_ERR_INVALID;
+        const int rcf = validate(problems[i + j], false);
+        if (rcf != E3K_OK) return rcf;
+        follower_of[i + j] = i;
+      }
+    }
+  }
+  for (int i = 0; i < n_problems; ++i) {
+    const e3k_gemm_problem& P = problems[i];
     const int64_t M = (int64_t)P.M1 * P.M2;
+    if (follower_of[i] >= 0) {
+      kind[i] = FWD_FOLLOWER;
+      continue;
+    }
+    if (P.chain > 0) {
+      kind[i] = FWD_PLAIN;
+      plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
+      continue;
+    }
     if (P.V > 0) kind[i] = FWD_OUTER;
     else if (P.K <= e3k::SK_KMAX && a_vec(P) && b_mode(P) == 1 && c_vec(P) && M >= sk_min_rows) kind[i] = FWD_SMALLK;
     else if (splitk_on && a_vec(P) && b_mode(P) == 2 && P.K >= 256 && P.K % 64 == 0 && ((M + 63) / 64) * ((P.N + e3k::BN - 1) / e3k::BN) < 128)
@@ -1366,13 +1436,22 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
     // K loops go first and the short ones fill the tail of the launch
     int order[MAX_CALL];
     for (int i = 0; i < n_problems; ++i) order[i] = i;
-    std::stable_sort(order, order + n_problems, [&](int a, int b) { return problems[a].K > problems[b].K; });
+    auto k_total = [&](int a) {
+      int kt = problems[a].K;
+      for (int j = 1; j <= problems[a].chain; ++j) kt += problems[a + j].K;
+      return kt;
+    };
+    std::stable_sort(order, order + n_problems, [&](int a, int b) { return k_total(a) > k_total(b); });
     for (int oi = 0; oi < n_problems; ++oi) {
       const int i = order[oi];
       if (kind[i] != k) continue;
       const e3k_gemm_problem& P = problems[i];
       const int64_t M = (int64_t)P.M1 * P.M2;
       if (M == 0) continue;
+      if (P.chain > 0 && b.gb.n + 1 + P.chain > e3k::GEMM_MAXP) {      // a chain does not straddle two launches
+        const int rc = flush();
+        if (rc != E3K_OK) return rc;
+      }
       const int rp = reps && reps[i] > 1 ? reps[i] : 1;
       const int tiles_n = (P.N + e3k::BN - 1) / e3k::BN;
       int64_t blocks;
@@ -1403,7 +1482,22 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       gb.aux[gb.n] = aux;
       gb.tile_start[gb.n] = b.blocks;
       b.blocks += (int)blocks;
-      if (++gb.n == e3k::GEMM_MAXP) {
+      ++gb.n;
+      for (int j = 1; j <= P.chain; ++j) {      // the followers: right behind their head, no tiles of their own
+        const e3k_gemm_problem& F = problems[i + j];
+        gb.p[gb.n] = F;
+        gb.p[gb.n].accumulate = P.accumulate;      // (the last link's descriptor runs the epilogue)
+        gb.p[gb.n].bias = P.bias;
+        gb.p[gb.n].act = P.act;
+        gb.p[gb.n].act_cst = P.act_cst;
+        gb.reps[gb.n] = rp;
+        gb.key_stride[gb.n] = rp > 1 ? key_stride[i + j] : 0;
+        gb.flags[gb.n] = (a_vec(F) ? 1 : 0) | (b_mode(F) << 1) | (int)kAblF;
+        gb.aux[gb.n] = 0;
+        gb.tile_start[gb.n] = b.blocks;
+        ++gb.n;
+      }
+      if (gb.n == e3k::GEMM_MAXP) {
         const int rc = flush();
         if (rc != E3K_OK) return rc;
       }

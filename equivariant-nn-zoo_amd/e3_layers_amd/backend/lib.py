@@ -32,7 +32,7 @@ class GemmProblem(C.Structure):
         ("a2_r1", C.c_int64),
         ("b_k", C.c_int64), ("b_n", C.c_int64),
         ("c_r1", C.c_int64), ("c_r2", C.c_int64), ("c_n", C.c_int64),
-        ("alpha", C.c_float), ("act", C.c_int32), ("act_cst", C.c_float), ("_pad", C.c_int32),
+        ("alpha", C.c_float), ("act", C.c_int32), ("act_cst", C.c_float), ("chain", C.c_int32),
     ]
 
 

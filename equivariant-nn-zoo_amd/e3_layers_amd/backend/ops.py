@@ -333,12 +333,44 @@ class LinearSpec:
         return out
 
 
+def _chain_rounds(rounds):
+    """Rounds of GEMM problems (round r + 1 accumulates onto blocks round r wrote) -> the same sums with the later rounds' problems
+    hung behind their round-0 problem as K-CHAIN followers (``e3k.h``: ``e3k_gemm_problem.chain``): one pass over C, one launch.
+    A problem that finds no head of its shape stays in its round."""
+    if len(rounds) < 2 or not _knob("E3K_GEMM_CHAIN"):
+        return rounds
+    heads = [[p] for p in rounds[0]]
+    where = {}
+    for i, (p,) in enumerate(heads):
+        if not p.V and not p.chain:
+            where[(p.C, p.M2, p.N, p.c_r1, p.c_r2, p.c_n)] = i
+    left = []
+    for r, group in enumerate(rounds[1:], 1):
+        rest = []
+        for p in group:
+            i = where.get((p.C, p.M2, p.N, p.c_r1, p.c_r2, p.c_n))
+            if i is None or p.V or p.bias or p.act != heads[i][0].act:
+                rest.append(p)
+            else:
+                heads[i].append(p)
+        left.append(rest)
+    first = []
+    for chain in heads:
+        chain[0].chain = len(chain) - 1
+        for f in chain[1:]:
+            f.chain = 0
+        first += chain
+    return [first] + [g for g in left if g]
+
+
 class _GemmTemplates:
     """Descriptor arrays of one (layer, pass), built once: pointer fields hold byte offsets (``e3k_gemm_rebased``)."""
 
     __slots__ = ("rounds", "shapes", "loose_bias")
 
-    def __init__(self, rounds: List[List[L.GemmProblem]], loose_bias=()):
+    def __init__(self, rounds: List[List[L.GemmProblem]], loose_bias=(), wgrad: bool = False):
+        if not wgrad:
+            rounds = _chain_rounds([g for g in rounds if g])
         self.rounds = [((L.GemmProblem * len(g))(*g), len(g)) for g in rounds if g]
         self.shapes = [[(p.M2, p.N, p.K, p.V) for p in g] for g in rounds if g]
         self.loose_bias = tuple(loose_bias)
@@ -453,7 +485,7 @@ def _lin_wgrad_templates(spec: "LinearSpec", scale: float):
         p.c_r1, p.c_r2, p.c_n = spec.d_out, c_r2, c_n
         p.alpha = ins.alpha * scale
         probs.append(p)
-    return _GemmTemplates([probs])
+    return _GemmTemplates([probs], wgrad=True)
 
 
 def _lin_wgrad_raw(x, gy, gw, spec: LinearSpec, scale: float) -> None:
@@ -1161,6 +1193,8 @@ def _grouped_templates(spec, m_off, mode: str):
                 rounds.append([])
             p.accumulate = 1 if (r > 0 or mode in ("wgrad", "dgrad_acc")) else 0
             rounds[r].append(p)
+        if mode != "wgrad":
+            rounds = _chain_rounds(rounds)
         return [((L.GemmProblem * len(g))(*g), len(g)) for g in rounds]
 
     return _templates(spec, ("grouped", mode, tuple(m_off)), build)

@@ -25,6 +25,7 @@ KNOBS: Dict[str, Tuple[object, str, str]] = {
     "E3K_LAYER_NATIVE": (1, "path", "the fused layer's launch sequence issued by csrc/e3k_layer.hip; 0: the same sequence from Python"),
     "E3K_FORCE_BLOCK": (1, "path", "force training: a layer as three autograd nodes on the value + slope tables (backend/conv_force.py); 0: composed per-edge path"),
     "E3K_FORCE_MATERIALIZE": (1, "path", "force block: per-edge weights / slopes interpolated once per layer and streamed; 0: every kernel gathers the table rows"),
+    "E3K_GEMM_CHAIN": (1, "path", "a Linear's terms that add onto one block (an irrep feeding two outputs: the second was an accumulating launch of its own) run as ONE K-chained GEMM problem; 0: one round of launches per term"),
     "E3K_FORCE_EDGE_ATOMICS": (0, "path", "force block: 1 = g_sh / g_r accumulated with float atomics across a plan's groups (rounds 4-5: forces not bit-reproducible); 0 = per-item partials combined in a fixed order"),
     "E3K_BLOCK_ADDEND": (1, "path", "layers with un-keyed node attributes run as fused blocks with the self-connection handed in as addend"),
     "E3K_ADDEND_INPLACE": (1, "path", "the addend tensor itself is the block's pre-gate buffer (no copy)"),

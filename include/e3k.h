@@ -72,7 +72,13 @@ typedef struct {
   float alpha;
   int32_t act;   /* 0 none; 1: C = act_cst * ssp(alpha*A.B + bias) fused into the epilogue (radial MLP layers) */
   float act_cst; /* second-moment normalisation constant of the activation */
-  int32_t _pad;
+  int32_t chain; /* K-chain (e3k_gemm, e3k_gemm_multi; forward / input-gradient problems only): the `chain` problems that FOLLOW
+                    this one in the array continue its K loop into the same accumulators,
+                        C = alpha_0 A_0.B_0 + alpha_1 A_1.B_1 + ...  (+ C if the head accumulates) (+ the head's bias, activation),
+                    in ONE pass over C instead of one accumulating launch per term -- e3nn's o3.Linear input gradient of an irrep
+                    that feeds several outputs (e3_layers/nn/pointwise.py:87-92: `0e` feeds the scalars and the gates).  A follower
+                    repeats the head's M1, M2, N, C, c_* strides, row_index / group_dev (keyed: the same groups) and has chain = 0,
+                    V = 0, no bias; it brings A, B, K, their strides and alpha.  Every link runs on the plain kernel. */
 } e3k_gemm_problem;
 
 int e3k_gemm(const e3k_gemm_problem* problems, int n_problems, void* stream);

@@ -187,6 +187,66 @@ def test_gemm_forward_epilogues_through_the_c_abi(dev, m1, m2, k, n, accumulate,
     assert rel_err(c, want) < 2e-6      # (the columns outside the block are part of the comparison: they must be untouched)
 
 
+@pytest.mark.parametrize("m1,m2,n,ks,accumulate,bias,kdgrad", [
+    (1000, 1, 192, (64, 256), 0, False, True),      # the trailing Linear's input gradient of `0e`: scalars' and gates' blocks (W^T: k-contiguous B)
+    (1000, 3, 64, (64, 128, 32), 1, True, False),   # three links, accumulating head, bias, n-contiguous B
+    (333, 5, 200, (96, 40), 0, False, True),        # edge tiles in rows and columns, K tails
+    (130, 1, 72, (64, 64), 1, False, False),
+])
+def test_gemm_k_chain_through_the_c_abi(dev, m1, m2, n, ks, accumulate, bias, kdgrad):
+    """e3k_gemm with a K-chain (round 6): C = sum_j alpha_j A_j B_j (+ C) (+ bias) in one pass -- the followers continue the head's K loop
+    into the same accumulators -- against float64 torch.  A second, unchained problem shares the launch (the batch's tile ranges must
+    skip the followers)."""
+    from e3_layers_amd.backend import lib as L
+
+    torch.manual_seed(m1 + n + sum(ks))
+    d_a, d_c = m2 * sum(ks) + 12, m2 * n + 20
+    a = torch.randn(m1, d_a, device=dev)
+    c = torch.randn(m1, d_c, device=dev)
+    bv = torch.randn(n, device=dev) if bias else None
+    alphas = [0.71, 0.33, 1.9][:len(ks)]
+    want = c.double().cpu().clone()
+    total = torch.zeros(m1 * m2, n, dtype=torch.float64)
+    probs, keep, pos = [], [], 4
+    for j, (k, al) in enumerate(zip(ks, alphas)):
+        b = torch.randn(n, k, device=dev) if kdgrad else torch.randn(k, n, device=dev)      # dgrad reads W^T: B[k, n] = W[n, k]
+        keep.append(b)
+        a_blk = a.cpu().double()[:, pos:pos + m2 * k].reshape(m1 * m2, k)
+        total += al * a_blk @ (b.cpu().double().T if kdgrad else b.cpu().double())
+        p = L.GemmProblem()
+        p.A, p.A2, p.B, p.C = a.data_ptr() + 4 * pos, None, b.data_ptr(), c.data_ptr() + 4 * 8
+        p.bias = bv.data_ptr() if (bias and j == 0) else None
+        p.row_index, p.group_dev = None, None
+        p.M1, p.M2, p.N, p.K, p.V, p.accumulate = m1, m2, n, k, 0, accumulate
+        p.a_r1, p.a_r2, p.a_k = d_a, k, 1
+        p.b_k, p.b_n = (1, k) if kdgrad else (n, 1)
+        p.c_r1, p.c_r2, p.c_n = d_c, n, 1
+        p.alpha, p.act, p.act_cst = al, 0, 1.0
+        p.chain = len(ks) - 1 if j == 0 else 0
+        probs.append(p)
+        pos += m2 * k
+    if bias:
+        total = total + bv.cpu().double()
+    blk = want[:, 8:8 + m2 * n].reshape(m1 * m2, n)
+    want[:, 8:8 + m2 * n] = ((blk + total) if accumulate else total).reshape(m1, m2 * n)
+    # the bystander: its own output, after the chain in the array
+    a2, b2, c2 = torch.randn(500, 64, device=dev), torch.randn(64, 128, device=dev), torch.zeros(500, 128, device=dev)
+    q = L.GemmProblem()
+    q.A, q.A2, q.B, q.C, q.bias, q.row_index, q.group_dev = a2.data_ptr(), None, b2.data_ptr(), c2.data_ptr(), None, None, None
+    q.M1, q.M2, q.N, q.K, q.V, q.accumulate = 500, 1, 128, 64, 0, 0
+    q.a_r1, q.a_r2, q.a_k, q.b_k, q.b_n, q.c_r1, q.c_r2, q.c_n = 64, 64, 1, 128, 1, 128, 128, 1
+    q.alpha, q.act, q.act_cst, q.chain = 1.0, 0, 1.0, 0
+    arr = (L.GemmProblem * (len(probs) + 1))(*probs, q)
+    L.check(L.load().e3k_gemm(arr, len(probs) + 1, L.stream_ptr()), "e3k_gemm")
+    torch.cuda.synchronize()
+    assert rel_err(c, want) < 2e-6
+    assert rel_err(c2, a2.double() @ b2.double()) < 2e-6
+    # a follower that does not repeat its head's output is refused
+    probs[1].N = n + 4
+    arr = (L.GemmProblem * len(probs))(*probs)
+    assert L.load().e3k_gemm(arr, len(probs), L.stream_ptr()) != 0
+
+
 @pytest.mark.parametrize("rows,width", [(4097, 1920), (700, 960), (33, 260)])
 def test_fully_connected_net_few_rows_wide_output(dev, rows, width):
     """The radial MLP on the knot table: few rows, a wide last layer -- its dgrad is the split-K kernel (K = width),

@@ -43,4 +43,7 @@ python3 tools/postlin_bench.py > $OUT/gemm_postlin_bench.txt 2>&1
 python3 tools/sample_bench.py 128 50 > $OUT/sampler.txt 2>&1
 python3 tools/micro/two_graphs2.py > $OUT/two_graphs_overlap.txt 2>&1
 python3 tools/micro/ext_event_torch.py > $OUT/ext_event_torch.txt 2>&1
+# 8. 5 x 1000 replayed steps (the knot-table guard at work: refinement, or -- E3K_RADIAL_KNOTS_MAX=512 -- a veto), the transpose's row order
+STEPS=1000 bash tools/soak.sh > $OUT/soak.txt 2>&1
+python3 tools/micro/transpose_order.py > $OUT/transpose_order.txt 2>&1
 ls $OUT; tail -c 600 $OUT/bench_default.json

@@ -83,7 +83,7 @@ with open(os.path.join(DST, "r06_tp_l2_hit.txt"), "w") as f:
             hm, mm = sum(h) / len(h), sum(m) / len(m)
             f.write(f"{k}: launches {len(h)} hits {hm / 1e6:.2f} M misses {mm / 1e6:.2f} M hit rate {hm / max(hm + mm, 1):.3f}\n")
 for name in ("tp_table_bench.txt", "trace_graph_energy_force.txt", "trace_graph_energy.txt", "trace_graph_energy_one_graph.txt", "gemm_postlin_bench.txt",
-             "sampler.txt", "two_graphs_overlap.txt", "ext_event_torch.txt"):
+             "sampler.txt", "two_graphs_overlap.txt", "ext_event_torch.txt", "soak.txt", "transpose_order.txt"):
     if os.path.exists(os.path.join(SRC, name)):
         shutil.copy(os.path.join(SRC, name), os.path.join(DST, "r06_" + name))
 # ---- MFMA busy of the GEMM kernels
