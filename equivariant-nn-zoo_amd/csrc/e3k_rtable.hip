@@ -38,8 +38,12 @@ __device__ __forceinline__ void nt_store4(float4* p, const float4& v) {
   __builtin_nontemporal_store(t, reinterpret_cast<f32x4*>(p));
 }
 __device__ __forceinline__ float4 nt_load4(const float4* p) {
+#ifdef E3K_NO_NT      // (experiment builds: tools/micro/nt_policy.sh)
+  return *p;
+#else
   const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
   return make_float4(t.x, t.y, t.z, t.w);
+#endif
 }
 
 constexpr int RT_CHUNK = 1024;      // edges ranked by one wave
