@@ -309,7 +309,10 @@ __device__ __forceinline__ void store_acc(const e3k_gemm_problem& P, const f32x1
 // ---------------------------------------------------------------------------------------
 // plain forward / dgrad, tile (32*WM) x 64 x 32
 // ---------------------------------------------------------------------------------------
-template <int WM>
+// CHAIN: the launch holds K-chains (e3k.h: e3k_gemm_problem.chain).  A second instantiation: the loop over a chain's links around the
+// body costs the compiler 56 more registers (100 -> 156: three waves per SIMD instead of five); launches without chains -- all but a
+// layer's input gradients -- keep the lean form.
+template <int WM, bool CHAIN>
 __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   constexpr int BM_ = 32 * WM;          // rows per tile
   constexpr int WN = 4 / WM;            // waves along n
@@ -331,7 +334,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   if (row0 >= M) return;  // block-uniform: surplus workgroup of a device-sized group
   const int t = threadIdx.x, lane = t & 63, w = t >> 6;
   const int wm = w % WM, wn = w / WM;
-  const int chain = head_.P.chain;
+  const int chain = CHAIN ? head_.P.chain : 0;
 
   f32x16 acc[NT];
 #pragma unroll
@@ -415,7 +418,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
       __syncthreads();
     }
   }
-  if (link == chain) break;
+  if (!CHAIN || link == chain) break;
   {      // the next link: acc holds sum / alpha of what is behind; alpha is applied once, in the epilogue, with the LAST link's value
     const float behind = P.alpha;
     fetch_follower(gb, head_.pi + link + 1, head_, bp_);
@@ -1305,9 +1308,11 @@ enum FwdKind { FWD_PLAIN = 0, FWD_SMALLK, FWD_OUTER, FWD_SPLITK, FWD_PERSIST, FW
 struct Batcher {
   e3k::GemmBatch gb{};
   int blocks = 0;
+  bool chained = false;      // the batch holds a K-chain
   void reset() {
     gb = e3k::GemmBatch{};
     blocks = 0;
+    chained = false;
   }
 };
 constexpr int MAX_CALL = 64;   // problems per C-ABI call
@@ -1415,7 +1420,10 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       int rc = E3K_OK;
       switch (k) {
         case FWD_PLAIN:
-          rc = small_grid ? launch_batch(e3k::gemm_kernel<2>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4>, b.gb, b.blocks, st);
+          if (b.chained)
+            rc = small_grid ? launch_batch(e3k::gemm_kernel<2, true>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4, true>, b.gb, b.blocks, st);
+          else
+            rc = small_grid ? launch_batch(e3k::gemm_kernel<2, false>, b.gb, b.blocks, st) : launch_batch(e3k::gemm_kernel<4, false>, b.gb, b.blocks, st);
           break;
         case FWD_SMALLK: rc = launch_batch(e3k::gemm_smallk_kernel, b.gb, b.blocks, st); break;
         case FWD_SPLITK: rc = launch_batch(e3k::gemm_splitk_kernel, b.gb, b.blocks, st); break;
@@ -1483,6 +1491,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       gb.tile_start[gb.n] = b.blocks;
       b.blocks += (int)blocks;
       ++gb.n;
+      if (P.chain > 0) b.chained = true;
       for (int j = 1; j <= P.chain; ++j) {      // the followers: right behind their head, no tiles of their own
         const e3k_gemm_problem& F = problems[i + j];
         gb.p[gb.n] = F;
