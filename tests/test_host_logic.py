@@ -419,3 +419,40 @@ def test_optimizer_checkpoint_layout_is_verified_or_remapped_by_name():
     assert layout_moves(a, None, assume_same_order=True) is None                   # the way in for pre-round-4 checkpoints
     d = [(0, 6, (2, 3), "w1"), (64, 4, (4,), "b")]
     assert layout_moves([(o, n, sh, None) for o, n, sh, _ in d], d) is None       # all shapes distinct: the sequence determines the order
+
+
+def test_linear_terms_that_add_onto_one_block_become_one_k_chain(monkeypatch):
+    """``ops._chain_rounds`` (round 6): the input gradient of the trailing Linear of a convolution (``e3_layers/nn/message_passing.py:58``,
+    ``o3.Linear``) has two terms for ``0e`` -- it feeds the scalars AND the gates -- which used to be an accumulating second launch.  The
+    template builder now hangs the second term behind the first as a K-chain follower (``e3k_gemm_problem.chain``): one round, the head's
+    ``chain`` counts its followers, a follower repeats the head's output block; the forward has one writer per block and stays as it was;
+    with the knob off the rounds are back."""
+    import torch
+
+    from e3_layers_amd.backend import ops
+    from e3_layers_amd.configs import config_energy
+    from e3_layers_amd.utils import build
+
+    model = build(config_energy.get_config(l_max=2).model_config)
+    spec = model.layer2.conv.tp.linear.spec("cf", "cf")
+    by_in = {}
+    for ins in spec.instr:
+        by_in.setdefault(ins.in_off, []).append(ins)
+    shared = [v for v in by_in.values() if len(v) > 1]
+    assert len(shared) == 1 and len(shared[0]) == 2          # `0e` -> 64x0e and 256x0e
+    t = ops._lin_dgrad_templates(spec, 0.3, False)
+    assert len(t.rounds) == 1
+    arr, n = t.rounds[0]
+    assert n == len(spec.instr)
+    heads = [i for i in range(n) if arr[i].chain > 0]
+    assert len(heads) == 1 and arr[heads[0]].chain == 1
+    h, f = arr[heads[0]], arr[heads[0] + 1]
+    assert f.chain == 0 and (f.C, f.N, f.M2, f.c_r1, f.c_r2, f.c_n) == (h.C, h.N, h.M2, h.c_r1, h.c_r2, h.c_n)
+    assert {h.K, f.K} == {64, 256} and h.A != f.A and h.B != f.B
+    fwd = ops._lin_fwd_templates(spec, 0.3, False, 0, 1.0, False)
+    assert len(fwd.rounds) == 1 and all(fwd.rounds[0][0][i].chain == 0 for i in range(fwd.rounds[0][1]))
+    monkeypatch.setenv("E3K_GEMM_CHAIN", "0")
+    plain = ops._lin_dgrad_templates(spec, 0.3, False)
+    assert [cnt for _, cnt in plain.rounds] == [n - 1, 1]
+    assert all(plain.rounds[r][0][i].chain == 0 for r in range(2) for i in range(plain.rounds[r][1]))
+    assert plain.rounds[1][0][0].accumulate == 1 and plain.rounds[1][0][0].C == h.C
