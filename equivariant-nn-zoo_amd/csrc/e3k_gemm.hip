@@ -1161,6 +1161,27 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G
   if (ph == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// Weight gradient of a Linear with ONE output column (the energy head's `64x0e -> 1x0e`, e3_layers/nn/pointwise.py:18): B[k] += alpha
+// sum_rows A[row, k] g[row] is a weighted column sum, not a GEMM -- on the MFMA tile kernels its 4 704 x 64 rows made 74 workgroups
+// wait 22 us for 1.2 MB.  Same shape as colsum_kernel: 64 columns x 4 row phases per block, grid.y splits the rows.
+__global__ __launch_bounds__(256) void wgrad_n1_kernel(const float* __restrict__ A, const float* __restrict__ g, int64_t M1, int M2,
+                                                        int K, int64_t a_r1, int64_t a_r2, int64_t a_k, int64_t c_r1, int64_t c_r2,
+                                                        int64_t b_k, float alpha, float* __restrict__ B) {
+  __shared__ float part[4][64];
+  const int k = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+  const int64_t rows = M1 * M2;
+  float s = 0.f;
+  if (k < K)
+    for (int64_t r = (int64_t)blockIdx.y * 4 + ph; r < rows; r += (int64_t)gridDim.y * 4) {
+      const int64_t r1 = r / M2, r2 = r - r1 * M2;
+      s = fmaf(A[r1 * a_r1 + r2 * a_r2 + k * a_k], g[r1 * c_r1 + r2 * c_r2], s);
+    }
+  part[ph][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ph == 0 && k < K)
+    atomicAdd(B + k * b_k, alpha * (part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]));
+}
+
 // Coalesced variant for V in {4, 8, 16, 32} (V/4 lanes share one u, a lane owns four consecutive v for the whole row):
 // one wave per (r1, r2) row streams the row's U*V floats as 16-byte loads, 1 KB per wave-instruction.  (The generic
 // kernel below lets every lane walk its own 4*V-byte segment: 64 cache lines in flight per instruction, 0.75 TB/s.)
@@ -1540,6 +1561,17 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
   E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
   bool taken[MAX_CALL] = {};
   if (n_problems > MAX_CALL) return E3K_ERR_INVALID;
+  // one output column, plain rows: a weighted column sum (wgrad_n1_kernel)
+  for (int i = 0; i < n_problems; ++i) {
+    const e3k_gemm_problem& P = problems[i];
+    if (P.N != 1 || P.V != 0 || P.row_index || (reps && reps[i] > 1) || (int64_t)P.M1 * P.M2 <= 0) continue;
+    const int64_t rows = (int64_t)P.M1 * P.M2;
+    int gy = (int)((rows + 31) / 32);
+    if (gy > 1024) gy = 1024;
+    hipLaunchKernelGGL(e3k::wgrad_n1_kernel, dim3((P.K + 63) / 64, gy), dim3(256), 0, st, P.A, P.C, (int64_t)P.M1, P.M2, P.K, P.a_r1,
+                       P.a_r2, P.a_k, P.c_r1, P.c_r2, P.b_k, P.alpha, const_cast<float*>(P.B));
+    taken[i] = true;
+  }
   auto g_vec = [](const e3k_gemm_problem& P) {
     return P.c_n == 1 && P.N % 4 == 0 && P.c_r1 % 4 == 0 && (P.M2 == 1 || P.c_r2 % 4 == 0) && aligned16(P.C);
   };

@@ -113,6 +113,9 @@ def test_linear_large_shapes(dev):
     (1, 1, 64, 64, False),         # a single row
     (1200, 3, 64, 128, True),      # gathered rows (the keyed self-connection's groups): node indices fetched one chunk ahead
     (640, 5, 192, 64, True),
+    (4704, 1, 64, 1, False),       # one output column (the energy head's Linear): the weighted column sum, not a tile kernel
+    (333, 3, 100, 1, False),
+    (500, 1, 64, 1, True),         # ... gathered rows keep the tile kernel
 ])
 def test_gemm_wgrad_through_the_c_abi(dev, m1, m2, k, n, gathered):
     """e3k_gemm_wgrad: B[k, n] += alpha * sum_rows A[row, k] G[row, n] for strided (node, component) rows, against float64
