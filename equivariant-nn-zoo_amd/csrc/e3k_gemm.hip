@@ -1161,6 +1161,29 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ G
   if (ph == 0 && c < cols) atomicAdd(out + c, part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 
+// Forward of a Linear with ONE output column (the energy head): C[row] = alpha <A[row, :], B> (+ bias) (+ C): a wave per row, the
+// lanes walk K, one butterfly.  (On the 64 x 64 tile kernel: 74 workgroups, 10.7 us for 1.2 MB.)
+__global__ __launch_bounds__(256) void gemm_n1_kernel(const float* __restrict__ A, const float* __restrict__ B, int64_t M1, int M2, int K,
+                                                       int64_t a_r1, int64_t a_r2, int64_t a_k, int64_t b_k, int64_t c_r1, int64_t c_r2,
+                                                       float alpha, const float* __restrict__ bias, int accumulate, int act, float act_cst,
+                                                       float* __restrict__ C) {
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M1 * M2) return;
+  const int lane = threadIdx.x & 63;
+  const int64_t r1 = r / M2, r2 = r - r1 * M2;
+  const float* __restrict__ a = A + r1 * a_r1 + r2 * a_r2;
+  float s = 0.f;
+  for (int k = lane; k < K; k += 64) s = fmaf(a[k * a_k], B[k * b_k], s);
+  s = wave_sum(s);
+  if (lane == 0) {
+    float* c = C + r1 * c_r1 + r2 * c_r2;
+    float v = fmaf(alpha, s, bias ? bias[0] : 0.f);
+    if (accumulate) v += *c;
+    if (act == 1) v = act_cst * (fmaxf(v, 0.f) + log1pf(expf(-fabsf(v))) - 0.6931471805599453f);
+    *c = v;
+  }
+}
+
 // Weight gradient of a Linear with ONE output column (the energy head's `64x0e -> 1x0e`, e3_layers/nn/pointwise.py:18): B[k] += alpha
 // sum_rows A[row, k] g[row] is a weighted column sum, not a GEMM -- on the MFMA tile kernels its 4 704 x 64 rows made 74 workgroups
 // wait 22 us for 1.2 MB.  Same shape as colsum_kernel: 64 columns x 4 row phases per block, grid.y splits the rows.
@@ -1373,6 +1396,13 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       kind[i] = FWD_FOLLOWER;
       continue;
     }
+    if (P.N == 1 && P.V == 0 && P.chain == 0 && !P.row_index && !(reps && reps[i] > 1)) {      // one output column: gemm_n1_kernel, at once
+      if (M > 0)
+        hipLaunchKernelGGL(e3k::gemm_n1_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, P.A, P.B, (int64_t)P.M1, P.M2, P.K, P.a_r1, P.a_r2,
+                           P.a_k, P.b_k, P.c_r1, P.c_r2, P.alpha, P.bias, P.accumulate, P.act, P.act_cst, P.C);
+      kind[i] = FWD_FOLLOWER;      // (nothing left for the batched kernels)
+      continue;
+    }
     if (P.chain > 0) {
       kind[i] = FWD_PLAIN;
       plain_tiles128 += ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
@@ -1400,6 +1430,23 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
           kind[i] = FWD_PLAIN;
           plain_tiles128 += (((int64_t)problems[i].M1 * problems[i].M2 + 127) / 128) * ((problems[i].N + e3k::BN - 1) / e3k::BN);
         }
+  }
+  // ... and the other way round: a PLAIN problem of a few tiles with a long-ish K loop (the radial stack's last-layer input gradient of
+  // layer 0: 9 tiles, K = 192, beside its siblings' K = 960 .. 1 920 which go split-K) waits 10 us in a launch of its own for nine
+  // serial K loops.  When the call has split-K problems anyway, it joins them.
+  {
+    bool any_splitk = false;
+    for (int i = 0; i < n_problems; ++i) any_splitk = any_splitk || kind[i] == FWD_SPLITK;
+    if (any_splitk && splitk_on)
+      for (int i = 0; i < n_problems; ++i) {
+        const e3k_gemm_problem& P = problems[i];
+        const int64_t M = (int64_t)P.M1 * P.M2;
+        if (kind[i] == FWD_PLAIN && P.chain == 0 && !(reps && reps[i] > 1) && a_vec(P) && b_mode(P) == 2 && P.K >= 128 && P.K % 64 == 0 &&
+            ((M + 63) / 64) * ((P.N + e3k::BN - 1) / e3k::BN) < 32) {
+          kind[i] = FWD_SPLITK;
+          plain_tiles128 -= ((M + 127) / 128) * ((P.N + e3k::BN - 1) / e3k::BN);
+        }
+      }
   }
   // plain problems with vector-loadable operands: the persistent kernel when the launch holds enough tiles for every
   // workgroup slot to walk a sequence of them (below that the one-tile-per-workgroup kernels start sooner)

@@ -156,6 +156,8 @@ def test_gemm_wgrad_through_the_c_abi(dev, m1, m2, k, n, gathered):
     (333, 5, 96, 200, 1, True),       # edge tiles in rows and columns (per-element predicates), K tail
     (130, 1, 64, 72, 1, False),       # 64-row tiles of the small-grid form, column tail
     (4700, 1, 384, 64, 1, False),     # enough tiles for the 128-row form
+    (4704, 1, 64, 1, 0, True),        # one output column (the energy head): a wave per row, not a tile kernel
+    (333, 3, 100, 1, 1, False),
 ])
 def test_gemm_forward_epilogues_through_the_c_abi(dev, m1, m2, k, n, accumulate, bias):
     """e3k_gemm: C[(r1, r2), n] = alpha * A B (+ C) (+ bias) on strided rows against float64 torch: interior and edge tiles of
