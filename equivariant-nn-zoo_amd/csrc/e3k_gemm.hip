@@ -95,7 +95,20 @@ struct BlockProblem {
   int pi, key;      // index of the problem in the batch; key group of a keyed problem (0 otherwise): what a K-chain's followers reuse
 };
 
-__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
+// COMPACT keyed grids (round 6; flags bit 6, gemm_kernel and gemm_smallk_kernel): a keyed problem used to get `reps` x the tiles of its
+// row bound M1 -- every key a full-size grid, the workgroups past a key's last row exit after reading their descriptor: 8 377
+// workgroups for ~1 300 tiles of work in a layer's linear_1 + self-connection launch, nine rounds of empty workgroups through the
+// CUs.  The key groups PARTITION the rows, so sum_k ceil(count_k M2 / bm) <= ceil(M1 M2 / bm) + reps row tiles suffice: a workgroup
+// finds its key by walking the (<= 32) device-side counts.  `bm`: rows per tile; `cols(P, aux)`: workgroups per row tile.
+template <class Cols>
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int bm, Cols cols);
+struct NoCols {
+  __device__ int operator()(const e3k_gemm_problem&, int) const { return 1; }
+};
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) { return fetch_problem(gb, 0, NoCols{}); }
+
+template <class Cols>
+__device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int bm, Cols cols) {
   // The batch lives in the kernel-argument segment: everything here is wave-uniform, so the compiler reads it with
   // scalar loads (s_load_dwordxN at a uniform dynamic offset) straight into SGPRs — no LDS copy, no barrier.
   const int n = gb.n;
@@ -112,7 +125,29 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb) {
   out.pi = pi;
   out.key = 0;
   const int reps = gb.reps[pi];
-  if (reps > 1) {  // keyed problem: which key group this workgroup belongs to
+  if (reps > 1 && bm > 0 && (out.flags & 64)) {      // compact keyed grid
+    const int c = cols(out.P, out.aux);
+    const int rt = out.local / c, col = out.local - rt * c;
+    int key = -1, rt_local = 0, base = 0;
+    for (int k = 0; k < reps; ++k) {
+      int cnt = uniform(out.P.group_dev[2 * k + 1]);
+      cnt = cnt < out.P.M1 ? cnt : out.P.M1;
+      const int t = (cnt * out.P.M2 + bm - 1) / bm;
+      if (key < 0 && rt < base + t) {
+        key = k;
+        rt_local = rt - base;
+      }
+      base += t;
+    }
+    if (key < 0) {      // surplus workgroup (the grid is sized by the bound)
+      out.local = -1;
+      return out;
+    }
+    out.local = rt_local * c + col;
+    out.P.B += (int64_t)key * gb.key_stride[pi];
+    out.P.group_dev += 2 * key;
+    out.key = key;
+  } else if (reps > 1) {  // keyed problem: which key group this workgroup belongs to
     const int per_key = (gb.tile_start[pi + 1] - gb.tile_start[pi]) / reps;
     const int key = out.local / per_key;
     out.local -= key * per_key;
@@ -324,7 +359,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float Bs[BK * LDB];
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
-  const BlockProblem head_ = fetch_problem(gb);
+  const BlockProblem head_ = fetch_problem(gb, BM_, [](const e3k_gemm_problem& Q, int) { return (Q.N + BN - 1) / BN; });
+  if (head_.local < 0) return;      // (block-uniform: surplus workgroup of a compact keyed grid)
   BlockProblem bp_ = head_;
   const e3k_gemm_problem& P = bp_.P;
   const int local = bp_.local;
@@ -539,7 +575,11 @@ __global__ __launch_bounds__(256) void gemm_smallk_kernel(const GemmBatch gb) {
   __shared__ long long rowA[BM_];
   __shared__ long long rowC[BM_];
   STAMP_DECL
-  const BlockProblem bp_ = fetch_problem(gb);
+  const BlockProblem bp_ = fetch_problem(gb, BM_, [](const e3k_gemm_problem& Q, int aux) {
+    const int tn = (Q.N + BN - 1) / BN;
+    return (tn + aux - 1) / aux;
+  });
+  if (bp_.local < 0) return;      // (block-uniform: surplus workgroup of a compact keyed grid)
   STAMP(0);
   const e3k_gemm_problem& P = bp_.P;
   const int local = bp_.local, ct = bp_.aux;
@@ -1373,6 +1413,7 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
   int64_t plain_tiles128 = 0;
   E3K_KNOB_INT(sk_min_rows, "E3K_SK_MIN_ROWS", 1024);
   E3K_KNOB_INT(splitk_on, "E3K_SPLITK", 1);
+  E3K_KNOB_INT(keyed_compact, "E3K_KEYED_COMPACT", 1);
   int follower_of[MAX_CALL];
   for (int i = 0; i < n_problems; ++i) follower_of[i] = -1;
   for (int i = 0; i < n_problems; ++i) {
@@ -1547,14 +1588,23 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
       } else {
         blocks = ((M + 127) / 128) * tiles_n;
       }
-      blocks *= rp;
+      bool compact = false;
+      if (rp > 1 && keyed_compact && P.group_dev && P.row_index && (k == FWD_SMALLK || (k == FWD_PLAIN))) {
+        // (blocks = row tiles x workgroups per row tile for both kernels: the key groups partition the rows, see fetch_problem)
+        const int64_t bm = k == FWD_SMALLK ? 128 : (small_grid ? 64 : 128);
+        const int64_t row_tiles = (M + bm - 1) / bm, per_row = blocks / row_tiles;
+        blocks = (row_tiles + rp) * per_row;
+        compact = true;
+      } else {
+        blocks *= rp;
+      }
       if (b.blocks + blocks > 0x7fffffffLL) return E3K_ERR_INVALID;
       e3k::GemmBatch& gb = b.gb;
       gb.p[gb.n] = P;
       gb.reps[gb.n] = rp;
       gb.key_stride[gb.n] = rp > 1 ? key_stride[i] : 0;
       E3K_KNOB_INT(kAblF, "E3K_GEMM_ABLATE", 0);
-      gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1) | (int)kAblF;
+      gb.flags[gb.n] = (a_vec(P) ? 1 : 0) | (b_mode(P) << 1) | (int)kAblF | (compact ? 64 : 0);
       gb.aux[gb.n] = aux;
       gb.tile_start[gb.n] = b.blocks;
       b.blocks += (int)blocks;
