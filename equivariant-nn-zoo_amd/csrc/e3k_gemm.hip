@@ -125,7 +125,8 @@ __device__ __forceinline__ BlockProblem fetch_problem(const GemmBatch& gb, int b
   out.pi = pi;
   out.key = 0;
   const int reps = gb.reps[pi];
-  if (reps > 1 && bm > 0 && (out.flags & 64)) {      // compact keyed grid
+  if (reps > 1 && bm != 0 && (out.flags & 64)) {      // compact keyed grid
+    if (bm < 0) bm = out.aux;                           // (the weight gradient's row tile = the rows of one split: in aux)
     const int c = cols(out.P, out.aux);
     const int rt = out.local / c, col = out.local - rt * c;
     int key = -1, rt_local = 0, base = 0;
@@ -1042,7 +1043,8 @@ __device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float*
   const int splits = bp_.aux;
   const int tile = local % (tiles_k * tiles_n), split = local / (tiles_k * tiles_n);
   const int k0 = (tile / tiles_n) * TK, n0 = (tile % tiles_n) * 64;
-  const int chunk_rows = ((M + splits - 1) / splits + W2R - 1) / W2R * W2R;
+  // (compact keyed grid, flags bit 6: aux IS the rows per split -- the same for every key: fetch_problem)
+  const int chunk_rows = (bp_.flags & 64) ? splits : ((M + splits - 1) / splits + W2R - 1) / W2R * W2R;
   const int rbeg = split * chunk_rows;
   const int rend = (rbeg + chunk_rows < M) ? rbeg + chunk_rows : M;
   if (rbeg >= M) return;
@@ -1171,7 +1173,10 @@ __device__ __forceinline__ void gemm_wgrad2_body(const BlockProblem& bp_, float*
 __global__ __launch_bounds__(256, 2) void gemm_wgrad2_kernel(const GemmBatch gb) {
   __shared__ __attribute__((aligned(16))) float As[2 * W2R * (128 + 4)];
   __shared__ __attribute__((aligned(16))) float Gs[2 * W2R * (64 + 4)];
-  const BlockProblem bp_ = fetch_problem(gb);
+  const BlockProblem bp_ = fetch_problem(gb, -1, [](const e3k_gemm_problem& Q, int) {
+    return ((Q.K + (Q.K > 64 ? 127 : 63)) / (Q.K > 64 ? 128 : 64)) * ((Q.N + 63) / 64);
+  });
+  if (bp_.local < 0) return;      // (block-uniform: surplus workgroup of a compact keyed grid)
   if (bp_.P.row_index) {
     if (bp_.P.K > 64) gemm_wgrad2_body<4, true>(bp_, As, Gs);
     else gemm_wgrad2_body<2, true>(bp_, As, Gs);
@@ -1656,6 +1661,7 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
   E3K_KNOB_INT(kBlocks, "E3K_WGRAD2_BLOCKS", 0);
   E3K_KNOB_INT(kMinChunks, "E3K_WGRAD2_MIN_CHUNKS", 2);
   E3K_KNOB_INT(kAbl, "E3K_WGRAD2_ABLATE", 0);
+  E3K_KNOB_INT(kCompact, "E3K_KEYED_COMPACT", 1);
   bool taken[MAX_CALL] = {};
   if (n_problems > MAX_CALL) return E3K_ERR_INVALID;
   // one output column, plain rows: a weighted column sum (wgrad_n1_kernel)
@@ -1709,7 +1715,15 @@ static int gemm_wgrad_impl(const e3k_gemm_problem* problems, int n_problems, con
       gb.flags[gb.n] = 9 | (int)kAbl;
       gb.aux[gb.n] = (int)splits;
       gb.tile_start[gb.n] = b.blocks;
-      b.blocks += tiles_of(P) * (int)splits * rp;
+      if (rp > 1 && kCompact && P.group_dev && P.row_index) {
+        // the key groups partition the M rows: `splits` splits of the whole (+ one per key for the remainders) instead of `splits` per key
+        const int64_t rows = ((M + splits - 1) / splits + chunk - 1) / chunk * chunk;
+        gb.flags[gb.n] |= 64;
+        gb.aux[gb.n] = (int)rows;
+        b.blocks += tiles_of(P) * (int)((M + rows - 1) / rows + rp);
+      } else {
+        b.blocks += tiles_of(P) * (int)splits * rp;
+      }
       if (++gb.n == e3k::GEMM_MAXP) {
         const int rc = flush();
         if (rc != E3K_OK) return rc;
