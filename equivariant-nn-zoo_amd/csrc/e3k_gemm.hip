@@ -1416,7 +1416,12 @@ static int gemm_fwd_impl(const e3k_gemm_problem* problems, int n_problems, const
   hipStream_t st = (hipStream_t)stream;
   int kind[MAX_CALL];
   int64_t plain_tiles128 = 0;
-  E3K_KNOB_INT(sk_min_rows, "E3K_SK_MIN_ROWS", 1024);
+  // The resident-A small-K kernel (gemm_smallk_kernel) is OFF since round 6: with the plain kernel back at five waves per SIMD and the
+  // keyed grids compact, every workload measured runs faster with its K <= 64 problems on gemm_kernel<2> -- 256 molecules 3.88 -> 3.82 ms
+  // (debug library), l_max 3 6.39 -> 6.28, 32 molecules 1.52 -> 1.47, force training 5.40 -> 5.33, config_diffusion (per-edge radial MLPs, the
+  // kernel's original customer) 3.34 -> 3.29, config_diffusion_CA 8.03 -> 7.76.  Its 51 KB of LDS and 152 registers leave three workgroups per
+  // CU where a launch has two rounds of them.  E3K_SK_MIN_ROWS=1024 (debug library) routes rows x K <= 64 problems to it again.
+  E3K_KNOB_INT(sk_min_rows, "E3K_SK_MIN_ROWS", 1LL << 40);
   E3K_KNOB_INT(splitk_on, "E3K_SPLITK", 1);
   E3K_KNOB_INT(keyed_compact, "E3K_KEYED_COMPACT", 1);
   int follower_of[MAX_CALL];
