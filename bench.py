@@ -867,7 +867,7 @@ def main():
         flops = sum(2.0 * e * k * w for _, _, (e, k, w) in recs)
         ms = sum(ev0.elapsed_time(ev1) for ev0, ev1, _ in recs)
         rows = sorted({e for _, _, (e, k, w) in recs})
-        kernels.append({"kernel": "e3k::gemm_smallk_kernel (radial MLP last layer, forward; rows per launch: "
+        kernels.append({"kernel": "e3k::gemm_kernel<2, false> (radial MLP last layer, forward; rows per launch: "
                                   + ("the knot table" if max(rows) < 10000 else "one per edge") + ")", "bound": "mfma",
                         "achieved": round(flops / (ms * 1e-3) / 1e12, 1), "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": round(flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, 4), "launches": len(recs),
